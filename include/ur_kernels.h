@@ -1,0 +1,174 @@
+/*
+ * ur_kernels.h -- C ABI of liburhip.so: the MI355X (gfx950) device ops of Uni-Renderer's
+ * dual-stream denoise step.
+ *
+ * Boundary contract:
+ *   - plain pointers and sizes only, no torch types; every pointer is a DEVICE pointer owned by the
+ *     caller (PyTorch allocates activations, packed weights and workspaces);
+ *   - the library keeps no state: every call is re-entrant and asynchronous on `stream`
+ *     (a hipStream_t passed as void*; 0 = the null stream); no host synchronisation inside;
+ *   - return value: 0 on success, a negative code on a bad descriptor (UR_E_*), or the negated
+ *     hipError_t of the launch; nothing throws across the ABI.
+ *   - dtype: 0 = fp16, 1 = bf16 (the storage type of activations/weights; accumulation, norm
+ *     statistics and softmax are always fp32).
+ *   - activations are NHWC ("channels last"): a [B,H,W,C] image is also the [B, H*W, C] token matrix.
+ *
+ * What each entry point replaces in the reference (all of it is stock PyTorch/diffusers CUDA
+ * dispatch there -- the reference has no custom kernel on this path):
+ *   ur_igemm        nn.Conv2d 3x3 / 1x1 and nn.Linear inside ResnetBlock2D, Transformer2DModel,
+ *                   Attention, FeedForward(GEGLU), Downsample2D, Upsample2D(+F.interpolate nearest),
+ *                   torch.cat([hidden, skip]) in front of the up-path resnets
+ *                   (models/unet_2d_blocks.py:1199-1217, 2546, 2575-2588, 2677, 2696-2701), the
+ *                   zero-conv feature exchange `skip + conv1x1(other_stream_skip)`
+ *                   (models/controlnet.py:1752-1769, 2446-2461, 2476-2477), conv_in/conv_out
+ *                   (controlnet.py:1019, 1157, 1720, 2521) and the time-embedding MLP (916, 2407).
+ *   ur_groupnorm_*  nn.GroupNorm(32)+SiLU in ResnetBlock2D / conv_norm_out (controlnet.py:1154-1156)
+ *                   and the GroupNorm(eps 1e-6) at Transformer2DModel entry.
+ *   ur_layernorm    the three nn.LayerNorm of BasicTransformerBlock.
+ *   ur_attention    F.scaled_dot_product_attention of AttnProcessor2_0 (self and 77-key cross).
+ *   ur_add          `down_block_res_sample + down_block_additional_residual`, `sample + mid residual`
+ *                   (controlnet.py:1078-1087, 1114-1115).
+ *   ur_timestep_embedding   diffusers Timesteps (controlnet.py:285, 909-914).
+ *   ur_nchw_to_nhwc / ur_nhwc_to_nchw   layout glue at the module boundary (the reference is NCHW).
+ */
+#ifndef UR_KERNELS_H
+#define UR_KERNELS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UR_ABI_VERSION 1
+
+#define UR_E_BADARG (-1001)   /* inconsistent descriptor (shape / alignment / null pointer)   */
+#define UR_E_UNSUPPORTED (-1002) /* shape outside what the kernels are instantiated for       */
+
+#define UR_DT_F16 0
+#define UR_DT_BF16 1
+
+#define UR_ACT_NONE 0
+#define UR_ACT_SILU 1
+#define UR_ACT_GEGLU 2
+
+/* Tile configurations of ur_igemm (rows x cols of the output tile computed by one workgroup). */
+#define UR_TILE_AUTO 0
+#define UR_TILE_128x128 1
+#define UR_TILE_128x64 2
+#define UR_TILE_64x64 3
+
+/*
+ * Implicit GEMM:  out[m][n] = epilogue( sum_k X[m][k] * W[n][k] )
+ *
+ *   X  (M rows)  is either a plain row-major matrix (taps == 1) or the im2col view of an NHWC image
+ *      gathered on the fly (taps == 9: 3x3, pad 1, stride 1|2, optional nearest-2x upsample in
+ *      front), optionally the channel-concatenation of two NHWC sources (x0 | x1).
+ *      K = taps * (c0 + c1), k = tap * (c0 + c1) + c.  c0, c1 must be multiples of 64.
+ *   W  (N rows)  is row-major [N][K] (K contiguous).
+ *   epilogue: +bias[n] (fp32), +rowadd[m / rows_per_b][n], activation, +res[m][n], *out_scale.
+ *      act == UR_ACT_GEGLU: packed columns come in groups of 8 = 4 value + 4 gate columns and the
+ *      output has N/2 columns: out[m][(p/8)*4 + p%4] = value * gelu(gate).
+ *   zbatch > 1: grid.z batches independent problems with element strides zx / zw / zout (used for the
+ *      transposed V projection  Vt[b] = Wv . X[b]^T ).
+ *   splitk > 1: K is split over grid.z (zbatch must be 1); `partial` is a caller-provided fp32
+ *      workspace of splitk * M * ldp floats and the epilogue runs in a second small kernel.
+ */
+typedef struct ur_igemm_desc {
+    const void* x0;
+    const void* x1;      /* second concat source or NULL                                   */
+    const void* w;
+    const float* bias;   /* [N] fp32 or NULL                                               */
+    const void* rowadd;  /* [*, ld_rowadd] dtype or NULL; row index = m / rows_per_b        */
+    const void* res;     /* [M][ldres] dtype or NULL                                       */
+    void* out;           /* [M][ldc] dtype                                                 */
+    float* partial;      /* split-K workspace or NULL                                      */
+    const void* zero_page; /* >= 256 zero bytes, 16-byte aligned (read for padding rows)     */
+    int64_t ldx0, ldx1;  /* element stride between consecutive pixels/rows of x0 / x1      */
+    int64_t ldw;         /* element stride between rows of W                               */
+    int64_t ldres, ldc;
+    int64_t zx, zw, zout; /* per-z element strides (zbatch > 1)                            */
+    int64_t ldp;         /* row stride (floats) of `partial`, multiple of 64               */
+    int32_t c0, c1;
+    int32_t B, Hin, Win, Hout, Wout; /* conv geometry (taps == 9); ignored for taps == 1   */
+    int32_t taps, stride, ups;
+    int32_t M, N, K;
+    int32_t n_store;     /* columns written per row (>= N writes zeros), <= ldc            */
+    int32_t ld_rowadd, rows_per_b;
+    int32_t act;
+    float out_scale;
+    int32_t zbatch, splitk;
+    int32_t tile;        /* UR_TILE_*                                                      */
+    int32_t dtype;
+} ur_igemm_desc;
+
+int ur_igemm(const ur_igemm_desc* d, void* stream);
+
+/* Workspace (in floats) ur_igemm needs in `partial` for this descriptor (0 when splitk <= 1). */
+int64_t ur_igemm_partial_floats(const ur_igemm_desc* d);
+
+/*
+ * GroupNorm over NHWC, optionally over the concatenation of two sources (x0 | x1), optional SiLU.
+ *   stats:  partial[b][chunk][g][2] = (sum, sumsq) over the rows of that chunk, fp32.
+ *   apply:  y = (x - mean) * rstd * gamma + beta  (-> SiLU), mean/rstd reduced from `partial`.
+ * rows = H*W per sample; nchunks = number of row chunks per sample (grid.x).
+ */
+int ur_groupnorm_stats(const void* x0, const void* x1, int c0, int c1, int B, int rows, int groups,
+                       int nchunks, float* partial, int dtype, void* stream);
+int ur_groupnorm_apply(const void* x0, const void* x1, int c0, int c1, int B, int rows, int groups,
+                       int nchunks, const float* partial, const float* gamma, const float* beta, float eps,
+                       int silu, void* out, int dtype, void* stream);
+
+/* LayerNorm over the last dimension of x[rows][C] (C % 8 == 0, C <= 4096), fp32 statistics. */
+int ur_layernorm(const void* x, const float* gamma, const float* beta, float eps, int rows, int C, void* out,
+                 int dtype, void* stream);
+
+/*
+ * softmax(Q K^T * scale) V for all (batch, head) pairs.
+ *   q  [B][Tq][ldq]   head h at columns q_off + h*d .. +d
+ *   k  [B][Tk][ldk]   head h at columns k_off + h*d .. +d
+ *   vt [B][H*d][ldvt] TRANSPOSED values: row h*d + j holds V[:, j] of head h over the keys;
+ *                     ldvt is a multiple of 64 and columns >= Tk are zero
+ *   o  [B][Tq][ldo]   head h at columns h*d .. +d
+ * d in {32, 40, 64, 80, 128, 160}.
+ */
+typedef struct ur_attn_desc {
+    const void* q;
+    const void* k;
+    const void* vt;
+    void* o;
+    const void* zero_page;
+    int64_t ldq, ldk, ldvt, ldo;
+    int32_t q_off, k_off;
+    int32_t B, H, Tq, Tk, d;
+    float scale;
+    int32_t dtype;
+} ur_attn_desc;
+
+int ur_attention(const ur_attn_desc* d, void* stream);
+
+/* out = a + b * alpha (elementwise, n % 8 == 0). */
+int ur_add(const void* a, const void* b, float alpha, void* out, int64_t n, int dtype, void* stream);
+
+/* Sinusoidal timestep embedding: out[b][:] = [cos | sin] (flip) or [sin | cos]; fp32 math. */
+int ur_timestep_embedding(const int64_t* t, int nt, int B, int dim, int flip_sin_to_cos, float freq_shift,
+                          void* out, int dtype, void* stream);
+
+/* Layout glue.  src_dtype/dst dtype: 0 f16, 1 bf16, 2 f32.  Channels >= C of the padded NHWC output
+ * are written as zeros. */
+int ur_nchw_to_nhwc(const void* src, int src_dtype, int B, int C, int H, int W, void* dst, int Cpad, int dtype,
+                    void* stream);
+int ur_nhwc_to_nchw(const void* src, int dtype, int B, int C, int H, int W, void* dst, int dst_dtype,
+                    void* stream);
+
+/* Library self-description. */
+int ur_abi_version(void);
+const char* ur_build_info(void);
+/* sizeof() of the descriptor structs as compiled, so a binding can verify its mirror of the layout. */
+int ur_sizeof_igemm_desc(void);
+int ur_sizeof_attn_desc(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UR_KERNELS_H */

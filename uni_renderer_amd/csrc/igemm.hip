@@ -1,0 +1,474 @@
+// Implicit GEMM on MFMA for gfx950: conv3x3 (stride 1/2, fused nearest-2x upsample, fused channel
+// concat of two sources), conv1x1 / Linear, and the batched transposed V projection, all with fused
+// epilogues (bias, per-sample time-embedding add, SiLU, GEGLU, residual / feature-exchange add, scale).
+//
+//   out[m][n] = epilogue( sum_k X[m][k] * W[n][k] ),  K chunked by 64 (one 128-byte line per row).
+//
+// Data path per workgroup (256 threads = 4 waves):
+//   * both operand tiles are copied global -> LDS with `global_load_lds` (16 B per lane, no VGPR
+//     round trip), double buffered, one barrier per K chunk;
+//   * a tile row is 128 B; its eight 16-B chunks are XOR-swizzled by (row & 7) -- applied on the global
+//     SOURCE address because the LDS-DMA destination is lane-linear -- so that the ds_read_b128 fragment
+//     reads of the 16-lane groups hit 16 distinct bank slots;
+//   * the image (im2col) gather is done by the loader: each lane owns fixed output pixels, and per
+//     K chunk only adds the (dy,dx) tap offset; out-of-image taps, rows >= M and rows >= N read a
+//     zero page;
+//   * MFMA v_mfma_f32_16x16x32_{f16,bf16} with the WEIGHT tile as operand A and the PIXEL tile as
+//     operand B, so a lane ends up with consecutive output channels of ONE pixel; the weight rows are
+//     permuted while loading so that those channels are 16 consecutive ones -> 32-byte vector
+//     stores/loads per lane and full 128-byte lines per pixel row in the epilogue.
+#include "ur_common.h"
+#include "../../include/ur_kernels.h"
+
+namespace ur {
+
+constexpr int BK = 64;  // elements per K chunk (128 bytes)
+
+template <typename T>
+__device__ __forceinline__ void epilogue16(const ur_igemm_desc& p, T* __restrict__ outz, int m, int nc,
+                                           float (&v)[16]) {
+    if (m >= p.M) return;
+    const bool full = (nc + 16 <= p.N);
+    const bool vec = (((p.ldc | p.ldres | (int64_t)p.ld_rowadd) & 7) == 0);
+    if (p.bias) {
+        if (full) {
+            const float4* b4 = reinterpret_cast<const float4*>(p.bias + nc);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float4 b = b4[i];
+                v[4 * i + 0] += b.x; v[4 * i + 1] += b.y; v[4 * i + 2] += b.z; v[4 * i + 3] += b.w;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if (nc + i < p.N) v[i] += p.bias[nc + i];
+        }
+    }
+    if (p.rowadd) {
+        const T* ra = reinterpret_cast<const T*>(p.rowadd) + (int64_t)(m / p.rows_per_b) * p.ld_rowadd + nc;
+        if (full && vec) {
+            float t[8];
+            load8(ra, t);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] += t[i];
+            load8(ra + 8, t);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[8 + i] += t[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if (nc + i < p.N) v[i] += to_f(ra[i]);
+        }
+    }
+    if (p.act == ACT_GEGLU) {
+        float o[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            o[i] = v[i] * gelu_erf_f(v[4 + i]);
+            o[4 + i] = v[8 + i] * gelu_erf_f(v[12 + i]);
+        }
+        const int oc = nc >> 1;
+        T* dst = outz + (int64_t)m * p.ldc + oc;
+        if (full && vec) {
+            store8(dst, o);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (oc + i < (p.N >> 1)) dst[i] = from_f<T>(o[i]);
+        }
+        return;
+    }
+    if (p.act == ACT_SILU) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = silu_f(v[i]);
+    }
+    if (p.res) {
+        const T* rp = reinterpret_cast<const T*>(p.res) + (int64_t)m * p.ldres + nc;
+        if (full && vec) {
+            float t[8];
+            load8(rp, t);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] += t[i];
+            load8(rp + 8, t);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[8 + i] += t[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if (nc + i < p.N) v[i] += to_f(rp[i]);
+        }
+    }
+    if (p.out_scale != 1.0f) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] *= p.out_scale;
+    }
+    T* dst = outz + (int64_t)m * p.ldc + nc;
+    if (vec && nc + 16 <= p.n_store) {
+        float t[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t[i] = v[i];
+        store8(dst, t);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t[i] = v[8 + i];
+        store8(dst + 8, t);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (nc + i < p.n_store) dst[i] = from_f<T>(v[i]);
+    }
+}
+
+template <typename T, int BM, int BN, int WM, int WN, bool CONV>
+__global__ void __launch_bounds__(256) igemm_kernel(const ur_igemm_desc p) {
+    typedef typename Vec8<T>::type vec8;
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    constexpr int MREP = BM / WM / 16;
+    constexpr int NREP = BN / WN / 16;
+    static_assert(NREP == 4, "a wave spans 64 output columns (epilogue layout)");
+    constexpr int XT_BYTES = BM * 128;
+    constexpr int WT_BYTES = BN * 128;
+    constexpr int STAGE = XT_BYTES + WT_BYTES;
+    constexpr int XI = BM / 32;  // LDS-DMA instructions per wave per X tile (8 rows each)
+    constexpr int WI = BN / 32;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int tile_n = blockIdx.x % tiles_n;
+    const int tile_m = blockIdx.x / tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const int kt_total = p.K / BK;
+    int kbeg = 0, kend = kt_total, zb = 0;
+    if (p.splitk > 1) {
+        const int per = (kt_total + p.splitk - 1) / p.splitk;
+        kbeg = blockIdx.z * per;
+        kend = min(kt_total, kbeg + per);
+    } else {
+        zb = blockIdx.z;
+    }
+    const char* x0 = reinterpret_cast<const char*>(reinterpret_cast<const T*>(p.x0) + (int64_t)zb * p.zx);
+    const char* x1 = reinterpret_cast<const char*>(p.x1);
+    const char* wp = reinterpret_cast<const char*>(reinterpret_cast<const T*>(p.w) + (int64_t)zb * p.zw);
+    const int js = (lane & 7) ^ (lane >> 3);  // swizzled source chunk of this lane's 16 bytes
+    const char* zp = reinterpret_cast<const char*>(p.zero_page) + (lane & 7) * 16;
+
+    // ---- per-lane row bookkeeping (fixed over the K loop) ----
+    // The K axis is walked as segments (tap, source) of c_src/64 chunks.  Per segment every lane
+    // recomputes one 64-bit pointer per owned row (pixel + tap offset, or the zero page when the tap
+    // falls outside the image / the row is >= M); inside a segment a chunk step is `ptr += inc`
+    // (inc = 128 bytes, or 0 for zero-page rows).
+    int xa[XI], xy[XI], xx[XI];
+#pragma unroll
+    for (int it = 0; it < XI; ++it) {
+        const int r = (wave * XI + it) * 8 + (lane >> 3);
+        const int m = m0 + r;
+        if (CONV) {
+            const int hw = p.Hout * p.Wout;
+            const int b = m / hw;
+            const int rem = m - b * hw;
+            const int oy = rem / p.Wout;
+            const int ox = rem - oy * p.Wout;
+            xa[it] = b * p.Hin * p.Win;
+            xy[it] = (m < p.M) ? oy * p.stride - 1 : -(1 << 20);
+            xx[it] = ox * p.stride - 1;
+        } else {
+            xa[it] = (m < p.M) ? m : -1;
+            xy[it] = 0;
+            xx[it] = 0;
+        }
+    }
+    const char* xptr[XI];
+    int xinc[XI];
+    const char* wptr[WI];
+    int winc[WI];
+#pragma unroll
+    for (int it = 0; it < WI; ++it) {
+        const int r = (wave * WI + it) * 8 + (lane >> 3);  // LDS row of the tile
+        const int rho = r & 63;
+        // LDS row (f, i) = f*16 + i holds semantic column (i>>2)*16 + f*4 + (i&3) of its 64-group
+        const int sem = (r & ~63) | (((rho >> 2) & 3) << 4) | ((rho >> 4) << 2) | (rho & 3);
+        const int n = n0 + sem;
+        const bool ok = n < p.N;
+        const int64_t off = ((int64_t)n * p.ldw + (int64_t)kbeg * BK + js * 8) * (int64_t)sizeof(T);
+        wptr[it] = ok ? wp + off : zp;
+        winc[it] = ok ? 128 : 0;
+    }
+
+    // segment state of the loader (all wave-uniform)
+    const int segs_per_tap = (p.c1 > 0) ? 2 : 1;
+    int seg_tap, seg_src, seg_left;
+    {
+        const int Cin = p.c0 + p.c1;
+        const int kglob = kbeg * BK;
+        seg_tap = kglob / Cin;
+        int cc = kglob - seg_tap * Cin;
+        seg_src = (cc >= p.c0) ? 1 : 0;
+        if (seg_src) cc -= p.c0;
+        seg_left = ((seg_src ? p.c1 : p.c0) - cc) / BK;
+        // pointers of the first segment, advanced to chunk cc
+        const char* sb = seg_src ? x1 : x0;
+        const int64_t ld = seg_src ? p.ldx1 : p.ldx0;
+        const int dy = seg_tap / 3, dx = seg_tap - dy * 3;
+#pragma unroll
+        for (int it = 0; it < XI; ++it) {
+            int pix;
+            bool ok;
+            if (CONV) {
+                const int iy = xy[it] + dy, ix = xx[it] + dx;
+                ok = ((unsigned)iy < (unsigned)(p.Hin << p.ups)) && ((unsigned)ix < (unsigned)(p.Win << p.ups));
+                pix = xa[it] + (iy >> p.ups) * p.Win + (ix >> p.ups);
+            } else {
+                ok = xa[it] >= 0;
+                pix = xa[it];
+            }
+            const int64_t off = ((int64_t)pix * ld + cc + js * 8) * (int64_t)sizeof(T);
+            xptr[it] = ok ? sb + off : zp;
+            xinc[it] = ok ? 128 : 0;
+        }
+    }
+
+    auto next_segment = [&]() {
+        seg_src += 1;
+        if (seg_src >= segs_per_tap) { seg_src = 0; seg_tap += 1; }
+        seg_left = (seg_src ? p.c1 : p.c0) / BK;
+        const char* sb = seg_src ? x1 : x0;
+        const int64_t ld = seg_src ? p.ldx1 : p.ldx0;
+        const int dy = seg_tap / 3, dx = seg_tap - dy * 3;
+#pragma unroll
+        for (int it = 0; it < XI; ++it) {
+            int pix;
+            bool ok;
+            if (CONV) {
+                const int iy = xy[it] + dy, ix = xx[it] + dx;
+                ok = ((unsigned)iy < (unsigned)(p.Hin << p.ups)) && ((unsigned)ix < (unsigned)(p.Win << p.ups));
+                pix = xa[it] + (iy >> p.ups) * p.Win + (ix >> p.ups);
+            } else {
+                ok = xa[it] >= 0;
+                pix = xa[it];
+            }
+            const int64_t off = ((int64_t)pix * ld + js * 8) * (int64_t)sizeof(T);
+            const char* cand = sb + off;
+            xptr[it] = ok ? cand : zp;
+            xinc[it] = ok ? 128 : 0;
+        }
+    };
+
+    // issue the LDS-DMA copies of the loader's current chunk into `buf`, then advance by one chunk
+    auto stage = [&](int buf) {
+        char* xs = smem + buf * STAGE;
+        char* ws = xs + XT_BYTES;
+#pragma unroll
+        for (int it = 0; it < XI; ++it) {
+            glds16(xptr[it], xs + (wave * XI + it) * 1024);
+            xptr[it] += xinc[it];
+        }
+#pragma unroll
+        for (int it = 0; it < WI; ++it) {
+            glds16(wptr[it], ws + (wave * WI + it) * 1024);
+            wptr[it] += winc[it];
+        }
+        seg_left -= 1;
+        if (seg_left == 0) next_segment();
+    };
+
+    f32x4 acc[MREP][NREP];
+#pragma unroll
+    for (int i = 0; i < MREP; ++i)
+#pragma unroll
+        for (int j = 0; j < NREP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = kend - kbeg;
+    if (nk > 0) {
+        stage(0);
+        __syncthreads();
+        const int l15 = lane & 15, q = lane >> 4;
+        for (int t = 0; t < nk; ++t) {
+            if (t + 1 < nk) stage((t + 1) & 1);
+            const char* xs = smem + (t & 1) * STAGE;
+            const char* ws = xs + XT_BYTES;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int c = ((kk * 4 + q) ^ (l15 & 7)) << 4;  // swizzled 16-B chunk of this lane
+                vec8 wf[NREP], xf[MREP];
+#pragma unroll
+                for (int f = 0; f < NREP; ++f)
+                    wf[f] = *reinterpret_cast<const vec8*>(ws + (wn * 64 + f * 16 + l15) * 128 + c);
+#pragma unroll
+                for (int mf = 0; mf < MREP; ++mf)
+                    xf[mf] = *reinterpret_cast<const vec8*>(xs + (wm * (16 * MREP) + mf * 16 + l15) * 128 + c);
+#pragma unroll
+                for (int mf = 0; mf < MREP; ++mf)
+#pragma unroll
+                    for (int f = 0; f < NREP; ++f) acc[mf][f] = mfma16(wf[f], xf[mf], acc[mf][f]);
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: lane (j = lane&15, q = lane>>4) holds pixel row j, channels q*16 .. q*16+15 ----
+    const int q = lane >> 4;
+    const int nc = n0 + wn * 64 + q * 16;
+#pragma unroll
+    for (int mf = 0; mf < MREP; ++mf) {
+        const int m = m0 + wm * (16 * MREP) + mf * 16 + (lane & 15);
+        float v[16];
+#pragma unroll
+        for (int f = 0; f < NREP; ++f)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[f * 4 + r] = acc[mf][f][r];
+        if (p.splitk > 1) {
+            if (m < p.M) {
+                float4* pp = reinterpret_cast<float4*>(p.partial + ((int64_t)blockIdx.z * p.M + m) * p.ldp + nc);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) pp[i] = make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+            }
+        } else {
+            epilogue16<T>(p, reinterpret_cast<T*>(p.out) + (int64_t)zb * p.zout, m, nc, v);
+        }
+    }
+}
+
+// Second pass of split-K: sum the fp32 slabs and run the epilogue.  One thread per (row, 16 columns).
+template <typename T>
+__global__ void __launch_bounds__(256) igemm_splitk_reduce(const ur_igemm_desc p) {
+    const int groups = (int)(p.ldp / 16);
+    const int64_t total = (int64_t)p.M * groups;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int m = (int)(idx / groups);
+        const int nc = (int)(idx - (int64_t)m * groups) * 16;
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = 0.f;
+        for (int z = 0; z < p.splitk; ++z) {
+            const float4* pp = reinterpret_cast<const float4*>(p.partial + ((int64_t)z * p.M + m) * p.ldp + nc);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float4 a = pp[i];
+                v[4 * i] += a.x; v[4 * i + 1] += a.y; v[4 * i + 2] += a.z; v[4 * i + 3] += a.w;
+            }
+        }
+        if (nc < p.n_store || nc < p.N) epilogue16<T>(p, reinterpret_cast<T*>(p.out), m, nc, v);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+struct TileCfg { int bm, bn; };
+static const TileCfg kTiles[4] = {{0, 0}, {128, 128}, {128, 64}, {64, 64}};
+
+static int pick_tile(const ur_igemm_desc& d) {
+    // Cost model: the busiest CU runs ceil(workgroups / 256) tiles; bigger tiles have a better
+    // MFMA : LDS-read ratio.  The Python host normally passes an explicit tile from its tuning table.
+    const double eff[4] = {0, 1.0, 0.85, 0.6};
+    int best = UR_TILE_64x64;
+    double best_cost = 1e30;
+    for (int t = 1; t <= 3; ++t) {
+        const int64_t tm = (d.M + kTiles[t].bm - 1) / kTiles[t].bm;
+        const int64_t tn = (d.N + kTiles[t].bn - 1) / kTiles[t].bn;
+        const int64_t wgs = tm * tn * (d.zbatch > 1 ? d.zbatch : 1) * (d.splitk > 1 ? d.splitk : 1);
+        const double cost = (double)((wgs + 255) / 256) * kTiles[t].bm * kTiles[t].bn / eff[t];
+        if (cost < best_cost) { best_cost = cost; best = t; }
+    }
+    return best;
+}
+
+template <typename T, int BM, int BN, int WM, int WN>
+static int launch_cfg(const ur_igemm_desc& d, hipStream_t s) {
+    const int tiles_m = (d.M + BM - 1) / BM, tiles_n = (d.N + BN - 1) / BN;
+    dim3 grid(tiles_m * tiles_n, 1, d.splitk > 1 ? d.splitk : (d.zbatch > 1 ? d.zbatch : 1));
+    const size_t lds = 2 * (BM + BN) * 128;
+    hipError_t e;
+    if (d.taps == 9) {
+        static bool once = false;
+        if (!once) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, WM, WN, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            once = true;
+        }
+        hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, true>), grid, dim3(256), lds, s, d);
+    } else {
+        static bool once = false;
+        if (!once) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, WM, WN, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            once = true;
+        }
+        hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, false>), grid, dim3(256), lds, s, d);
+    }
+    e = hipGetLastError();
+    if (e != hipSuccess) return -(int)e;
+    if (d.splitk > 1) {
+        const int64_t total = (int64_t)d.M * (d.ldp / 16);
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL((igemm_splitk_reduce<T>), dim3(blocks), dim3(256), 0, s, d);
+        e = hipGetLastError();
+        if (e != hipSuccess) return -(int)e;
+    }
+    return 0;
+}
+
+template <typename T>
+static int launch_dtype(ur_igemm_desc& d, hipStream_t s) {
+    switch (d.tile) {
+        case UR_TILE_128x128: return launch_cfg<T, 128, 128, 2, 2>(d, s);
+        case UR_TILE_128x64: return launch_cfg<T, 128, 64, 4, 1>(d, s);
+        case UR_TILE_64x64: return launch_cfg<T, 64, 64, 4, 1>(d, s);
+    }
+    return UR_E_BADARG;
+}
+
+static int64_t padded_ldp(const ur_igemm_desc& d, int tile) {
+    const int bn = kTiles[tile].bn;
+    return (int64_t)((d.N + bn - 1) / bn) * bn;
+}
+
+}  // namespace ur
+
+extern "C" int64_t ur_igemm_partial_floats(const ur_igemm_desc* d) {
+    if (!d || d->splitk <= 1) return 0;
+    // worst case over tiles: N padded to 128
+    return (int64_t)d->splitk * d->M * (((int64_t)d->N + 127) / 128 * 128);
+}
+
+extern "C" int ur_igemm(const ur_igemm_desc* din, void* stream) {
+    using namespace ur;
+    if (!din) return UR_E_BADARG;
+    ur_igemm_desc d = *din;
+    if (!d.x0 || !d.w || !d.out || !d.zero_page) return UR_E_BADARG;
+    if (d.M <= 0 || d.N <= 0 || d.K <= 0) return UR_E_BADARG;
+    if (d.taps != 1 && d.taps != 9) return UR_E_BADARG;
+    if ((d.c0 % BK) || (d.c1 % BK) || (d.c1 > 0 && !d.x1)) return UR_E_BADARG;
+    if (d.K != d.taps * (d.c0 + d.c1)) return UR_E_BADARG;
+    if ((d.ldx0 % 8) || (d.c1 > 0 && (d.ldx1 % 8)) || (d.ldw % 8)) return UR_E_BADARG;
+    if (d.taps == 9) {
+        if (d.B <= 0 || d.Hin <= 0 || d.Win <= 0 || d.Hout <= 0 || d.Wout <= 0) return UR_E_BADARG;
+        if (d.stride != 1 && d.stride != 2) return UR_E_BADARG;
+        if (d.M != d.B * d.Hout * d.Wout) return UR_E_BADARG;
+        if (d.ups && d.stride != 1) return UR_E_BADARG;
+    }
+    if (d.zbatch < 1) d.zbatch = 1;
+    if (d.splitk < 1) d.splitk = 1;
+    if (d.splitk > 1 && d.zbatch > 1) return UR_E_BADARG;
+    if (d.splitk > d.K / BK) d.splitk = d.K / BK;
+    if (d.splitk > 1 && !d.partial) return UR_E_BADARG;
+    if (d.rowadd && d.rows_per_b <= 0) return UR_E_BADARG;
+    if (d.act == UR_ACT_GEGLU && (d.N % 16)) return UR_E_BADARG;
+    if (d.n_store <= 0) d.n_store = (d.act == UR_ACT_GEGLU) ? d.N / 2 : d.N;
+    if (d.out_scale == 0.0f) d.out_scale = 1.0f;
+    if (d.tile == UR_TILE_AUTO) d.tile = pick_tile(d);
+    if (d.tile < 1 || d.tile > 3) return UR_E_BADARG;
+    d.ldp = padded_ldp(d, d.tile);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (d.dtype == UR_DT_F16) return launch_dtype<f16>(d, s);
+    if (d.dtype == UR_DT_BF16) return launch_dtype<bf16>(d, s);
+    return UR_E_BADARG;
+}

@@ -1,0 +1,167 @@
+// Small HBM-bound helpers: elementwise add (the enc->unet skip exchange), sinusoidal timestep
+// embedding, and NCHW <-> NHWC layout glue at the module boundary.
+#include "ur_common.h"
+#include "../../include/ur_kernels.h"
+
+namespace ur {
+
+template <typename T>
+__global__ void __launch_bounds__(256) add_kernel(const T* __restrict__ a, const T* __restrict__ b, float alpha,
+                                                  T* __restrict__ out, int64_t nvec) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+        float x[8], y[8];
+        load8(a + i * 8, x);
+        load8(b + i * 8, y);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) x[k] += alpha * y[k];
+        store8(out + i * 8, x);
+    }
+}
+
+// diffusers get_timestep_embedding: emb = t * exp(-ln(1e4) * i / (half - shift)); [sin | cos], flipped
+// to [cos | sin] when flip_sin_to_cos.
+template <typename T>
+__global__ void timestep_kernel(const int64_t* __restrict__ t, int nt, int B, int dim, int flip, float shift,
+                                T* __restrict__ out) {
+    const int half = dim / 2;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * half) return;
+    const int b = idx / half, i = idx - b * half;
+    const float tv = (float)t[nt == 1 ? 0 : b];
+    const float freq = expf(-9.210340371976184f * (float)i / ((float)half - shift));
+    const float arg = tv * freq;
+    const float s = sinf(arg), c = cosf(arg);
+    T* o = out + (int64_t)b * dim;
+    if (flip) { o[i] = (T)c; o[half + i] = (T)s; }
+    else { o[i] = (T)s; o[half + i] = (T)c; }
+    if ((dim & 1) && i == 0) o[dim - 1] = (T)0.f;
+}
+
+template <typename S> __device__ __forceinline__ float ld_any(const S* p, int64_t i) { return (float)p[i]; }
+
+template <typename S, typename T>
+__global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const S* __restrict__ src, int B, int C, int H, int W,
+                                                           T* __restrict__ dst, int Cpad) {
+    const int64_t total = (int64_t)B * H * W * Cpad;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % Cpad);
+        const int64_t pix = i / Cpad;
+        const int x = (int)(pix % W);
+        const int y = (int)((pix / W) % H);
+        const int b = (int)(pix / ((int64_t)W * H));
+        float v = 0.f;
+        if (c < C) v = (float)src[(((int64_t)b * C + c) * H + y) * W + x];
+        dst[i] = (T)v;
+    }
+}
+
+template <typename T, typename S>
+__global__ void __launch_bounds__(256) nhwc_to_nchw_kernel(const T* __restrict__ src, int B, int C, int H, int W,
+                                                           S* __restrict__ dst) {
+    const int64_t total = (int64_t)B * C * H * W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W);
+        const int y = (int)((i / W) % H);
+        const int c = (int)((i / ((int64_t)W * H)) % C);
+        const int b = (int)(i / ((int64_t)W * H * C));
+        dst[i] = (S)(float)src[(((int64_t)b * H + y) * W + x) * C + c];
+    }
+}
+
+static inline int grid_for(int64_t n) {
+    int64_t g = (n + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
+}
+
+}  // namespace ur
+
+using namespace ur;
+
+extern "C" int ur_add(const void* a, const void* b, float alpha, void* out, int64_t n, int dtype, void* stream) {
+    if (!a || !b || !out || n <= 0 || (n & 7)) return UR_E_BADARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int64_t nvec = n / 8;
+    if (dtype == UR_DT_F16)
+        hipLaunchKernelGGL((add_kernel<f16>), dim3(grid_for(nvec)), dim3(256), 0, s, (const f16*)a, (const f16*)b, alpha,
+                           (f16*)out, nvec);
+    else if (dtype == UR_DT_BF16)
+        hipLaunchKernelGGL((add_kernel<bf16>), dim3(grid_for(nvec)), dim3(256), 0, s, (const bf16*)a, (const bf16*)b,
+                           alpha, (bf16*)out, nvec);
+    else
+        return UR_E_BADARG;
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : -(int)e;
+}
+
+extern "C" int ur_timestep_embedding(const int64_t* t, int nt, int B, int dim, int flip_sin_to_cos, float freq_shift,
+                                     void* out, int dtype, void* stream) {
+    if (!t || !out || B <= 0 || dim < 2 || (nt != 1 && nt != B)) return UR_E_BADARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int n = B * (dim / 2);
+    dim3 grid((n + 255) / 256);
+    if (dtype == UR_DT_F16)
+        hipLaunchKernelGGL((timestep_kernel<f16>), grid, dim3(256), 0, s, t, nt, B, dim, flip_sin_to_cos, freq_shift,
+                           (f16*)out);
+    else if (dtype == UR_DT_BF16)
+        hipLaunchKernelGGL((timestep_kernel<bf16>), grid, dim3(256), 0, s, t, nt, B, dim, flip_sin_to_cos, freq_shift,
+                           (bf16*)out);
+    else
+        return UR_E_BADARG;
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : -(int)e;
+}
+
+template <typename S>
+static int to_nhwc_src(const void* src, int B, int C, int H, int W, void* dst, int Cpad, int dtype, hipStream_t s) {
+    const int64_t total = (int64_t)B * H * W * Cpad;
+    if (dtype == UR_DT_F16)
+        hipLaunchKernelGGL((nchw_to_nhwc_kernel<S, f16>), dim3(grid_for(total)), dim3(256), 0, s, (const S*)src, B, C, H,
+                           W, (f16*)dst, Cpad);
+    else if (dtype == UR_DT_BF16)
+        hipLaunchKernelGGL((nchw_to_nhwc_kernel<S, bf16>), dim3(grid_for(total)), dim3(256), 0, s, (const S*)src, B, C, H,
+                           W, (bf16*)dst, Cpad);
+    else
+        return UR_E_BADARG;
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : -(int)e;
+}
+
+extern "C" int ur_nchw_to_nhwc(const void* src, int src_dtype, int B, int C, int H, int W, void* dst, int Cpad,
+                               int dtype, void* stream) {
+    if (!src || !dst || B <= 0 || C <= 0 || H <= 0 || W <= 0 || Cpad < C) return UR_E_BADARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (src_dtype == 0) return to_nhwc_src<f16>(src, B, C, H, W, dst, Cpad, dtype, s);
+    if (src_dtype == 1) return to_nhwc_src<bf16>(src, B, C, H, W, dst, Cpad, dtype, s);
+    if (src_dtype == 2) return to_nhwc_src<float>(src, B, C, H, W, dst, Cpad, dtype, s);
+    return UR_E_BADARG;
+}
+
+template <typename T>
+static int to_nchw_dst(const void* src, int B, int C, int H, int W, void* dst, int dst_dtype, hipStream_t s) {
+    const int64_t total = (int64_t)B * C * H * W;
+    if (dst_dtype == 0)
+        hipLaunchKernelGGL((nhwc_to_nchw_kernel<T, f16>), dim3(grid_for(total)), dim3(256), 0, s, (const T*)src, B, C, H,
+                           W, (f16*)dst);
+    else if (dst_dtype == 1)
+        hipLaunchKernelGGL((nhwc_to_nchw_kernel<T, bf16>), dim3(grid_for(total)), dim3(256), 0, s, (const T*)src, B, C, H,
+                           W, (bf16*)dst);
+    else if (dst_dtype == 2)
+        hipLaunchKernelGGL((nhwc_to_nchw_kernel<T, float>), dim3(grid_for(total)), dim3(256), 0, s, (const T*)src, B, C, H,
+                           W, (float*)dst);
+    else
+        return UR_E_BADARG;
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : -(int)e;
+}
+
+extern "C" int ur_nhwc_to_nchw(const void* src, int dtype, int B, int C, int H, int W, void* dst, int dst_dtype,
+                               void* stream) {
+    if (!src || !dst || B <= 0 || C <= 0 || H <= 0 || W <= 0) return UR_E_BADARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == UR_DT_F16) return to_nchw_dst<f16>(src, B, C, H, W, dst, dst_dtype, s);
+    if (dtype == UR_DT_BF16) return to_nchw_dst<bf16>(src, B, C, H, W, dst, dst_dtype, s);
+    return UR_E_BADARG;
+}
+
+extern "C" int ur_abi_version(void) { return UR_ABI_VERSION; }
+extern "C" const char* ur_build_info(void) { return "liburhip gfx950 (hipcc, MFMA 16x16x32, LDS-DMA) abi 1"; }

@@ -1,0 +1,69 @@
+// Shared device helpers for the gfx950 (MI355X, CDNA4) kernels.  wave = 64 lanes everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ur {
+
+typedef _Float16 f16;
+typedef __bf16 bf16;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+enum : int { UR_F16 = 0, UR_BF16 = 1, UR_F32 = 2 };
+enum : int { ACT_NONE = 0, ACT_SILU = 1, ACT_GEGLU = 2 };
+
+template <typename T> struct Vec8;
+template <> struct Vec8<f16> { typedef f16x8 type; };
+template <> struct Vec8<bf16> { typedef bf16x8 type; };
+
+// D[i][j] += sum_k A[i][k] * B[k][j]; lane l feeds A[l&15][8*(l>>4)..+7] and B[8*(l>>4)..+7][l&15],
+// and receives D[4*(l>>4)+r][l&15], r = 0..3 (cdna_hip_programming.md §3).
+__device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+// Asynchronous 16-byte-per-lane global -> LDS copy.  The LDS destination is wave-uniform; the
+// hardware adds lane*16.  The global source is per lane.
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+template <typename T> __device__ __forceinline__ float to_f(T v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f(float v) { return (T)v; }
+
+template <typename T>
+__device__ __forceinline__ void load8(const T* p, float (&o)[8]) {
+    typename Vec8<T>::type v = *reinterpret_cast<const typename Vec8<T>::type*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (float)v[i];
+}
+template <typename T>
+__device__ __forceinline__ void store8(T* p, const float (&o)[8]) {
+    typename Vec8<T>::type v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (T)o[i];
+    *reinterpret_cast<typename Vec8<T>::type*>(p) = v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+}  // namespace ur
