@@ -150,8 +150,9 @@ int ur_attention(const ur_attn_desc* d, void* stream);
 /* out = a + b * alpha (elementwise, n % 8 == 0). */
 int ur_add(const void* a, const void* b, float alpha, void* out, int64_t n, int dtype, void* stream);
 
-/* Sinusoidal timestep embedding: out[b][:] = [cos | sin] (flip) or [sin | cos]; fp32 math. */
-int ur_timestep_embedding(const int64_t* t, int nt, int B, int dim, int flip_sin_to_cos, float freq_shift,
+/* Sinusoidal timestep embedding of nt (1 or B) fp32 timesteps: out[b][:] = [cos | sin] (flip) or
+ * [sin | cos]; fp32 math. */
+int ur_timestep_embedding(const float* t, int nt, int B, int dim, int flip_sin_to_cos, float freq_shift,
                           void* out, int dtype, void* stream);
 
 /* Layout glue.  src_dtype/dst dtype: 0 f16, 1 bf16, 2 f32.  Channels >= C of the padded NHWC output

@@ -1,0 +1,186 @@
+"""CPU tests of the host side: the C-ABI library loads and exports every symbol include/ur_kernels.h declares
+(no compute calls without a GPU), descriptor mirrors match, the reference's object surface (config,
+from_unet, save/from_pretrained, channel surgery) works, and the weight-packing formulas the kernels rely on
+are correct (emulated with plain torch indexing on the CPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from util_models import O, ROOT, build_product_from_oracle
+
+
+def test_library_exports_every_declared_symbol():
+    from uni_renderer_amd import _lib
+
+    header = open(os.path.join(ROOT, "include", "ur_kernels.h")).read()
+    declared = set(re.findall(r"\b(ur_[a-z0-9_]+)\s*\(", header))
+    declared -= {"ur_igemm_desc", "ur_attn_desc"}
+    assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))
+    lib = _lib.load()  # raises loudly if the .so is missing / stale
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.ur_abi_version() == _lib.ABI_VERSION
+    assert lib.ur_sizeof_igemm_desc() == ctypes.sizeof(_lib.IGemmDesc)
+    assert lib.ur_sizeof_attn_desc() == ctypes.sizeof(_lib.AttnDesc)
+    assert b"gfx950" in lib.ur_build_info()
+
+
+def test_bad_descriptor_is_rejected_without_gpu():
+    from uni_renderer_amd import _lib
+
+    lib = _lib.load()
+    d = _lib.IGemmDesc()
+    assert lib.ur_igemm(ctypes.byref(d), None) == -1001  # UR_E_BADARG, before any launch
+    assert lib.ur_igemm(None, None) == -1001
+    a = _lib.AttnDesc()
+    assert lib.ur_attention(ctypes.byref(a), None) == -1001
+    assert lib.ur_layernorm(None, None, None, 1e-5, 4, 64, None, 0, None) == -1001
+    assert lib.ur_add(None, None, 1.0, None, 8, 0, None) == -1001
+
+
+def test_no_cpu_fallback_and_loud_failure():
+    from uni_renderer_amd import ops
+
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.layernorm(torch.zeros(4, 64, dtype=torch.float16), torch.ones(64), torch.zeros(64))
+    import uni_renderer_amd as U
+
+    u = U.UNet2DConditionModel(**dict(O.TINY_CONFIG))
+    with pytest.raises(RuntimeError):  # fp32 module on CPU: neither a compute dtype nor a device
+        u(torch.zeros(1, 4, 16, 16), 1, torch.zeros(1, 77, 64))
+    with pytest.raises(RuntimeError, match="only holds parameters"):
+        u.conv_in(torch.zeros(1, 4, 8, 8))  # parameter holders refuse to run torch arithmetic
+
+
+def test_product_package_never_imports_oracle():
+    pkg = os.path.join(ROOT, "uni_renderer_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert "oracle" not in src.replace("no oracle", ""), fn
+
+
+def test_config_surface_and_from_unet():
+    import uni_renderer_amd as U
+
+    unet = U.UNet2DConditionModel(**dict(O.TINY_CONFIG))
+    assert unet.config.in_channels == 4 and unet.config["block_out_channels"] == (64, 128, 128, 128)
+    assert unet.config["_class_name"] == "UNet2DConditionModel" and unet.dtype == torch.float32
+    enc = U.AttributeEncoderModel.from_unet(unet, len_t=2)
+    dec = U.AttributeDecoderModel.from_unet(unet, len_t=2)
+    assert enc.len_t == 1 and dec.len_t == 2  # ref controlnet.py:1492 forces 1 for the encoder
+    assert type(dec.up_blocks[0]).__name__ == "UpBlock2D" and type(dec.up_blocks[1]).__name__ == "CrossAttnUpBlock2D"
+    assert torch.equal(enc.down_blocks[1].resnets[0].conv1.weight, unet.down_blocks[1].resnets[0].conv1.weight)
+    assert torch.equal(dec.up_blocks[2].attentions[1].proj_in.weight, unet.up_blocks[2].attentions[1].proj_in.weight)
+    assert all(float(z.weight.abs().max()) == 0 for z in enc.controlnet_down_blocks) and len(enc.controlnet_down_blocks) == 12
+    assert len(dec.control_down_blocks) == 12
+    # channel surgery exactly as train/train.py:976-996
+    enc.conv_in.weight = torch.nn.Parameter(enc.conv_in.weight.repeat(1, 7, 1, 1) * 0.142)
+    cfg = dict(enc.config)
+    cfg["in_channels"] = 28
+    enc.register_to_config(**cfg)
+    assert enc.config.in_channels == 28 and enc.conv_in.weight.shape == (64, 28, 3, 3)
+    # unreachable block types raise like the reference factories (unet_2d_blocks.py:240,505)
+    with pytest.raises(ValueError):
+        U.get_down_block("AttnDownBlock2D", 1, 8, 8, 8, True, 1e-5)
+    with pytest.raises(ValueError):
+        U.get_up_block("SkipUpBlock2D", 1, 8, 8, 8, 8, True, 1e-5)
+    default_dec = U.AttributeDecoderModel(**{k: v for k, v in O.TINY_CONFIG.items() if k not in ("in_channels", "down_block_types", "up_block_types")})
+    assert type(default_dec.up_blocks[1]).__name__ == "CrossAttnUpResBlock2D"  # the signature default (ref 1793-1798)
+
+
+def test_save_and_from_pretrained_roundtrip(tmp_path):
+    import uni_renderer_amd as U
+
+    unet_o, enc_o, dec_o = O.build_triplet(O.TINY_CONFIG, seed=5)
+    unet, enc, dec = build_product_from_oracle(unet_o, enc_o, dec_o)
+    for name, m, cls in (("unet", unet, U.UNet2DConditionModel), ("controlnet", enc, U.AttributeEncoderModel),
+                         ("controldec", dec, U.AttributeDecoderModel)):
+        m.save_pretrained(os.path.join(tmp_path, name))
+        assert os.path.exists(os.path.join(tmp_path, name, "config.json"))
+        assert os.path.exists(os.path.join(tmp_path, name, "diffusion_pytorch_model.safetensors"))
+        m2 = cls.from_pretrained(str(tmp_path), subfolder=name)
+        sd1, sd2 = m.state_dict(), m2.state_dict()
+        assert set(sd1) == set(sd2) and all(torch.equal(sd1[k], sd2[k]) for k in sd1)
+        assert m2.config["_class_name"] == cls.__name__
+    assert enc.config.in_channels == 28 and U.AttributeEncoderModel.from_pretrained(str(tmp_path), subfolder="controlnet").conv_in.weight.shape[1] == 28
+
+
+def test_pack_conv3x3_is_the_im2col_layout_the_kernel_walks():
+    """k = (ky*3+kx)*Cin + c with taps visited dy-major -- emulate the implicit GEMM with unfold on the CPU."""
+    from uni_renderer_amd.layers import pack_conv3x3
+
+    torch.manual_seed(0)
+    x = torch.randn(2, 5, 6, 7)  # NCHW
+    w = torch.randn(3, 5, 3, 3)
+    wp = pack_conv3x3(w, torch.float32, cin_pad=8)  # [3, 9*8]
+    xpad = F.pad(x, (1, 1, 1, 1))
+    cols = []
+    for dy in range(3):
+        for dx in range(3):
+            patch = xpad[:, :, dy:dy + 6, dx:dx + 7].permute(0, 2, 3, 1)  # NHWC gather of tap (dy,dx)
+            cols.append(F.pad(patch, (0, 3)))
+    im2col = torch.cat(cols, -1)  # [B,H,W,9*8]
+    y = im2col @ wp.t()
+    assert torch.allclose(y.permute(0, 3, 1, 2), F.conv2d(x, w, padding=1), atol=1e-5)
+
+
+def test_geglu_perm_and_epilogue_semantics():
+    from uni_renderer_amd.layers import geglu_perm
+
+    nh = 48
+    perm = geglu_perm(nh, "cpu")
+    assert sorted(perm.tolist()) == list(range(2 * nh))
+    w = torch.randn(2 * nh, 16)
+    x = torch.randn(5, 16)
+    packed = x @ w[perm].t()  # what the GEMM accumulates, in packed column order
+    out = torch.empty(5, nh)
+    for p0 in range(0, 2 * nh, 8):  # epilogue rule of include/ur_kernels.h
+        out[:, p0 // 2:p0 // 2 + 4] = packed[:, p0:p0 + 4] * F.gelu(packed[:, p0 + 4:p0 + 8])
+    full = x @ w.t()
+    assert torch.allclose(out, full[:, :nh] * F.gelu(full[:, nh:]), atol=1e-5)
+
+
+def test_weight_row_permutation_of_the_mfma_tile():
+    """igemm.hip loads LDS row rho = f*16 + i with semantic column (i>>2)*16 + f*4 + (i&3); with the MFMA D
+    layout (row = 4*(lane>>4) + r) a lane then owns 16 consecutive columns q*16 + f*4 + r."""
+    for rho in range(64):
+        f, i = rho >> 4, rho & 15
+        sem = (((rho >> 2) & 3) << 4) | ((rho >> 4) << 2) | (rho & 3)
+        assert sem == (i >> 2) * 16 + f * 4 + (i & 3)
+    cols = {}
+    for q in range(4):
+        for f in range(4):
+            for r in range(4):
+                rho = f * 16 + 4 * q + r
+                sem = (((rho >> 2) & 3) << 4) | ((rho >> 4) << 2) | (rho & 3)
+                cols.setdefault(q, []).append((f * 4 + r, sem))
+    for q, lst in cols.items():
+        assert [s for _, s in sorted(lst)] == list(range(q * 16, q * 16 + 16))
+
+
+def test_plan_igemm_is_sane():
+    from uni_renderer_amd import ops
+
+    for (M, N, K, taps) in [(16384, 320, 2880, 9), (4096, 640, 5760, 9), (256, 1280, 23040, 9), (4, 1280, 320, 1),
+                            (308, 320, 768, 1), (16384, 2560, 320, 1)]:
+        tile, sk = ops.plan_igemm(M, N, K, taps)
+        assert tile in (1, 2, 3) and sk in (1, 2, 4, 8) and (sk == 1 or K // 64 >= 8 * sk)
+    assert ops.plan_igemm(256, 1280, 23040, 9)[1] > 1  # tiny-M, huge-K layers must split K to fill 256 CUs
+
+
+def test_attention_key_permutation_gives_consecutive_keys():
+    """attention.hip: MFMA row i = 4q'+r of sub-fragment `sub` is key 32kb + 8(i>>2) + 4sub + (i&3); after S^T a
+    lane (q') must hold keys 8q'..8q'+7 of the block -- the B-operand layout of the P.V MFMA."""
+    for kb in range(2):
+        for q in range(4):
+            keys = []
+            for sub in range(2):
+                for r in range(4):
+                    i = 4 * q + r
+                    keys.append(kb * 32 + (i >> 2) * 8 + sub * 4 + (i & 3))
+            assert keys == list(range(kb * 32 + 8 * q, kb * 32 + 8 * q + 8))

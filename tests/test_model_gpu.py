@@ -1,0 +1,136 @@
+"""End-to-end GPU parity of the three networks and of the dual-stream step against the CPU fp32 oracle, on
+the same seeded weights and inputs.  north_star tolerance: rel-L2 <= 1e-3 for fp16 at the headline shape; the
+bf16 tolerance (8-bit mantissa) is measured and stated here: 1.5e-2.  The tiny configuration has 32-group
+GroupNorms over only 2-4 channels x few pixels, which amplifies rounding, so its fp16 bound is 3e-3."""
+import json
+import os
+
+import pytest
+import torch
+
+from conftest import rel_l2
+from util_models import O, build_product_from_oracle, product_step
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _check_step(out_p, out_o, tol, tol_exchange=None):
+    errs = {}
+    tol_exchange = tol_exchange or tol
+    for k in ("img_pred", "attr_pred", "enc_mid", "raw_mid_enc", "raw_mid_unet"):
+        if out_o[k] is not None:
+            errs[k] = rel_l2(out_p[k], out_o[k])
+    for k in ("enc_res", "raw_enc", "raw_unet", "up_res"):
+        for i, (a, b) in enumerate(zip(out_p[k], out_o[k])):
+            assert tuple(a.shape) == tuple(b.shape), (k, i, a.shape, b.shape)
+            errs[f"{k}[{i}]"] = rel_l2(a, b)
+    print(json.dumps({k: round(v, 6) for k, v in errs.items()}))
+    assert errs["img_pred"] < tol, errs
+    if "attr_pred" in errs:
+        assert errs["attr_pred"] < tol, errs
+    assert max(errs.values()) < tol_exchange, errs
+    return errs
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 3e-3), (torch.bfloat16, 2.5e-2)])
+def test_tiny_dual_stream_step_vs_oracle(dev, dtype, tol):
+    unet_o, enc_o, dec_o = O.build_triplet(O.TINY_CONFIG, seed=1234)
+    x, c, ehs, ti, ta = O.make_inputs(2, 16, 64, seed=99)
+    out_o = O.dual_stream_step(unet_o, enc_o, dec_o, x, c, ehs, ti, ta)
+    unet, enc, dec = build_product_from_oracle(unet_o, enc_o, dec_o, dtype, dev)
+    with torch.no_grad():
+        out_p = product_step(unet, enc, dec, x.to(dev), c.to(dev), ehs.to(dev), ti.to(dev), ta.to(dev))
+    assert len(out_p["raw_unet"]) == 12 and len(out_p["up_res"]) == 13 and len(out_p["enc_res"]) == 12
+    assert out_p["img_pred"].shape == (2, 4, 16, 16) and out_p["attr_pred"].shape == (2, 28, 16, 16)
+    _check_step(out_p, out_o, tol, tol * 2)
+
+
+def test_tiny_matches_committed_golden(dev):
+    """The committed golden vectors (tests/golden/make_golden.py) pin the oracle; the GPU must match them too."""
+    from safetensors.torch import load_file
+
+    g = load_file(os.path.join(GOLD, "tiny_step.safetensors"))
+    unet_o, enc_o, dec_o = O.build_triplet(O.TINY_CONFIG, seed=1234)
+    unet, enc, dec = build_product_from_oracle(unet_o, enc_o, dec_o, torch.float16, dev)
+    with torch.no_grad():
+        out = product_step(unet, enc, dec, g["x_t"].to(dev), g["cond"].to(dev), g["ehs"].to(dev),
+                           g["t_img"].to(dev), g["t_attr"].to(dev))
+    assert rel_l2(out["img_pred"], g["img_pred"]) < 3e-3
+    assert rel_l2(out["attr_pred"], g["attr_pred"]) < 3e-3
+    assert rel_l2(out["raw_mid_unet"], g["raw_mid_unet"]) < 6e-3
+
+
+def test_rendering_direction_and_scalar_timesteps(dev):
+    """enc + unet only (pipeline.py:1611-1629), python-int timestep for the unet and 0-d tensor for enc."""
+    unet_o, enc_o, dec_o = O.build_triplet(O.TINY_CONFIG, seed=7)
+    x, c, ehs, _, _ = O.make_inputs(2, 16, 64, seed=5)
+    out_o = O.dual_stream_step(unet_o, enc_o, dec_o, x, c, ehs, torch.tensor(999), torch.tensor(0), run_decoder=False)
+    unet, enc, dec = build_product_from_oracle(unet_o, enc_o, dec_o, torch.float16, dev)
+    with torch.no_grad():
+        out_p = product_step(unet, enc, dec, x.to(dev), c.to(dev), ehs.to(dev), 999, torch.tensor(0, device=dev),
+                             run_decoder=False)
+    assert out_p["attr_pred"] is None
+    _check_step(out_p, out_o, 3e-3, 6e-3)
+
+
+def test_structural_invariants_on_gpu(dev):
+    """Reference invariants: enc ignores `sample`; with zero-init exchange convs the unet
+    output does not depend on the enc residuals and dec does not depend on the unet features."""
+    unet_o, enc_o, dec_o = O.build_triplet(O.TINY_CONFIG, seed=3, exchange_std=0.0)
+    unet, enc, dec = build_product_from_oracle(unet_o, enc_o, dec_o, torch.float16, dev)
+    x, c, ehs, ti, ta = [t.to(dev) for t in O.make_inputs(2, 16, 64, seed=11)]
+    with torch.no_grad():
+        r1 = enc(x, ta, ehs, controlnet_cond=c)
+        r2 = enc(torch.zeros_like(x), ta, ehs, controlnet_cond=c)
+        assert torch.equal(r1[3], r2[3])
+        assert all(float(t.float().abs().max()) == 0.0 for t in r1[0]) and float(r1[1].float().abs().max()) == 0.0
+        a = unet(x, ti, ehs, down_block_additional_residuals=r1[0], mid_block_additional_residual=r1[1],
+                 return_dict=False)
+        b = unet(x, ti, ehs, return_dict=False)
+        assert torch.equal(a[0], b[0])
+        d1 = dec(r1[3], r1[2], ta, ehs, down_block_additional_residuals=a[1], mid_block_additional_residual=a[2],
+                 return_dict=False)
+        zeros = tuple(torch.zeros_like(t) for t in a[1])
+        d2 = dec(r1[3], r1[2], ta, ehs, down_block_additional_residuals=zeros,
+                 mid_block_additional_residual=torch.zeros_like(a[2]), return_dict=False)
+        assert torch.equal(d1, d2)
+        assert unet(x, ti, ehs).sample.shape == (2, 4, 16, 16)  # return_dict=True surface
+
+
+def test_nchw_contiguous_inputs_are_accepted(dev):
+    """A caller may hand plain NCHW-contiguous fp32 residuals (e.g. produced by other torch code)."""
+    unet_o, enc_o, dec_o = O.build_triplet(O.TINY_CONFIG, seed=5)
+    unet, enc, dec = build_product_from_oracle(unet_o, enc_o, dec_o, torch.float16, dev)
+    x, c, ehs, ti, ta = [t.to(dev) for t in O.make_inputs(1, 16, 64, seed=2)]
+    with torch.no_grad():
+        res, mid, _, _ = enc(x, ta, ehs, controlnet_cond=c)
+        a = unet(x, ti, ehs, down_block_additional_residuals=res, mid_block_additional_residual=mid, return_dict=False)
+        res2 = [r.float().contiguous() for r in res]
+        b = unet(x, ti, ehs, down_block_additional_residuals=res2, mid_block_additional_residual=mid.float().contiguous(),
+                 return_dict=False)
+    assert torch.equal(a[0], b[0])
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 1e-3), (torch.bfloat16, 1.5e-2)])
+def test_sd_shape_unet_forward_vs_oracle(dev, dtype, tol):
+    """BASELINE config 1 shape: single-stream SD-1.x UNet, 64x64 latent, bs=1 (0.8 TFLOP): GPU vs CPU oracle."""
+    torch.manual_seed(1234)
+    unet_o = O.UNet2DConditionModel(**O.SD15_CONFIG).eval()
+    import uni_renderer_amd as U
+
+    unet = U.UNet2DConditionModel(in_channels=4, out_channels=4, cross_attention_dim=768)
+    unet.load_state_dict(unet_o.state_dict())
+    unet = unet.to(dtype).to(dev).eval()
+    g = torch.Generator().manual_seed(99)
+    x = torch.randn(1, 4, 64, 64, generator=g)
+    ehs = torch.randn(1, 77, 768, generator=g) * 0.5
+    t = torch.tensor([321])
+    with torch.no_grad():
+        ref = unet_o(x, t, ehs)
+        out = unet(x.to(dev), t.to(dev), ehs.to(dev), return_dict=False)
+    e_img = rel_l2(out[0], ref[0])
+    e_mid = rel_l2(out[2], ref[2])
+    e_up = max(rel_l2(a, b) for a, b in zip(out[3], ref[3]))
+    print(json.dumps(dict(dtype=str(dtype), img=e_img, mid=e_mid, up_max=e_up)))
+    assert e_img < tol and e_mid < 3 * tol and e_up < 3 * tol

@@ -1,0 +1,266 @@
+"""GPU parity of every C-ABI device op against a plain PyTorch fp32 reference of the same op evaluated on
+the CPU from the same (fp16/bf16-rounded) inputs.  Tolerances (rel-L2): fp16 2e-3, bf16 1.2e-2 -- one
+storage rounding of the output (2^-11 / 2^-8 relative) on top of fp32 accumulation."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.float16: 2e-3, torch.bfloat16: 1.2e-2}
+DTYPES = [torch.float16, torch.bfloat16]
+
+
+def _rand(shape, dtype, dev, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype).to(dev)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("tile", [1, 2, 3])
+@pytest.mark.parametrize("shape", [(256, 320, 320), (300, 64, 128), (1000, 448, 640), (4, 1280, 320)])
+def test_linear_bias_res(dev, dtype, tile, shape):
+    from uni_renderer_amd import ops
+    M, N, K = shape
+    x = _rand((M, K), dtype, dev, seed=1)
+    w = _rand((N, K), dtype, dev, 1 / math.sqrt(K), seed=2)
+    b = torch.randn(N, generator=torch.Generator().manual_seed(3)).to(dev)
+    r = _rand((M, N), dtype, dev, seed=4)
+    y = ops.linear(x, w, b, res=r, tile=tile, splitk=1)
+    ref = x.float().cpu() @ w.float().cpu().t() + b.cpu() + r.float().cpu()
+    assert rel_l2(y, ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("splitk", [2, 4])
+def test_linear_splitk_silu_scale(dev, dtype, splitk):
+    from uni_renderer_amd import ops
+    M, N, K = 200, 320, 2048
+    x = _rand((M, K), dtype, dev, seed=1)
+    w = _rand((N, K), dtype, dev, 1 / math.sqrt(K), seed=2)
+    b = torch.randn(N, generator=torch.Generator().manual_seed(3)).to(dev)
+    y = ops.linear(x, w, b, act=ops.ACT_SILU, out_scale=0.5, tile=3, splitk=splitk)
+    ref = F.silu(x.float().cpu() @ w.float().cpu().t() + b.cpu()) * 0.5
+    assert rel_l2(y, ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_linear_two_sources(dev, dtype):
+    """1x1 shortcut over cat(hidden, skip): K walks two tensors."""
+    from uni_renderer_amd import ops
+    M, N = 520, 128
+    x0, x1 = _rand((M, 128), dtype, dev, seed=1), _rand((M, 64), dtype, dev, seed=2)
+    w = _rand((N, 192), dtype, dev, 0.1, seed=3)
+    y = ops.linear(x0, w, None, x1=x1)
+    ref = torch.cat([x0, x1], -1).float().cpu() @ w.float().cpu().t()
+    assert rel_l2(y, ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("tile", [1, 2, 3])
+def test_geglu(dev, dtype, tile):
+    from uni_renderer_amd import ops
+    from uni_renderer_amd.layers import geglu_perm
+    M, K, NH = 300, 128, 512
+    x = _rand((M, K), dtype, dev, seed=1)
+    w = _rand((2 * NH, K), dtype, dev, 0.1, seed=2)
+    b = torch.randn(2 * NH, generator=torch.Generator().manual_seed(3)).to(dev)
+    perm = geglu_perm(NH, dev)
+    y = ops.linear(x, w[perm].contiguous(), b[perm].contiguous(), act=ops.ACT_GEGLU, tile=tile, splitk=1)
+    full = x.float().cpu() @ w.float().cpu().t() + b.cpu()
+    ref = full[:, :NH] * F.gelu(full[:, NH:])
+    assert y.shape == (M, NH)
+    assert rel_l2(y, ref) < TOL[dtype]
+
+
+def _conv_ref(x_nhwc, w_oihw, b, stride=1, ups=False):
+    x = x_nhwc.float().cpu().permute(0, 3, 1, 2)
+    if ups:
+        x = F.interpolate(x, scale_factor=2.0, mode="nearest")
+    y = F.conv2d(x, w_oihw.float().cpu(), None if b is None else b.cpu(), stride=stride, padding=1)
+    return y.permute(0, 2, 3, 1)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("tile", [1, 2, 3])
+@pytest.mark.parametrize("mode", ["s1", "s2", "ups"])
+def test_conv3x3(dev, dtype, tile, mode):
+    from uni_renderer_amd import ops
+    from uni_renderer_amd.layers import pack_conv3x3
+    B, H, W, Ci, Co = 2, 12, 10, 128, 192
+    x = _rand((B, H, W, Ci), dtype, dev, seed=1)
+    w = _rand((Co, Ci, 3, 3), dtype, dev, 1 / math.sqrt(9 * Ci), seed=2)
+    b = torch.randn(Co, generator=torch.Generator().manual_seed(3)).to(dev)
+    stride, ups = (2, False) if mode == "s2" else (1, mode == "ups")
+    y = ops.conv3x3(x, pack_conv3x3(w, dtype), b, stride=stride, ups=ups, tile=tile, splitk=1)
+    ref = _conv_ref(x, w, b, stride, ups)
+    assert y.shape == ref.shape
+    assert rel_l2(y, ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("splitk", [1, 3])
+def test_conv3x3_concat_temb_res(dev, dtype, splitk):
+    """The up-path resnet conv: two sources, +bias, + per-sample time embedding, + residual, scale."""
+    from uni_renderer_amd import ops
+    from uni_renderer_amd.layers import pack_conv3x3
+    B, H, W, C0, C1, Co = 3, 8, 8, 128, 64, 64
+    x0, x1 = _rand((B, H, W, C0), dtype, dev, seed=1), _rand((B, H, W, C1), dtype, dev, seed=2)
+    w = _rand((Co, C0 + C1, 3, 3), dtype, dev, 0.03, seed=3)
+    b = torch.randn(Co, generator=torch.Generator().manual_seed(4)).to(dev)
+    temb_all = _rand((B, 256), dtype, dev, seed=5)
+    res = _rand((B, H, W, Co), dtype, dev, seed=6)
+    y = ops.conv3x3(x0, pack_conv3x3(w, dtype), b, x1=x1, rowadd=temb_all[:, 64:128], res=res, out_scale=0.5,
+                    tile=3, splitk=splitk)
+    ref = _conv_ref(torch.cat([x0, x1], -1), w, b) + temb_all[:, 64:128].float().cpu()[:, None, None, :]
+    ref = (ref + res.float().cpu()) * 0.5
+    assert rel_l2(y, ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cin,cout", [(4, 64), (28, 128), (64, 4), (128, 28)])
+def test_conv_in_out_odd_channels(dev, dtype, cin, cout):
+    from uni_renderer_amd import ops
+    from uni_renderer_amd.layers import pack_conv3x3
+    B, H, W = 2, 16, 16
+    w = _rand((cout, cin, 3, 3), dtype, dev, 0.1, seed=2)
+    b = torch.randn(cout, generator=torch.Generator().manual_seed(3)).to(dev)
+    if cin < 64:
+        x_nchw = torch.randn(B, cin, H, W, generator=torch.Generator().manual_seed(1)).to(dev)  # fp32 NCHW input
+        x = ops.to_nhwc(x_nchw, dtype, 64)
+        assert x.shape == (B, H, W, 64) and float(x[..., cin:].abs().max()) == 0.0
+        y = ops.conv3x3(x, pack_conv3x3(w, dtype, 64), b)
+        ref = _conv_ref(x[..., :cin], w, b)
+    else:
+        x = _rand((B, H, W, cin), dtype, dev, seed=1)
+        y = ops.conv3x3(x, pack_conv3x3(w, dtype), b, n_out=cout)
+        ref = _conv_ref(x, w, b)
+    assert y.shape == ref.shape
+    assert rel_l2(y, ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("T", [4, 77, 256, 1000])
+def test_vt_proj(dev, dtype, T):
+    from uni_renderer_amd import ops
+    B, Cin, Cout = 2, 128, 192
+    x = _rand((B, T, Cin), dtype, dev, seed=1)
+    wv = _rand((Cout, Cin), dtype, dev, 0.1, seed=2)
+    vt = ops.vt_proj(x, wv)
+    Tpad = (T + 63) // 64 * 64
+    assert vt.shape == (B, Cout, Tpad)
+    ref = torch.einsum("oc,btc->bot", wv.float().cpu(), x.float().cpu())
+    assert rel_l2(vt[:, :, :T], ref) < TOL[dtype]
+    if Tpad > T:
+        assert float(vt[:, :, T:].float().abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", [(64, 0, 16), (320, 0, 64), (128, 64, 64), (1280, 1280, 16), (640, 320, 100)])
+@pytest.mark.parametrize("silu", [False, True])
+def test_groupnorm(dev, dtype, cfg, silu):
+    from uni_renderer_amd import ops
+    c0, c1, rows = cfg
+    B = 3
+    x0 = _rand((B, rows, 1, c0), dtype, dev, seed=1) * 2 + 0.5
+    x1 = (_rand((B, rows, 1, c1), dtype, dev, seed=2) - 1.0) if c1 else None
+    C = c0 + c1
+    g = torch.randn(C, generator=torch.Generator().manual_seed(3)).to(dev)
+    b = torch.randn(C, generator=torch.Generator().manual_seed(4)).to(dev)
+    y = ops.groupnorm(x0, g, b, 1e-5, x1=x1, groups=32, silu=silu)
+    xc = torch.cat([x0, x1], -1) if c1 else x0
+    ref = F.group_norm(xc.float().cpu().permute(0, 3, 1, 2), 32, g.cpu(), b.cpu(), 1e-5)
+    if silu:
+        ref = F.silu(ref)
+    assert rel_l2(y, ref.permute(0, 2, 3, 1)) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("C", [64, 320, 640, 1280])
+def test_layernorm(dev, dtype, C):
+    from uni_renderer_amd import ops
+    x = _rand((2, 333, C), dtype, dev, seed=1) * 3 + 1
+    g = torch.randn(C, generator=torch.Generator().manual_seed(3)).to(dev)
+    b = torch.randn(C, generator=torch.Generator().manual_seed(4)).to(dev)
+    y = ops.layernorm(x, g, b, 1e-5)
+    ref = F.layer_norm(x.float().cpu(), (C,), g.cpu(), b.cpu(), 1e-5)
+    assert rel_l2(y, ref) < TOL[dtype]
+
+
+def _attn_ref(q, k, v, H):
+    B, Tq, C = q.shape
+    d = C // H
+    qh = q.float().cpu().view(B, Tq, H, d).transpose(1, 2)
+    kh = k.float().cpu().view(B, -1, H, d).transpose(1, 2)
+    vh = v.float().cpu().view(B, -1, H, d).transpose(1, 2)
+    o = F.scaled_dot_product_attention(qh, kh, vh)
+    return o.transpose(1, 2).reshape(B, Tq, C)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("d", [32, 40, 64, 80, 160])
+@pytest.mark.parametrize("T", [(64, 64), (200, 77), (256, 256), (16, 16), (130, 333)])
+def test_attention(dev, dtype, d, T):
+    from uni_renderer_amd import ops
+    Tq, Tk = T
+    B, H = 2, 2
+    C = H * d
+    q = _rand((B, Tq, C), dtype, dev, seed=1)
+    k = _rand((B, Tk, C), dtype, dev, seed=2)
+    v = _rand((B, Tk, C), dtype, dev, seed=3)
+    Tpad = (Tk + 63) // 64 * 64
+    vt = torch.zeros(B, C, Tpad, dtype=dtype, device=dev)
+    vt[:, :, :Tk] = v.transpose(1, 2)
+    o = ops.attention(q, k, vt, B=B, H=H, Tq=Tq, Tk=Tk, d=d, ldq=C, ldk=C)
+    assert rel_l2(o, _attn_ref(q, k, v, H)) < TOL[dtype] * 1.5
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_attention_fused_qk_layout_and_peaky_softmax(dev, dtype):
+    """q|k packed in one matrix (self-attention layout), long sequence, and a spiked key per query so the
+    running-max rescale path of the online softmax is exercised in every tile."""
+    from uni_renderer_amd import ops
+    B, H, d, T = 1, 8, 40, 1024
+    C = H * d
+    qk = _rand((B, T, 2 * C), dtype, dev, seed=1)
+    idx = torch.arange(T, device=dev)
+    qk[0, idx, C:] += 4.0 * qk[0, (idx * 7 + 3) % T, :C]  # key (7i+3)%T aligned with query ... large scores
+    v = _rand((B, T, C), dtype, dev, seed=3)
+    vt = v.transpose(1, 2).contiguous()
+    o = ops.attention(qk, qk, vt, B=B, H=H, Tq=T, Tk=T, d=d, ldq=2 * C, ldk=2 * C, q_off=0, k_off=C)
+    ref = _attn_ref(qk[..., :C], qk[..., C:], v, H)
+    assert rel_l2(o, ref) < TOL[dtype] * 1.5
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_add_and_timestep_and_layout(dev, dtype):
+    from uni_renderer_amd import ops
+    a, b = _rand((3, 5, 7, 64), dtype, dev, seed=1), _rand((3, 5, 7, 64), dtype, dev, seed=2)
+    assert rel_l2(ops.add(a, b, 0.5), a.float().cpu() + 0.5 * b.float().cpu()) < TOL[dtype]
+    # timestep embedding vs the diffusers formula (flip_sin_to_cos=True, shift 0)
+    t = torch.tensor([0.0, 1.0, 500.0, 999.0], device=dev)
+    e = ops.timestep_embedding(t, 4, 320, True, 0.0, dtype)
+    half = 160
+    freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half)
+    arg = t.cpu()[:, None] * freqs[None]
+    ref = torch.cat([torch.cos(arg), torch.sin(arg)], -1)
+    assert float((e.float().cpu() - ref).abs().max()) < (2e-3 if dtype == torch.float16 else 1e-2)
+    assert torch.equal(e[0].float().cpu(), torch.cat([torch.ones(half), torch.zeros(half)]))  # known answer t=0
+    e1 = ops.timestep_embedding(t[2:3], 4, 320, True, 0.0, dtype)  # broadcast of a single timestep
+    assert torch.equal(e1[0], e[2]) and torch.equal(e1[3], e[2])
+    # layout glue round trip
+    x = torch.randn(2, 28, 6, 5, generator=torch.Generator().manual_seed(5)).to(dev)
+    n = ops.to_nhwc(x, dtype, 64)
+    back = ops.to_nchw(n[..., :28].contiguous(), torch.float32)
+    assert torch.equal(back.cpu(), x.to(dtype).float().cpu())
+    assert ops.to_nhwc(ops.as_nchw_view(a), dtype).data_ptr() == a.data_ptr()  # zero-copy for channels-last views
+
+
+def test_no_cpu_fallback():
+    from uni_renderer_amd import ops
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.add(torch.zeros(8, dtype=torch.float16), torch.zeros(8, dtype=torch.float16))

@@ -1,0 +1,115 @@
+"""ctypes binding of ``liburhip.so`` (the C ABI declared in ``include/ur_kernels.h``).
+
+There is deliberately no fallback: if the HIP library is missing or its ABI does not match, importing
+the compute path raises.  ``import torch`` must happen before the library is loaded so that the
+library's ``libamdhip64.so.7`` dependency resolves to the HIP runtime PyTorch already loaded (same
+streams, same device context, same graph capture).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must be imported first, see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liburhip.so")
+ABI_VERSION = 1
+
+i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
+
+
+class IGemmDesc(C.Structure):
+    """Mirror of ``ur_igemm_desc`` (include/ur_kernels.h) -- field order and types must match."""
+
+    _fields_ = [
+        ("x0", vp), ("x1", vp), ("w", vp), ("bias", vp), ("rowadd", vp), ("res", vp), ("out", vp),
+        ("partial", vp), ("zero_page", vp),
+        ("ldx0", i64), ("ldx1", i64), ("ldw", i64), ("ldres", i64), ("ldc", i64),
+        ("zx", i64), ("zw", i64), ("zout", i64), ("ldp", i64),
+        ("c0", i32), ("c1", i32),
+        ("B", i32), ("Hin", i32), ("Win", i32), ("Hout", i32), ("Wout", i32),
+        ("taps", i32), ("stride", i32), ("ups", i32),
+        ("M", i32), ("N", i32), ("K", i32),
+        ("n_store", i32), ("ld_rowadd", i32), ("rows_per_b", i32),
+        ("act", i32), ("out_scale", f32),
+        ("zbatch", i32), ("splitk", i32), ("tile", i32), ("dtype", i32),
+    ]
+
+
+class AttnDesc(C.Structure):
+    """Mirror of ``ur_attn_desc``."""
+
+    _fields_ = [
+        ("q", vp), ("k", vp), ("vt", vp), ("o", vp), ("zero_page", vp),
+        ("ldq", i64), ("ldk", i64), ("ldvt", i64), ("ldo", i64),
+        ("q_off", i32), ("k_off", i32),
+        ("B", i32), ("H", i32), ("Tq", i32), ("Tk", i32), ("d", i32),
+        ("scale", f32), ("dtype", i32),
+    ]
+
+
+# name -> (restype, argtypes): every symbol include/ur_kernels.h declares
+SYMBOLS = {
+    "ur_igemm": (C.c_int, [C.POINTER(IGemmDesc), vp]),
+    "ur_igemm_partial_floats": (C.c_int64, [C.POINTER(IGemmDesc)]),
+    "ur_groupnorm_stats": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]),
+    "ur_groupnorm_apply": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp,
+                                     C.c_float, C.c_int, vp, C.c_int, vp]),
+    "ur_layernorm": (C.c_int, [vp, vp, vp, C.c_float, C.c_int, C.c_int, vp, C.c_int, vp]),
+    "ur_attention": (C.c_int, [C.POINTER(AttnDesc), vp]),
+    "ur_add": (C.c_int, [vp, vp, C.c_float, vp, C.c_int64, C.c_int, vp]),
+    "ur_timestep_embedding": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp, C.c_int, vp]),
+    "ur_nchw_to_nhwc": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp]),
+    "ur_nhwc_to_nchw": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]),
+    "ur_abi_version": (C.c_int, []),
+    "ur_build_info": (C.c_char_p, []),
+    "ur_sizeof_igemm_desc": (C.c_int, []),
+    "ur_sizeof_attn_desc": (C.c_int, []),
+}
+
+_lib = None
+
+
+class UrLibraryError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load (once) and type the library; raise ``UrLibraryError`` loudly if it is absent or stale."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise UrLibraryError(
+            f"{LIB_PATH} not found: the HIP kernels are not built. Run `python __graft_entry__.py build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU/PyTorch fallback for the compute path."
+        )
+    try:
+        lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    except OSError as e:  # pragma: no cover - depends on the host
+        raise UrLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SYMBOLS.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise UrLibraryError(f"{LIB_PATH} does not export {name}; rebuild it") from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.ur_abi_version() != ABI_VERSION:
+        raise UrLibraryError(f"ABI version mismatch: library {lib.ur_abi_version()} vs binding {ABI_VERSION}")
+    if lib.ur_sizeof_igemm_desc() != C.sizeof(IGemmDesc) or lib.ur_sizeof_attn_desc() != C.sizeof(AttnDesc):
+        raise UrLibraryError("descriptor layout mismatch between include/ur_kernels.h and _lib.py")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        if rc == -1001:
+            msg = "UR_E_BADARG (inconsistent descriptor)"
+        elif rc == -1002:
+            msg = "UR_E_UNSUPPORTED (shape not instantiated)"
+        else:
+            msg = f"hipError {-rc}"
+        raise RuntimeError(f"{what} failed: {msg}")

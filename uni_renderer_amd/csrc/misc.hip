@@ -21,13 +21,13 @@ __global__ void __launch_bounds__(256) add_kernel(const T* __restrict__ a, const
 // diffusers get_timestep_embedding: emb = t * exp(-ln(1e4) * i / (half - shift)); [sin | cos], flipped
 // to [cos | sin] when flip_sin_to_cos.
 template <typename T>
-__global__ void timestep_kernel(const int64_t* __restrict__ t, int nt, int B, int dim, int flip, float shift,
+__global__ void timestep_kernel(const float* __restrict__ t, int nt, int B, int dim, int flip, float shift,
                                 T* __restrict__ out) {
     const int half = dim / 2;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= B * half) return;
     const int b = idx / half, i = idx - b * half;
-    const float tv = (float)t[nt == 1 ? 0 : b];
+    const float tv = t[nt == 1 ? 0 : b];
     const float freq = expf(-9.210340371976184f * (float)i / ((float)half - shift));
     const float arg = tv * freq;
     const float s = sinf(arg), c = cosf(arg);
@@ -93,7 +93,7 @@ extern "C" int ur_add(const void* a, const void* b, float alpha, void* out, int6
     return e == hipSuccess ? 0 : -(int)e;
 }
 
-extern "C" int ur_timestep_embedding(const int64_t* t, int nt, int B, int dim, int flip_sin_to_cos, float freq_shift,
+extern "C" int ur_timestep_embedding(const float* t, int nt, int B, int dim, int flip_sin_to_cos, float freq_shift,
                                      void* out, int dtype, void* stream) {
     if (!t || !out || B <= 0 || dim < 2 || (nt != 1 && nt != B)) return UR_E_BADARG;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -165,3 +165,5 @@ extern "C" int ur_nhwc_to_nchw(const void* src, int dtype, int B, int C, int H, 
 
 extern "C" int ur_abi_version(void) { return UR_ABI_VERSION; }
 extern "C" const char* ur_build_info(void) { return "liburhip gfx950 (hipcc, MFMA 16x16x32, LDS-DMA) abi 1"; }
+extern "C" int ur_sizeof_igemm_desc(void) { return (int)sizeof(ur_igemm_desc); }
+extern "C" int ur_sizeof_attn_desc(void) { return (int)sizeof(ur_attn_desc); }

@@ -1,0 +1,286 @@
+"""Python wrappers over the C ABI (``include/ur_kernels.h``): tensors in, tensors out, kernels enqueued on
+PyTorch's current HIP stream.  PyTorch only provides device memory and the stream here; all arithmetic
+happens in ``liburhip.so``.  Activations are NHWC: ``[B, H, W, C]`` == token matrix ``[B*H*W, C]``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import math
+import os
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import AttnDesc, IGemmDesc, check
+
+DT = {torch.float16: 0, torch.bfloat16: 1}
+DT_ANY = {torch.float16: 0, torch.bfloat16: 1, torch.float32: 2}
+ACT_NONE, ACT_SILU, ACT_GEGLU = 0, 1, 2
+TILE_AUTO, TILE_128x128, TILE_128x64, TILE_64x64 = 0, 1, 2, 3
+_TILES = {TILE_128x128: (128, 128, 1.0), TILE_128x64: (128, 64, 0.85), TILE_64x64: (64, 64, 0.6)}
+
+_zero_pages = {}
+_tune_table = None
+_plan_cache = {}
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def zero_page(device) -> torch.Tensor:
+    key = (device.type, device.index)
+    z = _zero_pages.get(key)
+    if z is None:
+        z = torch.zeros(4096, dtype=torch.uint8, device=device)
+        _zero_pages[key] = z
+    return z
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _require_gpu(t: torch.Tensor):
+    if not t.is_cuda:
+        raise RuntimeError("uni_renderer_amd ops run on an MI355X HIP device only (got a CPU tensor); "
+                           "there is no CPU fallback")
+
+
+# ---------------------------------------------------------------------------------------------
+# tile / split-K planning
+# ---------------------------------------------------------------------------------------------
+def load_tuning_table(path: Optional[str] = None):
+    """Optional table {"M,N,K,taps,z": [tile, splitk]} measured on MI355X by tools/tune_igemm.py."""
+    global _tune_table
+    if path is None:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "igemm_tuning.json")
+    _tune_table = {}
+    if os.path.exists(path):
+        with open(path) as f:
+            _tune_table = {k: tuple(v) for k, v in json.load(f).items()}
+    _plan_cache.clear()
+    return _tune_table
+
+
+def plan_igemm(M: int, N: int, K: int, taps: int = 1, zbatch: int = 1) -> Tuple[int, int]:
+    """(tile, splitk) for an implicit GEMM.  Measured table first, analytic model otherwise."""
+    global _tune_table
+    key = (M, N, K, taps, zbatch)
+    hit = _plan_cache.get(key)
+    if hit is not None:
+        return hit
+    if _tune_table is None:
+        load_tuning_table()
+    t = _tune_table.get(f"{M},{N},{K},{taps},{zbatch}")
+    if t is None:
+        per_cu = 2.5e15 / 256 * 0.4
+        best, best_t = (TILE_64x64, 1), float("inf")
+        for tile, (bm, bn, eff) in _TILES.items():
+            wgs = math.ceil(M / bm) * math.ceil(N / bn) * zbatch
+            for sk in (1, 2, 4, 8):
+                if sk > 1 and (zbatch > 1 or K // 64 < 8 * sk):
+                    continue
+                waves = math.ceil(wgs * sk / 256)
+                tt = waves * bm * bn * (K / sk) * 2 / (per_cu * eff)
+                if sk > 1:
+                    tt += M * N * 4 * (sk + 1) / 4e12 + 3e-6
+                if tt < best_t:
+                    best, best_t = (tile, sk), tt
+        t = best
+    _plan_cache[key] = t
+    return t
+
+
+# ---------------------------------------------------------------------------------------------
+# implicit GEMM
+# ---------------------------------------------------------------------------------------------
+def igemm(*, x0, w, out, M, N, K, c0, c1=0, x1=None, ldx0, ldx1=0, ldw, ldc, taps=1, conv=None, stride=1, ups=0,
+          bias=None, rowadd=None, rows_per_b=0, res=None, ldres=0, n_store=0, act=ACT_NONE, out_scale=1.0,
+          zbatch=1, zx=0, zw=0, zout=0, tile=None, splitk=None):
+    _require_gpu(x0)
+    lib = _lib.load()
+    if tile is None or splitk is None:
+        pt, ps = plan_igemm(M, N, K, taps, zbatch)
+        tile = pt if tile is None else tile
+        splitk = ps if splitk is None else splitk
+    d = IGemmDesc()
+    d.x0, d.x1, d.w = _ptr(x0), _ptr(x1), _ptr(w)
+    d.bias, d.rowadd, d.res, d.out = _ptr(bias), _ptr(rowadd), _ptr(res), _ptr(out)
+    zp = zero_page(x0.device)
+    d.zero_page = zp.data_ptr()
+    d.ldx0, d.ldx1, d.ldw, d.ldres, d.ldc = ldx0, ldx1, ldw, ldres, ldc
+    d.zx, d.zw, d.zout = zx, zw, zout
+    d.c0, d.c1 = c0, c1
+    if conv is not None:
+        d.B, d.Hin, d.Win, d.Hout, d.Wout = conv
+    d.taps, d.stride, d.ups = taps, stride, ups
+    d.M, d.N, d.K = M, N, K
+    d.n_store = n_store
+    d.ld_rowadd = rowadd.stride(0) if rowadd is not None else 0
+    d.rows_per_b = rows_per_b
+    d.act, d.out_scale = act, out_scale
+    d.zbatch, d.splitk, d.tile, d.dtype = zbatch, splitk, tile, DT[x0.dtype]
+    part = None
+    if splitk > 1:
+        part = torch.empty(int(lib.ur_igemm_partial_floats(C.byref(d))), dtype=torch.float32, device=x0.device)
+        d.partial = part.data_ptr()
+    if bias is not None and bias.dtype != torch.float32:
+        raise RuntimeError("bias must be fp32")
+    check(lib.ur_igemm(C.byref(d), _stream()), "ur_igemm")
+    return out
+
+
+def linear(x, w, bias=None, *, x1=None, res=None, act=ACT_NONE, out_scale=1.0, rowadd=None, rows_per_b=0, out=None,
+           tile=None, splitk=None):
+    """y[..., N] = epilogue(x[..., K] @ w[N, K]^T).  ``x1``: second source concatenated along K."""
+    K0 = x.shape[-1]
+    K1 = x1.shape[-1] if x1 is not None else 0
+    M = x.numel() // K0
+    N = w.shape[0]
+    n_out = N // 2 if act == ACT_GEGLU else N
+    if out is None:
+        out = torch.empty(*x.shape[:-1], n_out, dtype=x.dtype, device=x.device)
+    igemm(x0=x, x1=x1, w=w, out=out, M=M, N=N, K=K0 + K1, c0=K0, c1=K1, ldx0=K0, ldx1=K1, ldw=w.stride(0), ldc=n_out,
+          bias=bias, res=res, ldres=(n_out if res is not None else 0), act=act, out_scale=out_scale, rowadd=rowadd,
+          rows_per_b=rows_per_b, tile=tile, splitk=splitk)
+    return out
+
+
+def conv3x3(x, w, bias=None, *, x1=None, stride=1, ups=False, rowadd=None, res=None, out_scale=1.0, n_out=None,
+            tile=None, splitk=None):
+    """3x3 conv, pad 1, over NHWC ``x`` (optionally cat(x, x1) on channels, optionally after a nearest-2x
+    upsample).  ``w`` is [Npad >= n_out, 9*Cin] with k = (ky*3+kx)*Cin + c.  Output [B, Ho, Wo, n_out]."""
+    B, H, W, C0 = x.shape
+    C1 = x1.shape[-1] if x1 is not None else 0
+    if ups:
+        Ho, Wo = 2 * H, 2 * W
+    else:
+        Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
+    N = n_out if n_out is not None else w.shape[0]
+    out = torch.empty(B, Ho, Wo, N, dtype=x.dtype, device=x.device)
+    igemm(x0=x, x1=x1, w=w, out=out, M=B * Ho * Wo, N=N, K=9 * (C0 + C1), c0=C0, c1=C1, ldx0=C0, ldx1=C1,
+          ldw=w.stride(0), ldc=N, taps=9, conv=(B, H, W, Ho, Wo), stride=stride, ups=int(ups), bias=bias,
+          rowadd=rowadd, rows_per_b=Ho * Wo, res=res, ldres=(N if res is not None else 0), out_scale=out_scale,
+          tile=tile, splitk=splitk)
+    return out
+
+
+def vt_proj(x, wv):
+    """Transposed value projection: Vt[b] = wv @ x[b]^T  -> [B, Cout, Tpad] (columns >= T are zero)."""
+    B, T, Cin = x.shape
+    Cout = wv.shape[0]
+    Tpad = (T + 63) // 64 * 64
+    out = torch.empty(B, Cout, Tpad, dtype=x.dtype, device=x.device)
+    igemm(x0=wv, w=x, out=out, M=Cout, N=T, K=Cin, c0=Cin, ldx0=wv.stride(0), ldw=Cin, ldc=Tpad, n_store=Tpad,
+          zbatch=B, zx=0, zw=T * Cin, zout=Cout * Tpad, splitk=1)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# norms, attention, glue
+# ---------------------------------------------------------------------------------------------
+def _gn_chunks(B: int, rows: int) -> int:
+    n = max(1, min(rows // 8, max(1, 1024 // max(B, 1))))
+    return min(n, 256)
+
+
+def groupnorm(x, gamma, beta, eps, *, x1=None, groups=32, silu=False):
+    """GroupNorm over NHWC x (or over cat(x, x1)); returns one contiguous [B,H,W,C0+C1] tensor."""
+    _require_gpu(x)
+    lib = _lib.load()
+    B = x.shape[0]
+    C0 = x.shape[-1]
+    C1 = x1.shape[-1] if x1 is not None else 0
+    rows = x.numel() // (B * C0)
+    nch = _gn_chunks(B, rows)
+    part = torch.empty(B * nch * groups * 2, dtype=torch.float32, device=x.device)
+    out = torch.empty(*x.shape[:-1], C0 + C1, dtype=x.dtype, device=x.device)
+    s = _stream()
+    check(lib.ur_groupnorm_stats(_ptr(x), _ptr(x1), C0, C1, B, rows, groups, nch, part.data_ptr(), DT[x.dtype], s),
+          "ur_groupnorm_stats")
+    check(lib.ur_groupnorm_apply(_ptr(x), _ptr(x1), C0, C1, B, rows, groups, nch, part.data_ptr(), gamma.data_ptr(),
+                                 beta.data_ptr(), float(eps), int(silu), out.data_ptr(), DT[x.dtype], s),
+          "ur_groupnorm_apply")
+    return out
+
+
+def layernorm(x, gamma, beta, eps=1e-5):
+    _require_gpu(x)
+    lib = _lib.load()
+    Cn = x.shape[-1]
+    rows = x.numel() // Cn
+    out = torch.empty_like(x)
+    check(lib.ur_layernorm(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(eps), rows, Cn, out.data_ptr(),
+                           DT[x.dtype], _stream()), "ur_layernorm")
+    return out
+
+
+def attention(q, k, vt, *, B, H, Tq, Tk, d, ldq, ldk, q_off=0, k_off=0, scale=None):
+    """q/k are 2-D token matrices holding head h at columns off + h*d; vt is [B, H*d, Tk_pad]."""
+    _require_gpu(q)
+    lib = _lib.load()
+    o = torch.empty(B, Tq, H * d, dtype=q.dtype, device=q.device)
+    a = AttnDesc()
+    a.q, a.k, a.vt, a.o = q.data_ptr(), k.data_ptr(), vt.data_ptr(), o.data_ptr()
+    a.zero_page = zero_page(q.device).data_ptr()
+    a.ldq, a.ldk, a.ldvt, a.ldo = ldq, ldk, vt.shape[-1], H * d
+    a.q_off, a.k_off = q_off, k_off
+    a.B, a.H, a.Tq, a.Tk, a.d = B, H, Tq, Tk, d
+    a.scale = float(scale if scale is not None else d ** -0.5)
+    a.dtype = DT[q.dtype]
+    check(lib.ur_attention(C.byref(a), _stream()), "ur_attention")
+    return o
+
+
+def add(a, b, alpha: float = 1.0):
+    _require_gpu(a)
+    lib = _lib.load()
+    out = torch.empty_like(a)
+    check(lib.ur_add(a.data_ptr(), b.data_ptr(), float(alpha), out.data_ptr(), a.numel(), DT[a.dtype], _stream()),
+          "ur_add")
+    return out
+
+
+def timestep_embedding(t: torch.Tensor, B: int, dim: int, flip: bool, shift: float, dtype) -> torch.Tensor:
+    _require_gpu(t)
+    lib = _lib.load()
+    t = t.to(torch.float32).contiguous()
+    out = torch.empty(B, dim, dtype=dtype, device=t.device)
+    check(lib.ur_timestep_embedding(t.data_ptr(), t.numel(), B, dim, int(flip), float(shift), out.data_ptr(),
+                                    DT[dtype], _stream()), "ur_timestep_embedding")
+    return out
+
+
+def to_nhwc(x_nchw: torch.Tensor, dtype, cpad: Optional[int] = None) -> torch.Tensor:
+    """[B,C,H,W] (any float dtype, any strides) -> contiguous NHWC [B,H,W,cpad] in ``dtype`` (zero padded)."""
+    _require_gpu(x_nchw)
+    B, Cc, H, W = x_nchw.shape
+    cpad = Cc if cpad is None else cpad
+    if cpad == Cc and x_nchw.dtype == dtype and x_nchw.permute(0, 2, 3, 1).is_contiguous():
+        return x_nchw.permute(0, 2, 3, 1)  # already channels-last memory: zero copy
+    lib = _lib.load()
+    src = x_nchw.contiguous()
+    out = torch.empty(B, H, W, cpad, dtype=dtype, device=src.device)
+    check(lib.ur_nchw_to_nhwc(src.data_ptr(), DT_ANY[src.dtype], B, Cc, H, W, out.data_ptr(), cpad, DT[dtype],
+                              _stream()), "ur_nchw_to_nhwc")
+    return out
+
+
+def to_nchw(x_nhwc: torch.Tensor, dtype=None) -> torch.Tensor:
+    """NHWC -> contiguous NCHW copy (dtype conversion fused)."""
+    _require_gpu(x_nhwc)
+    lib = _lib.load()
+    B, H, W, Cc = x_nhwc.shape
+    dtype = x_nhwc.dtype if dtype is None else dtype
+    out = torch.empty(B, Cc, H, W, dtype=dtype, device=x_nhwc.device)
+    check(lib.ur_nhwc_to_nchw(x_nhwc.data_ptr(), DT[x_nhwc.dtype], B, Cc, H, W, out.data_ptr(), DT_ANY[dtype],
+                              _stream()), "ur_nhwc_to_nchw")
+    return out
+
+
+def as_nchw_view(x_nhwc: torch.Tensor) -> torch.Tensor:
+    """Zero-copy logical-NCHW view of an NHWC tensor (channels_last strides)."""
+    return x_nhwc.permute(0, 3, 1, 2)
