@@ -1,0 +1,252 @@
+#!/usr/bin/env python3
+"""Headline benchmark: denoise-steps/sec of the dual-stream step (enc + unet + dec, SD-1.x size, 512x512 image
+=> 64x64 latent, batch 4 per GPU, fp16) on N MI355X -- BASELINE.json's metric on config[2] ("inverse-rendering
+direction, 512x512, bs=4, fp16"), the configuration the metric is quoted on.
+
+    python bench.py                                  # 1 GPU
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W     # N GPUs, one rank per GPU (RCCL only for the timing barrier)
+
+A "step" is one full pass enc -> unet -> dec over one batch of synthetic latents already resident in HBM,
+replayed as one HIP graph.  Batch-sharded data parallel inference has no data-path collective:
+every rank denoises its own batch of 4, scaling is "weak", value = N * K / max-over-ranks(time).
+
+Rank 0 additionally reports
+  roofline     -- the dominant kernel class of the step, measured live with HIP events around every launch of one
+                  eager step (events recorded on the launch stream): algorithmic FLOP (or bytes) / summed duration
+  cpu_baseline -- the CPU fp32 oracle (oracle/unirenderer_oracle.py, "port") timed on this host's cores on one
+                  step of the same shape.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_MFMA_TFLOPS = 2500.0  # dense fp16/bf16, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+
+def build_models(dev, dtype, seed=1234):
+    import uni_renderer_amd as U
+
+    torch.manual_seed(seed)
+    with torch.device(dev):
+        unet = U.UNet2DConditionModel(in_channels=4, out_channels=4, cross_attention_dim=768, sample_size=64)
+        enc = U.AttributeEncoderModel.from_unet(unet)
+        dec = U.AttributeDecoderModel.from_unet(unet)
+    # 4 -> 28 channel surgery of train/train.py:976-996
+    enc.conv_in.weight = torch.nn.Parameter(enc.conv_in.weight.repeat(1, 7, 1, 1) * 0.142)
+    enc.register_to_config(in_channels=28)
+    dec.conv_out.weight = torch.nn.Parameter(dec.conv_out.weight.repeat(7, 1, 1, 1) * 0.142)
+    dec.conv_out.bias = torch.nn.Parameter(dec.conv_out.bias.repeat(7) * 0.142)
+    dec.register_to_config(out_channels=28)
+    g = torch.Generator(device=dev).manual_seed(4321)
+    for z in list(enc.controlnet_down_blocks) + [enc.controlnet_mid_block] + list(dec.control_down_blocks) + [dec.control_mid_block]:
+        z.weight.data.normal_(0, 0.02, generator=g)  # exchange convs live
+        z.bias.data.normal_(0, 0.02, generator=g)
+    return [m.to(dev).to(dtype).eval() for m in (unet, enc, dec)]
+
+
+def make_inputs(B, L, dev, dtype, seed):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    x_t = torch.randn(B, 4, L, L, device=dev, generator=g).to(dtype)
+    cond = torch.randn(B, 28, L, L, device=dev, generator=g).to(dtype)
+    ehs = (torch.randn(B, 77, 768, device=dev, generator=g) * 0.5).to(dtype)
+    t_img = torch.randint(0, 1000, (B,), device=dev, generator=g)
+    t_attr = torch.randint(0, 1000, (B,), device=dev, generator=g)
+    return x_t, cond, ehs, t_img, t_attr
+
+
+def measure_roofline(models, inputs):
+    """One eager step with every launch bracketed by HIP events on the launch stream; per kernel class sums."""
+    from uni_renderer_amd import ops
+    from uni_renderer_amd.graph import dual_stream_step
+
+    rec = []
+    with torch.no_grad():
+        dual_stream_step(*models, *inputs)  # untimed, warm
+        torch.cuda.synchronize()
+        ops.profile_into(rec)
+        dual_stream_step(*models, *inputs)
+        torch.cuda.synchronize()
+        ops.profile_into(None)
+    agg = {}
+    for key, fl, by, e0, e1 in rec:
+        a = agg.setdefault(key, dict(calls=0, ms=0.0, flop=0.0, bytes=0.0))
+        a["calls"] += 1
+        a["ms"] += e0.elapsed_time(e1)
+        a["flop"] += fl
+        a["bytes"] += by
+    total_ms = sum(a["ms"] for a in agg.values())
+    table = []
+    for key, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
+        row = dict(kernel=key, calls=a["calls"], ms=round(a["ms"], 4), share=round(a["ms"] / total_ms, 4),
+                   avg_us=round(1e3 * a["ms"] / a["calls"], 2))
+        if a["flop"] > 0:
+            row["tflops"] = round(a["flop"] / (a["ms"] * 1e-3) / 1e12, 2)
+        else:
+            row["gbs"] = round(a["bytes"] / (a["ms"] * 1e-3) / 1e9, 1)
+        table.append(row)
+    dom = table[0]
+    if "tflops" in dom:
+        roof = dict(bound="mfma", kernel=dom["kernel"], achieved=dom["tflops"], peak=PEAK_MFMA_TFLOPS, unit="TFLOP/s",
+                    frac=round(dom["tflops"] / PEAK_MFMA_TFLOPS, 4))
+    else:
+        roof = dict(bound="hbm", kernel=dom["kernel"], achieved=dom["gbs"], peak=PEAK_HBM_GBS, unit="GB/s",
+                    frac=round(dom["gbs"] / PEAK_HBM_GBS, 4))
+    roof.update(calls_per_step=dom["calls"], avg_launch_us=dom["avg_us"], share_of_step=dom["share"], traffic=None)
+    tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")  # HBM bytes/launch from a separate rocprofv3 --pmc pass
+    if os.path.exists(tf):
+        try:
+            roof["traffic"] = json.load(open(tf)).get(dom["kernel"])
+        except Exception:
+            pass
+    return roof, table, total_ms
+
+
+def cpu_baseline(B, L):
+    """The oracle ("port") timed on this host: the same enc+unet+dec step, fp32, all cores."""
+    from oracle import unirenderer_oracle as O
+
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    with torch.device("meta"):
+        unet = O.UNet2DConditionModel(**O.SD15_CONFIG)
+        enc = O.AttributeEncoderModel(**dict(O.SD15_CONFIG, in_channels=28))
+        dec = O.AttributeDecoderModel(**dict(O.SD15_CONFIG, out_channels=28))
+    mods = []
+    g = torch.Generator().manual_seed(1)
+    for m in (unet, enc, dec):
+        m = m.to_empty(device="cpu")
+        for p in m.parameters():
+            p.data.normal_(0, 0.02, generator=g)
+        mods.append(m.eval())
+    xw = O.make_inputs(1, L, 768, seed=3)
+    O.dual_stream_step(*mods, *xw)  # untimed warm-up at batch 1
+    x = O.make_inputs(B, L, 768, seed=4)
+    t0 = time.perf_counter()
+    O.dual_stream_step(*mods, *x)
+    dt = time.perf_counter() - t0
+    return dict(value=round(1.0 / dt, 5), unit="denoise-steps/sec", cores=cores, kind="port",
+                sample=f"1 timed step (after a batch-1 warm-up) of the same enc+unet+dec step, batch {B}, "
+                       f"{L}x{L} latent, fp32, torch {torch.__version__} CPU ops, {dt:.2f} s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=4, help="per-GPU batch (headline: 4)")
+    ap.add_argument("--latent", type=int, default=64, help="latent side (headline: 64 = 512x512 image)")
+    ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="time eager launches instead of the HIP graph")
+    ap.add_argument("--kernel-table", action="store_true", help="print the per-kernel-class table to stderr")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)  # RCCL
+    dtype = torch.float16 if args.dtype == "fp16" else torch.bfloat16
+
+    from uni_renderer_amd import _lib
+    from uni_renderer_amd.graph import GraphedDualStreamStep, dual_stream_step
+
+    _lib.load()  # no HIP library -> fail loudly
+    models = build_models(dev, dtype)
+    inputs = make_inputs(args.batch, args.latent, dev, dtype, seed=100 + rank)
+    runner = GraphedDualStreamStep(*models, batch=args.batch, latent_hw=args.latent, cross_dim=768, dtype=dtype,
+                                   device=dev, run_decoder=True)
+    runner.load_inputs(*inputs)
+    if args.eager:
+        def one():
+            with torch.no_grad():
+                dual_stream_step(*models, runner.x_t, runner.cond, runner.ehs, runner.t_img, runner.t_attr)
+        one()
+    else:
+        runner.capture()
+        one = runner.replay
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    for _ in range(args.warmup):
+        one()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one()
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        out = {
+            "metric": "denoise-steps/sec (dual-UNet, 512^2 bs=4)",
+            "value": round(world * args.steps / dt, 4),
+            "unit": "denoise-steps/sec",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f16" if dtype == torch.float16 else "bf16",
+            "data": "synthetic",
+            "config": {
+                "workload": f"inverse-rendering denoise step: AttributeEncoderModel + UNet2DConditionModel + "
+                            f"AttributeDecoderModel forward (SD-1.x size, 1.74 G params, random init), "
+                            f"{args.latent * 8}x{args.latent * 8} image = {args.latent}x{args.latent} latent, 28-channel "
+                            f"attribute latent, 77x768 prompt embedding, batch {args.batch} per GPU",
+                "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
+                "launch": "eager" if args.eager else "hipGraph replay",
+                "algorithmic_tflop_per_step": round(1.623 * args.batch * (args.latent / 64) ** 2, 3),
+            },
+        }
+        if not args.no_roofline and world == 1:
+            roof, table, total_ms = measure_roofline(models, inputs)
+            out["roofline"] = roof
+            out["kernel_classes"] = table[:8]
+            out["config"]["sum_kernel_ms_eager_step"] = round(total_ms, 3)
+            if args.kernel_table:
+                for r in table:
+                    print(json.dumps(r), file=sys.stderr)
+        if not args.no_cpu_baseline and world == 1:
+            del runner
+            out["cpu_baseline"] = cpu_baseline(args.batch, args.latent)
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,87 @@
+"""The dual-stream denoise step as one replayable HIP graph.
+
+A step is ~700 kernel launches (enc + unet + dec at SD-1.x size); issued eagerly from Python the host is
+the bottleneck, so for fixed shapes the whole step is captured once into a hipGraph (through PyTorch's
+capture of the current stream -- our C-ABI launches land on that stream) and replayed.  Inputs live in
+static buffers; outputs are the tensors produced during capture.
+
+Call pattern reproduced: ``enc -> unet -> dec`` of models/pipeline.py:2660-2690 (inverse rendering) and
+train/train.py:1324-1354; ``run_decoder=False`` gives the rendering direction (pipeline.py:1611-1629).
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+
+def dual_stream_step(unet, enc, dec, x_t, cond, ehs, t_img, t_attr, run_decoder: bool = True) -> Dict[str, torch.Tensor]:
+    """Eager form of one step (same calls the reference's loops make)."""
+    res, mid, raw_enc, raw_mid_enc = enc(x_t, t_attr, encoder_hidden_states=ehs, controlnet_cond=cond,
+                                         return_dict=False)
+    img_pred, raw_unet, raw_mid_unet, _ = unet(
+        x_t, t_img, encoder_hidden_states=ehs, down_block_additional_residuals=res,
+        mid_block_additional_residual=mid, return_dict=False)
+    out = {"img_pred": img_pred}
+    if run_decoder:
+        out["attr_pred"] = dec(sample=raw_mid_enc, down_block_res_samples=raw_enc, timestep=t_attr,
+                               encoder_hidden_states=ehs, down_block_additional_residuals=raw_unet,
+                               mid_block_additional_residual=raw_mid_unet, return_dict=False)
+    return out
+
+
+class GraphedDualStreamStep:
+    """Capture once, replay many times.  ``step(...)`` copies new inputs into the static buffers (device to
+    device, on the replay stream) and launches the graph; the returned tensors are overwritten by the next call."""
+
+    def __init__(self, unet, enc, dec, batch: int, latent_hw, cross_dim: int, dtype=torch.float16,
+                 device="cuda", run_decoder: bool = True, cond_channels: int = 28, img_channels: int = 4,
+                 ctx_len: int = 77):
+        self.unet, self.enc, self.dec, self.run_decoder = unet, enc, dec, run_decoder
+        H, W = (latent_hw, latent_hw) if isinstance(latent_hw, int) else latent_hw
+        dev = torch.device(device)
+        self.x_t = torch.zeros(batch, img_channels, H, W, dtype=dtype, device=dev)
+        self.cond = torch.zeros(batch, cond_channels, H, W, dtype=dtype, device=dev)
+        self.ehs = torch.zeros(batch, ctx_len, cross_dim, dtype=dtype, device=dev)
+        self.t_img = torch.zeros(batch, dtype=torch.float32, device=dev)
+        self.t_attr = torch.zeros(batch, dtype=torch.float32, device=dev)
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self.out: Optional[Dict[str, torch.Tensor]] = None
+
+    def _run(self):
+        return dual_stream_step(self.unet, self.enc, self.dec, self.x_t, self.cond, self.ehs, self.t_img,
+                                self.t_attr, self.run_decoder)
+
+    def load_inputs(self, x_t, cond, ehs, t_img, t_attr):
+        self.x_t.copy_(x_t)
+        self.cond.copy_(cond)
+        self.ehs.copy_(ehs)
+        self.t_img.copy_(torch.as_tensor(t_img, device=self.t_img.device).float().expand_as(self.t_img))
+        self.t_attr.copy_(torch.as_tensor(t_attr, device=self.t_attr.device).float().expand_as(self.t_attr))
+
+    @torch.no_grad()
+    def capture(self, warmup: int = 2):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):  # packs weights, sizes LDS attributes, fills the allocator
+            for _ in range(warmup):
+                self._run()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = self._run()
+        torch.cuda.synchronize()
+        return self
+
+    @torch.no_grad()
+    def step(self, x_t=None, cond=None, ehs=None, t_img=None, t_attr=None):
+        if self.graph is None:
+            self.capture()
+        if x_t is not None:
+            self.load_inputs(x_t, cond, ehs, t_img, t_attr)
+        self.graph.replay()
+        return self.out
+
+    def replay(self):
+        self.graph.replay()

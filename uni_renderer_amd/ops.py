@@ -25,6 +25,32 @@ _zero_pages = {}
 _tune_table = None
 _plan_cache = {}
 
+# Optional per-launch timing (bench.py's roofline leg): when a list is installed with ``profile_into``, every
+# wrapper brackets its launch with HIP events recorded on the SAME stream the kernel is enqueued on and appends
+# (kernel-class key, algorithmic flops, algorithmic bytes, start, end).
+_prof = None
+
+
+def profile_into(records):
+    global _prof
+    _prof = records
+
+
+def _prof_begin():
+    if _prof is None:
+        return None
+    e = torch.cuda.Event(enable_timing=True)
+    e.record(torch.cuda.current_stream())
+    return e
+
+
+def _prof_end(e0, key, flops, nbytes):
+    if e0 is None:
+        return
+    e1 = torch.cuda.Event(enable_timing=True)
+    e1.record(torch.cuda.current_stream())
+    _prof.append((key, float(flops), float(nbytes), e0, e1))
+
 
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
@@ -129,7 +155,13 @@ def igemm(*, x0, w, out, M, N, K, c0, c1=0, x1=None, ldx0, ldx1=0, ldw, ldc, tap
         d.partial = part.data_ptr()
     if bias is not None and bias.dtype != torch.float32:
         raise RuntimeError("bias must be fp32")
+    e0 = _prof_begin()
     check(lib.ur_igemm(C.byref(d), _stream()), "ur_igemm")
+    if e0 is not None:
+        el = x0.element_size()
+        z = max(zbatch, 1)
+        key = f"igemm_{_TILES[tile][0]}x{_TILES[tile][1]}_{'conv3x3' if taps == 9 else 'gemm'}" + ("_splitk" if splitk > 1 else "")
+        _prof_end(e0, key, 2.0 * M * N * K * z, (M * K / taps + N * K + M * N) * el * z)
     return out
 
 
@@ -199,11 +231,15 @@ def groupnorm(x, gamma, beta, eps, *, x1=None, groups=32, silu=False):
     part = torch.empty(B * nch * groups * 2, dtype=torch.float32, device=x.device)
     out = torch.empty(*x.shape[:-1], C0 + C1, dtype=x.dtype, device=x.device)
     s = _stream()
+    e0 = _prof_begin()
     check(lib.ur_groupnorm_stats(_ptr(x), _ptr(x1), C0, C1, B, rows, groups, nch, part.data_ptr(), DT[x.dtype], s),
           "ur_groupnorm_stats")
+    _prof_end(e0, "gn_stats", 0.0, 1.0 * out.numel() * out.element_size())
+    e1 = _prof_begin()
     check(lib.ur_groupnorm_apply(_ptr(x), _ptr(x1), C0, C1, B, rows, groups, nch, part.data_ptr(), gamma.data_ptr(),
                                  beta.data_ptr(), float(eps), int(silu), out.data_ptr(), DT[x.dtype], s),
           "ur_groupnorm_apply")
+    _prof_end(e1, "gn_apply", 0.0, 2.0 * out.numel() * out.element_size())
     return out
 
 
@@ -213,8 +249,10 @@ def layernorm(x, gamma, beta, eps=1e-5):
     Cn = x.shape[-1]
     rows = x.numel() // Cn
     out = torch.empty_like(x)
+    e0 = _prof_begin()
     check(lib.ur_layernorm(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(eps), rows, Cn, out.data_ptr(),
                            DT[x.dtype], _stream()), "ur_layernorm")
+    _prof_end(e0, "layernorm", 0.0, 2.0 * out.numel() * out.element_size())
     return out
 
 
@@ -231,7 +269,9 @@ def attention(q, k, vt, *, B, H, Tq, Tk, d, ldq, ldk, q_off=0, k_off=0, scale=No
     a.B, a.H, a.Tq, a.Tk, a.d = B, H, Tq, Tk, d
     a.scale = float(scale if scale is not None else d ** -0.5)
     a.dtype = DT[q.dtype]
+    e0 = _prof_begin()
     check(lib.ur_attention(C.byref(a), _stream()), "ur_attention")
+    _prof_end(e0, f"attention_d{d}", 4.0 * B * H * Tq * Tk * d, (2.0 * B * Tq + 2.0 * B * Tk) * H * d * q.element_size())
     return o
 
 
@@ -239,8 +279,10 @@ def add(a, b, alpha: float = 1.0):
     _require_gpu(a)
     lib = _lib.load()
     out = torch.empty_like(a)
+    e0 = _prof_begin()
     check(lib.ur_add(a.data_ptr(), b.data_ptr(), float(alpha), out.data_ptr(), a.numel(), DT[a.dtype], _stream()),
           "ur_add")
+    _prof_end(e0, "add", 0.0, 3.0 * out.numel() * out.element_size())
     return out
 
 
