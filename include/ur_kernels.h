@@ -55,8 +55,13 @@ extern "C" {
 /* Tile configurations of ur_igemm (rows x cols of the output tile computed by one workgroup). */
 #define UR_TILE_AUTO 0
 #define UR_TILE_128x128 1
-#define UR_TILE_128x64 2
-#define UR_TILE_64x64 3
+#define UR_TILE_128x64 2      /* 3-deep LDS ring */
+#define UR_TILE_64x64 3       /* 3-deep */
+#define UR_TILE_128x128_S3 4  /* 3-deep (1 workgroup per CU) */
+#define UR_TILE_128x64_S2 5   /* 2-deep */
+#define UR_TILE_64x64_S4 6    /* 4-deep */
+#define UR_TILE_64x64_S2 7    /* 2-deep */
+#define UR_TILE_COUNT 8
 
 /*
  * Implicit GEMM:  out[m][n] = epilogue( sum_k X[m][k] * W[n][k] )
@@ -110,14 +115,15 @@ int64_t ur_igemm_partial_floats(const ur_igemm_desc* d);
 /*
  * GroupNorm over NHWC, optionally over the concatenation of two sources (x0 | x1), optional SiLU.
  *   stats:  partial[b][chunk][g][2] = (sum, sumsq) over the rows of that chunk, fp32.
- *   apply:  y = (x - mean) * rstd * gamma + beta  (-> SiLU), mean/rstd reduced from `partial`.
- * rows = H*W per sample; nchunks = number of row chunks per sample (grid.x).
+ *   apply:  y = (x - mean) * rstd * gamma + beta  (-> SiLU), mean/rstd reduced (fixed order) from the
+ *           `nstat` chunks of `partial` written by the stats pass.
+ * rows = H*W per sample; nchunks = number of row chunks per sample (grid.x) of the call at hand.
  */
 int ur_groupnorm_stats(const void* x0, const void* x1, int c0, int c1, int B, int rows, int groups,
                        int nchunks, float* partial, int dtype, void* stream);
 int ur_groupnorm_apply(const void* x0, const void* x1, int c0, int c1, int B, int rows, int groups,
-                       int nchunks, const float* partial, const float* gamma, const float* beta, float eps,
-                       int silu, void* out, int dtype, void* stream);
+                       int nstat, int nchunks, const float* partial, const float* gamma, const float* beta,
+                       float eps, int silu, void* out, int dtype, void* stream);
 
 /* LayerNorm over the last dimension of x[rows][C] (C % 8 == 0, C <= 4096), fp32 statistics. */
 int ur_layernorm(const void* x, const float* gamma, const float* beta, float eps, int rows, int C, void* out,
@@ -128,7 +134,8 @@ int ur_layernorm(const void* x, const float* gamma, const float* beta, float eps
  *   q  [B][Tq][ldq]   head h at columns q_off + h*d .. +d
  *   k  [B][Tk][ldk]   head h at columns k_off + h*d .. +d
  *   vt [B][H*d][ldvt] TRANSPOSED values: row h*d + j holds V[:, j] of head h over the keys;
- *                     ldvt is a multiple of 64 and columns >= Tk are zero
+ *                     ldvt is a multiple of 64 and columns >= Tk are zero; batch b starts at
+ *                     vt + b * vt_bstride elements (lets several layers share one batched projection)
  *   o  [B][Tq][ldo]   head h at columns h*d .. +d
  * d in {32, 40, 64, 80, 128, 160}.
  */
@@ -139,6 +146,7 @@ typedef struct ur_attn_desc {
     void* o;
     const void* zero_page;
     int64_t ldq, ldk, ldvt, ldo;
+    int64_t vt_bstride;
     int32_t q_off, k_off;
     int32_t B, H, Tq, Tk, d;
     float scale;

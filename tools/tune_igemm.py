@@ -1,0 +1,121 @@
+#!/usr/bin/env python3
+"""Measure, on a real MI355X, the best (tile, split-K) of ur_igemm for every distinct implicit-GEMM problem of a
+dual-stream step and write uni_renderer_amd/igemm_tuning.json (read by ops.plan_igemm).
+
+    python tools/tune_igemm.py [--batch 4] [--latent 64] [--dtype fp16] [--also "2,32;1,128"]
+
+One eager step is run with ops.igemm intercepted to collect the call arguments (tensors kept alive); each unique
+(M, N, K, taps, zbatch) is then re-launched with every candidate configuration, timed with HIP events on the
+launch stream (median of 3 rounds x 8 launches).
+"""
+import argparse
+import json
+import os
+import statistics
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def collect(models, inputs):
+    from uni_renderer_amd import ops
+    from uni_renderer_amd.graph import dual_stream_step
+
+    calls = {}
+    orig = ops.igemm
+
+    def spy(**kw):
+        key = (kw["M"], kw["N"], kw["K"], kw.get("taps", 1), kw.get("zbatch", 1))
+        if key not in calls:
+            calls[key] = dict(kw)
+        return orig(**kw)
+
+    ops.igemm = spy
+    try:
+        with torch.no_grad():
+            dual_stream_step(*models, *inputs)
+        torch.cuda.synchronize()
+    finally:
+        ops.igemm = orig
+    return calls
+
+
+def time_cfg(kw, tile, splitk, rounds=3, iters=8):
+    from uni_renderer_amd import ops
+
+    kw = dict(kw)
+    kw["tile"], kw["splitk"] = tile, splitk
+    try:
+        ops.igemm(**kw)  # warm (also sets the LDS attribute)
+        torch.cuda.synchronize()
+    except RuntimeError:
+        return None
+    ts = []
+    for _ in range(rounds):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            ops.igemm(**kw)
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) / iters)
+    return statistics.median(ts)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=4)
+    ap.add_argument("--latent", type=int, default=64)
+    ap.add_argument("--dtype", default="fp16")
+    ap.add_argument("--also", default="", help='extra "batch,latent" pairs separated by ;')
+    ap.add_argument("--out", default=os.path.join(ROOT, "uni_renderer_amd", "igemm_tuning.json"))
+    ap.add_argument("--report", default=os.path.join(ROOT, "gpurun_out", "tune_report.json"))
+    args = ap.parse_args()
+    import bench
+    from uni_renderer_amd import ops
+
+    dev = torch.device("cuda:0")
+    dtype = torch.float16 if args.dtype == "fp16" else torch.bfloat16
+    models = bench.build_models(dev, dtype)
+    shapes = [(args.batch, args.latent)] + [tuple(int(v) for v in p.split(",")) for p in args.also.split(";") if p]
+    ops.load_tuning_table("/nonexistent")  # start from the analytic planner
+    table, report = {}, []
+    if os.path.exists(args.out):
+        table = json.load(open(args.out))
+    for (B, L) in shapes:
+        calls = collect(models, bench.make_inputs(B, L, dev, dtype, seed=7))
+        print(f"[tune] batch {B} latent {L}: {len(calls)} distinct problems", flush=True)
+        for key, kw in sorted(calls.items()):
+            M, N, K, taps, zb = key
+            res = {}
+            for tile in ops._TILES:
+                for sk in (1, 2, 4, 8):
+                    if sk > 1 and (zb > 1 or K // 64 < 4 * sk):
+                        continue
+                    t = time_cfg(kw, tile, sk)
+                    if t is not None:
+                        res[(tile, sk)] = t
+            best = min(res, key=res.get)
+            default = ops.plan_igemm(M, N, K, taps, zb)
+            fl = 2.0 * M * N * K * zb
+            table[f"{M},{N},{K},{taps},{zb}"] = list(best)
+            report.append(dict(M=M, N=N, K=K, taps=taps, z=zb, best=list(best), best_us=round(res[best] * 1e3, 2),
+                               best_tflops=round(fl / res[best] / 1e9, 1), default=list(default),
+                               default_us=round(res.get(tuple(default), float("nan")) * 1e3, 2),
+                               all={f"{t},{s}": round(v * 1e3, 2) for (t, s), v in sorted(res.items())}))
+            print(f"  M={M:6d} N={N:5d} K={K:6d} taps={taps} z={zb}: best tile {best[0]} splitk {best[1]} "
+                  f"{res[best] * 1e3:8.2f} us ({fl / res[best] / 1e9:7.1f} TF/s)  planner {default} "
+                  f"{res.get(tuple(default), float('nan')) * 1e3:8.2f} us", flush=True)
+    with open(args.out, "w") as f:
+        json.dump(table, f, indent=0, sort_keys=True)
+    os.makedirs(os.path.dirname(args.report), exist_ok=True)
+    with open(args.report, "w") as f:
+        json.dump(report, f)
+    print(f"[tune] wrote {len(table)} entries to {args.out}")
+
+
+if __name__ == "__main__":
+    main()

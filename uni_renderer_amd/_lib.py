@@ -42,7 +42,7 @@ class AttnDesc(C.Structure):
 
     _fields_ = [
         ("q", vp), ("k", vp), ("vt", vp), ("o", vp), ("zero_page", vp),
-        ("ldq", i64), ("ldk", i64), ("ldvt", i64), ("ldo", i64),
+        ("ldq", i64), ("ldk", i64), ("ldvt", i64), ("ldo", i64), ("vt_bstride", i64),
         ("q_off", i32), ("k_off", i32),
         ("B", i32), ("H", i32), ("Tq", i32), ("Tk", i32), ("d", i32),
         ("scale", f32), ("dtype", i32),
@@ -54,7 +54,7 @@ SYMBOLS = {
     "ur_igemm": (C.c_int, [C.POINTER(IGemmDesc), vp]),
     "ur_igemm_partial_floats": (C.c_int64, [C.POINTER(IGemmDesc)]),
     "ur_groupnorm_stats": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]),
-    "ur_groupnorm_apply": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp,
+    "ur_groupnorm_apply": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp,
                                      C.c_float, C.c_int, vp, C.c_int, vp]),
     "ur_layernorm": (C.c_int, [vp, vp, vp, C.c_float, C.c_int, C.c_int, vp, C.c_int, vp]),
     "ur_attention": (C.c_int, [C.POINTER(AttnDesc), vp]),

@@ -22,7 +22,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .layers import Conv2d, Ctx, GroupNorm, PackCache, ResnetBlock2D, TimestepEmbedding, f32, pack_conv3x3, \
+from .layers import Attention, Conv2d, Ctx, GroupNorm, PackCache, ResnetBlock2D, TimestepEmbedding, f32, pack_conv3x3, \
     pack_matrix, zero_module
 from .modeling_utils import ConfigModelMixin, register_to_config
 from .unet_2d_blocks import UNetMidBlock2DCrossAttn, get_down_block, get_up_block
@@ -70,11 +70,24 @@ class _DenoiserBase(ConfigModelMixin, nn.Module):
             r.temb_slice = (off, off + r.out_channels)
             off += r.out_channels
         self._temb_total = off
+        off = 0
+        self._cross: List[Attention] = [m for m in self.modules() if isinstance(m, Attention) and m.is_cross]
+        for a in self._cross:
+            a.kv_slice = (off, off + a.inner)
+            off += a.inner
         self._pk = PackCache()
 
-    def _begin(self, B: int, timestep, device) -> Ctx:
+    def _begin(self, B: int, timestep, device, encoder_hidden_states) -> Ctx:
         dt = _compute_dtype(self.dtype, self.compute_dtype)
         ctx = Ctx(dt, B)
+        ctx.ehs = self._tokens(encoder_hidden_states, dt)
+        if self._cross:  # every cross-attention K and V^T of the network in two GEMMs (they only see the prompt)
+            wks = [a.to_k.weight for a in self._cross]
+            wvs = [a.to_v.weight for a in self._cross]
+            wk = self._pk.get("xk", wks, dt, lambda: torch.cat([pack_matrix(w, dt) for w in wks], 0).contiguous())
+            wv = self._pk.get("xv", wvs, dt, lambda: torch.cat([pack_matrix(w, dt) for w in wvs], 0).contiguous())
+            ctx.kc = ops.linear(ctx.ehs, wk)
+            ctx.vtc = ops.vt_proj(ctx.ehs, wv)
         t = timestep
         if not torch.is_tensor(t):
             t = torch.tensor([t], dtype=torch.float32, device=device)
@@ -275,9 +288,8 @@ class UNet2DConditionModel(_DenoiserBase):
         B, _, H, W = sample.shape
         f = 2 ** self.num_upsamplers
         forward_upsample_size = (H % f != 0) or (W % f != 0)  # ref 869-883
-        ctx = self._begin(B, timestep, sample.device)
+        ctx = self._begin(B, timestep, sample.device, encoder_hidden_states)
         dt = ctx.dtype
-        ctx.ehs = self._tokens(encoder_hidden_states, dt)
 
         x = self._conv_in(sample, ctx)
         skips = (x,)
@@ -435,8 +447,7 @@ class AttributeEncoderModel(_DenoiserBase):
         _reject_inactive(class_labels=class_labels, timestep_cond=timestep_cond, attention_mask=attention_mask,
                          added_cond_kwargs=added_cond_kwargs, cross_attention_kwargs=cross_attention_kwargs)
         B = controlnet_cond.shape[0]
-        ctx = self._begin(B, timestep, controlnet_cond.device)
-        ctx.ehs = self._tokens(encoder_hidden_states, ctx.dtype)
+        ctx = self._begin(B, timestep, controlnet_cond.device, encoder_hidden_states)
         x = self._conv_in(controlnet_cond, ctx)  # `sample` is ignored, as in the reference
         skips = (x,)
         for blk in self.down_blocks:
@@ -586,9 +597,8 @@ class AttributeDecoderModel(_DenoiserBase):
         H0, W0 = down_block_res_samples[0].shape[-2:]
         f = 2 ** self.num_upsamplers
         forward_upsample_size = (H0 % f != 0) or (W0 % f != 0)
-        ctx = self._begin(B, timestep, sample.device)
+        ctx = self._begin(B, timestep, sample.device, encoder_hidden_states)
         dt = ctx.dtype
-        ctx.ehs = self._tokens(encoder_hidden_states, dt)
         skips = tuple(ops.to_nhwc(s, dt) for s in down_block_res_samples)
         if down_block_additional_residuals is not None:  # ref 2446-2461
             skips = tuple(

@@ -53,7 +53,7 @@ __global__ void __launch_bounds__(256) attention_kernel(const ur_attn_desc p) {
 
     const T* Q = reinterpret_cast<const T*>(p.q) + (int64_t)b * p.Tq * p.ldq + p.q_off + h * D;
     const T* K = reinterpret_cast<const T*>(p.k) + (int64_t)b * p.Tk * p.ldk + p.k_off + h * D;
-    const T* VT = reinterpret_cast<const T*>(p.vt) + ((int64_t)b * p.H + h) * D * p.ldvt;
+    const T* VT = reinterpret_cast<const T*>(p.vt) + (int64_t)b * p.vt_bstride + (int64_t)h * D * p.ldvt;
     const T* zp = reinterpret_cast<const T*>(p.zero_page);
 
     // ---- Q fragments (B operand of S^T): lane (query l15 of fragment qf, qq) holds 8 d-values per k-step
@@ -258,7 +258,7 @@ extern "C" int ur_attention(const ur_attn_desc* d, void* stream) {
     if (d->B <= 0 || d->H <= 0 || d->Tq <= 0 || d->Tk <= 0) return UR_E_BADARG;
     if ((d->ldq & 7) || (d->ldk & 7) || (d->ldvt & 63) || (d->ldo & 3) || (d->q_off & 7) || (d->k_off & 7))
         return UR_E_BADARG;
-    if (d->ldvt < (d->Tk + 63) / 64 * 64) return UR_E_BADARG;
+    if (d->ldvt < (d->Tk + 63) / 64 * 64 || (d->vt_bstride & 7)) return UR_E_BADARG;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (d->dtype == UR_DT_F16) return launch_attn_d<f16>(*d, s);
     if (d->dtype == UR_DT_BF16) return launch_attn_d<bf16>(*d, s);

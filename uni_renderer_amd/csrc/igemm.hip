@@ -118,7 +118,7 @@ __device__ __forceinline__ void epilogue16(const ur_igemm_desc& p, T* __restrict
     }
 }
 
-template <typename T, int BM, int BN, int WM, int WN, bool CONV>
+template <typename T, int BM, int BN, int WM, int WN, int NSTAGE, bool CONV>
 __global__ void __launch_bounds__(256) igemm_kernel(const ur_igemm_desc p) {
     typedef typename Vec8<T>::type vec8;
     static_assert(WM * WN == 4, "4 waves per workgroup");
@@ -285,13 +285,29 @@ __global__ void __launch_bounds__(256) igemm_kernel(const ur_igemm_desc p) {
 
     const int nk = kend - kbeg;
     if (nk > 0) {
-        stage(0);
-        __syncthreads();
+        // NSTAGE-deep LDS ring, prefetch distance D = NSTAGE-1 chunks, ONE barrier per chunk:
+        //   wait (counted vmcnt: only chunk t must have landed, newer ones stay in flight) -> s_barrier
+        //   -> issue chunk t+D into the buffer every wave finished reading before that barrier -> MFMAs.
+        // Raw s_barrier + inline-asm vmcnt(N): __syncthreads() would drain the LDS-DMA queue (vmcnt(0)).
+        constexpr int D = NSTAGE - 1;
+        constexpr int LOADS = XI + WI;  // LDS-DMA instructions per wave per chunk
+#pragma unroll
+        for (int s = 0; s < D; ++s)
+            if (s < nk) stage(s);
         const int l15 = lane & 15, q = lane >> 4;
+        int buf = 0, nbuf = D % NSTAGE;
         for (int t = 0; t < nk; ++t) {
-            if (t + 1 < nk) stage((t + 1) & 1);
-            const char* xs = smem + (t & 1) * STAGE;
+            const int newer = min(D - 1, nk - 1 - t);  // chunks issued after chunk t that may stay in flight
+            if (newer >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LOADS) : "memory");
+            else if (newer == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (t + D < nk) stage(nbuf);
+            const char* xs = smem + buf * STAGE;
             const char* ws = xs + XT_BYTES;
+            buf = (buf + 1 == NSTAGE) ? 0 : buf + 1;
+            nbuf = (nbuf + 1 == NSTAGE) ? 0 : nbuf + 1;
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 const int c = ((kk * 4 + q) ^ (l15 & 7)) << 4;  // swizzled 16-B chunk of this lane
@@ -307,7 +323,6 @@ __global__ void __launch_bounds__(256) igemm_kernel(const ur_igemm_desc p) {
 #pragma unroll
                     for (int f = 0; f < NREP; ++f) acc[mf][f] = mfma16(wf[f], xf[mf], acc[mf][f]);
             }
-            __syncthreads();
         }
     }
 
@@ -361,8 +376,10 @@ __global__ void __launch_bounds__(256) igemm_splitk_reduce(const ur_igemm_desc p
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
-struct TileCfg { int bm, bn; };
-static const TileCfg kTiles[4] = {{0, 0}, {128, 128}, {128, 64}, {64, 64}};
+struct TileCfg { int bm, bn, stages; };
+// index = UR_TILE_* (include/ur_kernels.h)
+static const TileCfg kTiles[UR_TILE_COUNT] = {{0, 0, 0},      {128, 128, 2}, {128, 64, 3}, {64, 64, 3},
+                                              {128, 128, 3}, {128, 64, 2},  {64, 64, 4},  {64, 64, 2}};
 
 static int pick_tile(const ur_igemm_desc& d) {
     // Cost model: the busiest CU runs ceil(workgroups / 256) tiles; bigger tiles have a better
@@ -380,28 +397,28 @@ static int pick_tile(const ur_igemm_desc& d) {
     return best;
 }
 
-template <typename T, int BM, int BN, int WM, int WN>
+template <typename T, int BM, int BN, int WM, int WN, int NSTAGE>
 static int launch_cfg(const ur_igemm_desc& d, hipStream_t s) {
     const int tiles_m = (d.M + BM - 1) / BM, tiles_n = (d.N + BN - 1) / BN;
     dim3 grid(tiles_m * tiles_n, 1, d.splitk > 1 ? d.splitk : (d.zbatch > 1 ? d.zbatch : 1));
-    const size_t lds = 2 * (BM + BN) * 128;
+    const size_t lds = NSTAGE * (BM + BN) * 128;
     hipError_t e;
     if (d.taps == 9) {
         static bool once = false;
         if (!once) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, WM, WN, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, WM, WN, NSTAGE, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             once = true;
         }
-        hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, true>), grid, dim3(256), lds, s, d);
+        hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, NSTAGE, true>), grid, dim3(256), lds, s, d);
     } else {
         static bool once = false;
         if (!once) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, WM, WN, false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, WM, WN, NSTAGE, false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             once = true;
         }
-        hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, false>), grid, dim3(256), lds, s, d);
+        hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, NSTAGE, false>), grid, dim3(256), lds, s, d);
     }
     e = hipGetLastError();
     if (e != hipSuccess) return -(int)e;
@@ -419,9 +436,13 @@ static int launch_cfg(const ur_igemm_desc& d, hipStream_t s) {
 template <typename T>
 static int launch_dtype(ur_igemm_desc& d, hipStream_t s) {
     switch (d.tile) {
-        case UR_TILE_128x128: return launch_cfg<T, 128, 128, 2, 2>(d, s);
-        case UR_TILE_128x64: return launch_cfg<T, 128, 64, 4, 1>(d, s);
-        case UR_TILE_64x64: return launch_cfg<T, 64, 64, 4, 1>(d, s);
+        case UR_TILE_128x128: return launch_cfg<T, 128, 128, 2, 2, 2>(d, s);
+        case UR_TILE_128x64: return launch_cfg<T, 128, 64, 4, 1, 3>(d, s);
+        case UR_TILE_64x64: return launch_cfg<T, 64, 64, 4, 1, 3>(d, s);
+        case UR_TILE_128x128_S3: return launch_cfg<T, 128, 128, 2, 2, 3>(d, s);
+        case UR_TILE_128x64_S2: return launch_cfg<T, 128, 64, 4, 1, 2>(d, s);
+        case UR_TILE_64x64_S4: return launch_cfg<T, 64, 64, 4, 1, 4>(d, s);
+        case UR_TILE_64x64_S2: return launch_cfg<T, 64, 64, 4, 1, 2>(d, s);
     }
     return UR_E_BADARG;
 }
@@ -465,7 +486,7 @@ extern "C" int ur_igemm(const ur_igemm_desc* din, void* stream) {
     if (d.n_store <= 0) d.n_store = (d.act == UR_ACT_GEGLU) ? d.N / 2 : d.N;
     if (d.out_scale == 0.0f) d.out_scale = 1.0f;
     if (d.tile == UR_TILE_AUTO) d.tile = pick_tile(d);
-    if (d.tile < 1 || d.tile > 3) return UR_E_BADARG;
+    if (d.tile < 1 || d.tile >= UR_TILE_COUNT) return UR_E_BADARG;
     d.ldp = padded_ldp(d, d.tile);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (d.dtype == UR_DT_F16) return launch_dtype<f16>(d, s);

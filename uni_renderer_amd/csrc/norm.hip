@@ -39,7 +39,20 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(const T* __restrict__ x0,
             int co;
             if (cv < nv0) { base = x0 + (int64_t)b * rows * c0; ld = c0; co = cv * 8; }
             else { base = x1 + (int64_t)b * rows * c1; ld = c1; co = (cv - nv0) * 8; }
-            for (int r = rbeg + rsub; r < rend; r += rs) {
+            int r = rbeg + rsub;
+            for (; r + 3 * rs < rend; r += 4 * rs) {  // 4 independent 16-byte loads in flight per thread
+                float v0[8], v1[8], v2[8], v3[8];
+                load8(base + (int64_t)r * ld + co, v0);
+                load8(base + (int64_t)(r + rs) * ld + co, v1);
+                load8(base + (int64_t)(r + 2 * rs) * ld + co, v2);
+                load8(base + (int64_t)(r + 3 * rs) * ld + co, v3);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    s[i] += (v0[i] + v1[i]) + (v2[i] + v3[i]);
+                    ss[i] += (v0[i] * v0[i] + v1[i] * v1[i]) + (v2[i] * v2[i] + v3[i] * v3[i]);
+                }
+            }
+            for (; r < rend; r += rs) {
                 float v[8];
                 load8(base + (int64_t)r * ld + co, v);
 #pragma unroll
@@ -73,27 +86,37 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(const T* __restrict__ x0,
 
 template <typename T>
 __global__ void __launch_bounds__(256) gn_apply_kernel(const T* __restrict__ x0, const T* __restrict__ x1, int c0,
-                                                       int c1, int rows, int groups, int nchunks,
+                                                       int c1, int rows, int groups, int nstat, int nchunks,
                                                        const float* __restrict__ partial,
                                                        const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float eps, int silu,
                                                        T* __restrict__ out) {
     __shared__ float2 stat[64];  // (mean, rstd) per group
+    __shared__ float2 red[8][64];
     const int C = c0 + c1, nvec = C >> 3, cpg = C / groups;
     const int b = blockIdx.y, chunk = blockIdx.x;
     const int t = threadIdx.x;
-    if (t < groups) {
+    {   // reduce the stats partials of sample b: 8 thread-slices x groups, fixed order (deterministic)
+        const int g = t & 63, j = t >> 6;  // 4 slices of up to 64 groups
         float s = 0.f, ss = 0.f;
-        const float2* src = reinterpret_cast<const float2*>(partial) + (int64_t)b * nchunks * groups + t;
-        for (int k = 0; k < nchunks; ++k) {
-            float2 a = src[(int64_t)k * groups];
-            s += a.x;
-            ss += a.y;
+        if (g < groups) {
+            const float2* src = reinterpret_cast<const float2*>(partial) + (int64_t)b * nstat * groups + g;
+            for (int k = j; k < nstat; k += 4) {
+                float2 a = src[(int64_t)k * groups];
+                s += a.x;
+                ss += a.y;
+            }
         }
-        const float n = (float)rows * (float)cpg;
-        const float mean = s / n;
-        const float var = fmaxf(ss / n - mean * mean, 0.f);
-        stat[t] = make_float2(mean, rsqrtf(var + eps));
+        red[j][g] = make_float2(s, ss);
+        __syncthreads();
+        if (t < groups) {
+            float2 a0 = red[0][t], a1 = red[1][t], a2 = red[2][t], a3 = red[3][t];
+            const float sum = (a0.x + a1.x) + (a2.x + a3.x), sq = (a0.y + a1.y) + (a2.y + a3.y);
+            const float n = (float)rows * (float)cpg;
+            const float mean = sum / n;
+            const float var = fmaxf(sq / n - mean * mean, 0.f);
+            stat[t] = make_float2(mean, rsqrtf(var + eps));
+        }
     }
     __syncthreads();
     const int rpc = (rows + nchunks - 1) / nchunks;
@@ -216,18 +239,18 @@ extern "C" int ur_groupnorm_stats(const void* x0, const void* x1, int c0, int c1
 }
 
 extern "C" int ur_groupnorm_apply(const void* x0, const void* x1, int c0, int c1, int B, int rows, int groups,
-                                  int nchunks, const float* partial, const float* gamma, const float* beta,
-                                  float eps, int silu, void* out, int dtype, void* stream) {
+                                  int nstat, int nchunks, const float* partial, const float* gamma,
+                                  const float* beta, float eps, int silu, void* out, int dtype, void* stream) {
     int rc = gn_check(x0, x1, c0, c1, B, rows, groups, nchunks);
-    if (rc || !partial || !gamma || !beta || !out) return rc ? rc : UR_E_BADARG;
+    if (rc || nstat <= 0 || !partial || !gamma || !beta || !out) return rc ? rc : UR_E_BADARG;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     dim3 grid(nchunks, B);
     if (dtype == UR_DT_F16)
         hipLaunchKernelGGL((gn_apply_kernel<f16>), grid, dim3(256), 0, s, (const f16*)x0, (const f16*)x1, c0, c1, rows,
-                           groups, nchunks, partial, gamma, beta, eps, silu, (f16*)out);
+                           groups, nstat, nchunks, partial, gamma, beta, eps, silu, (f16*)out);
     else if (dtype == UR_DT_BF16)
         hipLaunchKernelGGL((gn_apply_kernel<bf16>), grid, dim3(256), 0, s, (const bf16*)x0, (const bf16*)x1, c0, c1,
-                           rows, groups, nchunks, partial, gamma, beta, eps, silu, (bf16*)out);
+                           rows, groups, nstat, nchunks, partial, gamma, beta, eps, silu, (bf16*)out);
     else
         return UR_E_BADARG;
     hipError_t e = hipGetLastError();

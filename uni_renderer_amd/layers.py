@@ -98,13 +98,15 @@ def f32(t: torch.Tensor) -> torch.Tensor:
 class Ctx:
     """Per-forward context handed down the module tree."""
 
-    __slots__ = ("dtype", "temb", "ehs", "B")
+    __slots__ = ("dtype", "temb", "ehs", "B", "kc", "vtc")
 
     def __init__(self, dtype, B):
         self.dtype = dtype
         self.B = B
         self.temb = None  # [B, sum(Cout of all resnets)] = time_emb_proj(silu(emb)) of every resnet, batched
         self.ehs = None   # [B, 77, cross_dim] tokens in compute dtype
+        self.kc = None    # [B, 77, sum(C)]   to_k(ehs) of every cross-attention of the network, one GEMM
+        self.vtc = None   # [B, sum(C), 128]  to_v(ehs)^T of every cross-attention, one GEMM
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -184,6 +186,7 @@ class Attention(nn.Module):
         self.to_k = Linear(kv, inner, bias=False)
         self.to_v = Linear(kv, inner, bias=False)
         self.to_out = nn.ModuleList([Linear(inner, query_dim), nn.Dropout(0.0)])
+        self.kv_slice = None  # rows of the network-wide batched K / V^T projection (cross-attention only)
         self._pk = PackCache()
 
     def forward(self, xn, ctx: Ctx, residual):
@@ -194,6 +197,14 @@ class Attention(nn.Module):
         H, d, C = self.heads, self.dim_head, self.inner
         wo = pk.get("wo", [self.to_out[0].weight], dt, lambda: pack_matrix(self.to_out[0].weight, dt))
         bo = pk.get("bo", [self.to_out[0].bias], dt, lambda: f32(self.to_out[0].bias))
+        if self.is_cross and ctx.kc is not None and self.kv_slice is not None:
+            # K / V^T of the prompt were projected once for the whole network (controlnet._begin)
+            lo, hi = self.kv_slice
+            wq = pk.get("wq", [self.to_q.weight], dt, lambda: pack_matrix(self.to_q.weight, dt))
+            q = ops.linear(xn, wq)
+            o = ops.attention(q, ctx.kc[:, :, lo:hi], ctx.vtc[:, lo:hi], B=B, H=H, Tq=T, Tk=ctx.kc.shape[1], d=d,
+                              ldq=C, ldk=ctx.kc.stride(1))
+            return ops.linear(o, wo, bo, res=residual)
         wv = pk.get("wv", [self.to_v.weight], dt, lambda: pack_matrix(self.to_v.weight, dt))
         if not self.is_cross:
             wqk = pk.get("wqk", [self.to_q.weight, self.to_k.weight], dt,

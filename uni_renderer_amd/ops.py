@@ -19,7 +19,12 @@ DT = {torch.float16: 0, torch.bfloat16: 1}
 DT_ANY = {torch.float16: 0, torch.bfloat16: 1, torch.float32: 2}
 ACT_NONE, ACT_SILU, ACT_GEGLU = 0, 1, 2
 TILE_AUTO, TILE_128x128, TILE_128x64, TILE_64x64 = 0, 1, 2, 3
-_TILES = {TILE_128x128: (128, 128, 1.0), TILE_128x64: (128, 64, 0.85), TILE_64x64: (64, 64, 0.6)}
+TILE_128x128_S3, TILE_128x64_S2, TILE_64x64_S4, TILE_64x64_S2 = 4, 5, 6, 7
+# tile id -> (BM, BN, relative efficiency guess for the analytic planner, LDS ring depth)
+_TILES = {TILE_128x128: (128, 128, 1.0, 2), TILE_128x64: (128, 64, 0.85, 3), TILE_64x64: (64, 64, 0.6, 3),
+          TILE_128x128_S3: (128, 128, 0.9, 3), TILE_128x64_S2: (128, 64, 0.7, 2), TILE_64x64_S4: (64, 64, 0.6, 4),
+          TILE_64x64_S2: (64, 64, 0.5, 2)}
+_PLANNER_TILES = (TILE_128x128, TILE_128x64, TILE_64x64)
 
 _zero_pages = {}
 _tune_table = None
@@ -104,7 +109,8 @@ def plan_igemm(M: int, N: int, K: int, taps: int = 1, zbatch: int = 1) -> Tuple[
     if t is None:
         per_cu = 2.5e15 / 256 * 0.4
         best, best_t = (TILE_64x64, 1), float("inf")
-        for tile, (bm, bn, eff) in _TILES.items():
+        for tile in _PLANNER_TILES:
+            bm, bn, eff, _ = _TILES[tile]
             wgs = math.ceil(M / bm) * math.ceil(N / bn) * zbatch
             for sk in (1, 2, 4, 8):
                 if sk > 1 and (zbatch > 1 or K // 64 < 8 * sk):
@@ -160,7 +166,8 @@ def igemm(*, x0, w, out, M, N, K, c0, c1=0, x1=None, ldx0, ldx1=0, ldw, ldc, tap
     if e0 is not None:
         el = x0.element_size()
         z = max(zbatch, 1)
-        key = f"igemm_{_TILES[tile][0]}x{_TILES[tile][1]}_{'conv3x3' if taps == 9 else 'gemm'}" + ("_splitk" if splitk > 1 else "")
+        key = (f"igemm_{_TILES[tile][0]}x{_TILES[tile][1]}s{_TILES[tile][3]}_{'conv3x3' if taps == 9 else 'gemm'}"
+               + ("_splitk" if splitk > 1 else ""))
         _prof_end(e0, key, 2.0 * M * N * K * z, (M * K / taps + N * K + M * N) * el * z)
     return out
 
@@ -214,9 +221,12 @@ def vt_proj(x, wv):
 # ---------------------------------------------------------------------------------------------
 # norms, attention, glue
 # ---------------------------------------------------------------------------------------------
-def _gn_chunks(B: int, rows: int) -> int:
-    n = max(1, min(rows // 8, max(1, 1024 // max(B, 1))))
-    return min(n, 256)
+def _gn_chunks(B: int, rows: int):
+    """(stats chunks, apply chunks) per sample: >= 64 rows per stats workgroup (its reduction has a fixed
+    cost), ~16 rows per apply workgroup, both capped so that the grids stay around 1-2k workgroups."""
+    nstat = max(1, min(rows // 64, 64))
+    napply = max(1, min(rows // 16, max(1, 2048 // max(B, 1)), 256))
+    return nstat, napply
 
 
 def groupnorm(x, gamma, beta, eps, *, x1=None, groups=32, silu=False):
@@ -227,17 +237,18 @@ def groupnorm(x, gamma, beta, eps, *, x1=None, groups=32, silu=False):
     C0 = x.shape[-1]
     C1 = x1.shape[-1] if x1 is not None else 0
     rows = x.numel() // (B * C0)
-    nch = _gn_chunks(B, rows)
-    part = torch.empty(B * nch * groups * 2, dtype=torch.float32, device=x.device)
+    nstat, napply = _gn_chunks(B, rows)
+    part = torch.empty(B * nstat * groups * 2, dtype=torch.float32, device=x.device)
     out = torch.empty(*x.shape[:-1], C0 + C1, dtype=x.dtype, device=x.device)
     s = _stream()
     e0 = _prof_begin()
-    check(lib.ur_groupnorm_stats(_ptr(x), _ptr(x1), C0, C1, B, rows, groups, nch, part.data_ptr(), DT[x.dtype], s),
+    check(lib.ur_groupnorm_stats(_ptr(x), _ptr(x1), C0, C1, B, rows, groups, nstat, part.data_ptr(), DT[x.dtype], s),
           "ur_groupnorm_stats")
     _prof_end(e0, "gn_stats", 0.0, 1.0 * out.numel() * out.element_size())
     e1 = _prof_begin()
-    check(lib.ur_groupnorm_apply(_ptr(x), _ptr(x1), C0, C1, B, rows, groups, nch, part.data_ptr(), gamma.data_ptr(),
-                                 beta.data_ptr(), float(eps), int(silu), out.data_ptr(), DT[x.dtype], s),
+    check(lib.ur_groupnorm_apply(_ptr(x), _ptr(x1), C0, C1, B, rows, groups, nstat, napply, part.data_ptr(),
+                                 gamma.data_ptr(), beta.data_ptr(), float(eps), int(silu), out.data_ptr(),
+                                 DT[x.dtype], s),
           "ur_groupnorm_apply")
     _prof_end(e1, "gn_apply", 0.0, 2.0 * out.numel() * out.element_size())
     return out
@@ -257,14 +268,16 @@ def layernorm(x, gamma, beta, eps=1e-5):
 
 
 def attention(q, k, vt, *, B, H, Tq, Tk, d, ldq, ldk, q_off=0, k_off=0, scale=None):
-    """q/k are 2-D token matrices holding head h at columns off + h*d; vt is [B, H*d, Tk_pad]."""
+    """q/k are token matrices holding head h at columns off + h*d (row strides ldq/ldk, batches contiguous);
+    vt is a [B, H*d, Tk_pad] tensor or a row-slice view of a wider batched projection."""
     _require_gpu(q)
     lib = _lib.load()
     o = torch.empty(B, Tq, H * d, dtype=q.dtype, device=q.device)
     a = AttnDesc()
     a.q, a.k, a.vt, a.o = q.data_ptr(), k.data_ptr(), vt.data_ptr(), o.data_ptr()
     a.zero_page = zero_page(q.device).data_ptr()
-    a.ldq, a.ldk, a.ldvt, a.ldo = ldq, ldk, vt.shape[-1], H * d
+    a.ldq, a.ldk, a.ldvt, a.ldo = ldq, ldk, vt.stride(1), H * d
+    a.vt_bstride = vt.stride(0)
     a.q_off, a.k_off = q_off, k_off
     a.B, a.H, a.Tq, a.Tk, a.d = B, H, Tq, Tk, d
     a.scale = float(scale if scale is not None else d ** -0.5)
