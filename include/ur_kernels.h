@@ -61,7 +61,11 @@ extern "C" {
 #define UR_TILE_128x64_S2 5   /* 2-deep */
 #define UR_TILE_64x64_S4 6    /* 4-deep */
 #define UR_TILE_64x64_S2 7    /* 2-deep */
-#define UR_TILE_COUNT 8
+#define UR_TILE_256x128 8     /* 8 waves, 2-deep */
+#define UR_TILE_128x320 9     /* 10 waves, 2-deep: N = 320 layers without a ragged N tile */
+#define UR_TILE_128x256 10    /* 8 waves, 2-deep */
+#define UR_TILE_256x256 11    /* 16 waves, 2-deep */
+#define UR_TILE_COUNT 12
 
 /*
  * Implicit GEMM:  out[m][n] = epilogue( sum_k X[m][k] * W[n][k] )

@@ -48,8 +48,10 @@ __global__ void __launch_bounds__(256) attention_kernel(const ur_attn_desc p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, qq = lane >> 4;
-    const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int lid = xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);  // a (b,h) stays on one XCD
+    const int bh = lid / gridDim.x, qt = lid - bh * gridDim.x;
+    const int b = bh / p.H, h = bh - b * p.H;
+    const int q0 = qt * 128 + wave * 32;
 
     const T* Q = reinterpret_cast<const T*>(p.q) + (int64_t)b * p.Tq * p.ldq + p.q_off + h * D;
     const T* K = reinterpret_cast<const T*>(p.k) + (int64_t)b * p.Tk * p.ldk + p.k_off + h * D;

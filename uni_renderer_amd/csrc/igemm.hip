@@ -119,17 +119,18 @@ __device__ __forceinline__ void epilogue16(const ur_igemm_desc& p, T* __restrict
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int NSTAGE, bool CONV>
-__global__ void __launch_bounds__(256) igemm_kernel(const ur_igemm_desc p) {
+__global__ void __launch_bounds__(WM * WN * 64) igemm_kernel(const ur_igemm_desc p) {
     typedef typename Vec8<T>::type vec8;
-    static_assert(WM * WN == 4, "4 waves per workgroup");
+    constexpr int NW = WM * WN;  // waves per workgroup
     constexpr int MREP = BM / WM / 16;
     constexpr int NREP = BN / WN / 16;
     static_assert(NREP == 4, "a wave spans 64 output columns (epilogue layout)");
     constexpr int XT_BYTES = BM * 128;
     constexpr int WT_BYTES = BN * 128;
     constexpr int STAGE = XT_BYTES + WT_BYTES;
-    constexpr int XI = BM / 32;  // LDS-DMA instructions per wave per X tile (8 rows each)
-    constexpr int WI = BN / 32;
+    constexpr int XI = (BM / 8 + NW - 1) / NW;  // LDS-DMA instructions per wave per X tile (8 rows each)
+    constexpr int WI = (BN / 8 + NW - 1) / NW;
+    static_assert(NSTAGE == 2 || ((BM / 8) % NW == 0 && (BN / 8) % NW == 0), "counted vmcnt needs uniform loads per wave");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -139,18 +140,23 @@ __global__ void __launch_bounds__(256) igemm_kernel(const ur_igemm_desc p) {
     const int wm = wave / WN, wn = wave % WN;
 
     const int tiles_n = (p.N + BN - 1) / BN;
-    const int tile_n = blockIdx.x % tiles_n;
-    const int tile_m = blockIdx.x / tiles_n;
+    // XCD-aware mapping: logical ids are tile-major within one z slice, n fastest, so an XCD works on a
+    // contiguous run of m-tiles x all n-tiles (activation rows fetched once per XCD, weights shared in its L2)
+    const int lid = xcd_remap(blockIdx.x + gridDim.x * blockIdx.z, gridDim.x * gridDim.z);
+    const int zidx = lid / gridDim.x;
+    const int tid_xy = lid - zidx * gridDim.x;
+    const int tile_n = tid_xy % tiles_n;
+    const int tile_m = tid_xy / tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     const int kt_total = p.K / BK;
     int kbeg = 0, kend = kt_total, zb = 0;
     if (p.splitk > 1) {
         const int per = (kt_total + p.splitk - 1) / p.splitk;
-        kbeg = blockIdx.z * per;
+        kbeg = zidx * per;
         kend = min(kt_total, kbeg + per);
     } else {
-        zb = blockIdx.z;
+        zb = zidx;
     }
     const char* x0 = reinterpret_cast<const char*>(reinterpret_cast<const T*>(p.x0) + (int64_t)zb * p.zx);
     const char* x1 = reinterpret_cast<const char*>(p.x1);
@@ -166,7 +172,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(const ur_igemm_desc p) {
     int xa[XI], xy[XI], xx[XI];
 #pragma unroll
     for (int it = 0; it < XI; ++it) {
-        const int r = (wave * XI + it) * 8 + (lane >> 3);
+        const int r = (it * NW + wave) * 8 + (lane >> 3);
         const int m = m0 + r;
         if (CONV) {
             const int hw = p.Hout * p.Wout;
@@ -189,7 +195,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(const ur_igemm_desc p) {
     int winc[WI];
 #pragma unroll
     for (int it = 0; it < WI; ++it) {
-        const int r = (wave * WI + it) * 8 + (lane >> 3);  // LDS row of the tile
+        const int r = (it * NW + wave) * 8 + (lane >> 3);  // LDS row of the tile
         const int rho = r & 63;
         // LDS row (f, i) = f*16 + i holds semantic column (i>>2)*16 + f*4 + (i&3) of its 64-group
         const int sem = (r & ~63) | (((rho >> 2) & 3) << 4) | ((rho >> 4) << 2) | (rho & 3);
@@ -265,12 +271,12 @@ __global__ void __launch_bounds__(256) igemm_kernel(const ur_igemm_desc p) {
         char* ws = xs + XT_BYTES;
 #pragma unroll
         for (int it = 0; it < XI; ++it) {
-            glds16(xptr[it], xs + (wave * XI + it) * 1024);
+            if (it * NW + wave < BM / 8) glds16(xptr[it], xs + (it * NW + wave) * 1024);
             xptr[it] += xinc[it];
         }
 #pragma unroll
         for (int it = 0; it < WI; ++it) {
-            glds16(wptr[it], ws + (wave * WI + it) * 1024);
+            if (it * NW + wave < BN / 8) glds16(wptr[it], ws + (it * NW + wave) * 1024);
             wptr[it] += winc[it];
         }
         seg_left -= 1;
@@ -339,7 +345,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(const ur_igemm_desc p) {
             for (int r = 0; r < 4; ++r) v[f * 4 + r] = acc[mf][f][r];
         if (p.splitk > 1) {
             if (m < p.M) {
-                float4* pp = reinterpret_cast<float4*>(p.partial + ((int64_t)blockIdx.z * p.M + m) * p.ldp + nc);
+                float4* pp = reinterpret_cast<float4*>(p.partial + ((int64_t)zidx * p.M + m) * p.ldp + nc);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) pp[i] = make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
             }
@@ -379,7 +385,8 @@ __global__ void __launch_bounds__(256) igemm_splitk_reduce(const ur_igemm_desc p
 struct TileCfg { int bm, bn, stages; };
 // index = UR_TILE_* (include/ur_kernels.h)
 static const TileCfg kTiles[UR_TILE_COUNT] = {{0, 0, 0},      {128, 128, 2}, {128, 64, 3}, {64, 64, 3},
-                                              {128, 128, 3}, {128, 64, 2},  {64, 64, 4},  {64, 64, 2}};
+                                              {128, 128, 3}, {128, 64, 2},  {64, 64, 4},  {64, 64, 2},
+                                              {256, 128, 2}, {128, 320, 2}, {128, 256, 2}, {256, 256, 2}};
 
 static int pick_tile(const ur_igemm_desc& d) {
     // Cost model: the busiest CU runs ceil(workgroups / 256) tiles; bigger tiles have a better
@@ -410,7 +417,7 @@ static int launch_cfg(const ur_igemm_desc& d, hipStream_t s) {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             once = true;
         }
-        hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, NSTAGE, true>), grid, dim3(256), lds, s, d);
+        hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, NSTAGE, true>), grid, dim3(WM * WN * 64), lds, s, d);
     } else {
         static bool once = false;
         if (!once) {
@@ -418,7 +425,7 @@ static int launch_cfg(const ur_igemm_desc& d, hipStream_t s) {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             once = true;
         }
-        hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, NSTAGE, false>), grid, dim3(256), lds, s, d);
+        hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, NSTAGE, false>), grid, dim3(WM * WN * 64), lds, s, d);
     }
     e = hipGetLastError();
     if (e != hipSuccess) return -(int)e;
@@ -443,6 +450,10 @@ static int launch_dtype(ur_igemm_desc& d, hipStream_t s) {
         case UR_TILE_128x64_S2: return launch_cfg<T, 128, 64, 4, 1, 2>(d, s);
         case UR_TILE_64x64_S4: return launch_cfg<T, 64, 64, 4, 1, 4>(d, s);
         case UR_TILE_64x64_S2: return launch_cfg<T, 64, 64, 4, 1, 2>(d, s);
+        case UR_TILE_256x128: return launch_cfg<T, 256, 128, 4, 2, 2>(d, s);
+        case UR_TILE_128x320: return launch_cfg<T, 128, 320, 2, 5, 2>(d, s);
+        case UR_TILE_128x256: return launch_cfg<T, 128, 256, 2, 4, 2>(d, s);
+        case UR_TILE_256x256: return launch_cfg<T, 256, 256, 4, 4, 2>(d, s);
     }
     return UR_E_BADARG;
 }
@@ -456,8 +467,14 @@ static int64_t padded_ldp(const ur_igemm_desc& d, int tile) {
 
 extern "C" int64_t ur_igemm_partial_floats(const ur_igemm_desc* d) {
     if (!d || d->splitk <= 1) return 0;
-    // worst case over tiles: N padded to 128
-    return (int64_t)d->splitk * d->M * (((int64_t)d->N + 127) / 128 * 128);
+    // worst case over the tile configurations: N padded to a multiple of the tile width
+    int64_t ldp = 0;
+    for (int t = 1; t < UR_TILE_COUNT; ++t) {
+        const int64_t bn = ur::kTiles[t].bn;
+        const int64_t v = (d->N + bn - 1) / bn * bn;
+        if (v > ldp) ldp = v;
+    }
+    return (int64_t)d->splitk * d->M * ldp;
 }
 
 extern "C" int ur_igemm(const ur_igemm_desc* din, void* stream) {

@@ -23,7 +23,8 @@ TILE_128x128_S3, TILE_128x64_S2, TILE_64x64_S4, TILE_64x64_S2 = 4, 5, 6, 7
 # tile id -> (BM, BN, relative efficiency guess for the analytic planner, LDS ring depth)
 _TILES = {TILE_128x128: (128, 128, 1.0, 2), TILE_128x64: (128, 64, 0.85, 3), TILE_64x64: (64, 64, 0.6, 3),
           TILE_128x128_S3: (128, 128, 0.9, 3), TILE_128x64_S2: (128, 64, 0.7, 2), TILE_64x64_S4: (64, 64, 0.6, 4),
-          TILE_64x64_S2: (64, 64, 0.5, 2)}
+          TILE_64x64_S2: (64, 64, 0.5, 2), 8: (256, 128, 1.1, 2), 9: (128, 320, 1.1, 2), 10: (128, 256, 1.1, 2),
+          11: (256, 256, 1.2, 2)}
 _PLANNER_TILES = (TILE_128x128, TILE_128x64, TILE_64x64)
 
 _zero_pages = {}
