@@ -103,7 +103,8 @@ __global__ void __launch_bounds__(256) attention_kernel(const ur_attn_desc p) {
         acc_o[i][0] = f32x4{0.f, 0.f, 0.f, 0.f};
         acc_o[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    float m_run[2] = {-INFINITY, -INFINITY};
+    constexpr float NEG_BIG = -1.0e30f;
+    float m_run[2] = {NEG_BIG, NEG_BIG};
     float l_run[2] = {0.f, 0.f};
     const float cs = p.scale * 1.44269504088896341f;  // softmax in base 2
 
@@ -138,7 +139,9 @@ __global__ void __launch_bounds__(256) attention_kernel(const ur_attn_desc p) {
                 }
         }
 
-        // ---- online softmax (per query fragment f; this lane's query is l15 of that fragment)
+        // ---- online softmax (per query fragment f; this lane's query is l15 of that fragment).
+        // Raw scores are kept unscaled: max in the raw domain (scale > 0), p = exp2(s*cs - m*cs) is ONE fma
+        // feeding v_exp_f32.  Masked keys use a large finite negative (exp2 -> 0) so no inf/NaN arithmetic.
         const bool tail = (kt * 64 + 64 > p.Tk);
         vec8 pf[2][2];  // [kb][f] : P^T fragment = 8 consecutive keys of this lane's query
 #pragma unroll
@@ -150,25 +153,26 @@ __global__ void __launch_bounds__(256) attention_kernel(const ur_attn_desc p) {
                 for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        float v = acc_s[kb][sub][f][r] * cs;
+                        float v = acc_s[kb][sub][f][r];
                         if (tail) {
                             const int key = kt * 64 + kb * 32 + qq * 8 + sub * 4 + r;
-                            if (key >= p.Tk) v = -INFINITY;
+                            if (key >= p.Tk) v = NEG_BIG;
                         }
                         t[kb * 8 + sub * 4 + r] = v;
                     }
-            float mx = t[0];
+            float mx = fmaxf(fmaxf(t[0], t[1]), fmaxf(t[2], t[3]));
 #pragma unroll
-            for (int i = 1; i < 16; ++i) mx = fmaxf(mx, t[i]);
+            for (int i = 4; i < 16; i += 4) mx = fmaxf(mx, fmaxf(fmaxf(t[i], t[i + 1]), fmaxf(t[i + 2], t[i + 3])));
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float m_new = fmaxf(m_run[f], mx);
-            const float alpha = exp2f(m_run[f] - m_new);
+            const float alpha = __builtin_amdgcn_exp2f((m_run[f] - m_new) * cs);
+            const float mc = -m_new * cs;
             m_run[f] = m_new;
             float ps = 0.f;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                t[i] = exp2f(t[i] - m_new);
+                t[i] = __builtin_amdgcn_exp2f(fmaf(t[i], cs, mc));
                 ps += t[i];
             }
             l_run[f] = l_run[f] * alpha + ps;

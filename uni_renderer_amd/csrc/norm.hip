@@ -40,16 +40,28 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(const T* __restrict__ x0,
             if (cv < nv0) { base = x0 + (int64_t)b * rows * c0; ld = c0; co = cv * 8; }
             else { base = x1 + (int64_t)b * rows * c1; ld = c1; co = (cv - nv0) * 8; }
             int r = rbeg + rsub;
-            for (; r + 3 * rs < rend; r += 4 * rs) {  // 4 independent 16-byte loads in flight per thread
-                float v0[8], v1[8], v2[8], v3[8];
+            for (; r + 7 * rs < rend; r += 8 * rs) {  // 8 independent 16-byte loads in flight per thread
+                typename Vec8<T>::type raw[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    raw[u] = *reinterpret_cast<const typename Vec8<T>::type*>(base + (int64_t)(r + u * rs) * ld + co);
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float v = (float)raw[u][i];
+                        s[i] += v;
+                        ss[i] += v * v;
+                    }
+            }
+            for (; r + 1 * rs < rend; r += 2 * rs) {
+                float v0[8], v1[8];
                 load8(base + (int64_t)r * ld + co, v0);
                 load8(base + (int64_t)(r + rs) * ld + co, v1);
-                load8(base + (int64_t)(r + 2 * rs) * ld + co, v2);
-                load8(base + (int64_t)(r + 3 * rs) * ld + co, v3);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    s[i] += (v0[i] + v1[i]) + (v2[i] + v3[i]);
-                    ss[i] += (v0[i] * v0[i] + v1[i] * v1[i]) + (v2[i] * v2[i] + v3[i] * v3[i]);
+                    s[i] += v0[i] + v1[i];
+                    ss[i] += v0[i] * v0[i] + v1[i] * v1[i];
                 }
             }
             for (; r < rend; r += rs) {
@@ -141,12 +153,29 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const T* __restrict__ x0,
         if (cv < nv0) { base = x0 + (int64_t)b * rows * c0; ld = c0; co = cv * 8; }
         else { base = x1 + (int64_t)b * rows * c1; ld = c1; co = (cv - nv0) * 8; }
         T* ob = out + (int64_t)b * rows * C + cv * 8;
-        for (int r = rbeg + rsub; r < rend; r += rs) {
+        int r = rbeg + rsub;
+        for (; r + 3 * rs < rend; r += 4 * rs) {  // 4 loads in flight, then normalise + store
+            typename Vec8<T>::type raw[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                raw[u] = *reinterpret_cast<const typename Vec8<T>::type*>(base + (int64_t)(r + u * rs) * ld + co);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float y = (float)raw[u][i] * a[i] + sh[i];
+                    v[i] = silu ? silu_f(y) : y;
+                }
+                store8(ob + (int64_t)(r + u * rs) * C, v);
+            }
+        }
+        for (; r < rend; r += rs) {
             float v[8];
             load8(base + (int64_t)r * ld + co, v);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                float y = v[i] * a[i] + sh[i];
+                const float y = v[i] * a[i] + sh[i];
                 v[i] = silu ? silu_f(y) : y;
             }
             store8(ob + (int64_t)r * C, v);

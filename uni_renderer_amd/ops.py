@@ -230,7 +230,7 @@ def _gn_chunks(B: int, rows: int):
     return nstat, napply
 
 
-def groupnorm(x, gamma, beta, eps, *, x1=None, groups=32, silu=False):
+def groupnorm(x, gamma, beta, eps, *, x1=None, groups=32, silu=False, nstat=None, napply=None):
     """GroupNorm over NHWC x (or over cat(x, x1)); returns one contiguous [B,H,W,C0+C1] tensor."""
     _require_gpu(x)
     lib = _lib.load()
@@ -238,7 +238,8 @@ def groupnorm(x, gamma, beta, eps, *, x1=None, groups=32, silu=False):
     C0 = x.shape[-1]
     C1 = x1.shape[-1] if x1 is not None else 0
     rows = x.numel() // (B * C0)
-    nstat, napply = _gn_chunks(B, rows)
+    _ns, _na = _gn_chunks(B, rows)
+    nstat, napply = (nstat or _ns), (napply or _na)
     part = torch.empty(B * nstat * groups * 2, dtype=torch.float32, device=x.device)
     out = torch.empty(*x.shape[:-1], C0 + C1, dtype=x.dtype, device=x.device)
     s = _stream()

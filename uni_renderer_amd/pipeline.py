@@ -1,0 +1,345 @@
+"""L3 sampling pipeline (mirror of the reference's ``models/pipeline.py`` ``UniRendererPipeline``, 124-4290).
+
+The reference class has no ``__call__``; its live entry points are kept with their names,
+keyword blocks and return conventions:
+
+  ``real_image2mask_3mod_albedo`` (ref 2391-2808)  inverse rendering of a real image   enc + unet + dec per step
+  ``image2mask_3mod_albedo``      (ref 1990-2390)  same, tensor inputs in [0, 1]
+  ``mask2image_3mod_albedo``      (ref 1368-1697)  rendering from attributes             enc + unet per step
+
+Per step the three networks run through ``graph.GraphedDualStreamStep`` (one hipGraph replay) when shapes are
+static, otherwise eagerly; both only enqueue HIP kernels.  The frozen side models (VAE, CLIP text encoder --
+SURVEY.md S2) are duck-typed objects supplied by the caller exactly as in ``eval/test_real.py:470-495`` and are
+out of scope here; ``prompt_embeds=`` / tensor latents let the loop run without them.  Schedulers follow the
+diffusers protocol (``scheduler_img`` ... ``scheduler_env`` attributes, test_real.py:485-492); a built-in x0
+DDIM (schedulers.py) is attached by default.  The 11 legacy 12/16-channel methods of the reference
+ are not reproduced.
+"""
+from __future__ import annotations
+
+import os
+from contextlib import contextmanager
+from typing import Any, Callable, Dict, List, Optional, Sequence, Tuple, Union
+
+import torch
+
+from .controlnet import AttributeDecoderModel, AttributeEncoderModel, UNet2DConditionModel
+from .graph import GraphedDualStreamStep, dual_stream_step
+from .schedulers import DDIMScheduler, retrieve_timesteps
+
+SCHEDULER_NAMES = ("img", "attr", "material", "albedo", "normal", "spec_light", "diff_light", "env")
+ATTR_GROUPS = ("material", "normal", "albedo", "spec_light", "diff_light", "env")  # after the mask group
+
+
+class UniRendererPipeline:
+    def __init__(self, vae=None, text_encoder=None, tokenizer=None, unet: UNet2DConditionModel = None,
+                 controlnet: AttributeEncoderModel = None, controldec: AttributeDecoderModel = None, scheduler=None,
+                 safety_checker=None, feature_extractor=None, image_encoder=None, requires_safety_checker: bool = False):
+        self.vae, self.text_encoder, self.tokenizer = vae, text_encoder, tokenizer
+        self.unet, self.controlnet, self.controldec = unet, controlnet, controldec
+        self.safety_checker, self.feature_extractor, self.image_encoder = safety_checker, feature_extractor, image_encoder
+        for n in SCHEDULER_NAMES:  # test_real.py:485-492 overwrites these with UniPC instances
+            setattr(self, f"scheduler_{n}", scheduler if (scheduler is not None and n == "img") else DDIMScheduler())
+        self.vae_scale_factor = 8
+        self.use_hip_graph = True
+        self._graphs: Dict[Tuple, GraphedDualStreamStep] = {}
+        self._progress_kwargs: Dict[str, Any] = {}
+        self._guidance_scale = 0.0
+        self._num_timesteps = 0
+
+    # ---- construction / placement ---------------------------------------------------------------
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path: str, torch_dtype=None, **components):
+        """Components given as keywords are used as-is (test_real.py:470-482); unet / controlnet / controldec
+        missing from the keywords are loaded from the diffusers-layout subfolders of the path."""
+        for name, klass in (("unet", UNet2DConditionModel), ("controlnet", AttributeEncoderModel),
+                            ("controldec", AttributeDecoderModel)):
+            if components.get(name) is None and os.path.isdir(os.path.join(pretrained_model_name_or_path, name)):
+                components[name] = klass.from_pretrained(pretrained_model_name_or_path, subfolder=name,
+                                                         torch_dtype=torch_dtype)
+        known = ("vae", "text_encoder", "tokenizer", "unet", "controlnet", "controldec", "scheduler", "safety_checker",
+                 "feature_extractor", "image_encoder", "requires_safety_checker")
+        return cls(**{k: v for k, v in components.items() if k in known})
+
+    def to(self, *args, **kwargs):
+        for n in ("vae", "text_encoder", "unet", "controlnet", "controldec"):
+            m = getattr(self, n)
+            if m is not None and hasattr(m, "to"):
+                setattr(self, n, m.to(*args, **kwargs))
+        self._graphs.clear()
+        return self
+
+    @property
+    def device(self):
+        return self.unet.device
+
+    _execution_device = device
+
+    def set_progress_bar_config(self, **kwargs):
+        self._progress_kwargs = kwargs
+
+    @contextmanager
+    def progress_bar(self, total=None):
+        try:
+            from tqdm.auto import tqdm
+
+            bar = tqdm(total=total, **self._progress_kwargs)
+        except Exception:  # pragma: no cover
+            bar = None
+        try:
+            yield bar if bar is not None else _NullBar()
+        finally:
+            if bar is not None:
+                bar.close()
+
+    @property
+    def guidance_scale(self):
+        return self._guidance_scale
+
+    @property
+    def do_classifier_free_guidance(self):
+        return self._guidance_scale != 0  # ref 806-808
+
+    # ---- helpers (ref 251-431, 674-719) --------------------------------------------------------------
+    def encode_prompt(self, prompt, device, num_images_per_prompt, do_classifier_free_guidance, negative_prompt=None,
+                      prompt_embeds=None, negative_prompt_embeds=None, lora_scale=None, clip_skip=None):
+        if prompt_embeds is None:
+            if self.text_encoder is None or self.tokenizer is None:
+                raise ValueError("pass prompt_embeds= or attach tokenizer + text_encoder (CLIP is out of scope here)")
+            prompts = [prompt] if isinstance(prompt, str) else list(prompt)
+            ids = self.tokenizer(prompts, padding="max_length", max_length=self.tokenizer.model_max_length,
+                                 truncation=True, return_tensors="pt").input_ids
+            prompt_embeds = self.text_encoder(ids.to(device))[0]
+        bs = prompt_embeds.shape[0]
+        prompt_embeds = prompt_embeds.to(device=device).repeat(1, num_images_per_prompt, 1).view(
+            bs * num_images_per_prompt, prompt_embeds.shape[1], -1)
+        if do_classifier_free_guidance and negative_prompt_embeds is None:
+            if self.text_encoder is not None and self.tokenizer is not None:
+                neg = [""] * bs if negative_prompt is None else ([negative_prompt] * bs if isinstance(negative_prompt, str) else list(negative_prompt))
+                ids = self.tokenizer(neg, padding="max_length", max_length=prompt_embeds.shape[1], truncation=True,
+                                     return_tensors="pt").input_ids
+                negative_prompt_embeds = self.text_encoder(ids.to(device))[0]
+            else:
+                negative_prompt_embeds = torch.zeros_like(prompt_embeds[:bs])
+        if do_classifier_free_guidance:
+            negative_prompt_embeds = negative_prompt_embeds.to(device=device, dtype=prompt_embeds.dtype).repeat(
+                1, num_images_per_prompt, 1).view(bs * num_images_per_prompt, prompt_embeds.shape[1], -1)
+        return prompt_embeds, negative_prompt_embeds
+
+    def prepare_image(self, image, width, height, batch_size, num_images_per_prompt, device, dtype,
+                      do_classifier_free_guidance=False, guess_mode=False):
+        """PIL / ndarray / tensor -> [B,3,H,W] in [-1, 1] (VaeImageProcessor.preprocess semantics)."""
+        if not torch.is_tensor(image):
+            import numpy as np
+
+            imgs = image if isinstance(image, (list, tuple)) else [image]
+            arr = []
+            for im in imgs:
+                if hasattr(im, "resize"):  # PIL
+                    im = np.asarray(im.convert("RGB").resize((width, height)), dtype=np.float32) / 255.0
+                arr.append(torch.from_numpy(np.asarray(im, dtype=np.float32)).permute(2, 0, 1))
+            image = torch.stack(arr) * 2.0 - 1.0
+        if image.shape[0] == 1 and batch_size > 1:
+            image = image.repeat(batch_size, 1, 1, 1)
+        return image.to(device=device, dtype=dtype)
+
+    def prepare_latents(self, batch_size, num_channels_latents, height, width, dtype, device, generator, latents=None):
+        shape = (batch_size, num_channels_latents, height // self.vae_scale_factor, width // self.vae_scale_factor)
+        if latents is None:
+            latents = torch.randn(shape, generator=generator, device=device, dtype=dtype)
+        else:
+            latents = latents.to(device)
+        return latents * self.scheduler_img.init_noise_sigma  # ref 719
+
+    def _batch_prompt(self, prompt_embeds, negative_prompt_embeds, batch_size):
+        """Broadcast a single prompt to the image batch (ref 2504-2507), then stack [uncond, cond] for CFG."""
+        if prompt_embeds.shape[0] == 1 and batch_size > 1:
+            prompt_embeds = prompt_embeds.repeat(batch_size, 1, 1)
+        if self.do_classifier_free_guidance:
+            neg = negative_prompt_embeds
+            if neg.shape[0] == 1 and batch_size > 1:
+                neg = neg.repeat(batch_size, 1, 1)
+            prompt_embeds = torch.cat([neg, prompt_embeds])
+        return prompt_embeds
+
+    def _vae_encode(self, image):
+        w = getattr(self.vae, "dtype", image.dtype)
+        return self.vae.encode(image.to(dtype=w)).latent_dist.sample() * self.vae.config.scaling_factor
+
+    def _vae_decode(self, latents, generator=None):
+        return self.vae.decode(latents / self.vae.config.scaling_factor, return_dict=False)[0]
+
+    @staticmethod
+    def _postprocess(image: torch.Tensor, output_type: str):
+        image = (image.float() / 2 + 0.5).clamp(0, 1)
+        if output_type == "pt":
+            return image
+        arr = image.cpu().permute(0, 2, 3, 1).numpy()
+        if output_type == "np":
+            return arr
+        from PIL import Image
+
+        return [Image.fromarray((a * 255).round().astype("uint8")) for a in arr]
+
+    # ---- one denoise step of the three networks ----------------------------------------------------------
+    def _step(self, x_img, cond28, ehs, t_img, t_attr, run_decoder: bool, cond_scale: float = 1.0):
+        B, _, h, w = x_img.shape
+        dt = self.unet.dtype
+        if self.use_hip_graph and x_img.is_cuda and cond_scale == 1.0:
+            key = (B, h, w, ehs.shape[1], ehs.shape[2], run_decoder, dt)
+            g = self._graphs.get(key)
+            if g is None:
+                g = GraphedDualStreamStep(self.unet, self.controlnet, self.controldec, B, (h, w), ehs.shape[2], dtype=dt,
+                                          device=x_img.device, run_decoder=run_decoder, cond_channels=cond28.shape[1],
+                                          img_channels=x_img.shape[1], ctx_len=ehs.shape[1])
+                g.load_inputs(x_img, cond28, ehs, t_img, t_attr)
+                g.capture()
+                self._graphs[key] = g
+            return g.step(x_img, cond28, ehs, t_img, t_attr)
+        tb = lambda t: torch.as_tensor(t, device=x_img.device).float().reshape(-1)
+        return dual_stream_step(self.unet, self.controlnet, self.controldec, x_img.to(dt), cond28.to(dt), ehs.to(dt),
+                                tb(t_img), tb(t_attr), run_decoder)
+
+    # =====================================================================================================
+    @torch.no_grad()
+    def real_image2mask_3mod_albedo(
+        self, prompt: Union[str, List[str]] = None, image=None, masks=None, height: Optional[int] = None,
+        width: Optional[int] = None, num_inference_steps: int = 50, timesteps: List[int] = None,
+        guidance_scale: float = 7.5, negative_prompt=None, num_images_per_prompt: Optional[int] = 1, eta: float = 0.0,
+        generator=None, latents=None, prompt_embeds=None, negative_prompt_embeds=None, ip_adapter_image=None,
+        output_type: Optional[str] = "pil", return_dict: bool = True, cross_attention_kwargs=None,
+        controlnet_conditioning_scale: Union[float, List[float]] = 1.0, guess_mode: bool = False,
+        control_guidance_start=0.0, control_guidance_end=1.0, clip_skip=None, callback_on_step_end=None,
+        callback_on_step_end_tensor_inputs: List[str] = ["latents"], image_latents=None, mask_latents=None, **kwargs,
+    ):
+        """Inverse rendering: image (+ mask) -> material / normal / albedo / specular / diffuse / environment.
+        Returns ``(material_latents, normal, albedo, spec_light, diff_light, env)`` like the reference (2808).
+        ``image_latents`` / ``mask_latents`` (already VAE-encoded, scaled) bypass the VAE; ``output_type="latent"``
+        returns the six latents instead of decoded images."""
+        self._guidance_scale = guidance_scale
+        device = self._execution_device
+        batch_size = 1 if isinstance(prompt, str) else (len(prompt) if prompt is not None else prompt_embeds.shape[0])
+        prompt_embeds, negative_prompt_embeds = self.encode_prompt(
+            prompt, device, num_images_per_prompt, self.do_classifier_free_guidance, negative_prompt,
+            prompt_embeds=prompt_embeds, negative_prompt_embeds=negative_prompt_embeds)
+        timesteps_attr, num_inference_steps = retrieve_timesteps(self.scheduler_attr, num_inference_steps, device)
+        for n in ATTR_GROUPS:
+            retrieve_timesteps(getattr(self, f"scheduler_{n}"), num_inference_steps, device)
+        self._num_timesteps = len(timesteps_attr)
+        timesteps_img = torch.zeros_like(timesteps_attr)  # the image latent is clean: t_img = 0 (ref 2476)
+
+        if image_latents is None:
+            if not torch.is_tensor(image):
+                image = self.prepare_image(image, width, height, batch_size * num_images_per_prompt, num_images_per_prompt,
+                                           device, self.controlnet.dtype)
+                masks = self.prepare_image(masks, width, height, batch_size * num_images_per_prompt, num_images_per_prompt,
+                                           device, self.controlnet.dtype)
+            else:  # ref 2504-2507
+                batch_size = image.shape[0]
+            image_latents, mask_latents = self._vae_encode(image), self._vae_encode(masks)
+        else:
+            batch_size = image_latents.shape[0]
+        prompt_embeds = self._batch_prompt(prompt_embeds, negative_prompt_embeds, batch_size)
+        h8, w8 = image_latents.shape[-2:]
+        height, width = height or h8 * self.vae_scale_factor, width or w8 * self.vae_scale_factor
+        nlat = self.unet.config.in_channels
+        lat = {n: self.prepare_latents(batch_size * num_images_per_prompt, nlat, height, width, prompt_embeds.dtype,
+                                       device, generator, latents) for n in ATTR_GROUPS}
+        cfg = self.do_classifier_free_guidance
+        dup = (lambda t: torch.cat([t, t])) if cfg else (lambda t: t)
+        x_img = self.scheduler_img.scale_model_input(dup(image_latents), 0)
+        x_mask = self.scheduler_img.scale_model_input(dup(mask_latents), 0)
+        cond_scale = float(controlnet_conditioning_scale)
+
+        with self.progress_bar(total=num_inference_steps) as bar:
+            for i, (t_img, t_attr) in enumerate(zip(timesteps_img, timesteps_attr)):
+                cat = torch.cat([dup(lat[n]) for n in ATTR_GROUPS], dim=1)
+                cat = self.scheduler_attr.scale_model_input(cat, t_attr)
+                cond28 = torch.cat((x_mask.to(cat.dtype), cat), dim=1)  # mask latent first: 4 + 6*4 = 28 channels
+                out = self._step(x_img, cond28, prompt_embeds, t_img, t_attr, run_decoder=True, cond_scale=cond_scale)
+                label_pred = out["attr_pred"][:, 4:]  # drop the mask group (ref 2691)
+                for k, n in enumerate(ATTR_GROUPS):
+                    pred = label_pred[:, 4 * k:4 * k + 4]
+                    if cfg:
+                        # chunk order exactly as the reference reads it (2697-2721)
+                        p_cond, p_uncond = pred.chunk(2)
+                        pred = p_uncond + self.guidance_scale * (p_cond - p_uncond) if n == "material" else p_cond
+                    lat[n] = getattr(self, f"scheduler_{n}").step(pred, t_attr, lat[n], return_dict=False)[0]
+                if callback_on_step_end is not None:
+                    callback_on_step_end(self, i, t_attr, {"latents": lat["material"]})
+                bar.update()
+        if output_type == "latent":
+            return tuple(lat[n] for n in ATTR_GROUPS)
+        imgs = [self._postprocess(self._vae_decode(lat[n], generator), output_type) for n in ATTR_GROUPS[1:]]
+        return (lat["material"], *imgs)
+
+    @torch.no_grad()
+    def image2mask_3mod_albedo(self, prompt=None, image: torch.Tensor = None, masks: torch.Tensor = None, **kwargs):
+        """Dataset-evaluation variant (ref 1990-2390): tensor inputs in [0, 1] are normalised to [-1, 1] first."""
+        if image is not None:
+            image = image * 2.0 - 1.0
+        if masks is not None:
+            masks = masks * 2.0 - 1.0
+        return self.real_image2mask_3mod_albedo(prompt=prompt, image=image, masks=masks, **kwargs)
+
+    @torch.no_grad()
+    def mask2image_3mod_albedo(
+        self, prompt=None, masks_image=None, material_num=None, normal_image=None, albedo_image=None,
+        spec_light_image=None, diff_light_image=None, env_image=None, height: Optional[int] = None,
+        width: Optional[int] = None, num_inference_steps: int = 50, timesteps=None, guidance_scale: float = 7.5,
+        negative_prompt=None, num_images_per_prompt: Optional[int] = 1, eta: float = 0.0, generator=None, latents=None,
+        prompt_embeds=None, negative_prompt_embeds=None, output_type: Optional[str] = "pil", return_dict: bool = True,
+        cross_attention_kwargs=None, controlnet_conditioning_scale: float = 1.0, guess_mode: bool = False,
+        attr_latents: Optional[torch.Tensor] = None, **kwargs,
+    ):
+        """Rendering: attributes -> image (enc + unet per step; the decoder is not run, ref 1631-1639).
+        ``attr_latents`` ([B,28,h,w], mask first) bypasses the VAE encodes of the seven attribute images."""
+        self._guidance_scale = guidance_scale
+        device = self._execution_device
+        batch_size = 1 if isinstance(prompt, str) else (len(prompt) if prompt is not None else prompt_embeds.shape[0])
+        prompt_embeds, negative_prompt_embeds = self.encode_prompt(
+            prompt, device, num_images_per_prompt, self.do_classifier_free_guidance, negative_prompt,
+            prompt_embeds=prompt_embeds, negative_prompt_embeds=negative_prompt_embeds)
+        timesteps, num_inference_steps = retrieve_timesteps(self.scheduler_img, num_inference_steps, device)
+        self._num_timesteps = len(timesteps)
+        timesteps_attr = torch.zeros_like(timesteps)  # attributes are clean (ref 1455)
+        if attr_latents is None:
+            bs = batch_size * num_images_per_prompt
+            prep = lambda im: self.prepare_image(im, width, height, bs, num_images_per_prompt, device, self.controlnet.dtype)
+            l_normal = self._vae_encode(prep(normal_image))
+            m = torch.as_tensor(material_num, device=l_normal.device, dtype=l_normal.dtype)
+            metallic = torch.zeros_like(l_normal[:, :2]) + m[0]
+            rough = torch.zeros_like(l_normal[:, :2]) + m[1]
+            l_material = torch.cat((metallic, rough), dim=1) * 2 - 1.0  # constant 2+2 channels (ref 1534-1541)
+            parts = [self._vae_encode(prep(masks_image)), l_material, l_normal, self._vae_encode(prep(albedo_image)),
+                     self._vae_encode(prep(spec_light_image)), self._vae_encode(prep(diff_light_image)),
+                     self._vae_encode(prep(env_image))]
+            attr_latents = torch.cat(parts, dim=1)
+        batch_size = attr_latents.shape[0]
+        prompt_embeds = self._batch_prompt(prompt_embeds, negative_prompt_embeds, batch_size)
+        h8, w8 = attr_latents.shape[-2:]
+        height, width = height or h8 * self.vae_scale_factor, width or w8 * self.vae_scale_factor
+        latents_img = self.prepare_latents(batch_size, 4, height, width, prompt_embeds.dtype, device, generator, latents)
+        cfg = self.do_classifier_free_guidance
+        dup = (lambda t: torch.cat([t, t])) if cfg else (lambda t: t)
+        cond28 = dup(self.scheduler_img.scale_model_input(attr_latents, 0))
+        with self.progress_bar(total=num_inference_steps) as bar:
+            for i in range(len(timesteps)):
+                t_img, t_attr = timesteps[i], timesteps_attr[i]
+                x = self.scheduler_img.scale_model_input(dup(latents_img), t_img)
+                out = self._step(x, cond28, prompt_embeds, t_img, t_attr, run_decoder=False,
+                                 cond_scale=float(controlnet_conditioning_scale))
+                img_pred = out["img_pred"]
+                if cfg:
+                    p_cond, p_uncond = img_pred.chunk(2)  # ref 1642-1644
+                    img_pred = p_uncond + self.guidance_scale * (p_cond - p_uncond)
+                latents_img = self.scheduler_img.step(img_pred, t_img, latents_img, return_dict=False)[0]
+                bar.update()
+        if output_type == "latent":
+            return latents_img
+        return self._postprocess(self._vae_decode(latents_img, generator), output_type)
+
+
+class _NullBar:
+    def update(self, *_):
+        return None
