@@ -63,7 +63,7 @@ def make_inputs(B, L, dev, dtype, seed):
     return x_t, cond, ehs, t_img, t_attr
 
 
-def measure_roofline(models, inputs):
+def measure_roofline(models, inputs, by_shape=False):
     """One eager step with every launch bracketed by HIP events on the launch stream; per kernel class sums."""
     from uni_renderer_amd import ops
     from uni_renderer_amd.graph import dual_stream_step
@@ -72,7 +72,7 @@ def measure_roofline(models, inputs):
     with torch.no_grad():
         dual_stream_step(*models, *inputs)  # untimed, warm
         torch.cuda.synchronize()
-        ops.profile_into(rec)
+        ops.profile_into(rec, by_shape)
         dual_stream_step(*models, *inputs)
         torch.cuda.synchronize()
         ops.profile_into(None)
@@ -178,6 +178,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="time eager launches instead of the HIP graph")
     ap.add_argument("--kernel-table", action="store_true", help="print the per-kernel-class table to stderr")
+    ap.add_argument("--shape-table", default="", help="write a per-(kernel, problem shape) table (JSON) to this path")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -264,6 +265,10 @@ def main():
             if args.kernel_table:
                 for r in table:
                     print(json.dumps(r), file=sys.stderr)
+            if args.shape_table:
+                _, stable, _ = measure_roofline(models, inputs, by_shape=True)
+                with open(args.shape_table, "w") as f:
+                    json.dump(stable, f)
         if not args.no_cpu_baseline and world == 1:
             del runner
             out["cpu_baseline"] = cpu_baseline(args.batch, args.latent)

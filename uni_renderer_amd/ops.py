@@ -35,11 +35,13 @@ _plan_cache = {}
 # wrapper brackets its launch with HIP events recorded on the SAME stream the kernel is enqueued on and appends
 # (kernel-class key, algorithmic flops, algorithmic bytes, start, end).
 _prof = None
+_prof_by_shape = False
 
 
-def profile_into(records):
-    global _prof
+def profile_into(records, by_shape: bool = False):
+    global _prof, _prof_by_shape
     _prof = records
+    _prof_by_shape = by_shape
 
 
 def _prof_begin():
@@ -169,6 +171,8 @@ def igemm(*, x0, w, out, M, N, K, c0, c1=0, x1=None, ldx0, ldx1=0, ldw, ldc, tap
         z = max(zbatch, 1)
         key = (f"igemm_{_TILES[tile][0]}x{_TILES[tile][1]}s{_TILES[tile][3]}_{'conv3x3' if taps == 9 else 'gemm'}"
                + ("_splitk" if splitk > 1 else ""))
+        if _prof_by_shape:
+            key += f"|M{M}_N{N}_K{K}_z{z}_sk{splitk}"
         _prof_end(e0, key, 2.0 * M * N * K * z, (M * K / taps + N * K + M * N) * el * z)
     return out
 
@@ -222,12 +226,13 @@ def vt_proj(x, wv):
 # ---------------------------------------------------------------------------------------------
 # norms, attention, glue
 # ---------------------------------------------------------------------------------------------
-def _gn_chunks(B: int, rows: int):
-    """(stats chunks, apply chunks) per sample: >= 64 rows per stats workgroup (its reduction has a fixed
-    cost), ~16 rows per apply workgroup, both capped so that the grids stay around 1-2k workgroups."""
-    nstat = max(1, min(rows // 64, 64))
-    napply = max(1, min(rows // 16, max(1, 2048 // max(B, 1)), 256))
-    return nstat, napply
+def _gn_chunks_bytes(B: int, rows: int, C: int, esize: int = 2):
+    """Chunking by BYTES per workgroup: a stats workgroup streams ~32 KB, an apply workgroup ~8 KB in + 8 KB out;
+    never fewer than 2 rows per chunk, stats partials capped at 64 per sample (the apply prologue re-reduces them)."""
+    sample_bytes = rows * C * esize
+    nstat = max(1, min(sample_bytes // (32 << 10), rows // 2, 64))
+    napply = max(1, min(sample_bytes // (8 << 10), rows // 2, 512, max(1, 4096 // max(B, 1))))
+    return int(nstat), int(napply)
 
 
 def groupnorm(x, gamma, beta, eps, *, x1=None, groups=32, silu=False, nstat=None, napply=None):
@@ -238,7 +243,7 @@ def groupnorm(x, gamma, beta, eps, *, x1=None, groups=32, silu=False, nstat=None
     C0 = x.shape[-1]
     C1 = x1.shape[-1] if x1 is not None else 0
     rows = x.numel() // (B * C0)
-    _ns, _na = _gn_chunks(B, rows)
+    _ns, _na = _gn_chunks_bytes(B, rows, C0 + C1, x.element_size())
     nstat, napply = (nstat or _ns), (napply or _na)
     part = torch.empty(B * nstat * groups * 2, dtype=torch.float32, device=x.device)
     out = torch.empty(*x.shape[:-1], C0 + C1, dtype=x.dtype, device=x.device)
