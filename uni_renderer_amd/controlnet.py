@@ -285,26 +285,35 @@ class UNet2DConditionModel(_DenoiserBase):
                          cross_attention_kwargs=cross_attention_kwargs, added_cond_kwargs=added_cond_kwargs,
                          down_intrablock_additional_residuals=down_intrablock_additional_residuals,
                          encoder_attention_mask=encoder_attention_mask)
-        B, _, H, W = sample.shape
-        f = 2 ** self.num_upsamplers
-        forward_upsample_size = (H % f != 0) or (W % f != 0)  # ref 869-883
-        ctx = self._begin(B, timestep, sample.device, encoder_hidden_states)
-        dt = ctx.dtype
+        state = self.forward_down_mid(sample, timestep, encoder_hidden_states)
+        return self.forward_up(state, down_block_additional_residuals, mid_block_additional_residual, return_dict)
 
+    # The forward is split at the point where the other stream's features enter (ref 1078-1087): the down path +
+    # mid block do not depend on the encoder, so `graph.GraphedDualStreamStep` runs them concurrently with it.
+    def forward_down_mid(self, sample, timestep, encoder_hidden_states):
+        B, _, H, W = sample.shape
+        ctx = self._begin(B, timestep, sample.device, encoder_hidden_states)
         x = self._conv_in(sample, ctx)
         skips = (x,)
         for blk in self.down_blocks:
             x, st = blk(x, ctx)
             skips += st
-        raw_down = skips
+        raw_mid = self.mid_block(x, ctx)
+        return dict(ctx=ctx, raw_down=skips, raw_mid=raw_mid, hw=(H, W))
+
+    def forward_up(self, state, down_block_additional_residuals=None, mid_block_additional_residual=None,
+                   return_dict: bool = True):
+        ctx, raw_down, raw_mid = state["ctx"], state["raw_down"], state["raw_mid"]
+        H, W = state["hw"]
+        dt = ctx.dtype
+        f = 2 ** self.num_upsamplers
+        forward_upsample_size = (H % f != 0) or (W % f != 0)  # ref 869-883
+        skips, x = raw_down, raw_mid
         is_controlnet = mid_block_additional_residual is not None and down_block_additional_residuals is not None
         if down_block_additional_residuals is not None and not is_controlnet:
             raise NotImplementedError("T2I-adapter style down_block_additional_residuals without a mid residual")
-        if is_controlnet:  # ref 1078-1087: 12 exchange adds
+        if is_controlnet:  # ref 1078-1087: 12 exchange adds; ref 1114-1115: mid
             skips = tuple(ops.add(s, ops.to_nhwc(e, dt)) for s, e in zip(skips, down_block_additional_residuals))
-        x = self.mid_block(x, ctx)
-        raw_mid = x
-        if is_controlnet:  # ref 1114-1115
             x = ops.add(x, ops.to_nhwc(mid_block_additional_residual, dt))
         up_res = (x,)
         for i, blk in enumerate(self.up_blocks):

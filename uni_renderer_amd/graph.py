@@ -1,9 +1,17 @@
-"""The dual-stream denoise step as one replayable HIP graph.
+"""The dual-stream denoise step as one replayable HIP graph with two concurrent branches.
 
-A step is ~700 kernel launches (enc + unet + dec at SD-1.x size); issued eagerly from Python the host is
-the bottleneck, so for fixed shapes the whole step is captured once into a hipGraph (through PyTorch's
-capture of the current stream -- our C-ABI launches land on that stream) and replayed.  Inputs live in
-static buffers; outputs are the tensors produced during capture.
+A step is ~870 kernel launches (enc + unet + dec at SD-1.x size), most of them small (a few hundred workgroups,
+latency-bound on a 256-CU part).  Two MI355X-side measures:
+
+  * the step is captured once into a hipGraph (through PyTorch's capture of the current stream -- the C-ABI
+    launches land on that stream) and replayed, which removes the host from the loop;
+  * the two diffusion streams are independent for most of the step -- the attribute ENCODER does not depend on
+    the UNet's down path + mid block, and the attribute DECODER does not depend on the UNet's up path -- so they
+    are enqueued on two HIP streams (fork/join with events) and become parallel branches of the graph: kernels
+    of the two branches share the GPU and fill each other's idle CUs.
+
+            main:  unet.conv_in/down/mid ----+--> (+enc residuals) unet.up/conv_out ---+--> join
+            side:  enc (down/mid/zero-convs) -+--> dec (exchange 1x1 + up/conv_out) ----+
 
 Call pattern reproduced: ``enc -> unet -> dec`` of models/pipeline.py:2660-2690 (inverse rendering) and
 train/train.py:1324-1354; ``run_decoder=False`` gives the rendering direction (pipeline.py:1611-1629).
@@ -14,19 +22,50 @@ from typing import Dict, Optional
 
 import torch
 
+from . import ops
 
-def dual_stream_step(unet, enc, dec, x_t, cond, ehs, t_img, t_attr, run_decoder: bool = True) -> Dict[str, torch.Tensor]:
-    """Eager form of one step (same calls the reference's loops make)."""
-    res, mid, raw_enc, raw_mid_enc = enc(x_t, t_attr, encoder_hidden_states=ehs, controlnet_cond=cond,
-                                         return_dict=False)
-    img_pred, raw_unet, raw_mid_unet, _ = unet(
-        x_t, t_img, encoder_hidden_states=ehs, down_block_additional_residuals=res,
-        mid_block_additional_residual=mid, return_dict=False)
-    out = {"img_pred": img_pred}
+
+def dual_stream_step(unet, enc, dec, x_t, cond, ehs, t_img, t_attr, run_decoder: bool = True,
+                     side: Optional[torch.cuda.Stream] = None) -> Dict[str, torch.Tensor]:
+    """One step: the same calls the reference's loops make.  With ``side`` (a second HIP stream) the encoder and
+    the decoder run concurrently with the UNet's down and up halves; without it everything is serial."""
+    if side is None:
+        res, mid, raw_enc, raw_mid_enc = enc(x_t, t_attr, encoder_hidden_states=ehs, controlnet_cond=cond,
+                                             return_dict=False)
+        img_pred, raw_unet, raw_mid_unet, _ = unet(
+            x_t, t_img, encoder_hidden_states=ehs, down_block_additional_residuals=res,
+            mid_block_additional_residual=mid, return_dict=False)
+        out = {"img_pred": img_pred}
+        if run_decoder:
+            out["attr_pred"] = dec(sample=raw_mid_enc, down_block_res_samples=raw_enc, timestep=t_attr,
+                                   encoder_hidden_states=ehs, down_block_additional_residuals=raw_unet,
+                                   mid_block_additional_residual=raw_mid_unet, return_dict=False)
+        return out
+
+    main = torch.cuda.current_stream()
+    side.wait_stream(main)  # fork: inputs are ready
+    with torch.cuda.stream(side):
+        res, mid, raw_enc, raw_mid_enc = enc(x_t, t_attr, encoder_hidden_states=ehs, controlnet_cond=cond,
+                                             return_dict=False)
+    state = unet.forward_down_mid(x_t, t_img, ehs)  # main, concurrent with the encoder
+    raw_unet = tuple(ops.as_nchw_view(s) for s in state["raw_down"])
+    raw_mid_unet = ops.as_nchw_view(state["raw_mid"])
+    main.wait_stream(side)  # the UNet's up half needs the encoder's residuals
+    for t in list(res) + [mid]:
+        t.record_stream(main)
+    out = {}
     if run_decoder:
-        out["attr_pred"] = dec(sample=raw_mid_enc, down_block_res_samples=raw_enc, timestep=t_attr,
-                               encoder_hidden_states=ehs, down_block_additional_residuals=raw_unet,
-                               mid_block_additional_residual=raw_mid_unet, return_dict=False)
+        side.wait_stream(main)  # the decoder needs the UNet's raw skips (everything enqueued on main so far)
+        for t in raw_unet + (raw_mid_unet,):
+            t.record_stream(side)
+        with torch.cuda.stream(side):
+            out["attr_pred"] = dec(sample=raw_mid_enc, down_block_res_samples=raw_enc, timestep=t_attr,
+                                   encoder_hidden_states=ehs, down_block_additional_residuals=raw_unet,
+                                   mid_block_additional_residual=raw_mid_unet, return_dict=False)
+    out["img_pred"] = unet.forward_up(state, res, mid, return_dict=False)[0]  # main, concurrent with the decoder
+    main.wait_stream(side)  # join
+    if run_decoder:
+        out["attr_pred"].record_stream(main)
     return out
 
 
@@ -36,7 +75,7 @@ class GraphedDualStreamStep:
 
     def __init__(self, unet, enc, dec, batch: int, latent_hw, cross_dim: int, dtype=torch.float16,
                  device="cuda", run_decoder: bool = True, cond_channels: int = 28, img_channels: int = 4,
-                 ctx_len: int = 77):
+                 ctx_len: int = 77, concurrent: bool = True):
         self.unet, self.enc, self.dec, self.run_decoder = unet, enc, dec, run_decoder
         H, W = (latent_hw, latent_hw) if isinstance(latent_hw, int) else latent_hw
         dev = torch.device(device)
@@ -45,12 +84,13 @@ class GraphedDualStreamStep:
         self.ehs = torch.zeros(batch, ctx_len, cross_dim, dtype=dtype, device=dev)
         self.t_img = torch.zeros(batch, dtype=torch.float32, device=dev)
         self.t_attr = torch.zeros(batch, dtype=torch.float32, device=dev)
+        self.side = torch.cuda.Stream(device=dev) if concurrent else None
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.out: Optional[Dict[str, torch.Tensor]] = None
 
     def _run(self):
         return dual_stream_step(self.unet, self.enc, self.dec, self.x_t, self.cond, self.ehs, self.t_img,
-                                self.t_attr, self.run_decoder)
+                                self.t_attr, self.run_decoder, side=self.side)
 
     def load_inputs(self, x_t, cond, ehs, t_img, t_attr):
         self.x_t.copy_(x_t)
@@ -61,12 +101,12 @@ class GraphedDualStreamStep:
 
     @torch.no_grad()
     def capture(self, warmup: int = 2):
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):  # packs weights, sizes LDS attributes, fills the allocator
+        warm = torch.cuda.Stream()
+        warm.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(warm):  # packs weights, sizes LDS attributes, fills the allocator
             for _ in range(warmup):
                 self._run()
-        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.current_stream().wait_stream(warm)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
