@@ -15,6 +15,8 @@
 // ([B][H*d][Tk_pad]) from the projection GEMM (ur_igemm with swapped operands), so there is no
 // transposing store anywhere.  The running max/sum live per lane (the 4 lanes sharing a query hold
 // identical maxima, partial sums are combined once at the end).
+#include <type_traits>
+
 #include "ur_common.h"
 #include "../../include/ur_kernels.h"
 
@@ -111,7 +113,10 @@ __global__ void __launch_bounds__(256) attention_kernel(const ur_attn_desc p) {
     const int nkt = (p.Tk + 63) / 64;
     stage(0, 0);
     __syncthreads();
-    for (int kt = 0; kt < nkt; ++kt) {
+    // The tile body is instantiated twice: full tiles carry no key masking at all; only a ragged last tile
+    // (Tk % 64 != 0, e.g. the 77 prompt tokens) pays for the per-score compare/select.
+    auto tile = [&](const int kt, auto tail_tag) {
+        constexpr bool tail = decltype(tail_tag)::value;
         if (kt + 1 < nkt) stage((kt + 1) & 1, kt + 1);
         const char* ks_ = smem + (kt & 1) * STAGE;
         const char* vs_ = ks_ + KT_BYTES;
@@ -142,7 +147,6 @@ __global__ void __launch_bounds__(256) attention_kernel(const ur_attn_desc p) {
         // ---- online softmax (per query fragment f; this lane's query is l15 of that fragment).
         // Raw scores are kept unscaled: max in the raw domain (scale > 0), p = exp2(s*cs - m*cs) is ONE fma
         // feeding v_exp_f32.  Masked keys use a large finite negative (exp2 -> 0) so no inf/NaN arithmetic.
-        const bool tail = (kt * 64 + 64 > p.Tk);
         vec8 pf[2][2];  // [kb][f] : P^T fragment = 8 consecutive keys of this lane's query
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
@@ -200,7 +204,10 @@ __global__ void __launch_bounds__(256) attention_kernel(const ur_attn_desc p) {
             }
         }
         __syncthreads();
-    }
+    };
+    const int nfull = p.Tk >> 6;
+    for (int kt = 0; kt < nfull; ++kt) tile(kt, std::false_type{});
+    if (nfull < nkt) tile(nfull, std::true_type{});
 
     // ---- finalize: combine the partial row sums of the 4 lanes sharing a query, normalise, store
 #pragma unroll
