@@ -65,7 +65,12 @@ extern "C" {
 #define UR_TILE_128x320 9     /* 10 waves, 2-deep: N = 320 layers without a ragged N tile */
 #define UR_TILE_128x256 10    /* 8 waves, 2-deep */
 #define UR_TILE_256x256 11    /* 16 waves, 2-deep */
-#define UR_TILE_COUNT 12
+#define UR_TILE_64x64_R 12    /* register-staged loader (global_load -> ds_write), 2 LDS buffers */
+#define UR_TILE_128x64_R 13
+#define UR_TILE_128x128_R 14
+#define UR_TILE_128x320_R 15
+#define UR_TILE_256x128_R 16
+#define UR_TILE_COUNT 17
 
 /*
  * Implicit GEMM:  out[m][n] = epilogue( sum_k X[m][k] * W[n][k] )

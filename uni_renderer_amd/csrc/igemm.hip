@@ -128,9 +128,10 @@ __global__ void __launch_bounds__(WM * WN * 64) igemm_kernel(const ur_igemm_desc
     constexpr int XT_BYTES = BM * 128;
     constexpr int WT_BYTES = BN * 128;
     constexpr int STAGE = XT_BYTES + WT_BYTES;
+    constexpr bool REGSTAGE = NSTAGE < 0;  // register-staged loader with 2 LDS buffers
     constexpr int XI = (BM / 8 + NW - 1) / NW;  // LDS-DMA instructions per wave per X tile (8 rows each)
     constexpr int WI = (BN / 8 + NW - 1) / NW;
-    static_assert(NSTAGE == 2 || ((BM / 8) % NW == 0 && (BN / 8) % NW == 0), "counted vmcnt needs uniform loads per wave");
+    static_assert(NSTAGE <= 2 || ((BM / 8) % NW == 0 && (BN / 8) % NW == 0), "counted vmcnt needs uniform loads per wave");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -283,24 +284,86 @@ __global__ void __launch_bounds__(WM * WN * 64) igemm_kernel(const ur_igemm_desc
         if (seg_left == 0) next_segment();
     };
 
+    // Register-staged alternative (NSTAGE < 0): plain 16-byte global loads into VGPRs, issued BEFORE the MFMAs of
+    // the current chunk and written to the other LDS buffer AFTER them (ds_write_b128).  Same LDS image as the DMA
+    // path (the swizzle lives in the source address), so the MFMA side is unchanged.  A global_load costs a few
+    // issue cycles against 60-185 for an LDS-DMA piece (MI355X_MICROARCH.md), which is what bounds small tiles.
+    u32x4 xr[XI], wr[WI];
+    auto gload = [&]() {
+#pragma unroll
+        for (int it = 0; it < XI; ++it) {
+            if (it * NW + wave < BM / 8) xr[it] = *reinterpret_cast<const u32x4*>(xptr[it]);
+            xptr[it] += xinc[it];
+        }
+#pragma unroll
+        for (int it = 0; it < WI; ++it) {
+            if (it * NW + wave < BN / 8) wr[it] = *reinterpret_cast<const u32x4*>(wptr[it]);
+            wptr[it] += winc[it];
+        }
+        seg_left -= 1;
+        if (seg_left == 0) next_segment();
+    };
+    auto lstore = [&](int buf) {
+        char* xs = smem + buf * STAGE + lane * 16;
+        char* ws = xs + XT_BYTES;
+#pragma unroll
+        for (int it = 0; it < XI; ++it)
+            if (it * NW + wave < BM / 8) *reinterpret_cast<u32x4*>(xs + (it * NW + wave) * 1024) = xr[it];
+#pragma unroll
+        for (int it = 0; it < WI; ++it)
+            if (it * NW + wave < BN / 8) *reinterpret_cast<u32x4*>(ws + (it * NW + wave) * 1024) = wr[it];
+    };
+
     f32x4 acc[MREP][NREP];
 #pragma unroll
     for (int i = 0; i < MREP; ++i)
 #pragma unroll
         for (int j = 0; j < NREP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    const int l15 = lane & 15, q = lane >> 4;
+    auto compute = [&](int buf) {
+        const char* xs = smem + buf * STAGE;
+        const char* ws = xs + XT_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int c = ((kk * 4 + q) ^ (l15 & 7)) << 4;  // swizzled 16-B chunk of this lane
+            vec8 wf[NREP], xf[MREP];
+#pragma unroll
+            for (int f = 0; f < NREP; ++f)
+                wf[f] = *reinterpret_cast<const vec8*>(ws + (wn * 64 + f * 16 + l15) * 128 + c);
+#pragma unroll
+            for (int mf = 0; mf < MREP; ++mf)
+                xf[mf] = *reinterpret_cast<const vec8*>(xs + (wm * (16 * MREP) + mf * 16 + l15) * 128 + c);
+#pragma unroll
+            for (int mf = 0; mf < MREP; ++mf)
+#pragma unroll
+                for (int f = 0; f < NREP; ++f) acc[mf][f] = mfma16(wf[f], xf[mf], acc[mf][f]);
+        }
+    };
+
     const int nk = kend - kbeg;
-    if (nk > 0) {
+    if constexpr (REGSTAGE) {
+        if (nk > 0) {
+            gload();
+            lstore(0);
+            __syncthreads();
+            for (int t = 0; t < nk; ++t) {
+                if (t + 1 < nk) gload();           // chunk t+1 in flight while chunk t is multiplied
+                compute(t & 1);
+                if (t + 1 < nk) lstore((t + 1) & 1);  // the buffer every wave left before the last barrier
+                __syncthreads();
+            }
+        }
+    } else if (nk > 0) {
         // NSTAGE-deep LDS ring, prefetch distance D = NSTAGE-1 chunks, ONE barrier per chunk:
         //   wait (counted vmcnt: only chunk t must have landed, newer ones stay in flight) -> s_barrier
         //   -> issue chunk t+D into the buffer every wave finished reading before that barrier -> MFMAs.
         // Raw s_barrier + inline-asm vmcnt(N): __syncthreads() would drain the LDS-DMA queue (vmcnt(0)).
-        constexpr int D = NSTAGE - 1;
+        constexpr int D = (NSTAGE > 0 ? NSTAGE : 2) - 1;
         constexpr int LOADS = XI + WI;  // LDS-DMA instructions per wave per chunk
 #pragma unroll
         for (int s = 0; s < D; ++s)
             if (s < nk) stage(s);
-        const int l15 = lane & 15, q = lane >> 4;
         int buf = 0, nbuf = D % NSTAGE;
         for (int t = 0; t < nk; ++t) {
             const int newer = min(D - 1, nk - 1 - t);  // chunks issued after chunk t that may stay in flight
@@ -310,30 +373,13 @@ __global__ void __launch_bounds__(WM * WN * 64) igemm_kernel(const ur_igemm_desc
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             if (t + D < nk) stage(nbuf);
-            const char* xs = smem + buf * STAGE;
-            const char* ws = xs + XT_BYTES;
+            compute(buf);
             buf = (buf + 1 == NSTAGE) ? 0 : buf + 1;
             nbuf = (nbuf + 1 == NSTAGE) ? 0 : nbuf + 1;
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                const int c = ((kk * 4 + q) ^ (l15 & 7)) << 4;  // swizzled 16-B chunk of this lane
-                vec8 wf[NREP], xf[MREP];
-#pragma unroll
-                for (int f = 0; f < NREP; ++f)
-                    wf[f] = *reinterpret_cast<const vec8*>(ws + (wn * 64 + f * 16 + l15) * 128 + c);
-#pragma unroll
-                for (int mf = 0; mf < MREP; ++mf)
-                    xf[mf] = *reinterpret_cast<const vec8*>(xs + (wm * (16 * MREP) + mf * 16 + l15) * 128 + c);
-#pragma unroll
-                for (int mf = 0; mf < MREP; ++mf)
-#pragma unroll
-                    for (int f = 0; f < NREP; ++f) acc[mf][f] = mfma16(wf[f], xf[mf], acc[mf][f]);
-            }
         }
     }
 
     // ---- epilogue: lane (j = lane&15, q = lane>>4) holds pixel row j, channels q*16 .. q*16+15 ----
-    const int q = lane >> 4;
     const int nc = n0 + wn * 64 + q * 16;
 #pragma unroll
     for (int mf = 0; mf < MREP; ++mf) {
@@ -386,7 +432,9 @@ struct TileCfg { int bm, bn, stages; };
 // index = UR_TILE_* (include/ur_kernels.h)
 static const TileCfg kTiles[UR_TILE_COUNT] = {{0, 0, 0},      {128, 128, 2}, {128, 64, 3}, {64, 64, 3},
                                               {128, 128, 3}, {128, 64, 2},  {64, 64, 4},  {64, 64, 2},
-                                              {256, 128, 2}, {128, 320, 2}, {128, 256, 2}, {256, 256, 2}};
+                                              {256, 128, 2}, {128, 320, 2}, {128, 256, 2}, {256, 256, 2},
+                                              {64, 64, -2},  {128, 64, -2}, {128, 128, -2}, {128, 320, -2},
+                                              {256, 128, -2}};
 
 static int pick_tile(const ur_igemm_desc& d) {
     // Cost model: the busiest CU runs ceil(workgroups / 256) tiles; bigger tiles have a better
@@ -408,7 +456,7 @@ template <typename T, int BM, int BN, int WM, int WN, int NSTAGE>
 static int launch_cfg(const ur_igemm_desc& d, hipStream_t s) {
     const int tiles_m = (d.M + BM - 1) / BM, tiles_n = (d.N + BN - 1) / BN;
     dim3 grid(tiles_m * tiles_n, 1, d.splitk > 1 ? d.splitk : (d.zbatch > 1 ? d.zbatch : 1));
-    const size_t lds = NSTAGE * (BM + BN) * 128;
+    const size_t lds = (NSTAGE > 0 ? NSTAGE : 2) * (BM + BN) * 128;
     hipError_t e;
     if (d.taps == 9) {
         static bool once = false;
@@ -454,6 +502,11 @@ static int launch_dtype(ur_igemm_desc& d, hipStream_t s) {
         case UR_TILE_128x320: return launch_cfg<T, 128, 320, 2, 5, 2>(d, s);
         case UR_TILE_128x256: return launch_cfg<T, 128, 256, 2, 4, 2>(d, s);
         case UR_TILE_256x256: return launch_cfg<T, 256, 256, 4, 4, 2>(d, s);
+        case UR_TILE_64x64_R: return launch_cfg<T, 64, 64, 4, 1, -2>(d, s);
+        case UR_TILE_128x64_R: return launch_cfg<T, 128, 64, 4, 1, -2>(d, s);
+        case UR_TILE_128x128_R: return launch_cfg<T, 128, 128, 2, 2, -2>(d, s);
+        case UR_TILE_128x320_R: return launch_cfg<T, 128, 320, 2, 5, -2>(d, s);
+        case UR_TILE_256x128_R: return launch_cfg<T, 256, 128, 4, 2, -2>(d, s);
     }
     return UR_E_BADARG;
 }

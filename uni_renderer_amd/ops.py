@@ -24,7 +24,10 @@ TILE_128x128_S3, TILE_128x64_S2, TILE_64x64_S4, TILE_64x64_S2 = 4, 5, 6, 7
 _TILES = {TILE_128x128: (128, 128, 1.0, 2), TILE_128x64: (128, 64, 0.85, 3), TILE_64x64: (64, 64, 0.6, 3),
           TILE_128x128_S3: (128, 128, 0.9, 3), TILE_128x64_S2: (128, 64, 0.7, 2), TILE_64x64_S4: (64, 64, 0.6, 4),
           TILE_64x64_S2: (64, 64, 0.5, 2), 8: (256, 128, 1.1, 2), 9: (128, 320, 1.1, 2), 10: (128, 256, 1.1, 2),
-          11: (256, 256, 1.2, 2)}
+          11: (256, 256, 1.2, 2),
+          # register-staged loader variants (global_load -> VGPR -> ds_write), "stages" = "r"
+          12: (64, 64, 0.6, "r"), 13: (128, 64, 0.85, "r"), 14: (128, 128, 1.0, "r"), 15: (128, 320, 1.1, "r"),
+          16: (256, 128, 1.1, "r")}
 _PLANNER_TILES = (TILE_128x128, TILE_128x64, TILE_64x64)
 
 _zero_pages = {}
