@@ -70,7 +70,12 @@ extern "C" {
 #define UR_TILE_128x128_R 14
 #define UR_TILE_128x320_R 15
 #define UR_TILE_256x128_R 16
-#define UR_TILE_COUNT 17
+#define UR_TILE_64x64_W1 17     /* ONE wave per workgroup: the wave owns the whole 64x64 tile (0.5 KB LDS read / MFMA) */
+#define UR_TILE_128x64_W2 18    /* two waves, 64x64 each */
+#define UR_TILE_64x64_W1_S3 19
+#define UR_TILE_64x128_W2 20
+#define UR_TILE_64x64_W1_S4 21
+#define UR_TILE_COUNT 22
 
 /*
  * Implicit GEMM:  out[m][n] = epilogue( sum_k X[m][k] * W[n][k] )

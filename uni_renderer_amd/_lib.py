@@ -13,7 +13,7 @@ import os
 import torch  # noqa: F401  (must be imported first, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liburhip.so")
+LIB_PATH = os.environ.get("UR_LIB_PATH", os.path.join(_HERE, "liburhip.so"))  # override = kernel experiments only
 ABI_VERSION = 1
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p

@@ -268,6 +268,9 @@ __global__ void __launch_bounds__(WM * WN * 64) igemm_kernel(const ur_igemm_desc
 
     // issue the LDS-DMA copies of the loader's current chunk into `buf`, then advance by one chunk
     auto stage = [&](int buf) {
+#if defined(UR_ABLATE) && UR_ABLATE == 1
+        if (buf >= 0) { seg_left -= 1; if (seg_left == 0) next_segment(); return; }
+#endif
         char* xs = smem + buf * STAGE;
         char* ws = xs + XT_BYTES;
 #pragma unroll
@@ -322,6 +325,9 @@ __global__ void __launch_bounds__(WM * WN * 64) igemm_kernel(const ur_igemm_desc
 
     const int l15 = lane & 15, q = lane >> 4;
     auto compute = [&](int buf) {
+#if defined(UR_ABLATE) && UR_ABLATE == 2
+        if (buf >= 0) return;
+#endif
         const char* xs = smem + buf * STAGE;
         const char* ws = xs + XT_BYTES;
 #pragma unroll
@@ -434,7 +440,8 @@ static const TileCfg kTiles[UR_TILE_COUNT] = {{0, 0, 0},      {128, 128, 2}, {12
                                               {128, 128, 3}, {128, 64, 2},  {64, 64, 4},  {64, 64, 2},
                                               {256, 128, 2}, {128, 320, 2}, {128, 256, 2}, {256, 256, 2},
                                               {64, 64, -2},  {128, 64, -2}, {128, 128, -2}, {128, 320, -2},
-                                              {256, 128, -2}};
+                                              {256, 128, -2}, {64, 64, 2},   {128, 64, 2},   {64, 64, 3},
+                                              {64, 128, 2},  {64, 64, 4}};
 
 static int pick_tile(const ur_igemm_desc& d) {
     // Cost model: the busiest CU runs ceil(workgroups / 256) tiles; bigger tiles have a better
@@ -507,6 +514,11 @@ static int launch_dtype(ur_igemm_desc& d, hipStream_t s) {
         case UR_TILE_128x128_R: return launch_cfg<T, 128, 128, 2, 2, -2>(d, s);
         case UR_TILE_128x320_R: return launch_cfg<T, 128, 320, 2, 5, -2>(d, s);
         case UR_TILE_256x128_R: return launch_cfg<T, 256, 128, 4, 2, -2>(d, s);
+        case UR_TILE_64x64_W1: return launch_cfg<T, 64, 64, 1, 1, 2>(d, s);
+        case UR_TILE_128x64_W2: return launch_cfg<T, 128, 64, 2, 1, 2>(d, s);
+        case UR_TILE_64x64_W1_S3: return launch_cfg<T, 64, 64, 1, 1, 3>(d, s);
+        case UR_TILE_64x128_W2: return launch_cfg<T, 64, 128, 1, 2, 2>(d, s);
+        case UR_TILE_64x64_W1_S4: return launch_cfg<T, 64, 64, 1, 1, 4>(d, s);
     }
     return UR_E_BADARG;
 }

@@ -27,7 +27,10 @@ _TILES = {TILE_128x128: (128, 128, 1.0, 2), TILE_128x64: (128, 64, 0.85, 3), TIL
           11: (256, 256, 1.2, 2),
           # register-staged loader variants (global_load -> VGPR -> ds_write), "stages" = "r"
           12: (64, 64, 0.6, "r"), 13: (128, 64, 0.85, "r"), 14: (128, 128, 1.0, "r"), 15: (128, 320, 1.1, "r"),
-          16: (256, 128, 1.1, "r")}
+          16: (256, 128, 1.1, "r"),
+          # few-wave workgroups: every wave owns a full 64x64 tile (0.5 KB of LDS reads per MFMA instead of 1.25)
+          17: (64, 64, 0.8, "2w1"), 18: (128, 64, 0.9, "2w2"), 19: (64, 64, 0.8, "3w1"), 20: (64, 128, 0.9, "2w2n"),
+          21: (64, 64, 0.8, "4w1")}
 _PLANNER_TILES = (TILE_128x128, TILE_128x64, TILE_64x64)
 
 _zero_pages = {}
