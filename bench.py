@@ -178,6 +178,8 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="time eager launches instead of the HIP graph")
     ap.add_argument("--no-concurrent", action="store_true", help="capture the three networks serially on one stream")
+    ap.add_argument("--mode", default=None, choices=["grouped", "concurrent", "serial"],
+                    help="step execution: grouped launches of the two streams (default), two concurrent graph branches, or serial")
     ap.add_argument("--kernel-table", action="store_true", help="print the per-kernel-class table to stderr")
     ap.add_argument("--shape-table", default="", help="write a per-(kernel, problem shape) table (JSON) to this path")
     args = ap.parse_args()
@@ -204,7 +206,7 @@ def main():
     models = build_models(dev, dtype)
     inputs = make_inputs(args.batch, args.latent, dev, dtype, seed=100 + rank)
     runner = GraphedDualStreamStep(*models, batch=args.batch, latent_hw=args.latent, cross_dim=768, dtype=dtype,
-                                   device=dev, run_decoder=True, concurrent=not args.no_concurrent)
+                                   device=dev, run_decoder=True, concurrent=not args.no_concurrent, mode=args.mode)
     runner.load_inputs(*inputs)
     if args.eager:
         def one():
@@ -254,7 +256,9 @@ def main():
                             f"{args.latent * 8}x{args.latent * 8} image = {args.latent}x{args.latent} latent, 28-channel "
                             f"attribute latent, 77x768 prompt embedding, batch {args.batch} per GPU",
                 "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
-                "launch": "eager" if args.eager else ("hipGraph replay, serial" if args.no_concurrent else "hipGraph replay, 2 concurrent branches (enc || unet.down, dec || unet.up)"),
+                "launch": "eager" if args.eager else {"grouped": "hipGraph replay; enc||unet.down and unet.up||dec issued as grouped (zbatch=2) launches",
+                                                      "concurrent": "hipGraph replay, 2 concurrent branches (enc || unet.down, dec || unet.up)",
+                                                      "serial": "hipGraph replay, serial"}[runner.mode],
                 "algorithmic_tflop_per_step": round(1.623 * args.batch * (args.latent / 64) ** 2, 3),
             },
         }

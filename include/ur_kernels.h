@@ -88,10 +88,11 @@ extern "C" {
  *   epilogue: +bias[n] (fp32), +rowadd[m / rows_per_b][n], activation, +res[m][n], *out_scale.
  *      act == UR_ACT_GEGLU: packed columns come in groups of 8 = 4 value + 4 gate columns and the
  *      output has N/2 columns: out[m][(p/8)*4 + p%4] = value * gelu(gate).
- *   zbatch > 1: grid.z batches independent problems with element strides zx / zw / zout (used for the
- *      transposed V projection  Vt[b] = Wv . X[b]^T ).
- *   splitk > 1: K is split over grid.z (zbatch must be 1); `partial` is a caller-provided fp32
- *      workspace of splitk * M * ldp floats and the epilogue runs in a second small kernel.
+ *   zbatch > 1: grid.z batches independent problems of one shape; every operand has its own per-z element
+ *      stride (zx, zx1, zw, zbias, zrow, zres, zout).  Used for the transposed V projection
+ *      Vt[b] = Wv . X[b]^T and for executing the two diffusion streams as ONE grouped launch.
+ *   splitk > 1: K is additionally split over grid.z; `partial` is a caller-provided fp32 workspace of
+ *      zbatch * splitk * M * ldp floats and the epilogue runs in a second small kernel.
  */
 typedef struct ur_igemm_desc {
     const void* x0;
@@ -106,7 +107,8 @@ typedef struct ur_igemm_desc {
     int64_t ldx0, ldx1;  /* element stride between consecutive pixels/rows of x0 / x1      */
     int64_t ldw;         /* element stride between rows of W                               */
     int64_t ldres, ldc;
-    int64_t zx, zw, zout; /* per-z element strides (zbatch > 1)                            */
+    int64_t zx, zw, zout; /* per-z element strides (zbatch > 1) of x0, w, out               */
+    int64_t zx1, zbias, zrow, zres; /* per-z element strides of x1, bias, rowadd, res (may be negative) */
     int64_t ldp;         /* row stride (floats) of `partial`, multiple of 64               */
     int32_t c0, c1;
     int32_t B, Hin, Win, Hout, Wout; /* conv geometry (taps == 9); ignored for taps == 1   */
@@ -117,6 +119,7 @@ typedef struct ur_igemm_desc {
     int32_t act;
     float out_scale;
     int32_t zbatch, splitk;
+    int32_t zx_div;      /* x0 of problem z starts at x0 + (z / zx_div) * zx (0/1 = every z)   */
     int32_t tile;        /* UR_TILE_*                                                      */
     int32_t dtype;
 } ur_igemm_desc;
@@ -132,16 +135,18 @@ int64_t ur_igemm_partial_floats(const ur_igemm_desc* d);
  *   apply:  y = (x - mean) * rstd * gamma + beta  (-> SiLU), mean/rstd reduced (fixed order) from the
  *           `nstat` chunks of `partial` written by the stats pass.
  * rows = H*W per sample; nchunks = number of row chunks per sample (grid.x) of the call at hand.
+ * bper > 0: sample b uses gamma/beta + (b / bper) * pstride (grouped execution of several streams).
  */
 int ur_groupnorm_stats(const void* x0, const void* x1, int c0, int c1, int B, int rows, int groups,
                        int nchunks, float* partial, int dtype, void* stream);
 int ur_groupnorm_apply(const void* x0, const void* x1, int c0, int c1, int B, int rows, int groups,
                        int nstat, int nchunks, const float* partial, const float* gamma, const float* beta,
-                       float eps, int silu, void* out, int dtype, void* stream);
+                       float eps, int silu, int bper, int pstride, void* out, int dtype, void* stream);
 
-/* LayerNorm over the last dimension of x[rows][C] (C % 8 == 0, C <= 4096), fp32 statistics. */
-int ur_layernorm(const void* x, const float* gamma, const float* beta, float eps, int rows, int C, void* out,
-                 int dtype, void* stream);
+/* LayerNorm over the last dimension of x[rows][C] (C % 8 == 0, C <= 4096), fp32 statistics.
+ * rows_per_set > 0: row r uses gamma/beta + (r / rows_per_set) * pstride. */
+int ur_layernorm(const void* x, const float* gamma, const float* beta, float eps, int rows, int C,
+                 int rows_per_set, int pstride, void* out, int dtype, void* stream);
 
 /*
  * softmax(Q K^T * scale) V for all (batch, head) pairs.

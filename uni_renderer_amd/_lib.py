@@ -26,14 +26,15 @@ class IGemmDesc(C.Structure):
         ("x0", vp), ("x1", vp), ("w", vp), ("bias", vp), ("rowadd", vp), ("res", vp), ("out", vp),
         ("partial", vp), ("zero_page", vp),
         ("ldx0", i64), ("ldx1", i64), ("ldw", i64), ("ldres", i64), ("ldc", i64),
-        ("zx", i64), ("zw", i64), ("zout", i64), ("ldp", i64),
+        ("zx", i64), ("zw", i64), ("zout", i64), ("zx1", i64), ("zbias", i64), ("zrow", i64), ("zres", i64),
+        ("ldp", i64),
         ("c0", i32), ("c1", i32),
         ("B", i32), ("Hin", i32), ("Win", i32), ("Hout", i32), ("Wout", i32),
         ("taps", i32), ("stride", i32), ("ups", i32),
         ("M", i32), ("N", i32), ("K", i32),
         ("n_store", i32), ("ld_rowadd", i32), ("rows_per_b", i32),
         ("act", i32), ("out_scale", f32),
-        ("zbatch", i32), ("splitk", i32), ("tile", i32), ("dtype", i32),
+        ("zbatch", i32), ("splitk", i32), ("zx_div", i32), ("tile", i32), ("dtype", i32),
     ]
 
 
@@ -55,8 +56,8 @@ SYMBOLS = {
     "ur_igemm_partial_floats": (C.c_int64, [C.POINTER(IGemmDesc)]),
     "ur_groupnorm_stats": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]),
     "ur_groupnorm_apply": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp,
-                                     C.c_float, C.c_int, vp, C.c_int, vp]),
-    "ur_layernorm": (C.c_int, [vp, vp, vp, C.c_float, C.c_int, C.c_int, vp, C.c_int, vp]),
+                                     C.c_float, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]),
+    "ur_layernorm": (C.c_int, [vp, vp, vp, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]),
     "ur_attention": (C.c_int, [C.POINTER(AttnDesc), vp]),
     "ur_add": (C.c_int, [vp, vp, C.c_float, vp, C.c_int64, C.c_int, vp]),
     "ur_timestep_embedding": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp, C.c_int, vp]),

@@ -25,14 +25,14 @@ namespace ur {
 constexpr int BK = 64;  // elements per K chunk (128 bytes)
 
 template <typename T>
-__device__ __forceinline__ void epilogue16(const ur_igemm_desc& p, T* __restrict__ outz, int m, int nc,
-                                           float (&v)[16]) {
+__device__ __forceinline__ void epilogue16(const ur_igemm_desc& p, T* __restrict__ outz, const float* biasz,
+                                           const T* rowaddz, const T* resz, int m, int nc, float (&v)[16]) {
     if (m >= p.M) return;
     const bool full = (nc + 16 <= p.N);
     const bool vec = (((p.ldc | p.ldres | (int64_t)p.ld_rowadd) & 7) == 0);
-    if (p.bias) {
+    if (biasz) {
         if (full) {
-            const float4* b4 = reinterpret_cast<const float4*>(p.bias + nc);
+            const float4* b4 = reinterpret_cast<const float4*>(biasz + nc);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 float4 b = b4[i];
@@ -41,11 +41,11 @@ __device__ __forceinline__ void epilogue16(const ur_igemm_desc& p, T* __restrict
         } else {
 #pragma unroll
             for (int i = 0; i < 16; ++i)
-                if (nc + i < p.N) v[i] += p.bias[nc + i];
+                if (nc + i < p.N) v[i] += biasz[nc + i];
         }
     }
-    if (p.rowadd) {
-        const T* ra = reinterpret_cast<const T*>(p.rowadd) + (int64_t)(m / p.rows_per_b) * p.ld_rowadd + nc;
+    if (rowaddz) {
+        const T* ra = rowaddz + (int64_t)(m / p.rows_per_b) * p.ld_rowadd + nc;
         if (full && vec) {
             float t[8];
             load8(ra, t);
@@ -82,8 +82,8 @@ __device__ __forceinline__ void epilogue16(const ur_igemm_desc& p, T* __restrict
 #pragma unroll
         for (int i = 0; i < 16; ++i) v[i] = silu_f(v[i]);
     }
-    if (p.res) {
-        const T* rp = reinterpret_cast<const T*>(p.res) + (int64_t)m * p.ldres + nc;
+    if (resz) {
+        const T* rp = resz + (int64_t)m * p.ldres + nc;
         if (full && vec) {
             float t[8];
             load8(rp, t);
@@ -151,16 +151,16 @@ __global__ void __launch_bounds__(WM * WN * 64) igemm_kernel(const ur_igemm_desc
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     const int kt_total = p.K / BK;
-    int kbeg = 0, kend = kt_total, zb = 0;
+    int kbeg = 0, kend = kt_total, zb = zidx;  // grid.z = zbatch * splitk, split index fastest
     if (p.splitk > 1) {
+        zb = zidx / p.splitk;
+        const int ks = zidx - zb * p.splitk;
         const int per = (kt_total + p.splitk - 1) / p.splitk;
-        kbeg = zidx * per;
+        kbeg = ks * per;
         kend = min(kt_total, kbeg + per);
-    } else {
-        zb = zidx;
     }
-    const char* x0 = reinterpret_cast<const char*>(reinterpret_cast<const T*>(p.x0) + (int64_t)zb * p.zx);
-    const char* x1 = reinterpret_cast<const char*>(p.x1);
+    const char* x0 = reinterpret_cast<const char*>(reinterpret_cast<const T*>(p.x0) + (int64_t)(zb / p.zx_div) * p.zx);
+    const char* x1 = reinterpret_cast<const char*>(reinterpret_cast<const T*>(p.x1) + (int64_t)zb * p.zx1);
     const char* wp = reinterpret_cast<const char*>(reinterpret_cast<const T*>(p.w) + (int64_t)zb * p.zw);
     const int js = (lane & 7) ^ (lane >> 3);  // swizzled source chunk of this lane's 16 bytes
     const char* zp = reinterpret_cast<const char*>(p.zero_page) + (lane & 7) * 16;
@@ -402,7 +402,10 @@ __global__ void __launch_bounds__(WM * WN * 64) igemm_kernel(const ur_igemm_desc
                 for (int i = 0; i < 4; ++i) pp[i] = make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
             }
         } else {
-            epilogue16<T>(p, reinterpret_cast<T*>(p.out) + (int64_t)zb * p.zout, m, nc, v);
+            epilogue16<T>(p, reinterpret_cast<T*>(p.out) + (int64_t)zb * p.zout,
+                          p.bias ? p.bias + (int64_t)zb * p.zbias : nullptr,
+                          p.rowadd ? reinterpret_cast<const T*>(p.rowadd) + (int64_t)zb * p.zrow : nullptr,
+                          p.res ? reinterpret_cast<const T*>(p.res) + (int64_t)zb * p.zres : nullptr, m, nc, v);
         }
     }
 }
@@ -419,15 +422,21 @@ __global__ void __launch_bounds__(256) igemm_splitk_reduce(const ur_igemm_desc p
         float v[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) v[i] = 0.f;
+        const int zb = blockIdx.y;
         for (int z = 0; z < p.splitk; ++z) {
-            const float4* pp = reinterpret_cast<const float4*>(p.partial + ((int64_t)z * p.M + m) * p.ldp + nc);
+            const float4* pp =
+                reinterpret_cast<const float4*>(p.partial + (((int64_t)zb * p.splitk + z) * p.M + m) * p.ldp + nc);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 float4 a = pp[i];
                 v[4 * i] += a.x; v[4 * i + 1] += a.y; v[4 * i + 2] += a.z; v[4 * i + 3] += a.w;
             }
         }
-        if (nc < p.n_store || nc < p.N) epilogue16<T>(p, reinterpret_cast<T*>(p.out), m, nc, v);
+        if (nc < p.n_store || nc < p.N)
+            epilogue16<T>(p, reinterpret_cast<T*>(p.out) + (int64_t)zb * p.zout,
+                          p.bias ? p.bias + (int64_t)zb * p.zbias : nullptr,
+                          p.rowadd ? reinterpret_cast<const T*>(p.rowadd) + (int64_t)zb * p.zrow : nullptr,
+                          p.res ? reinterpret_cast<const T*>(p.res) + (int64_t)zb * p.zres : nullptr, m, nc, v);
     }
 }
 
@@ -462,7 +471,7 @@ static int pick_tile(const ur_igemm_desc& d) {
 template <typename T, int BM, int BN, int WM, int WN, int NSTAGE>
 static int launch_cfg(const ur_igemm_desc& d, hipStream_t s) {
     const int tiles_m = (d.M + BM - 1) / BM, tiles_n = (d.N + BN - 1) / BN;
-    dim3 grid(tiles_m * tiles_n, 1, d.splitk > 1 ? d.splitk : (d.zbatch > 1 ? d.zbatch : 1));
+    dim3 grid(tiles_m * tiles_n, 1, d.zbatch * d.splitk);
     const size_t lds = (NSTAGE > 0 ? NSTAGE : 2) * (BM + BN) * 128;
     hipError_t e;
     if (d.taps == 9) {
@@ -488,7 +497,7 @@ static int launch_cfg(const ur_igemm_desc& d, hipStream_t s) {
         const int64_t total = (int64_t)d.M * (d.ldp / 16);
         int blocks = (int)((total + 255) / 256);
         if (blocks > 4096) blocks = 4096;
-        hipLaunchKernelGGL((igemm_splitk_reduce<T>), dim3(blocks), dim3(256), 0, s, d);
+        hipLaunchKernelGGL((igemm_splitk_reduce<T>), dim3(blocks, d.zbatch), dim3(256), 0, s, d);
         e = hipGetLastError();
         if (e != hipSuccess) return -(int)e;
     }
@@ -539,7 +548,7 @@ extern "C" int64_t ur_igemm_partial_floats(const ur_igemm_desc* d) {
         const int64_t v = (d->N + bn - 1) / bn * bn;
         if (v > ldp) ldp = v;
     }
-    return (int64_t)d->splitk * d->M * ldp;
+    return (int64_t)d->splitk * (d->zbatch > 1 ? d->zbatch : 1) * d->M * ldp;
 }
 
 extern "C" int ur_igemm(const ur_igemm_desc* din, void* stream) {
@@ -559,8 +568,8 @@ extern "C" int ur_igemm(const ur_igemm_desc* din, void* stream) {
         if (d.ups && d.stride != 1) return UR_E_BADARG;
     }
     if (d.zbatch < 1) d.zbatch = 1;
+    if (d.zx_div < 1) d.zx_div = 1;
     if (d.splitk < 1) d.splitk = 1;
-    if (d.splitk > 1 && d.zbatch > 1) return UR_E_BADARG;
     if (d.splitk > d.K / BK) d.splitk = d.K / BK;
     if (d.splitk > 1 && !d.partial) return UR_E_BADARG;
     if (d.rowadd && d.rows_per_b <= 0) return UR_E_BADARG;

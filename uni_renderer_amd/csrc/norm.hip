@@ -102,7 +102,7 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const T* __restrict__ x0,
                                                        const float* __restrict__ partial,
                                                        const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float eps, int silu,
-                                                       T* __restrict__ out) {
+                                                       int bper, int pstride, T* __restrict__ out) {
     __shared__ float2 stat[64];  // (mean, rstd) per group
     __shared__ float2 red[8][64];
     const int C = c0 + c1, nvec = C >> 3, cpg = C / groups;
@@ -138,14 +138,15 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const T* __restrict__ x0,
     const int rsub = t / tpr, cvl = t - rsub * tpr;
     const int nv0 = c0 >> 3;
     if (rsub >= rs) return;
+    const int poff = bper > 0 ? (b / bper) * pstride : 0;  // per-stream affine parameters (grouped execution)
     for (int cv = cvl; cv < nvec; cv += tpr) {
         float a[8], sh[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int c = cv * 8 + i;
             const float2 st = stat[c / cpg];
-            a[i] = st.y * gamma[c];
-            sh[i] = beta[c] - st.x * a[i];
+            a[i] = st.y * gamma[poff + c];
+            sh[i] = beta[poff + c] - st.x * a[i];
         }
         const T* base;
         int64_t ld;
@@ -189,10 +190,13 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const T* __restrict__ x0,
 template <typename T, int MAXV>
 __global__ void __launch_bounds__(256) layernorm_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps, int rows, int C,
-                                                        T* __restrict__ out) {
+                                                        int rows_per_set, int pstride, T* __restrict__ out) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
+    const int poff = rows_per_set > 0 ? (row / rows_per_set) * pstride : 0;  // per-stream affine parameters
+    gamma += poff;
+    beta += poff;
     const int nvec = C >> 3;
     const T* xr = x + (int64_t)row * C;
     float v[MAXV][8];
@@ -269,17 +273,18 @@ extern "C" int ur_groupnorm_stats(const void* x0, const void* x1, int c0, int c1
 
 extern "C" int ur_groupnorm_apply(const void* x0, const void* x1, int c0, int c1, int B, int rows, int groups,
                                   int nstat, int nchunks, const float* partial, const float* gamma,
-                                  const float* beta, float eps, int silu, void* out, int dtype, void* stream) {
+                                  const float* beta, float eps, int silu, int bper, int pstride, void* out,
+                                  int dtype, void* stream) {
     int rc = gn_check(x0, x1, c0, c1, B, rows, groups, nchunks);
     if (rc || nstat <= 0 || !partial || !gamma || !beta || !out) return rc ? rc : UR_E_BADARG;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     dim3 grid(nchunks, B);
     if (dtype == UR_DT_F16)
         hipLaunchKernelGGL((gn_apply_kernel<f16>), grid, dim3(256), 0, s, (const f16*)x0, (const f16*)x1, c0, c1, rows,
-                           groups, nstat, nchunks, partial, gamma, beta, eps, silu, (f16*)out);
+                           groups, nstat, nchunks, partial, gamma, beta, eps, silu, bper, pstride, (f16*)out);
     else if (dtype == UR_DT_BF16)
         hipLaunchKernelGGL((gn_apply_kernel<bf16>), grid, dim3(256), 0, s, (const bf16*)x0, (const bf16*)x1, c0, c1,
-                           rows, groups, nstat, nchunks, partial, gamma, beta, eps, silu, (bf16*)out);
+                           rows, groups, nstat, nchunks, partial, gamma, beta, eps, silu, bper, pstride, (bf16*)out);
     else
         return UR_E_BADARG;
     hipError_t e = hipGetLastError();
@@ -287,7 +292,7 @@ extern "C" int ur_groupnorm_apply(const void* x0, const void* x1, int c0, int c1
 }
 
 extern "C" int ur_layernorm(const void* x, const float* gamma, const float* beta, float eps, int rows, int C,
-                            void* out, int dtype, void* stream) {
+                            int rows_per_set, int pstride, void* out, int dtype, void* stream) {
     if (!x || !gamma || !beta || !out || rows <= 0 || C <= 0 || (C & 7) || C > 4096) return UR_E_BADARG;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     dim3 grid((rows + 3) / 4);
@@ -295,17 +300,17 @@ extern "C" int ur_layernorm(const void* x, const float* gamma, const float* beta
     if (dtype == UR_DT_F16) {
         if (small)
             hipLaunchKernelGGL((layernorm_kernel<f16, 4>), grid, dim3(256), 0, s, (const f16*)x, gamma, beta, eps, rows,
-                               C, (f16*)out);
+                               C, rows_per_set, pstride, (f16*)out);
         else
             hipLaunchKernelGGL((layernorm_kernel<f16, 8>), grid, dim3(256), 0, s, (const f16*)x, gamma, beta, eps, rows,
-                               C, (f16*)out);
+                               C, rows_per_set, pstride, (f16*)out);
     } else if (dtype == UR_DT_BF16) {
         if (small)
             hipLaunchKernelGGL((layernorm_kernel<bf16, 4>), grid, dim3(256), 0, s, (const bf16*)x, gamma, beta, eps,
-                               rows, C, (bf16*)out);
+                               rows, C, rows_per_set, pstride, (bf16*)out);
         else
             hipLaunchKernelGGL((layernorm_kernel<bf16, 8>), grid, dim3(256), 0, s, (const bf16*)x, gamma, beta, eps,
-                               rows, C, (bf16*)out);
+                               rows, C, rows_per_set, pstride, (bf16*)out);
     } else {
         return UR_E_BADARG;
     }

@@ -1,0 +1,320 @@
+"""Grouped ("two streams, one launch") execution of the dual-stream denoise step.
+
+Uni-Renderer's step is three networks, but structurally it is TWO copies of one UNet running side by side:
+
+    phase 1   AttributeEncoder.{conv_in, down, mid}   ||   UNet.{conv_in, down, mid}     (same shapes, different weights)
+    phase 2   the 13 + 13 exchange 1x1 convs           (enc -> unet  and  unet -> dec, pairwise the same shapes)
+    phase 3   UNet.{up, conv_out}                      ||   AttributeDecoder.{up, conv_out}
+
+(`from_unet` guarantees the shape identity: controlnet.py:1437-1507, 2115-2192 of the reference.)  On a 256-CU
+MI355X a batch-4 layer is too small to use large GEMM tiles -- throughput is bounded by the global->LDS fill rate
+per CU, i.e. by the tile's arithmetic intensity -- so instead of launching the two copies one after the other (or
+concurrently on two streams) every op of a pair is issued ONCE with `zbatch = 2`: activations are stacked
+stream-major ([2B, H, W, C]), weights are stacked [2, N, K], and `ur_igemm` / norms select per-stream operands by
+stride.  M doubles, tiles grow, launches halve.  The exchange uses one grouped 1x1 GEMM per skip whose residual
+operand is the OTHER stream's tensor (negative per-z stride), which directly produces the stacked inputs of phase 3:
+    [unet_skip + zc_i(enc_skip) ; enc_skip + cd_i(unet_skip)].
+
+This is an execution strategy for the SAME arithmetic as the module-by-module path (controlnet.py classes); parity
+between the two is tested bit-for-bit-close in tests/test_fused_gpu.py.  The module API remains the drop-in surface.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import ops
+from .controlnet import CIN_PAD, _compute_dtype
+from .layers import (Attention, BasicTransformerBlock, ResnetBlock2D, Transformer2DModel, f32, geglu_perm,
+                     pack_conv3x3, pack_matrix)
+
+
+class _Packs:
+    """Cache of stream-stacked packed tensors keyed by (name, module ids, dtype) + parameter versions."""
+
+    def __init__(self):
+        self._store = {}
+
+    def get(self, name, mods, params, dtype, build):
+        key = (name, tuple(id(m) for m in mods), dtype)
+        ver = tuple((p.data_ptr(), p._version) for p in params)
+        hit = self._store.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        with torch.no_grad():
+            val = build()
+        self._store[key] = (ver, val)
+        return val
+
+
+def _stk(ts):
+    return torch.stack(list(ts), 0).contiguous()
+
+
+class GroupedDualStreamStep:
+    """enc + unet + dec step with every op of the two diffusion streams issued as one grouped kernel."""
+
+    def __init__(self, unet, enc, dec):
+        self.unet, self.enc, self.dec = unet, enc, dec
+        self.pk = _Packs()
+
+    # ------------------------------------------------------------------ leaves (S streams in lockstep)
+    def _resnet(self, rs: Sequence[ResnetBlock2D], x, temb, slice_, x1=None):
+        S, pk, dt = len(rs), self.pk, x.dtype
+        r0 = rs[0]
+        g1 = pk.get("r.g1", rs, [r.norm1.weight for r in rs], dt, lambda: _stk(f32(r.norm1.weight) for r in rs))
+        b1 = pk.get("r.b1", rs, [r.norm1.bias for r in rs], dt, lambda: _stk(f32(r.norm1.bias) for r in rs))
+        g2 = pk.get("r.g2", rs, [r.norm2.weight for r in rs], dt, lambda: _stk(f32(r.norm2.weight) for r in rs))
+        b2 = pk.get("r.b2", rs, [r.norm2.bias for r in rs], dt, lambda: _stk(f32(r.norm2.bias) for r in rs))
+        w1 = pk.get("r.w1", rs, [r.conv1.weight for r in rs], dt, lambda: _stk(pack_conv3x3(r.conv1.weight, dt) for r in rs))
+        c1 = pk.get("r.c1", rs, [r.conv1.bias for r in rs], dt, lambda: _stk(f32(r.conv1.bias) for r in rs))
+        w2 = pk.get("r.w2", rs, [r.conv2.weight for r in rs], dt, lambda: _stk(pack_conv3x3(r.conv2.weight, dt) for r in rs))
+        c2 = pk.get("r.c2", rs, [r.conv2.bias for r in rs], dt, lambda: _stk(f32(r.conv2.bias) for r in rs))
+        lo, hi = slice_
+        h = ops.groupnorm(x, g1, b1, r0.eps, x1=x1, groups=r0.groups, silu=True, streams=S)
+        h = ops.conv3x3(h, w1, c1, rowadd=temb[:, lo:hi], streams=S)
+        h = ops.groupnorm(h, g2, b2, r0.eps, groups=r0.groups, silu=True, streams=S)
+        if r0.conv_shortcut is not None:
+            ws = pk.get("r.ws", rs, [r.conv_shortcut.weight for r in rs], dt,
+                        lambda: _stk(pack_matrix(r.conv_shortcut.weight, dt) for r in rs))
+            bs = pk.get("r.bs", rs, [r.conv_shortcut.bias for r in rs], dt, lambda: _stk(f32(r.conv_shortcut.bias) for r in rs))
+            sc = ops.linear(x, ws, bs, x1=x1, streams=S)
+        else:
+            sc = x
+        return ops.conv3x3(h, w2, c2, res=sc, out_scale=1.0 / r0.output_scale_factor, streams=S)
+
+    def _attn(self, as_: Sequence[Attention], xn, residual, kc, vtc, kv_slice):
+        S, pk, dt = len(as_), self.pk, xn.dtype
+        a0 = as_[0]
+        Bt, T, _ = xn.shape
+        H, d, C = a0.heads, a0.dim_head, a0.inner
+        wo = pk.get("a.wo", as_, [a.to_out[0].weight for a in as_], dt, lambda: _stk(pack_matrix(a.to_out[0].weight, dt) for a in as_))
+        bo = pk.get("a.bo", as_, [a.to_out[0].bias for a in as_], dt, lambda: _stk(f32(a.to_out[0].bias) for a in as_))
+        if not a0.is_cross:
+            wqk = pk.get("a.wqk", as_, [p for a in as_ for p in (a.to_q.weight, a.to_k.weight)], dt,
+                         lambda: _stk(torch.cat([pack_matrix(a.to_q.weight, dt), pack_matrix(a.to_k.weight, dt)], 0) for a in as_))
+            wv = pk.get("a.wv", as_, [a.to_v.weight for a in as_], dt, lambda: _stk(pack_matrix(a.to_v.weight, dt) for a in as_))
+            qk = ops.linear(xn, wqk, streams=S)
+            vt = ops.vt_proj(xn, wv, streams=S)
+            o = ops.attention(qk, qk, vt, B=Bt, H=H, Tq=T, Tk=T, d=d, ldq=2 * C, ldk=2 * C, q_off=0, k_off=C)
+        else:
+            wq = pk.get("a.wq", as_, [a.to_q.weight for a in as_], dt, lambda: _stk(pack_matrix(a.to_q.weight, dt) for a in as_))
+            q = ops.linear(xn, wq, streams=S)
+            lo, hi = kv_slice
+            o = ops.attention(q, kc[:, :, lo:hi], vtc[:, lo:hi], B=Bt, H=H, Tq=T, Tk=kc.shape[1], d=d, ldq=C,
+                              ldk=kc.stride(1))
+        return ops.linear(o, wo, bo, res=residual, streams=S)
+
+    def _tblock(self, bs: Sequence[BasicTransformerBlock], x, kc, vtc, kv_slice):
+        S, pk, dt = len(bs), self.pk, x.dtype
+
+        def ln(name, get):
+            g = pk.get(name + ".g", bs, [get(b).weight for b in bs], dt, lambda: _stk(f32(get(b).weight) for b in bs))
+            b_ = pk.get(name + ".b", bs, [get(b).bias for b in bs], dt, lambda: _stk(f32(get(b).bias) for b in bs))
+            return g, b_
+
+        g, b_ = ln("t.n1", lambda b: b.norm1)
+        x = self._attn([b.attn1 for b in bs], ops.layernorm(x, g, b_, bs[0].norm1.eps, streams=S), x, None, None, None)
+        g, b_ = ln("t.n2", lambda b: b.norm2)
+        x = self._attn([b.attn2 for b in bs], ops.layernorm(x, g, b_, bs[0].norm2.eps, streams=S), x, kc, vtc, kv_slice)
+        g, b_ = ln("t.n3", lambda b: b.norm3)
+        xn = ops.layernorm(x, g, b_, bs[0].norm3.eps, streams=S)
+        projs = [b.ff.net[0].proj for b in bs]
+        outs = [b.ff.net[2] for b in bs]
+        nh = projs[0].weight.shape[0] // 2
+
+        def build_in():
+            perm = geglu_perm(nh, projs[0].weight.device)
+            return (_stk(pack_matrix(p.weight, dt)[perm] for p in projs), _stk(f32(p.bias)[perm] for p in projs))
+
+        w_in, b_in = pk.get("t.ffi", bs, [p for pr in projs for p in (pr.weight, pr.bias)], dt, build_in)
+        w_out = pk.get("t.ffo", bs, [o.weight for o in outs], dt, lambda: _stk(pack_matrix(o.weight, dt) for o in outs))
+        b_out = pk.get("t.ffb", bs, [o.bias for o in outs], dt, lambda: _stk(f32(o.bias) for o in outs))
+        gg = ops.linear(xn, w_in, b_in, act=ops.ACT_GEGLU, streams=S)
+        return ops.linear(gg, w_out, b_out, res=x, streams=S)
+
+    def _transformer(self, ts: Sequence[Transformer2DModel], x, kc, vtc, kv_slices):
+        S, pk, dt = len(ts), self.pk, x.dtype
+        Bt, H, W, Cc = x.shape
+        g = pk.get("x.g", ts, [t.norm.weight for t in ts], dt, lambda: _stk(f32(t.norm.weight) for t in ts))
+        b_ = pk.get("x.b", ts, [t.norm.bias for t in ts], dt, lambda: _stk(f32(t.norm.bias) for t in ts))
+        wi = pk.get("x.wi", ts, [t.proj_in.weight for t in ts], dt, lambda: _stk(pack_matrix(t.proj_in.weight, dt) for t in ts))
+        bi = pk.get("x.bi", ts, [t.proj_in.bias for t in ts], dt, lambda: _stk(f32(t.proj_in.bias) for t in ts))
+        wo = pk.get("x.wo", ts, [t.proj_out.weight for t in ts], dt, lambda: _stk(pack_matrix(t.proj_out.weight, dt) for t in ts))
+        bo = pk.get("x.bo", ts, [t.proj_out.bias for t in ts], dt, lambda: _stk(f32(t.proj_out.bias) for t in ts))
+        h = ops.groupnorm(x, g, b_, ts[0].norm.eps, groups=ts[0].groups, silu=False, streams=S)
+        h = ops.linear(h.view(Bt, H * W, Cc), wi, bi, streams=S)
+        for j in range(len(ts[0].transformer_blocks)):
+            h = self._tblock([t.transformer_blocks[j] for t in ts], h, kc, vtc, kv_slices[j])
+        return ops.linear(h, wo, bo, res=x.view(Bt, H * W, Cc), streams=S).view(Bt, H, W, Cc)
+
+    def _conv(self, name, convs, x, stride=1, ups=False):
+        S, pk, dt = len(convs), self.pk, x.dtype
+        w = pk.get(name + ".w", convs, [c.weight for c in convs], dt, lambda: _stk(pack_conv3x3(c.weight, dt) for c in convs))
+        b = pk.get(name + ".b", convs, [c.bias for c in convs], dt, lambda: _stk(f32(c.bias) for c in convs))
+        return ops.conv3x3(x, w, b, stride=stride, ups=ups, streams=S)
+
+    # ------------------------------------------------------------------ per-phase context (temb, prompt K / V^T)
+    def _phase_ctx(self, nets, resnet_lists, cross_lists, semb, ehs):
+        """Batched per-resnet time projections and per-cross-attention prompt K / V^T of ONE phase, grouped over the
+        streams.  Column layouts are identical across streams because the module lists are."""
+        S, pk, dt = len(nets), self.pk, semb.dtype
+        key = tuple(id(r) for rl in resnet_lists for r in rl)
+        wt = pk.get(("p.wt", key), nets, [r.time_emb_proj.weight for rl in resnet_lists for r in rl], dt,
+                    lambda: _stk(torch.cat([pack_matrix(r.time_emb_proj.weight, dt) for r in rl], 0) for rl in resnet_lists))
+        bt = pk.get(("p.bt", key), nets, [r.time_emb_proj.bias for rl in resnet_lists for r in rl], dt,
+                    lambda: _stk(torch.cat([f32(r.time_emb_proj.bias) for r in rl], 0) for rl in resnet_lists))
+        temb = ops.linear(semb, wt, bt, streams=S)  # [S*B, sum Cout]
+        tslices, off = {}, 0
+        for r in resnet_lists[0]:
+            tslices[id(r)] = (off, off + r.out_channels)
+            off += r.out_channels
+        kc = vtc = None
+        kslices = {}
+        if cross_lists[0]:
+            ckey = tuple(id(a) for al in cross_lists for a in al)
+            wk = pk.get(("p.wk", ckey), nets, [a.to_k.weight for al in cross_lists for a in al], dt,
+                        lambda: _stk(torch.cat([pack_matrix(a.to_k.weight, dt) for a in al], 0) for al in cross_lists))
+            wv = pk.get(("p.wv", ckey), nets, [a.to_v.weight for al in cross_lists for a in al], dt,
+                        lambda: _stk(torch.cat([pack_matrix(a.to_v.weight, dt) for a in al], 0) for al in cross_lists))
+            B, Tk, Cc = ehs.shape
+            n = wk.shape[1]
+            kc = torch.empty(S * B, Tk, n, dtype=dt, device=ehs.device)
+            ops.igemm(x0=ehs, w=wk, out=kc, M=B * Tk, N=n, K=Cc, c0=Cc, ldx0=Cc, ldw=Cc, ldc=n, zbatch=S, zx=0,
+                      zw=wk.stride(0), zout=B * Tk * n)  # the prompt is shared by the streams (zx = 0)
+            vtc = ops.vt_proj(ehs, wv, streams=S, shared_x=True)
+            off = 0
+            for a in cross_lists[0]:
+                kslices[id(a)] = (off, off + a.inner)
+                off += a.inner
+        return temb, tslices, kc, vtc, kslices
+
+    @staticmethod
+    def _resnets_of(mods):
+        return [m for mod in mods for m in mod.modules() if isinstance(m, ResnetBlock2D)]
+
+    @staticmethod
+    def _cross_of(mods):
+        return [m for mod in mods for m in mod.modules() if isinstance(m, Attention) and m.is_cross]
+
+    def _kvs(self, t0: Transformer2DModel, kslices):
+        return [kslices[id(b.attn2)] for b in t0.transformer_blocks]
+
+    # ------------------------------------------------------------------ the step
+    @torch.no_grad()
+    def __call__(self, x_t, cond, ehs, t_img, t_attr, run_decoder: bool = True, conditioning_scale: float = 1.0
+                 ) -> Dict[str, torch.Tensor]:
+        unet, enc, dec, pk = self.unet, self.enc, self.dec, self.pk
+        dt = _compute_dtype(unet.dtype, unet.compute_dtype)
+        dev = x_t.device
+        B, _, H, W = x_t.shape
+        ehs = ehs.to(dt).contiguous() if (ehs.dtype != dt or not ehs.is_contiguous()) else ehs
+        if ehs.shape[0] == 1 and B > 1:
+            ehs = ehs.expand(B, -1, -1).contiguous()
+
+        def tvec(t):
+            t = torch.as_tensor(t, device=dev, dtype=torch.float32).reshape(-1)
+            return t.expand(B) if t.numel() == 1 else t
+
+        # --- time embeddings of the three networks in one grouped chain: rows [enc | unet | dec]
+        nets3 = [enc, unet, dec] if run_decoder else [enc, unet]
+        ts = torch.cat([tvec(t_attr), tvec(t_img)] + ([tvec(t_attr)] if run_decoder else [])).contiguous()
+        S3 = len(nets3)
+        c = unet.config
+        t_emb = ops.timestep_embedding(ts, S3 * B, c["block_out_channels"][0], c["flip_sin_to_cos"], c["freq_shift"], dt)
+        tes = [n.time_embedding for n in nets3]
+        w1 = pk.get("te.w1", tes, [t.linear_1.weight for t in tes], dt, lambda: _stk(pack_matrix(t.linear_1.weight, dt) for t in tes))
+        b1 = pk.get("te.b1", tes, [t.linear_1.bias for t in tes], dt, lambda: _stk(f32(t.linear_1.bias) for t in tes))
+        w2 = pk.get("te.w2", tes, [t.linear_2.weight for t in tes], dt, lambda: _stk(pack_matrix(t.linear_2.weight, dt) for t in tes))
+        b2 = pk.get("te.b2", tes, [t.linear_2.bias for t in tes], dt, lambda: _stk(f32(t.linear_2.bias) for t in tes))
+        semb = ops.linear(ops.linear(t_emb, w1, b1, act=ops.ACT_SILU, streams=S3), w2, b2, act=ops.ACT_SILU, streams=S3)
+
+        # ================= phase 1: enc || unet : conv_in, down, mid =================
+        pair = [enc, unet]
+        parts = [[n.down_blocks, n.mid_block] for n in pair]
+        rl = [self._resnets_of(p) for p in parts]
+        cl = [self._cross_of(p) for p in parts]
+        temb, tsl, kc, vtc, ksl = self._phase_ctx(pair, rl, cl, semb[: 2 * B], ehs)
+        x_in = torch.cat([ops.to_nhwc(cond, dt, CIN_PAD), ops.to_nhwc(x_t, dt, CIN_PAD)], 0)
+        cins = [n.conv_in for n in pair]
+        wci = pk.get("cin.w", cins, [m.weight for m in cins], dt, lambda: _stk(pack_conv3x3(m.weight, dt, CIN_PAD) for m in cins))
+        bci = pk.get("cin.b", cins, [m.bias for m in cins], dt, lambda: _stk(f32(m.bias) for m in cins))
+        x = ops.conv3x3(x_in, wci, bci, streams=2)
+        skips = [x]
+        for bi_ in range(len(enc.down_blocks)):
+            blks = [n.down_blocks[bi_] for n in pair]
+            for li, r0 in enumerate(blks[0].resnets):
+                x = self._resnet([b.resnets[li] for b in blks], x, temb, tsl[id(r0)])
+                if getattr(blks[0], "has_cross_attention", False):
+                    tsf = [b.attentions[li] for b in blks]
+                    x = self._transformer(tsf, x, kc, vtc, self._kvs(tsf[0], ksl))
+                skips.append(x)
+            if blks[0].downsamplers is not None:
+                x = self._conv("ds", [b.downsamplers[0].conv for b in blks], x, stride=2)
+                skips.append(x)
+        mids = [n.mid_block for n in pair]
+        x = self._resnet([m.resnets[0] for m in mids], x, temb, tsl[id(mids[0].resnets[0])])
+        for ai, a0 in enumerate(mids[0].attentions):
+            tsf = [m.attentions[ai] for m in mids]
+            x = self._transformer(tsf, x, kc, vtc, self._kvs(tsf[0], ksl))
+            x = self._resnet([m.resnets[ai + 1] for m in mids], x, temb, tsl[id(mids[0].resnets[ai + 1])])
+        mid = x  # [enc_mid ; unet_mid]
+
+        # ================= phase 2: the exchange, one grouped 1x1 GEMM per skip =================
+        scale = float(conditioning_scale)
+
+        def exchange(name, z_enc, z_dec, t):
+            """t = [enc ; unet] stacked.  Returns [unet + zc(enc)*scale ; enc + cd(unet)] (or only the first half)."""
+            half = t.numel() // 2
+            Cc = t.shape[-1]
+            if run_decoder:
+                mods = [z_enc, z_dec]
+                w = pk.get((name, "w", scale), mods, [m.weight for m in mods], dt,
+                           lambda: _stk([pack_matrix(z_enc.weight, dt) * scale if scale != 1.0 else pack_matrix(z_enc.weight, dt),
+                                         pack_matrix(z_dec.weight, dt)]))
+                b = pk.get((name, "b", scale), mods, [m.bias for m in mods], dt,
+                           lambda: _stk([f32(z_enc.bias) * scale, f32(z_dec.bias)]))
+                tt = t.view(2, -1, Cc)
+                return ops.linear(tt, w, b, res=tt[1], res_zstride=-half, streams=2).view(t.shape)
+            w = pk.get((name, "w1", scale), [z_enc], [z_enc.weight], dt, lambda: (pack_matrix(z_enc.weight, dt) * scale).contiguous())
+            b = pk.get((name, "b1", scale), [z_enc], [z_enc.bias], dt, lambda: f32(z_enc.bias) * scale)
+            return ops.linear(t[:B], w, b, res=t[B:])
+
+        up_skips = [exchange(f"ex{i}", enc.controlnet_down_blocks[i], dec.control_down_blocks[i] if run_decoder else None, s)
+                    for i, s in enumerate(skips)]
+        x = exchange("exm", enc.controlnet_mid_block, dec.control_mid_block if run_decoder else None, mid)
+
+        # ================= phase 3: unet || dec : up path, conv_out =================
+        pair = [unet, dec] if run_decoder else [unet]
+        S = len(pair)
+        rl = [self._resnets_of([n.up_blocks]) for n in pair]
+        cl = [self._cross_of([n.up_blocks]) for n in pair]
+        temb, tsl, kc, vtc, ksl = self._phase_ctx(pair, rl, cl, semb[B: B + S * B], ehs)
+        for bi_ in range(len(unet.up_blocks)):
+            blks = [n.up_blocks[bi_] for n in pair]
+            for li, r0 in enumerate(blks[0].resnets):
+                s = up_skips.pop()
+                x = self._resnet([b.resnets[li] for b in blks], x, temb, tsl[id(r0)], x1=s)
+                if getattr(blks[0], "has_cross_attention", False):
+                    tsf = [b.attentions[li] for b in blks]
+                    x = self._transformer(tsf, x, kc, vtc, self._kvs(tsf[0], ksl))
+            if blks[0].upsamplers is not None:
+                x = self._conv("us", [b.upsamplers[0].conv for b in blks], x, ups=True)
+        norms = [n.conv_norm_out for n in pair]
+        g = pk.get("out.g", norms, [m.weight for m in norms], dt, lambda: _stk(f32(m.weight) for m in norms))
+        b_ = pk.get("out.b", norms, [m.bias for m in norms], dt, lambda: _stk(f32(m.bias) for m in norms))
+        h = ops.groupnorm(x, g, b_, norms[0].eps, groups=norms[0].num_groups, silu=True, streams=S)
+        couts = [n.conv_out for n in pair]
+        n_out = max(m.weight.shape[0] for m in couts)  # 4 (image) / 28 (attributes): pad to the widest
+
+        def pad_rows(t, n):
+            return t if t.shape[0] == n else torch.cat([t, t.new_zeros((n - t.shape[0],) + tuple(t.shape[1:]))], 0)
+
+        wco = pk.get("out.w", couts, [m.weight for m in couts], dt, lambda: _stk(pad_rows(pack_conv3x3(m.weight, dt), n_out) for m in couts))
+        bco = pk.get("out.cb", couts, [m.bias for m in couts], dt, lambda: _stk(pad_rows(f32(m.bias), n_out) for m in couts))
+        y = ops.conv3x3(h, wco, bco, n_out=n_out, streams=S)  # [S*B, H, W, n_out]
+        out = {"img_pred": ops.as_nchw_view(y[:B, :, :, : couts[0].weight.shape[0]])}
+        if run_decoder:
+            out["attr_pred"] = ops.as_nchw_view(y[B:])
+        return out

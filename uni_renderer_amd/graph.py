@@ -75,8 +75,14 @@ class GraphedDualStreamStep:
 
     def __init__(self, unet, enc, dec, batch: int, latent_hw, cross_dim: int, dtype=torch.float16,
                  device="cuda", run_decoder: bool = True, cond_channels: int = 28, img_channels: int = 4,
-                 ctx_len: int = 77, concurrent: bool = True):
+                 ctx_len: int = 77, concurrent: bool = True, mode: Optional[str] = None):
+        """mode: "grouped" (default: the two streams as one grouped launch per op, fused.py), "concurrent" (module
+        path, two graph branches on two HIP streams), "serial" (module path, one stream)."""
         self.unet, self.enc, self.dec, self.run_decoder = unet, enc, dec, run_decoder
+        self.mode = mode or ("grouped" if concurrent else "serial")
+        if self.mode not in ("grouped", "concurrent", "serial"):
+            raise ValueError(self.mode)
+        self._grouped = None
         H, W = (latent_hw, latent_hw) if isinstance(latent_hw, int) else latent_hw
         dev = torch.device(device)
         self.x_t = torch.zeros(batch, img_channels, H, W, dtype=dtype, device=dev)
@@ -84,11 +90,17 @@ class GraphedDualStreamStep:
         self.ehs = torch.zeros(batch, ctx_len, cross_dim, dtype=dtype, device=dev)
         self.t_img = torch.zeros(batch, dtype=torch.float32, device=dev)
         self.t_attr = torch.zeros(batch, dtype=torch.float32, device=dev)
-        self.side = torch.cuda.Stream(device=dev) if concurrent else None
+        self.side = torch.cuda.Stream(device=dev) if self.mode == "concurrent" else None
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.out: Optional[Dict[str, torch.Tensor]] = None
 
     def _run(self):
+        if self.mode == "grouped":
+            if self._grouped is None:
+                from .fused import GroupedDualStreamStep
+
+                self._grouped = GroupedDualStreamStep(self.unet, self.enc, self.dec)
+            return self._grouped(self.x_t, self.cond, self.ehs, self.t_img, self.t_attr, self.run_decoder)
         return dual_stream_step(self.unet, self.enc, self.dec, self.x_t, self.cond, self.ehs, self.t_img,
                                 self.t_attr, self.run_decoder, side=self.side)
 

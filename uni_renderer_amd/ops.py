@@ -140,7 +140,7 @@ def plan_igemm(M: int, N: int, K: int, taps: int = 1, zbatch: int = 1) -> Tuple[
 # ---------------------------------------------------------------------------------------------
 def igemm(*, x0, w, out, M, N, K, c0, c1=0, x1=None, ldx0, ldx1=0, ldw, ldc, taps=1, conv=None, stride=1, ups=0,
           bias=None, rowadd=None, rows_per_b=0, res=None, ldres=0, n_store=0, act=ACT_NONE, out_scale=1.0,
-          zbatch=1, zx=0, zw=0, zout=0, tile=None, splitk=None):
+          zbatch=1, zx=0, zw=0, zout=0, zx1=0, zbias=0, zrow=0, zres=0, zx_div=1, tile=None, splitk=None):
     _require_gpu(x0)
     lib = _lib.load()
     if tile is None or splitk is None:
@@ -154,6 +154,7 @@ def igemm(*, x0, w, out, M, N, K, c0, c1=0, x1=None, ldx0, ldx1=0, ldw, ldc, tap
     d.zero_page = zp.data_ptr()
     d.ldx0, d.ldx1, d.ldw, d.ldres, d.ldc = ldx0, ldx1, ldw, ldres, ldc
     d.zx, d.zw, d.zout = zx, zw, zout
+    d.zx1, d.zbias, d.zrow, d.zres, d.zx_div = zx1, zbias, zrow, zres, zx_div
     d.c0, d.c1 = c0, c1
     if conv is not None:
         d.B, d.Hin, d.Win, d.Hout, d.Wout = conv
@@ -184,48 +185,75 @@ def igemm(*, x0, w, out, M, N, K, c0, c1=0, x1=None, ldx0, ldx1=0, ldw, ldc, tap
 
 
 def linear(x, w, bias=None, *, x1=None, res=None, act=ACT_NONE, out_scale=1.0, rowadd=None, rows_per_b=0, out=None,
-           tile=None, splitk=None):
-    """y[..., N] = epilogue(x[..., K] @ w[N, K]^T).  ``x1``: second source concatenated along K."""
+           tile=None, splitk=None, streams=1, res_zstride=None):
+    """y[..., N] = epilogue(x[..., K] @ w[N, K]^T).  ``x1``: second source concatenated along K.
+
+    ``streams=S`` > 1 runs S independent problems of one shape as ONE grouped launch: x (x1, res, out) hold the
+    S row-blocks back to back, ``w`` is [S, N, K], ``bias`` [S, N], ``rowadd`` has its rows grouped per stream.
+    ``res_zstride`` overrides the per-stream element stride of ``res`` (the exchange GEMMs read the OTHER stream's
+    tensor as residual: pointer at the second half, negative stride)."""
     K0 = x.shape[-1]
     K1 = x1.shape[-1] if x1 is not None else 0
-    M = x.numel() // K0
-    N = w.shape[0]
+    M = x.numel() // K0 // streams
+    N = w.shape[-2]
     n_out = N // 2 if act == ACT_GEGLU else N
     if out is None:
         out = torch.empty(*x.shape[:-1], n_out, dtype=x.dtype, device=x.device)
-    igemm(x0=x, x1=x1, w=w, out=out, M=M, N=N, K=K0 + K1, c0=K0, c1=K1, ldx0=K0, ldx1=K1, ldw=w.stride(0), ldc=n_out,
+    z = {}
+    if streams > 1:
+        z = dict(zbatch=streams, zx=M * K0, zx1=M * K1, zw=w.stride(0), zout=M * n_out,
+                 zbias=(bias.stride(0) if bias is not None else 0),
+                 zres=(res_zstride if res_zstride is not None else M * n_out) if res is not None else 0,
+                 zrow=(rowadd.stride(0) * (rowadd.shape[0] // streams)) if rowadd is not None else 0)
+    igemm(x0=x, x1=x1, w=w, out=out, M=M, N=N, K=K0 + K1, c0=K0, c1=K1, ldx0=K0, ldx1=K1, ldw=w.stride(-2), ldc=n_out,
           bias=bias, res=res, ldres=(n_out if res is not None else 0), act=act, out_scale=out_scale, rowadd=rowadd,
-          rows_per_b=rows_per_b, tile=tile, splitk=splitk)
+          rows_per_b=rows_per_b, tile=tile, splitk=splitk, **z)
     return out
 
 
 def conv3x3(x, w, bias=None, *, x1=None, stride=1, ups=False, rowadd=None, res=None, out_scale=1.0, n_out=None,
-            tile=None, splitk=None):
+            tile=None, splitk=None, streams=1):
     """3x3 conv, pad 1, over NHWC ``x`` (optionally cat(x, x1) on channels, optionally after a nearest-2x
-    upsample).  ``w`` is [Npad >= n_out, 9*Cin] with k = (ky*3+kx)*Cin + c.  Output [B, Ho, Wo, n_out]."""
-    B, H, W, C0 = x.shape
+    upsample).  ``w`` is [Npad >= n_out, 9*Cin] with k = (ky*3+kx)*Cin + c.  Output [B, Ho, Wo, n_out].
+    ``streams=S``: x is [S*B, H, W, C] (stream-major), ``w`` [S, N, 9*Cin], ``bias`` [S, N]: one grouped launch."""
+    Bt, H, W, C0 = x.shape
+    B = Bt // streams
     C1 = x1.shape[-1] if x1 is not None else 0
     if ups:
         Ho, Wo = 2 * H, 2 * W
     else:
         Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
-    N = n_out if n_out is not None else w.shape[0]
-    out = torch.empty(B, Ho, Wo, N, dtype=x.dtype, device=x.device)
-    igemm(x0=x, x1=x1, w=w, out=out, M=B * Ho * Wo, N=N, K=9 * (C0 + C1), c0=C0, c1=C1, ldx0=C0, ldx1=C1,
-          ldw=w.stride(0), ldc=N, taps=9, conv=(B, H, W, Ho, Wo), stride=stride, ups=int(ups), bias=bias,
+    N = n_out if n_out is not None else w.shape[-2]
+    out = torch.empty(Bt, Ho, Wo, N, dtype=x.dtype, device=x.device)
+    M = B * Ho * Wo
+    z = {}
+    if streams > 1:
+        z = dict(zbatch=streams, zx=B * H * W * C0, zx1=B * H * W * C1, zw=w.stride(0), zout=M * N,
+                 zbias=(bias.stride(0) if bias is not None else 0), zres=(M * N if res is not None else 0),
+                 zrow=(rowadd.stride(0) * B) if rowadd is not None else 0)
+    igemm(x0=x, x1=x1, w=w, out=out, M=M, N=N, K=9 * (C0 + C1), c0=C0, c1=C1, ldx0=C0, ldx1=C1,
+          ldw=w.stride(-2), ldc=N, taps=9, conv=(B, H, W, Ho, Wo), stride=stride, ups=int(ups), bias=bias,
           rowadd=rowadd, rows_per_b=Ho * Wo, res=res, ldres=(N if res is not None else 0), out_scale=out_scale,
-          tile=tile, splitk=splitk)
+          tile=tile, splitk=splitk, **z)
     return out
 
 
-def vt_proj(x, wv):
-    """Transposed value projection: Vt[b] = wv @ x[b]^T  -> [B, Cout, Tpad] (columns >= T are zero)."""
-    B, T, Cin = x.shape
-    Cout = wv.shape[0]
+def vt_proj(x, wv, streams=1, shared_x=False):
+    """Transposed value projection: Vt[b] = wv @ x[b]^T  -> [B, Cout, Tpad] (columns >= T are zero).
+    ``streams=S``: ``wv`` is [S, Cout, Cin] and sample b of stream s uses wv[s]; ``x`` is [S*B, T, Cin], or
+    [B, T, Cin] shared by all streams when ``shared_x`` (the prompt embedding); output [S*B, Cout, Tpad]."""
+    Bx, T, Cin = x.shape
+    B = Bx if shared_x else Bx // streams
+    Cout = wv.shape[-2]
     Tpad = (T + 63) // 64 * 64
-    out = torch.empty(B, Cout, Tpad, dtype=x.dtype, device=x.device)
-    igemm(x0=wv, w=x, out=out, M=Cout, N=T, K=Cin, c0=Cin, ldx0=wv.stride(0), ldw=Cin, ldc=Tpad, n_store=Tpad,
-          zbatch=B, zx=0, zw=T * Cin, zout=Cout * Tpad, splitk=1)
+    out = torch.empty(streams * B, Cout, Tpad, dtype=x.dtype, device=x.device)
+    if shared_x and streams > 1:  # z = s * B + b reads x[b]: issue per stream (B problems each)
+        for s_ in range(streams):
+            igemm(x0=wv[s_], w=x, out=out[s_ * B:(s_ + 1) * B], M=Cout, N=T, K=Cin, c0=Cin, ldx0=wv.stride(-2), ldw=Cin,
+                  ldc=Tpad, n_store=Tpad, zbatch=B, zx=0, zw=T * Cin, zout=Cout * Tpad, splitk=1)
+        return out
+    igemm(x0=wv, w=x, out=out, M=Cout, N=T, K=Cin, c0=Cin, ldx0=wv.stride(-2), ldw=Cin, ldc=Tpad, n_store=Tpad,
+          zbatch=streams * B, zx=(wv.stride(0) if streams > 1 else 0), zx_div=B, zw=T * Cin, zout=Cout * Tpad, splitk=1)
     return out
 
 
@@ -241,7 +269,7 @@ def _gn_chunks_bytes(B: int, rows: int, C: int, esize: int = 2):
     return int(nstat), int(napply)
 
 
-def groupnorm(x, gamma, beta, eps, *, x1=None, groups=32, silu=False, nstat=None, napply=None):
+def groupnorm(x, gamma, beta, eps, *, x1=None, groups=32, silu=False, nstat=None, napply=None, streams=1):
     """GroupNorm over NHWC x (or over cat(x, x1)); returns one contiguous [B,H,W,C0+C1] tensor."""
     _require_gpu(x)
     lib = _lib.load()
@@ -260,21 +288,23 @@ def groupnorm(x, gamma, beta, eps, *, x1=None, groups=32, silu=False, nstat=None
     _prof_end(e0, "gn_stats", 0.0, 1.0 * out.numel() * out.element_size())
     e1 = _prof_begin()
     check(lib.ur_groupnorm_apply(_ptr(x), _ptr(x1), C0, C1, B, rows, groups, nstat, napply, part.data_ptr(),
-                                 gamma.data_ptr(), beta.data_ptr(), float(eps), int(silu), out.data_ptr(),
+                                 gamma.data_ptr(), beta.data_ptr(), float(eps), int(silu),
+                                 (B // streams if streams > 1 else 0), (C0 + C1 if streams > 1 else 0), out.data_ptr(),
                                  DT[x.dtype], s),
           "ur_groupnorm_apply")
     _prof_end(e1, "gn_apply", 0.0, 2.0 * out.numel() * out.element_size())
     return out
 
 
-def layernorm(x, gamma, beta, eps=1e-5):
+def layernorm(x, gamma, beta, eps=1e-5, streams=1):
     _require_gpu(x)
     lib = _lib.load()
     Cn = x.shape[-1]
     rows = x.numel() // Cn
     out = torch.empty_like(x)
     e0 = _prof_begin()
-    check(lib.ur_layernorm(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(eps), rows, Cn, out.data_ptr(),
+    check(lib.ur_layernorm(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(eps), rows, Cn,
+                           (rows // streams if streams > 1 else 0), (Cn if streams > 1 else 0), out.data_ptr(),
                            DT[x.dtype], _stream()), "ur_layernorm")
     _prof_end(e0, "layernorm", 0.0, 2.0 * out.numel() * out.element_size())
     return out
