@@ -20,8 +20,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def collect(models, inputs):
+def collect(models, inputs, grouped=False):
     from uni_renderer_amd import ops
+    from uni_renderer_amd.fused import GroupedDualStreamStep
     from uni_renderer_amd.graph import dual_stream_step
 
     calls = {}
@@ -36,7 +37,10 @@ def collect(models, inputs):
     ops.igemm = spy
     try:
         with torch.no_grad():
-            dual_stream_step(*models, *inputs)
+            if grouped:
+                GroupedDualStreamStep(*models)(*inputs)
+            else:
+                dual_stream_step(*models, *inputs)
         torch.cuda.synchronize()
     finally:
         ops.igemm = orig
@@ -71,6 +75,7 @@ def main():
     ap.add_argument("--latent", type=int, default=64)
     ap.add_argument("--dtype", default="fp16")
     ap.add_argument("--also", default="", help='extra "batch,latent" pairs separated by ;')
+    ap.add_argument("--only-missing", action="store_true", help="tune only problems absent from the existing table")
     ap.add_argument("--out", default=os.path.join(ROOT, "uni_renderer_amd", "igemm_tuning.json"))
     ap.add_argument("--report", default=os.path.join(ROOT, "gpurun_out", "tune_report.json"))
     args = ap.parse_args()
@@ -83,17 +88,23 @@ def main():
     shapes = [(args.batch, args.latent)] + [tuple(int(v) for v in p.split(",")) for p in args.also.split(";") if p]
     ops.load_tuning_table("/nonexistent")  # start from the analytic planner
     table, report = {}, []
-    if os.path.exists(args.out):
-        table = json.load(open(args.out))
+    seed_table = os.path.join(ROOT, "uni_renderer_amd", "igemm_tuning.json")
+    for pth in (seed_table, args.out):
+        if os.path.exists(pth):
+            table.update(json.load(open(pth)))
     for (B, L) in shapes:
         calls = collect(models, bench.make_inputs(B, L, dev, dtype, seed=7))
+        calls_g = collect(models, bench.make_inputs(B, L, dev, dtype, seed=7), grouped=True)
+        calls.update({k: v for k, v in calls_g.items() if k not in calls})
+        if args.only_missing:
+            calls = {k: v for k, v in calls.items() if f"{k[0]},{k[1]},{k[2]},{k[3]},{k[4]}" not in table}
         print(f"[tune] batch {B} latent {L}: {len(calls)} distinct problems", flush=True)
         for key, kw in sorted(calls.items()):
             M, N, K, taps, zb = key
             res = {}
             for tile in ops._TILES:
                 for sk in (1, 2, 4, 8):
-                    if sk > 1 and (zb > 1 or K // 64 < 4 * sk):
+                    if sk > 1 and (zb > 4 or K // 64 < 4 * sk):
                         continue
                     t = time_cfg(kw, tile, sk)
                     if t is not None:

@@ -122,7 +122,7 @@ def plan_igemm(M: int, N: int, K: int, taps: int = 1, zbatch: int = 1) -> Tuple[
             bm, bn, eff, _ = _TILES[tile]
             wgs = math.ceil(M / bm) * math.ceil(N / bn) * zbatch
             for sk in (1, 2, 4, 8):
-                if sk > 1 and (zbatch > 1 or K // 64 < 8 * sk):
+                if sk > 1 and (zbatch > 4 or K // 64 < 8 * sk):
                     continue
                 waves = math.ceil(wgs * sk / 256)
                 tt = waves * bm * bn * (K / sk) * 2 / (per_cu * eff)
