@@ -63,17 +63,17 @@ def make_inputs(B, L, dev, dtype, seed):
     return x_t, cond, ehs, t_img, t_attr
 
 
-def measure_roofline(models, inputs, by_shape=False):
-    """One eager step with every launch bracketed by HIP events on the launch stream; per kernel class sums."""
+def measure_roofline(step_fn, by_shape=False):
+    """One eager step (same executor as the timed mode, launched serially on one stream) with every launch
+    bracketed by HIP events on the launch stream; per kernel class sums."""
     from uni_renderer_amd import ops
-    from uni_renderer_amd.graph import dual_stream_step
 
     rec = []
     with torch.no_grad():
-        dual_stream_step(*models, *inputs)  # untimed, warm
+        step_fn()  # untimed, warm
         torch.cuda.synchronize()
         ops.profile_into(rec, by_shape)
-        dual_stream_step(*models, *inputs)
+        step_fn()
         torch.cuda.synchronize()
         ops.profile_into(None)
     agg = {}
@@ -263,7 +263,8 @@ def main():
             },
         }
         if not args.no_roofline and world == 1:
-            roof, table, total_ms = measure_roofline(models, inputs)
+            side, runner.side = runner.side, None  # serial launches for per-kernel timing
+            roof, table, total_ms = measure_roofline(runner._run)
             out["roofline"] = roof
             out["kernel_classes"] = table[:8]
             out["config"]["sum_kernel_ms_eager_step"] = round(total_ms, 3)
@@ -271,7 +272,7 @@ def main():
                 for r in table:
                     print(json.dumps(r), file=sys.stderr)
             if args.shape_table:
-                _, stable, _ = measure_roofline(models, inputs, by_shape=True)
+                _, stable, _ = measure_roofline(runner._run, by_shape=True)
                 with open(args.shape_table, "w") as f:
                     json.dump(stable, f)
         if not args.no_cpu_baseline and world == 1:
