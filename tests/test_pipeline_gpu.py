@@ -72,13 +72,38 @@ def test_graph_replay_equals_eager(dev):
     pipe, _, img, mask, ehs, noise = _setup(dev)
     kw = dict(prompt_embeds=ehs.to(dev).half(), image_latents=img.to(dev), mask_latents=mask.to(dev), latents=noise,
               num_inference_steps=2, guidance_scale=0.0, output_type="latent")
-    pipe.use_hip_graph = True
+    pipe.use_hip_graph = True  # grouped executor, replayed as a hipGraph
     a = pipe.real_image2mask_3mod_albedo(**kw)
+    a2 = pipe.real_image2mask_3mod_albedo(**kw)
     assert len(pipe._graphs) == 1
-    pipe.use_hip_graph = False
+    for x, y in zip(a, a2):
+        assert torch.equal(x, y)  # replay is deterministic
+    pipe.use_hip_graph = False  # module-by-module eager launches (different tile choices: close, not bit-equal)
     b = pipe.real_image2mask_3mod_albedo(**kw)
     for x, y in zip(a, b):
-        assert torch.equal(x, y)
+        assert rel_l2(x, y) < 3e-3
+
+
+def test_graph_modes_agree(dev):
+    """grouped / concurrent (two graph branches) / serial capture of the same step."""
+    from uni_renderer_amd.graph import GraphedDualStreamStep, dual_stream_step
+
+    pipe, _, img, mask, ehs, noise = _setup(dev)
+    g = torch.Generator().manual_seed(3)
+    cond = torch.randn(2, 28, 16, 16, generator=g).to(dev).half()
+    x = img.to(dev).half()
+    e = ehs.repeat(2, 1, 1).to(dev).half()
+    t1, t2 = torch.tensor([10.0, 500.0], device=dev), torch.tensor([999.0, 3.0], device=dev)
+    with torch.no_grad():
+        ref = dual_stream_step(pipe.unet, pipe.controlnet, pipe.controldec, x, cond, e, t1, t2)
+    outs = {}
+    for mode in ("serial", "concurrent", "grouped"):
+        r = GraphedDualStreamStep(pipe.unet, pipe.controlnet, pipe.controldec, 2, 16, 64, mode=mode)
+        o = r.step(x, cond, e, t1, t2)
+        outs[mode] = {k: v.clone() for k, v in o.items()}
+    for k in ("img_pred", "attr_pred"):
+        assert torch.equal(outs["serial"][k], ref[k]) and torch.equal(outs["concurrent"][k], ref[k])
+        assert rel_l2(outs["grouped"][k], ref[k]) < 3e-3
 
 
 def test_rendering_loop_matches_oracle_loop(dev):
