@@ -9,8 +9,25 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def _cpu_threads() -> int:
+    """Threads for the CPU oracle: the cgroup quota if there is one (a 256-thread pool on a 16-core quota thrashes)."""
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = max(1, min(n, int(int(q) / int(p))))
+    except Exception:
+        pass
+    return min(n, 64)
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    torch.set_num_threads(_cpu_threads())
 
 
 def pytest_collection_modifyitems(config, items):
