@@ -104,7 +104,10 @@ def measure_roofline(step_fn, by_shape=False):
     tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")  # HBM bytes/launch from a separate rocprofv3 --pmc pass
     if os.path.exists(tf):
         try:
-            roof["traffic"] = json.load(open(tf)).get(dom["kernel"])
+            ent = json.load(open(tf)).get(dom["kernel"].replace("_splitk", ""))
+            if ent:
+                roof["traffic"] = ent["hbm_bytes_per_launch"]  # PMC: FETCH_SIZE*2 + WRITE_SIZE, bytes per launch
+                roof["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
         except Exception:
             pass
     return roof, table, total_ms
