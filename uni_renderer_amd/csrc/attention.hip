@@ -73,27 +73,45 @@ __global__ void __launch_bounds__(256) attention_kernel(const ur_attn_desc p) {
         }
     }
 
+    // ---- loader state, hoisted out of the key loop: every lane owns fixed (row, chunk) slots of the K and V^T
+    // tiles; per tile only a wave-uniform offset is added (64 keys further) and the ragged-tail test re-done.
+    const char* kbase[KI];
+    int krow[KI];
+#pragma unroll
+    for (int it = 0; it < KI; ++it) {
+        const int g = (wave * KI + it) * 64 + lane;  // linear 16-byte chunk of the K tile
+        const int row = g / CPR, c = g - row * CPR;
+        const int cl = c ^ k_swz<CPR>(row);
+        krow[it] = (cl * 8 < D) ? row : (1 << 30);  // padded head-dim chunks always read zeros
+        kbase[it] = reinterpret_cast<const char*>(K + (int64_t)row * p.ldk + cl * 8);
+    }
+    const char* vbase[VI];
+    bool vok[VI];
+#pragma unroll
+    for (int it = 0; it < VI; ++it) {
+        const int row = (wave * VI + it) * 8 + (lane >> 3);
+        const int cl = (lane & 7) ^ (lane >> 3);
+        vok[it] = row < D;
+        vbase[it] = reinterpret_cast<const char*>(VT + (int64_t)row * p.ldvt + cl * 8);
+    }
+    const char* zpc = reinterpret_cast<const char*>(zp);
+    const int64_t kstep = (int64_t)64 * p.ldk * (int64_t)sizeof(T);
+
     auto stage = [&](int buf, int kt) {
         char* ks_ = smem + buf * STAGE;
         char* vs_ = ks_ + KT_BYTES;
         const int key0 = kt * 64;
+        const int64_t koff = (int64_t)kt * kstep;
 #pragma unroll
         for (int it = 0; it < KI; ++it) {
-            const int ii = wave * KI + it;
-            const int g = ii * 64 + lane;  // linear 16-byte chunk of the K tile
-            const int row = g / CPR, c = g - row * CPR;
-            const int cl = c ^ k_swz<CPR>(row);
-            const int key = key0 + row;
-            const T* src = (key < p.Tk && cl * 8 < D) ? K + (int64_t)key * p.ldk + cl * 8 : zp;
-            glds16(src, ks_ + ii * 1024);
+            const char* src = (key0 + krow[it] < p.Tk) ? kbase[it] + koff : zpc;
+            glds16(src, ks_ + (wave * KI + it) * 1024);
         }
 #pragma unroll
         for (int it = 0; it < VI; ++it) {
             const int ii = wave * VI + it;  // 8-row group of the V^T tile
             if (ii < VROWS8) {
-                const int row = ii * 8 + (lane >> 3);
-                const int cl = (lane & 7) ^ (lane >> 3);
-                const T* src = (row < D) ? VT + (int64_t)row * p.ldvt + key0 + cl * 8 : zp;
+                const char* src = vok[it] ? vbase[it] + key0 * (int)sizeof(T) : zpc;
                 glds16(src, vs_ + ii * 1024);
             }
         }
