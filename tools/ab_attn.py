@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Time ur_attention at the headline self-/cross-attention shapes (HIP events, median of 5 x 20 launches).
+Run once per library build (UR_LIB_PATH=...) for a same-box A/B."""
+import json
+import os
+import statistics
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from uni_renderer_amd import ops  # noqa: E402
+
+
+def timeit(fn, rounds=5, iters=20):
+    fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(rounds):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) / iters * 1e3)
+    return statistics.median(ts)
+
+
+def main():
+    dev = torch.device("cuda:0")
+    out = []
+    for dt in (torch.float16, torch.bfloat16):
+        for (B, H, T, Tk, d) in [(8, 8, 4096, 4096, 40), (8, 8, 1024, 1024, 80), (8, 8, 256, 256, 160),
+                                 (8, 8, 4096, 77, 40), (1, 8, 16384, 16384, 40)]:
+            C = H * d
+            g = torch.Generator(device="cpu").manual_seed(1)
+            q = torch.randn(B, T, C, generator=g).to(dev).to(dt)
+            k = torch.randn(B, Tk, C, generator=g).to(dev).to(dt)
+            v = torch.randn(B, Tk, C, generator=g).to(dev).to(dt)
+            Tkp = (Tk + 63) // 64 * 64
+            vt = torch.zeros(B, C, Tkp, device=dev, dtype=dt)
+            vt[:, :, :Tk] = v.transpose(1, 2)
+            o = ops.attention(q, k, vt, B=B, H=H, Tq=T, Tk=Tk, d=d, ldq=C, ldk=C)
+            ref = torch.nn.functional.scaled_dot_product_attention(
+                q.view(B, T, H, d).transpose(1, 2).float(), k.view(B, Tk, H, d).transpose(1, 2).float(),
+                v.view(B, Tk, H, d).transpose(1, 2).float()).transpose(1, 2).reshape(B, T, C)
+            err = float((o.float() - ref).norm() / ref.norm())
+            us = timeit(lambda: ops.attention(q, k, vt, B=B, H=H, Tq=T, Tk=Tk, d=d, ldq=C, ldk=C))
+            out.append(dict(dtype=str(dt), B=B, H=H, T=T, Tk=Tk, d=d, us=round(us, 1), rel_l2=err,
+                            tflops=round(4.0 * B * H * T * Tk * d / us / 1e6, 1)))
+            print(json.dumps(out[-1]), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -31,6 +31,19 @@ __device__ __forceinline__ int k_swz(int row) {
     return (row ^ (row >> 2)) & 3;
 }
 
+// max over the 4 lanes {l15 + 16*q'} that share a query, without LDS permutes: gfx950 swaps whole 16-lane rows
+// (v_permlane16_swap: odd rows of a <-> even rows of b) and 32-lane halves (v_permlane32_swap).
+__device__ __forceinline__ float xor16_max(float v) {
+    const unsigned u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xor32_max(float v) {
+    const unsigned u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
 template <typename T, int D>
 __global__ void __launch_bounds__(256) attention_kernel(const ur_attn_desc p) {
     typedef typename Vec8<T>::type vec8;
@@ -45,6 +58,10 @@ __global__ void __launch_bounds__(256) attention_kernel(const ur_attn_desc p) {
     constexpr int KI = CPR / 4;          // K-tile LDS-DMA instructions per wave
     constexpr int VROWS8 = DV / 8;       // V^T tile 8-row groups (one instruction each)
     constexpr int VI = (VROWS8 + 3) / 4;
+    // Head dims with zero-padded V^T rows (d = 40 -> 48 rows) get the softmax denominator from the MFMA for free:
+    // padding row D of the LDS tile is all ones, so O^T row D accumulates sum_k P[k] (of the SAME rounded P that
+    // multiplies V) and follows every rescale of the accumulator.  The padding rows are written once, not loaded.
+    constexpr bool MFMA_ROWSUM = (DV > D) && (D % 8 == 0);
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -110,7 +127,7 @@ __global__ void __launch_bounds__(256) attention_kernel(const ur_attn_desc p) {
 #pragma unroll
         for (int it = 0; it < VI; ++it) {
             const int ii = wave * VI + it;  // 8-row group of the V^T tile
-            if (ii < VROWS8) {
+            if (ii < VROWS8 && !(MFMA_ROWSUM && ii * 8 >= D)) {
                 const char* src = vok[it] ? vbase[it] + key0 * (int)sizeof(T) : zpc;
                 glds16(src, vs_ + ii * 1024);
             }
@@ -124,11 +141,21 @@ __global__ void __launch_bounds__(256) attention_kernel(const ur_attn_desc p) {
         acc_o[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     constexpr float NEG_BIG = -1.0e30f;
-    float m_run[2] = {NEG_BIG, NEG_BIG};
-    float l_run[2] = {0.f, 0.f};
+    constexpr float RESCALE_THR = 8.0f;
     const float cs = p.scale * 1.44269504088896341f;  // softmax in base 2
+    float m_run[2] = {NEG_BIG, NEG_BIG};
+    float mc_run[2] = {-NEG_BIG * cs, -NEG_BIG * cs};  // -m_run * cs, the addend of p = exp2(s*cs - m*cs)
+    float l_run[2] = {0.f, 0.f};
 
     const int nkt = (p.Tk + 63) / 64;
+    if (MFMA_ROWSUM) {
+        constexpr int PER = (DV - D) * 64;  // padding elements per stage buffer
+        for (int i = tid; i < 2 * PER; i += 256) {
+            const int buf = i / PER, rem = i - buf * PER;
+            const int row = D + (rem >> 6), col = rem & 63;
+            reinterpret_cast<T*>(smem + buf * STAGE + KT_BYTES + row * 128)[col] = (T)(row == D ? 1.0f : 0.0f);
+        }
+    }
     stage(0, 0);
     __syncthreads();
     // The tile body is instantiated twice: full tiles carry no key masking at all; only a ragged last tile
@@ -166,45 +193,62 @@ __global__ void __launch_bounds__(256) attention_kernel(const ur_attn_desc p) {
         // Raw scores are kept unscaled: max in the raw domain (scale > 0), p = exp2(s*cs - m*cs) is ONE fma
         // feeding v_exp_f32.  Masked keys use a large finite negative (exp2 -> 0) so no inf/NaN arithmetic.
         vec8 pf[2][2];  // [kb][f] : P^T fragment = 8 consecutive keys of this lane's query
-#pragma unroll
-        for (int f = 0; f < 2; ++f) {
-            float t[16];
+        float mx[2];
+        if (tail) {
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        float v = acc_s[kb][sub][f][r];
-                        if (tail) {
-                            const int key = kt * 64 + kb * 32 + qq * 8 + sub * 4 + r;
-                            if (key >= p.Tk) v = NEG_BIG;
+                        const int key = kt * 64 + kb * 32 + qq * 8 + sub * 4 + r;
+                        if (key >= p.Tk) {
+                            acc_s[kb][sub][0][r] = NEG_BIG;
+                            acc_s[kb][sub][1][r] = NEG_BIG;
                         }
-                        t[kb * 8 + sub * 4 + r] = v;
                     }
-            float mx = fmaxf(fmaxf(t[0], t[1]), fmaxf(t[2], t[3]));
+        }
 #pragma unroll
-            for (int i = 4; i < 16; i += 4) mx = fmaxf(mx, fmaxf(fmaxf(t[i], t[i + 1]), fmaxf(t[i + 2], t[i + 3])));
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m_run[f], mx);
-            const float alpha = __builtin_amdgcn_exp2f((m_run[f] - m_new) * cs);
-            const float mc = -m_new * cs;
-            m_run[f] = m_new;
-            float ps = 0.f;
+        for (int f = 0; f < 2; ++f) {
+            float m4[4];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                t[i] = __builtin_amdgcn_exp2f(fmaf(t[i], cs, mc));
-                ps += t[i];
+            for (int i = 0; i < 4; ++i) {
+                const f32x4 v = acc_s[i >> 1][i & 1][f];
+                m4[i] = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
             }
-            l_run[f] = l_run[f] * alpha + ps;
+            float m = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
+            // the 4 lanes (l15, q' = 0..3) sharing a query: gfx950 row / half swaps instead of LDS permutes
+            m = xor16_max(m);
+            mx[f] = xor32_max(m);
+        }
+        // Lazy rescale: the reference maximum of a query only moves when some score of this tile exceeds it by
+        // more than 2^RESCALE_THR (then p would outgrow the fp16/bf16 range); otherwise P keeps the old reference
+        // and the accumulator / row-sum rescale is skipped.  The test is wave-uniform, so it is one scalar branch.
+        const bool grow = (fmaf(mx[0], cs, mc_run[0]) > RESCALE_THR) || (fmaf(mx[1], cs, mc_run[1]) > RESCALE_THR);
+        if (__builtin_amdgcn_ballot_w64(grow) != 0) {
 #pragma unroll
-            for (int i = 0; i < DFR; ++i) acc_o[i][f] *= alpha;
+            for (int f = 0; f < 2; ++f) {
+                const float m_new = fmaxf(m_run[f], mx[f]);
+                const float alpha = __builtin_amdgcn_exp2f((m_run[f] - m_new) * cs);
+                m_run[f] = m_new;
+                mc_run[f] = -m_new * cs;
+                l_run[f] *= alpha;
+#pragma unroll
+                for (int i = 0; i < DFR; ++i) acc_o[i][f] *= alpha;
+            }
+        }
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            const float mc = mc_run[f];
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
+                float t[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) t[i] = __builtin_amdgcn_exp2f(fmaf(acc_s[kb][i >> 2][f][i & 3], cs, mc));
+                if (!MFMA_ROWSUM) l_run[f] += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
                 vec8 pv;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) pv[i] = (T)t[kb * 8 + i];
+                for (int i = 0; i < 8; ++i) pv[i] = (T)t[i];
                 pf[kb][f] = pv;
             }
         }
@@ -230,9 +274,14 @@ __global__ void __launch_bounds__(256) attention_kernel(const ur_attn_desc p) {
     // ---- finalize: combine the partial row sums of the 4 lanes sharing a query, normalise, store
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
-        float l = l_run[f];
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
+        float l;
+        if (MFMA_ROWSUM) {
+            l = __shfl(acc_o[DFR - 1][f][(D % 16) % 4], ((D % 16) / 4) * 16 + l15, 64);
+        } else {
+            l = l_run[f];
+            l += __shfl_xor(l, 16, 64);
+            l += __shfl_xor(l, 32, 64);
+        }
         const float inv = 1.0f / l;
         const int qrow = q0 + f * 16 + l15;
         if (qrow < p.Tq) {

@@ -24,41 +24,74 @@ namespace ur {
 
 constexpr int BK = 64;  // elements per K chunk (128 bytes)
 
+struct V16 { float v[16]; };
+
+// Rare path (ragged N tile, conv_out with 4 / 28 channels, unaligned leading dimensions): element-wise with
+// masks.  Kept OUT OF LINE so that the hot kernels carry only the straight-line vector epilogue.
+template <typename T>
+__device__ __noinline__ void epilogue16_slow(const ur_igemm_desc& p, T* __restrict__ outz, const float* biasz,
+                                             const T* rowaddz, const T* resz, int m, int nc, V16 a) {
+    float (&v)[16] = a.v;
+    if (biasz) {
+        for (int i = 0; i < 16; ++i)
+            if (nc + i < p.N) v[i] += biasz[nc + i];
+    }
+    if (rowaddz) {
+        const T* ra = rowaddz + (int64_t)(m / p.rows_per_b) * p.ld_rowadd + nc;
+        for (int i = 0; i < 16; ++i)
+            if (nc + i < p.N) v[i] += to_f(ra[i]);
+    }
+    if (p.act == ACT_GEGLU) {
+        const int oc = nc >> 1;
+        T* dst = outz + (int64_t)m * p.ldc + oc;
+        for (int i = 0; i < 8; ++i) {
+            const int src = (i < 4) ? i : 4 + i;  // value columns 0-3 / 8-11, gates 4 columns further
+            if (oc + i < (p.N >> 1)) dst[i] = from_f<T>(v[src] * gelu_erf_f(v[src + 4]));
+        }
+        return;
+    }
+    if (p.act == ACT_SILU)
+        for (int i = 0; i < 16; ++i) v[i] = silu_f(v[i]);
+    if (resz) {
+        const T* rp = resz + (int64_t)m * p.ldres + nc;
+        for (int i = 0; i < 16; ++i)
+            if (nc + i < p.N) v[i] += to_f(rp[i]);
+    }
+    T* dst = outz + (int64_t)m * p.ldc + nc;
+    for (int i = 0; i < 16; ++i)
+        if (nc + i < p.n_store) dst[i] = from_f<T>(v[i] * p.out_scale);
+}
+
 template <typename T>
 __device__ __forceinline__ void epilogue16(const ur_igemm_desc& p, T* __restrict__ outz, const float* biasz,
                                            const T* rowaddz, const T* resz, int m, int nc, float (&v)[16]) {
     if (m >= p.M) return;
-    const bool full = (nc + 16 <= p.N);
     const bool vec = (((p.ldc | p.ldres | (int64_t)p.ld_rowadd) & 7) == 0);
+    const int n_out_end = (p.act == ACT_GEGLU) ? (nc >> 1) + 8 : nc + 16;
+    if (__builtin_expect(!(vec && nc + 16 <= p.N && n_out_end <= p.n_store), 0)) {
+        V16 a;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) a.v[i] = v[i];
+        epilogue16_slow<T>(p, outz, biasz, rowaddz, resz, m, nc, a);
+        return;
+    }
     if (biasz) {
-        if (full) {
-            const float4* b4 = reinterpret_cast<const float4*>(biasz + nc);
+        const float4* b4 = reinterpret_cast<const float4*>(biasz + nc);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float4 b = b4[i];
-                v[4 * i + 0] += b.x; v[4 * i + 1] += b.y; v[4 * i + 2] += b.z; v[4 * i + 3] += b.w;
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 16; ++i)
-                if (nc + i < p.N) v[i] += biasz[nc + i];
+        for (int i = 0; i < 4; ++i) {
+            float4 b = b4[i];
+            v[4 * i + 0] += b.x; v[4 * i + 1] += b.y; v[4 * i + 2] += b.z; v[4 * i + 3] += b.w;
         }
     }
     if (rowaddz) {
         const T* ra = rowaddz + (int64_t)(m / p.rows_per_b) * p.ld_rowadd + nc;
-        if (full && vec) {
-            float t[8];
-            load8(ra, t);
+        float t[8];
+        load8(ra, t);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] += t[i];
-            load8(ra + 8, t);
+        for (int i = 0; i < 8; ++i) v[i] += t[i];
+        load8(ra + 8, t);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[8 + i] += t[i];
-        } else {
-#pragma unroll
-            for (int i = 0; i < 16; ++i)
-                if (nc + i < p.N) v[i] += to_f(ra[i]);
-        }
+        for (int i = 0; i < 8; ++i) v[8 + i] += t[i];
     }
     if (p.act == ACT_GEGLU) {
         float o[8];
@@ -67,15 +100,7 @@ __device__ __forceinline__ void epilogue16(const ur_igemm_desc& p, T* __restrict
             o[i] = v[i] * gelu_erf_f(v[4 + i]);
             o[4 + i] = v[8 + i] * gelu_erf_f(v[12 + i]);
         }
-        const int oc = nc >> 1;
-        T* dst = outz + (int64_t)m * p.ldc + oc;
-        if (full && vec) {
-            store8(dst, o);
-        } else {
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-                if (oc + i < (p.N >> 1)) dst[i] = from_f<T>(o[i]);
-        }
+        store8(outz + (int64_t)m * p.ldc + (nc >> 1), o);
         return;
     }
     if (p.act == ACT_SILU) {
@@ -84,38 +109,26 @@ __device__ __forceinline__ void epilogue16(const ur_igemm_desc& p, T* __restrict
     }
     if (resz) {
         const T* rp = resz + (int64_t)m * p.ldres + nc;
-        if (full && vec) {
-            float t[8];
-            load8(rp, t);
+        float t[8];
+        load8(rp, t);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] += t[i];
-            load8(rp + 8, t);
+        for (int i = 0; i < 8; ++i) v[i] += t[i];
+        load8(rp + 8, t);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[8 + i] += t[i];
-        } else {
-#pragma unroll
-            for (int i = 0; i < 16; ++i)
-                if (nc + i < p.N) v[i] += to_f(rp[i]);
-        }
+        for (int i = 0; i < 8; ++i) v[8 + i] += t[i];
     }
     if (p.out_scale != 1.0f) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) v[i] *= p.out_scale;
     }
     T* dst = outz + (int64_t)m * p.ldc + nc;
-    if (vec && nc + 16 <= p.n_store) {
-        float t[8];
+    float t[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) t[i] = v[i];
-        store8(dst, t);
+    for (int i = 0; i < 8; ++i) t[i] = v[i];
+    store8(dst, t);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) t[i] = v[8 + i];
-        store8(dst + 8, t);
-    } else {
-#pragma unroll
-        for (int i = 0; i < 16; ++i)
-            if (nc + i < p.n_store) dst[i] = from_f<T>(v[i]);
-    }
+    for (int i = 0; i < 8; ++i) t[i] = v[8 + i];
+    store8(dst + 8, t);
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int NSTAGE, bool CONV>
