@@ -157,6 +157,9 @@ int ur_layernorm(const void* x, const float* gamma, const float* beta, float eps
  *                     vt + b * vt_bstride elements (lets several layers share one batched projection)
  *   o  [B][Tq][ldo]   head h at columns h*d .. +d
  * d in {32, 40, 64, 80, 128, 160}.
+ * scale > 0: the usual softmax scale (the reference passes d^-1/2, AttnProcessor2_0).
+ * scale <= 0: Q.K^T is ALREADY in log2 units, i.e. the caller folded scale*log2(e) into the q / k projections
+ *             (ur_igemm out_scale, applied in fp32 before the single rounding); p = exp2(q.k - max).
  */
 typedef struct ur_attn_desc {
     const void* q;
@@ -168,7 +171,7 @@ typedef struct ur_attn_desc {
     int64_t vt_bstride;
     int32_t q_off, k_off;
     int32_t B, H, Tq, Tk, d;
-    float scale;
+    float scale;  /* see above: <= 0 selects "scores already in log2 units" */
     int32_t dtype;
 } ur_attn_desc;
 

@@ -237,6 +237,54 @@ def test_attention_fused_qk_layout_and_peaky_softmax(dev, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("d", [32, 40, 64, 80, 160])
+@pytest.mark.parametrize("T", [(256, 256), (200, 77), (128, 40), (1024, 1000)])
+def test_attention_prescaled_log2_scores(dev, dtype, d, T):
+    """scale=0: q.k already carries d^-1/2 * log2(e) (folded into the projections by the modules).  For d = 40
+    this runs the kernel variant that keeps the softmax reference in the zero-padded k column of Q."""
+    from uni_renderer_amd import ops
+    Tq, Tk = T
+    B, H = 2, 2
+    C = H * d
+    q = _rand((B, Tq, C), dtype, dev, seed=1)
+    k = _rand((B, Tk, C), dtype, dev, seed=2)
+    v = _rand((B, Tk, C), dtype, dev, seed=3)
+    Tpad = (Tk + 63) // 64 * 64
+    vt = torch.zeros(B, C, Tpad, dtype=dtype, device=dev)
+    vt[:, :, :Tk] = v.transpose(1, 2)
+    cs = d ** -0.5 * 1.4426950408889634
+    qs = (q.float() * cs).to(dtype)  # what the q projection epilogue stores
+    o = ops.attention(qs, k, vt, B=B, H=H, Tq=Tq, Tk=Tk, d=d, ldq=C, ldk=C, scale=0.0)
+    ref = _attn_ref((qs.float() / cs), k, v, H)  # reference on the SAME rounded operands
+    assert rel_l2(o, ref) < TOL[dtype] * 1.5
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shift", [-60.0, 0.0, 60.0])
+def test_attention_prescaled_reference_tracking(dev, dtype, shift):
+    """Scores far below / above zero and a spiked key per query: the first tile must SET the reference (also
+    downwards), later tiles must raise it when a score outgrows it by 2^8 (lazy rescale), in both kernel variants."""
+    from uni_renderer_amd import ops
+    B, H, d, T = 1, 4, 40, 512
+    C = H * d
+    cs = d ** -0.5 * 1.4426950408889634
+    q = _rand((B, T, C), dtype, dev, seed=4)
+    k = _rand((B, T, C), dtype, dev, seed=5)
+    idx = torch.arange(T, device=dev)
+    k[0, idx] += 3.0 * q[0, (idx * 5 + 1) % T]  # every query has one dominant key somewhere along the sequence
+    # a constant offset of all scores of a head: one extra-large shared component in q and k
+    q[..., 0::d] = 8.0
+    k[..., 0::d] = shift / 8.0 / cs
+    v = _rand((B, T, C), dtype, dev, seed=6)
+    vt = v.transpose(1, 2).contiguous()
+    qs = (q.float() * cs).to(dtype)
+    o = ops.attention(qs, k, vt, B=B, H=H, Tq=T, Tk=T, d=d, ldq=C, ldk=C, scale=0.0)
+    ref = _attn_ref(qs.float() / cs, k, v, H)
+    assert bool(torch.isfinite(o.float()).all())
+    assert rel_l2(o, ref) < TOL[dtype] * 2
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_add_and_timestep_and_layout(dev, dtype):
     from uni_renderer_amd import ops
     a, b = _rand((3, 5, 7, 64), dtype, dev, seed=1), _rand((3, 5, 7, 64), dtype, dev, seed=2)

@@ -91,46 +91,49 @@ __global__ void __launch_bounds__(256) attention_kernel(const ur_attn_desc p) {
     }
 
     // ---- loader state, hoisted out of the key loop: every lane owns fixed (row, chunk) slots of the K and V^T
-    // tiles; per tile only a wave-uniform offset is added (64 keys further) and the ragged-tail test re-done.
-    const char* kbase[KI];
-    int krow[KI];
+    // tiles and walks them with one pointer each (+64 keys per tile; zero-page lanes stand still).  Only a ragged
+    // LAST tile re-tests its key rows against Tk.
+    const char* zpc = reinterpret_cast<const char*>(zp);
+    const char* kptr[KI];
+    int kinc[KI], krow[KI];
+    const int kstep = 64 * (int)p.ldk * (int)sizeof(T);
 #pragma unroll
     for (int it = 0; it < KI; ++it) {
         const int g = (wave * KI + it) * 64 + lane;  // linear 16-byte chunk of the K tile
         const int row = g / CPR, c = g - row * CPR;
         const int cl = c ^ k_swz<CPR>(row);
-        krow[it] = (cl * 8 < D) ? row : (1 << 30);  // padded head-dim chunks always read zeros
-        kbase[it] = reinterpret_cast<const char*>(K + (int64_t)row * p.ldk + cl * 8);
+        const bool real = cl * 8 < D;  // padded head-dim chunks always read zeros
+        krow[it] = real ? row : (1 << 30);
+        kptr[it] = real ? reinterpret_cast<const char*>(K + (int64_t)row * p.ldk + cl * 8) : zpc;
+        kinc[it] = real ? kstep : 0;
     }
-    const char* vbase[VI];
-    bool vok[VI];
+    const char* vptr[VI];
+    int vinc[VI];
 #pragma unroll
     for (int it = 0; it < VI; ++it) {
         const int row = (wave * VI + it) * 8 + (lane >> 3);
         const int cl = (lane & 7) ^ (lane >> 3);
-        vok[it] = row < D;
-        vbase[it] = reinterpret_cast<const char*>(VT + (int64_t)row * p.ldvt + cl * 8);
+        const bool real = row < D;
+        vptr[it] = real ? reinterpret_cast<const char*>(VT + (int64_t)row * p.ldvt + cl * 8) : zpc;
+        vinc[it] = real ? 128 : 0;
     }
-    const char* zpc = reinterpret_cast<const char*>(zp);
-    const int64_t kstep = (int64_t)64 * p.ldk * (int64_t)sizeof(T);
 
-    auto stage = [&](int buf, int kt) {
+    auto stage = [&](int buf, int kt, auto tail_tag) {
+        constexpr bool tail = decltype(tail_tag)::value;
         char* ks_ = smem + buf * STAGE;
         char* vs_ = ks_ + KT_BYTES;
-        const int key0 = kt * 64;
-        const int64_t koff = (int64_t)kt * kstep;
 #pragma unroll
         for (int it = 0; it < KI; ++it) {
-            const char* src = (key0 + krow[it] < p.Tk) ? kbase[it] + koff : zpc;
+            const char* src = kptr[it];
+            if (tail) src = (kt * 64 + krow[it] < p.Tk) ? src : zpc;
             glds16(src, ks_ + (wave * KI + it) * 1024);
+            kptr[it] += kinc[it];
         }
 #pragma unroll
         for (int it = 0; it < VI; ++it) {
             const int ii = wave * VI + it;  // 8-row group of the V^T tile
-            if (ii < VROWS8 && !(MFMA_ROWSUM && ii * 8 >= D)) {
-                const char* src = vok[it] ? vbase[it] + key0 * (int)sizeof(T) : zpc;
-                glds16(src, vs_ + ii * 1024);
-            }
+            if (ii < VROWS8 && !(MFMA_ROWSUM && ii * 8 >= D)) glds16(vptr[it], vs_ + ii * 1024);
+            vptr[it] += vinc[it];
         }
     };
 
@@ -142,7 +145,7 @@ __global__ void __launch_bounds__(256) attention_kernel(const ur_attn_desc p) {
     }
     constexpr float NEG_BIG = -1.0e30f;
     constexpr float RESCALE_THR = 8.0f;
-    const float cs = p.scale * 1.44269504088896341f;  // softmax in base 2
+    const float cs = (p.scale > 0.f) ? p.scale * 1.44269504088896341f : 1.0f;  // softmax in base 2; scale <= 0: Q.K^T is already in log2 units
     float m_run[2] = {NEG_BIG, NEG_BIG};
     float mc_run[2] = {-NEG_BIG * cs, -NEG_BIG * cs};  // -m_run * cs, the addend of p = exp2(s*cs - m*cs)
     float l_run[2] = {0.f, 0.f};
@@ -156,13 +159,16 @@ __global__ void __launch_bounds__(256) attention_kernel(const ur_attn_desc p) {
             reinterpret_cast<T*>(smem + buf * STAGE + KT_BYTES + row * 128)[col] = (T)(row == D ? 1.0f : 0.0f);
         }
     }
-    stage(0, 0);
+    const int nfull = p.Tk >> 6;
+    if (nfull > 0) stage(0, 0, std::false_type{});
+    else stage(0, 0, std::true_type{});
     __syncthreads();
     // The tile body is instantiated twice: full tiles carry no key masking at all; only a ragged last tile
     // (Tk % 64 != 0, e.g. the 77 prompt tokens) pays for the per-score compare/select.
     auto tile = [&](const int kt, auto tail_tag) {
         constexpr bool tail = decltype(tail_tag)::value;
-        if (kt + 1 < nkt) stage((kt + 1) & 1, kt + 1);
+        if (kt + 1 < nfull) stage((kt + 1) & 1, kt + 1, std::false_type{});
+        else if (kt + 1 < nkt) stage((kt + 1) & 1, kt + 1, std::true_type{});
         const char* ks_ = smem + (kt & 1) * STAGE;
         const char* vs_ = ks_ + KT_BYTES;
 
@@ -210,13 +216,15 @@ __global__ void __launch_bounds__(256) attention_kernel(const ur_attn_desc p) {
         }
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
-            float m4[4];
+            // two independent v_max3 chains over the lane's 16 scores
+            auto e = [&](int kb, int i) { return acc_s[kb][i >> 2][f][i & 3]; };
+            float ma = fmaxf(e(0, 0), e(0, 7)), mb = fmaxf(e(1, 0), e(1, 7));
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const f32x4 v = acc_s[i >> 1][i & 1][f];
-                m4[i] = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+            for (int i = 1; i < 7; i += 2) {
+                ma = fmaxf(fmaxf(ma, e(0, i)), e(0, i + 1));
+                mb = fmaxf(fmaxf(mb, e(1, i)), e(1, i + 1));
             }
-            float m = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
+            float m = fmaxf(ma, mb);
             // the 4 lanes (l15, q' = 0..3) sharing a query: gfx950 row / half swaps instead of LDS permutes
             m = xor16_max(m);
             mx[f] = xor32_max(m);
@@ -267,7 +275,6 @@ __global__ void __launch_bounds__(256) attention_kernel(const ur_attn_desc p) {
         }
         __syncthreads();
     };
-    const int nfull = p.Tk >> 6;
     for (int kt = 0; kt < nfull; ++kt) tile(kt, std::false_type{});
     if (nfull < nkt) tile(nfull, std::true_type{});
 
@@ -301,6 +308,288 @@ __global__ void __launch_bounds__(256) attention_kernel(const ur_attn_desc p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Head dims <= 64 (SD-1.x level 0: d = 40, the 4096-token self-attention that dominates the step) run on the
+// 32x32x16 MFMA: the 16x16x32 shape issues at ~27 cycles per instruction on this chip against its nominal 16
+// (tools/ubench/mfma_rate.hip), which made the kernel above MFMA-issue bound at d = 40; the 32x32x16 shape does the
+// same work in half the instructions at its nominal 32 cycles.
+//
+// Same transposed formulation, one 32-query block per wave:
+//   S^T[key][query] = K . Q^T : A = 32 key rows, B = Q rows.  Lane (query j = l&31, h = l>>5) receives, in register
+//       v = 4g + r, MFMA row 8g + 4h + r.  The A fragment of MFMA row i reads LDS key row
+//       16*(g>>1) + 8h + 4*(g&1) + r, so that the lane's registers 8*s .. 8*s+7 are the 8 CONSECUTIVE keys
+//       16s + 8h + (0..7) -- the B operand of P.V k-step s without any cross-lane traffic.
+//   O^T[d][query] = V^T . P^T : A = 32 rows of the V^T tile (d = 40 -> 2 blocks, rows 40.. are padding; row 40 is
+//       all ones so that O^T row 40 is the softmax denominator), B = P.
+// K tile rows are 128 B (64 halfs, head dim zero padded), V^T rows 128 B (64 keys); both XOR-swizzled by
+// ((row >> 1) & 7) on the LDS-DMA source side (conflict-free for 32-consecutive-row b128 reads, lds_bank_check.py).
+template <typename T, int D, bool SLOT>
+__global__ void __launch_bounds__(256) attention32_kernel(const ur_attn_desc p) {
+    typedef typename Vec8<T>::type vec8;
+    static_assert(D <= 64 && D % 8 == 0, "32x32 path: head dim <= 64");
+    constexpr int KSTEPS = (D + 15) / 16;  // k-steps of Q.K^T
+    constexpr int DB = (D + 31) / 32;      // 32-row blocks of O^T
+    constexpr int DV = DB * 32;
+    constexpr int KT_BYTES = 64 * 128;
+    constexpr int VT_BYTES = DV * 128;
+    constexpr int STAGE = KT_BYTES + VT_BYTES;
+    constexpr int VROWS8 = D / 8;  // 8-row groups of V^T that hold data
+    constexpr int VI = (VROWS8 + 3) / 4;
+    constexpr bool MFMA_ROWSUM = DV > D;
+    // SLOT (scores pre-scaled to log2 units by the projections, and a zero-padded k-slot at d = D): Q carries
+    // -m_ref of its query in that slot and K a constant 1, so S^T comes out of the MFMA already shifted by the
+    // softmax reference and P = exp2(S) needs NO per-score multiply-add.  Any reference within 2^RESCALE_THR of the
+    // true maximum is valid, so m_ref is kept at storage-type precision.
+    static_assert(!SLOT || (KSTEPS * 16 > D), "the reference slot needs a padded k column");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int lid = xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
+    const int bh = lid / gridDim.x, qt = lid - bh * gridDim.x;
+    const int b = bh / p.H, h = bh - b * p.H;
+    const int q0 = qt * 128 + wave * 32;
+
+    const T* Q = reinterpret_cast<const T*>(p.q) + (int64_t)b * p.Tq * p.ldq + p.q_off + h * D;
+    const T* K = reinterpret_cast<const T*>(p.k) + (int64_t)b * p.Tk * p.ldk + p.k_off + h * D;
+    const T* VT = reinterpret_cast<const T*>(p.vt) + (int64_t)b * p.vt_bstride + (int64_t)h * D * p.ldvt;
+    const char* zpc = reinterpret_cast<const char*>(p.zero_page);
+
+    // Q fragments (B operand): lane (query l31, half hh) holds d = 16*ks + 8*hh .. +7
+    vec8 qf[KSTEPS];
+    {
+        const int qrow = q0 + l31;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            const int dc = ks * 16 + hh * 8;
+            const void* src = (qrow < p.Tq && dc < D) ? (const void*)(Q + (int64_t)qrow * p.ldq + dc) : (const void*)zpc;
+            qf[ks] = *reinterpret_cast<const vec8*>(src);
+        }
+    }
+
+    // loader: lane owns (row = 8*piece + lane/8, LDS chunk lane%8) of every 1 KiB piece; pointers walk 64 keys per tile
+    const char* kptr[2];
+    int kinc[2], krow[2];
+    const int kstep = 64 * (int)p.ldk * (int)sizeof(T);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int row = (wave * 2 + it) * 8 + (lane >> 3);
+        const int cl = (lane & 7) ^ ((row >> 1) & 7);
+        const bool real = cl * 8 < D;
+        krow[it] = real ? row : (1 << 30);
+        kptr[it] = real ? reinterpret_cast<const char*>(K + (int64_t)row * p.ldk + cl * 8) : zpc;
+        kinc[it] = real ? kstep : 0;
+    }
+    const char* vptr[VI];
+#pragma unroll
+    for (int it = 0; it < VI; ++it) {
+        const int row = (wave * VI + it) * 8 + (lane >> 3);
+        const int cl = (lane & 7) ^ ((row >> 1) & 7);
+        vptr[it] = reinterpret_cast<const char*>(VT + (int64_t)min(row, D - 1) * p.ldvt + cl * 8);
+    }
+
+    auto stage = [&](int buf, int kt, auto tail_tag) {
+        constexpr bool tail = decltype(tail_tag)::value;
+        char* ks_ = smem + buf * STAGE;
+        char* vs_ = ks_ + KT_BYTES;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const char* src = kptr[it];
+            if (tail) src = (kt * 64 + krow[it] < p.Tk) ? src : zpc;
+            if (SLOT) {  // padded chunks keep their one-time image (lane-masked DMA)
+                if (kinc[it] != 0) glds16(src, ks_ + (wave * 2 + it) * 1024);
+            } else {
+                glds16(src, ks_ + (wave * 2 + it) * 1024);
+            }
+            kptr[it] += kinc[it];
+        }
+#pragma unroll
+        for (int it = 0; it < VI; ++it) {
+            const int ii = wave * VI + it;
+            if (ii < VROWS8) glds16(vptr[it], vs_ + ii * 1024);
+            vptr[it] += 128;
+        }
+    };
+
+    f32x16 acc_o[DB];
+#pragma unroll
+    for (int i = 0; i < DB; ++i)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc_o[i][v] = 0.f;
+    constexpr float NEG_BIG = -1.0e30f;
+    constexpr float RESCALE_THR = 8.0f;
+    const float cs = (p.scale > 0.f) ? p.scale * 1.44269504088896341f : 1.0f;  // scale <= 0: already log2 units
+    float m_run = NEG_BIG, mc_run = -NEG_BIG * cs, l_run = 0.f;
+    float m_ref = 0.f;  // SLOT: reference currently stored (negated) in the Q slot
+
+    const int nkt = (p.Tk + 63) / 64;
+    const int nfull = p.Tk >> 6;
+    if (DV > D) {  // padding rows of the V^T tiles: written once (row D = ones when it carries the row sums)
+        constexpr int PER = (DV - D) * 64;
+        for (int i = tid; i < 2 * PER; i += 256) {
+            const int buf = i / PER, rem = i - buf * PER;
+            const int row = D + (rem >> 6), col = rem & 63;
+            reinterpret_cast<T*>(smem + buf * STAGE + KT_BYTES + row * 128)[col] = (T)((MFMA_ROWSUM && row == D) ? 1.0f : 0.0f);
+        }
+    }
+    if (SLOT) {  // K tile chunk d = D..D+7 of every row: {1, 0, ...}; never touched by the DMA afterwards
+        for (int i = tid; i < 2 * 64; i += 256) {
+            const int buf = i >> 6, row = i & 63;
+            vec8 one;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) one[j] = (T)(j == 0 ? 1.0f : 0.0f);
+            *reinterpret_cast<vec8*>(smem + buf * STAGE + row * 128 + (((D / 8) ^ ((row >> 1) & 7)) << 4)) = one;
+        }
+    }
+    if (nfull > 0) stage(0, 0, std::false_type{});
+    else stage(0, 0, std::true_type{});
+    __syncthreads();
+
+    // LDS byte offsets of this lane's fragments (without the k-step chunk)
+    const int krow_l = 16 * (l31 >> 4) + 8 * ((l31 >> 2) & 1) + 4 * ((l31 >> 3) & 1) + (l31 & 3);  // key row of MFMA row l31
+    const int kswz = (krow_l >> 1) & 7, vswz = (l31 >> 1) & 7;
+
+    auto tile = [&](const int kt, auto tail_tag) {
+        constexpr bool tail = decltype(tail_tag)::value;
+        if (kt + 1 < nfull) stage((kt + 1) & 1, kt + 1, std::false_type{});
+        else if (kt + 1 < nkt) stage((kt + 1) & 1, kt + 1, std::true_type{});
+        const char* ks_ = smem + (kt & 1) * STAGE;
+        const char* vs_ = ks_ + KT_BYTES;
+
+        f32x16 acc_s[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc_s[kb][v] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                const vec8 kf = *reinterpret_cast<const vec8*>(ks_ + (kb * 32 + krow_l) * 128 + (((ks * 2 + hh) ^ kswz) << 4));
+                acc_s[kb] = mfma32(kf, qf[ks], acc_s[kb]);
+            }
+        if (tail) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int key = kt * 64 + kb * 32 + (v >> 3) * 16 + hh * 8 + (v & 7);
+                    if (key >= p.Tk) acc_s[kb][v] = NEG_BIG;
+                }
+        }
+        float ma = fmaxf(acc_s[0][0], acc_s[0][15]), mb = fmaxf(acc_s[1][0], acc_s[1][15]);
+#pragma unroll
+        for (int v = 1; v < 15; v += 2) {
+            ma = fmaxf(fmaxf(ma, acc_s[0][v]), acc_s[0][v + 1]);
+            mb = fmaxf(fmaxf(mb, acc_s[1][v]), acc_s[1][v + 1]);
+        }
+        const float mx = xor32_max(fmaxf(ma, mb));  // the two lanes (l31, hh = 0/1) of a query
+        if (SLOT) {
+            // acc_s is already relative to m_ref.  Move the reference only when a score outgrows it by 2^THR (or on
+            // the first tile, which sets it); the scores of THIS tile are then shifted by hand (rare path).
+            if (kt == 0 || __builtin_amdgcn_ballot_w64(mx > RESCALE_THR) != 0) {
+                const float up = (kt == 0) ? mx : fmaxf(mx, 0.f);
+                const float ref_new = (float)(T)(m_ref + up);
+                const float delta = ref_new - m_ref;
+                const float alpha = __builtin_amdgcn_exp2f(-delta);
+                m_ref = ref_new;
+                if (hh == 1) qf[KSTEPS - 1][0] = (T)(-ref_new);  // slot d = D lives in the upper half's fragment
+#pragma unroll
+                for (int i = 0; i < DB; ++i) acc_o[i] *= alpha;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) acc_s[kb] -= delta;
+            }
+        } else if (__builtin_amdgcn_ballot_w64(fmaf(mx, cs, mc_run) > RESCALE_THR) != 0) {  // lazy rescale, wave-uniform
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * cs);
+            m_run = m_new;
+            mc_run = -m_new * cs;
+            l_run *= alpha;
+#pragma unroll
+            for (int i = 0; i < DB; ++i) acc_o[i] *= alpha;
+        }
+        vec8 pf[2][2];  // [kb][s]: keys 32kb + 16s + 8hh + (0..7) of this lane's query
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                float t[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    t[i] = SLOT ? __builtin_amdgcn_exp2f(acc_s[kb][s2 * 8 + i])
+                                : __builtin_amdgcn_exp2f(fmaf(acc_s[kb][s2 * 8 + i], cs, mc_run));
+                if (!MFMA_ROWSUM) l_run += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+                vec8 pv;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) pv[i] = (T)t[i];
+                pf[kb][s2] = pv;
+            }
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int db = 0; db < DB; ++db) {
+                    const vec8 vf = *reinterpret_cast<const vec8*>(vs_ + (db * 32 + l31) * 128 + (((kb * 4 + s2 * 2 + hh) ^ vswz) << 4));
+                    acc_o[db] = mfma32(vf, pf[kb][s2], acc_o[db]);
+                }
+        __syncthreads();
+    };
+    for (int kt = 0; kt < nfull; ++kt) tile(kt, std::false_type{});
+    if (nfull < nkt) tile(nfull, std::true_type{});
+
+    // finalize: lane (query l31, half hh) holds O^T rows d = 32*db + 8g + 4hh + r in register 4g + r
+    float l;
+    if (MFMA_ROWSUM) {
+        constexpr int R = D % 32;  // row of the ones inside the last block: register 4*(R/8) on half (R/4)&1
+        l = __shfl(acc_o[DB - 1][4 * (R / 8) + (R % 4)], ((R / 4) & 1) * 32 + l31, 64);
+    } else {
+        l = l_run + __shfl_xor(l_run, 32, 64);
+    }
+    const float inv = 1.0f / l;
+    const int qrow = q0 + l31;
+    if (qrow < p.Tq) {
+        T* orow = reinterpret_cast<T*>(p.o) + ((int64_t)b * p.Tq + qrow) * p.ldo + h * D;
+        typedef T vec4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int dd = db * 32 + g * 8 + hh * 4;
+                if (dd + 4 <= D) {
+                    vec4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = (T)(acc_o[db][4 * g + r] * inv);
+                    *reinterpret_cast<vec4*>(orow + dd) = o;
+                }
+            }
+    }
+}
+
+template <typename T, int D>
+static int launch_attn32(const ur_attn_desc& d, hipStream_t s) {
+    constexpr size_t lds = 2 * (64 * 128 + (D + 31) / 32 * 32 * 128);
+    constexpr bool HAS_SLOT = ((D + 15) / 16 * 16 > D) && ((D + 31) / 32 * 32 > D);
+    static bool once = false;
+    if (!once) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention32_kernel<T, D, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (HAS_SLOT)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention32_kernel<T, D, HAS_SLOT>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        once = true;
+    }
+    dim3 grid((d.Tq + 127) / 128, d.B * d.H);
+    if (HAS_SLOT && d.scale <= 0.f)
+        hipLaunchKernelGGL((attention32_kernel<T, D, HAS_SLOT>), grid, dim3(256), lds, s, d);
+    else
+        hipLaunchKernelGGL((attention32_kernel<T, D, false>), grid, dim3(256), lds, s, d);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : -(int)e;
+}
+
 template <typename T, int D>
 static int launch_attn(const ur_attn_desc& d, hipStream_t s) {
     constexpr int DK = (D + 31) / 32 * 32, DV = (D + 15) / 16 * 16;
@@ -320,9 +609,9 @@ static int launch_attn(const ur_attn_desc& d, hipStream_t s) {
 template <typename T>
 static int launch_attn_d(const ur_attn_desc& d, hipStream_t s) {
     switch (d.d) {
-        case 32: return launch_attn<T, 32>(d, s);
-        case 40: return launch_attn<T, 40>(d, s);
-        case 64: return launch_attn<T, 64>(d, s);
+        case 32: return launch_attn32<T, 32>(d, s);
+        case 40: return launch_attn32<T, 40>(d, s);
+        case 64: return launch_attn32<T, 64>(d, s);
         case 80: return launch_attn<T, 80>(d, s);
         case 128: return launch_attn<T, 128>(d, s);
         case 160: return launch_attn<T, 160>(d, s);

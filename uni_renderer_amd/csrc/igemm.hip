@@ -25,12 +25,15 @@ namespace ur {
 constexpr int BK = 64;  // elements per K chunk (128 bytes)
 
 struct V16 { float v[16]; };
+// the scalars of the descriptor the masked epilogue needs, passed BY VALUE: handing the kernel-argument struct to
+// an out-of-line function by reference would force a scratch copy of it and turn every p.field into a scratch load
+struct EpiArgs { int N, n_store, rows_per_b, ld_rowadd, act; int64_t ldc, ldres; float out_scale; };
 
 // Rare path (ragged N tile, conv_out with 4 / 28 channels, unaligned leading dimensions): element-wise with
 // masks.  Kept OUT OF LINE so that the hot kernels carry only the straight-line vector epilogue.
 template <typename T>
-__device__ __noinline__ void epilogue16_slow(const ur_igemm_desc& p, T* __restrict__ outz, const float* biasz,
-                                             const T* rowaddz, const T* resz, int m, int nc, V16 a) {
+__device__ __noinline__ void epilogue16_slow(EpiArgs p, T* __restrict__ outz, const float* biasz, const T* rowaddz,
+                                             const T* resz, int m, int nc, V16 a) {
     float (&v)[16] = a.v;
     if (biasz) {
         for (int i = 0; i < 16; ++i)
@@ -72,7 +75,8 @@ __device__ __forceinline__ void epilogue16(const ur_igemm_desc& p, T* __restrict
         V16 a;
 #pragma unroll
         for (int i = 0; i < 16; ++i) a.v[i] = v[i];
-        epilogue16_slow<T>(p, outz, biasz, rowaddz, resz, m, nc, a);
+        const EpiArgs e{p.N, p.n_store, p.rows_per_b, p.ld_rowadd, p.act, p.ldc, p.ldres, p.out_scale};
+        epilogue16_slow<T>(e, outz, biasz, rowaddz, resz, m, nc, a);
         return;
     }
     if (biasz) {

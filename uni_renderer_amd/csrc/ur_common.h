@@ -10,6 +10,7 @@ typedef __bf16 bf16;
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 enum : int { UR_F16 = 0, UR_BF16 = 1, UR_F32 = 2 };
@@ -26,6 +27,17 @@ __device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) {
 }
 __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+// 32x32x16: lane l feeds A[l&31][8*(l>>5)..+7] and B[8*(l>>5)..+7][l&31] and receives, for v = 0..15,
+// D[8*(v>>2) + 4*(l>>5) + (v&3)][l&31].  Issue-bound rates measured on MI355X (tools/ubench/mfma_rate.hip): 1.9 PFLOP/s
+// against 1.16 PFLOP/s for the 16x16x32 shape -- but the igemm tiles are not MFMA-issue bound: a 32x32x16 build of
+// them measured 9 % slower over the step's heaviest problems, so they stay on mfma16.
+__device__ __forceinline__ f32x16 mfma32(f16x8 a, f16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
 // Asynchronous 16-byte-per-lane global -> LDS copy.  The LDS destination is wave-uniform; the

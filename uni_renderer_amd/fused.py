@@ -20,13 +20,14 @@ between the two is tested bit-for-bit-close in tests/test_fused_gpu.py.  The mod
 """
 from __future__ import annotations
 
+import math
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
 
 from . import ops
 from .controlnet import CIN_PAD, _compute_dtype
-from .layers import (Attention, BasicTransformerBlock, ResnetBlock2D, Transformer2DModel, f32, geglu_perm,
+from .layers import (LOG2E, Attention, BasicTransformerBlock, ResnetBlock2D, Transformer2DModel, f32, geglu_perm,
                      pack_conv3x3, pack_matrix)
 
 
@@ -89,21 +90,22 @@ class GroupedDualStreamStep:
         a0 = as_[0]
         Bt, T, _ = xn.shape
         H, d, C = a0.heads, a0.dim_head, a0.inner
+        cs = d ** -0.5 * LOG2E
         wo = pk.get("a.wo", as_, [a.to_out[0].weight for a in as_], dt, lambda: _stk(pack_matrix(a.to_out[0].weight, dt) for a in as_))
         bo = pk.get("a.bo", as_, [a.to_out[0].bias for a in as_], dt, lambda: _stk(f32(a.to_out[0].bias) for a in as_))
         if not a0.is_cross:
             wqk = pk.get("a.wqk", as_, [p for a in as_ for p in (a.to_q.weight, a.to_k.weight)], dt,
                          lambda: _stk(torch.cat([pack_matrix(a.to_q.weight, dt), pack_matrix(a.to_k.weight, dt)], 0) for a in as_))
             wv = pk.get("a.wv", as_, [a.to_v.weight for a in as_], dt, lambda: _stk(pack_matrix(a.to_v.weight, dt) for a in as_))
-            qk = ops.linear(xn, wqk, streams=S)
+            qk = ops.linear(xn, wqk, streams=S, out_scale=math.sqrt(cs))  # scale folded in, see layers.Attention
             vt = ops.vt_proj(xn, wv, streams=S)
-            o = ops.attention(qk, qk, vt, B=Bt, H=H, Tq=T, Tk=T, d=d, ldq=2 * C, ldk=2 * C, q_off=0, k_off=C)
+            o = ops.attention(qk, qk, vt, B=Bt, H=H, Tq=T, Tk=T, d=d, ldq=2 * C, ldk=2 * C, q_off=0, k_off=C, scale=0.0)
         else:
             wq = pk.get("a.wq", as_, [a.to_q.weight for a in as_], dt, lambda: _stk(pack_matrix(a.to_q.weight, dt) for a in as_))
-            q = ops.linear(xn, wq, streams=S)
+            q = ops.linear(xn, wq, streams=S, out_scale=cs)
             lo, hi = kv_slice
             o = ops.attention(q, kc[:, :, lo:hi], vtc[:, lo:hi], B=Bt, H=H, Tq=T, Tk=kc.shape[1], d=d, ldq=C,
-                              ldk=kc.stride(1))
+                              ldk=kc.stride(1), scale=0.0)
         return ops.linear(o, wo, bo, res=residual, streams=S)
 
     def _tblock(self, bs: Sequence[BasicTransformerBlock], x, kc, vtc, kv_slice):

@@ -50,6 +50,9 @@ def _ceil(v: int, m: int) -> int:
     return (v + m - 1) // m * m
 
 
+LOG2E = 1.4426950408889634
+
+
 class PackCache:
     """Per-module cache of packed tensors keyed by (name, dtype, device, parameter versions)."""
 
@@ -195,32 +198,36 @@ class Attention(nn.Module):
         pk = self._pk
         B, T, _ = xn.shape
         H, d, C = self.heads, self.dim_head, self.inner
+        # The softmax scale and the change to base 2 are folded into the q (and, when q|k come from one GEMM, k)
+        # projection epilogues in fp32 -- before the single rounding to fp16/bf16 -- so the attention kernel sees
+        # scores in log2 units (ur_attention scale = 0) and spends no multiply-add per score.
+        cs = d ** -0.5 * LOG2E
         wo = pk.get("wo", [self.to_out[0].weight], dt, lambda: pack_matrix(self.to_out[0].weight, dt))
         bo = pk.get("bo", [self.to_out[0].bias], dt, lambda: f32(self.to_out[0].bias))
         if self.is_cross and ctx.kc is not None and self.kv_slice is not None:
             # K / V^T of the prompt were projected once for the whole network (controlnet._begin)
             lo, hi = self.kv_slice
             wq = pk.get("wq", [self.to_q.weight], dt, lambda: pack_matrix(self.to_q.weight, dt))
-            q = ops.linear(xn, wq)
+            q = ops.linear(xn, wq, out_scale=cs)
             o = ops.attention(q, ctx.kc[:, :, lo:hi], ctx.vtc[:, lo:hi], B=B, H=H, Tq=T, Tk=ctx.kc.shape[1], d=d,
-                              ldq=C, ldk=ctx.kc.stride(1))
+                              ldq=C, ldk=ctx.kc.stride(1), scale=0.0)
             return ops.linear(o, wo, bo, res=residual)
         wv = pk.get("wv", [self.to_v.weight], dt, lambda: pack_matrix(self.to_v.weight, dt))
         if not self.is_cross:
             wqk = pk.get("wqk", [self.to_q.weight, self.to_k.weight], dt,
                          lambda: torch.cat([pack_matrix(self.to_q.weight, dt), pack_matrix(self.to_k.weight, dt)], 0))
-            qk = ops.linear(xn, wqk)                       # [B,T,2C] = q | k
+            qk = ops.linear(xn, wqk, out_scale=math.sqrt(cs))  # [B,T,2C] = q | k, each carrying sqrt(cs)
             vt = ops.vt_proj(xn, wv)                       # [B,C,Tpad]
-            o = ops.attention(qk, qk, vt, B=B, H=H, Tq=T, Tk=T, d=d, ldq=2 * C, ldk=2 * C, q_off=0, k_off=C)
+            o = ops.attention(qk, qk, vt, B=B, H=H, Tq=T, Tk=T, d=d, ldq=2 * C, ldk=2 * C, q_off=0, k_off=C, scale=0.0)
         else:
             wq = pk.get("wq", [self.to_q.weight], dt, lambda: pack_matrix(self.to_q.weight, dt))
             wk = pk.get("wk", [self.to_k.weight], dt, lambda: pack_matrix(self.to_k.weight, dt))
             ehs = ctx.ehs
             Tk = ehs.shape[1]
-            q = ops.linear(xn, wq)
+            q = ops.linear(xn, wq, out_scale=cs)
             k = ops.linear(ehs, wk)                        # [B,Tk,C]
             vt = ops.vt_proj(ehs, wv)                      # [B,C,ceil64(Tk)]
-            o = ops.attention(q, k, vt, B=B, H=H, Tq=T, Tk=Tk, d=d, ldq=C, ldk=C)
+            o = ops.attention(q, k, vt, B=B, H=H, Tq=T, Tk=Tk, d=d, ldq=C, ldk=C, scale=0.0)
         return ops.linear(o, wo, bo, res=residual)
 
 

@@ -312,7 +312,9 @@ def layernorm(x, gamma, beta, eps=1e-5, streams=1):
 
 def attention(q, k, vt, *, B, H, Tq, Tk, d, ldq, ldk, q_off=0, k_off=0, scale=None):
     """q/k are token matrices holding head h at columns off + h*d (row strides ldq/ldk, batches contiguous);
-    vt is a [B, H*d, Tk_pad] tensor or a row-slice view of a wider batched projection."""
+    vt is a [B, H*d, Tk_pad] tensor or a row-slice view of a wider batched projection.
+    ``scale=None``: d**-0.5.  ``scale=0``: q.k is already in log2 units (the projections folded scale*log2(e) in),
+    which for head dims with a zero-padded k column (d = 40) also selects the kernel without per-score multiply-adds."""
     _require_gpu(q)
     lib = _lib.load()
     o = torch.empty(B, Tq, H * d, dtype=q.dtype, device=q.device)
