@@ -390,10 +390,10 @@ __global__ void __launch_bounds__(256) attention32_kernel(const ur_attn_desc p) 
         vptr[it] = reinterpret_cast<const char*>(VT + (int64_t)min(row, D - 1) * p.ldvt + cl * 8);
     }
 
-    // K(kt) -> K buffer kt&1, V(kt) -> V buffer kt&1 (the two rings run one tile apart, see the main loop)
-    auto stage_k = [&](int kt) {
-        char* ks_ = smem + (kt & 1) * STAGE;
-        const bool tail = kt * 64 + 64 > p.Tk;  // wave-uniform
+    auto stage = [&](int buf, int kt, auto tail_tag) {
+        constexpr bool tail = decltype(tail_tag)::value;
+        char* ks_ = smem + buf * STAGE;
+        char* vs_ = ks_ + KT_BYTES;
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             const char* src = kptr[it];
@@ -405,9 +405,6 @@ __global__ void __launch_bounds__(256) attention32_kernel(const ur_attn_desc p) 
             }
             kptr[it] += kinc[it];
         }
-    };
-    auto stage_v = [&](int kt) {
-        char* vs_ = smem + (kt & 1) * STAGE + KT_BYTES;
 #pragma unroll
         for (int it = 0; it < VI; ++it) {
             const int ii = wave * VI + it;
@@ -446,64 +443,52 @@ __global__ void __launch_bounds__(256) attention32_kernel(const ur_attn_desc p) 
             *reinterpret_cast<vec8*>(smem + buf * STAGE + row * 128 + (((D / 8) ^ ((row >> 1) & 7)) << 4)) = one;
         }
     }
+    if (nfull > 0) stage(0, 0, std::false_type{});
+    else stage(0, 0, std::true_type{});
+    __syncthreads();
+
     // LDS byte offsets of this lane's fragments (without the k-step chunk)
     const int krow_l = 16 * (l31 >> 4) + 8 * ((l31 >> 2) & 1) + 4 * ((l31 >> 3) & 1) + (l31 & 3);  // key row of MFMA row l31
     const int kswz = (krow_l >> 1) & 7, vswz = (l31 >> 1) & 7;
 
-    // S^T of one 64-key tile (two 32-key blocks) from K buffer kt&1
-    auto qk = [&](int kt, f32x16 (&sc)[2]) {
+    auto tile = [&](const int kt, auto tail_tag) {
+        constexpr bool tail = decltype(tail_tag)::value;
+        if (kt + 1 < nfull) stage((kt + 1) & 1, kt + 1, std::false_type{});
+        else if (kt + 1 < nkt) stage((kt + 1) & 1, kt + 1, std::true_type{});
         const char* ks_ = smem + (kt & 1) * STAGE;
+        const char* vs_ = ks_ + KT_BYTES;
+
+        f32x16 acc_s[2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int v = 0; v < 16; ++v) sc[kb][v] = 0.f;
+            for (int v = 0; v < 16; ++v) acc_s[kb][v] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks)
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
                 const vec8 kf = *reinterpret_cast<const vec8*>(ks_ + (kb * 32 + krow_l) * 128 + (((ks * 2 + hh) ^ kswz) << 4));
-                sc[kb] = mfma32(kf, qf[ks], sc[kb]);
+                acc_s[kb] = mfma32(kf, qf[ks], acc_s[kb]);
             }
-    };
-
-    float pend = 0.f;  // SLOT: reference shift owed to a score tile that was multiplied before the last rescale
-
-    // One software-pipelined step: the QK^T MFMAs of tile kt+1 are issued FIRST, so the matrix pipe works on them
-    // while this wave's VALU runs the softmax of tile kt; then P.V of tile kt.  `cur` was produced one step earlier.
-    auto step = [&](const int kt, f32x16 (&cur)[2], f32x16 (&nxt)[2]) {
-        if (kt + 2 < nkt) stage_k(kt + 2);  // into the buffer K(kt) was read from during the previous step
-        if (kt + 1 < nkt) {
-            stage_v(kt + 1);
-            qk(kt + 1, nxt);
-        }
-        const char* vs_ = smem + (kt & 1) * STAGE + KT_BYTES;
-        if (SLOT) {
-            if (__builtin_amdgcn_ballot_w64(pend != 0.f) != 0) {  // rare: `cur` still refers to the previous reference
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb) cur[kb] -= pend;
-                pend = 0.f;
-            }
-        }
-        if (kt * 64 + 64 > p.Tk) {  // ragged last tile (wave-uniform)
+        if (tail) {
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int v = 0; v < 16; ++v) {
                     const int key = kt * 64 + kb * 32 + (v >> 3) * 16 + hh * 8 + (v & 7);
-                    if (key >= p.Tk) cur[kb][v] = NEG_BIG;
+                    if (key >= p.Tk) acc_s[kb][v] = NEG_BIG;
                 }
         }
-        float ma = fmaxf(cur[0][0], cur[0][15]), mb = fmaxf(cur[1][0], cur[1][15]);
+        float ma = fmaxf(acc_s[0][0], acc_s[0][15]), mb = fmaxf(acc_s[1][0], acc_s[1][15]);
 #pragma unroll
         for (int v = 1; v < 15; v += 2) {
-            ma = fmaxf(fmaxf(ma, cur[0][v]), cur[0][v + 1]);
-            mb = fmaxf(fmaxf(mb, cur[1][v]), cur[1][v + 1]);
+            ma = fmaxf(fmaxf(ma, acc_s[0][v]), acc_s[0][v + 1]);
+            mb = fmaxf(fmaxf(mb, acc_s[1][v]), acc_s[1][v + 1]);
         }
         const float mx = xor32_max(fmaxf(ma, mb));  // the two lanes (l31, hh = 0/1) of a query
         if (SLOT) {
-            // `cur` is already relative to m_ref.  Move the reference only when a score outgrows it by 2^THR (or on
-            // the first tile, which sets it); the scores of THIS tile are then shifted by hand (rare path), and the
-            // tile already multiplied for the next step gets the same shift there (`pend`).
+            // acc_s is already relative to m_ref.  Move the reference only when a score outgrows it by 2^THR (or on
+            // the first tile, which sets it); the scores of THIS tile are then shifted by hand (rare path).
             if (kt == 0 || __builtin_amdgcn_ballot_w64(mx > RESCALE_THR) != 0) {
                 const float up = (kt == 0) ? mx : fmaxf(mx, 0.f);
                 const float ref_new = (float)(T)(m_ref + up);
@@ -514,8 +499,7 @@ __global__ void __launch_bounds__(256) attention32_kernel(const ur_attn_desc p) 
 #pragma unroll
                 for (int i = 0; i < DB; ++i) acc_o[i] *= alpha;
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb) cur[kb] -= delta;
-                pend = delta;
+                for (int kb = 0; kb < 2; ++kb) acc_s[kb] -= delta;
             }
         } else if (__builtin_amdgcn_ballot_w64(fmaf(mx, cs, mc_run) > RESCALE_THR) != 0) {  // lazy rescale, wave-uniform
             const float m_new = fmaxf(m_run, mx);
@@ -534,8 +518,8 @@ __global__ void __launch_bounds__(256) attention32_kernel(const ur_attn_desc p) 
                 float t[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i)
-                    t[i] = SLOT ? __builtin_amdgcn_exp2f(cur[kb][s2 * 8 + i])
-                                : __builtin_amdgcn_exp2f(fmaf(cur[kb][s2 * 8 + i], cs, mc_run));
+                    t[i] = SLOT ? __builtin_amdgcn_exp2f(acc_s[kb][s2 * 8 + i])
+                                : __builtin_amdgcn_exp2f(fmaf(acc_s[kb][s2 * 8 + i], cs, mc_run));
                 if (!MFMA_ROWSUM) l_run += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
                 vec8 pv;
 #pragma unroll
@@ -551,23 +535,10 @@ __global__ void __launch_bounds__(256) attention32_kernel(const ur_attn_desc p) 
                     const vec8 vf = *reinterpret_cast<const vec8*>(vs_ + (db * 32 + l31) * 128 + (((kb * 4 + s2 * 2 + hh) ^ vswz) << 4));
                     acc_o[db] = mfma32(vf, pf[kb][s2], acc_o[db]);
                 }
-        __syncthreads();  // K(kt+2), V(kt+1) landed (vmcnt(0)) and every wave is done with K(kt+1), V(kt)
-    };
-
-    f32x16 sa[2], sb[2];
-    stage_k(0);
-    stage_v(0);
-    __syncthreads();
-    qk(0, sa);
-    __syncthreads();  // every wave has read K(0) before step 0 refills its buffer with K(2)
-    if (nkt > 1) {
-        stage_k(1);
         __syncthreads();
-    }
-    for (int kt = 0; kt < nkt; kt += 2) {
-        step(kt, sa, sb);
-        if (kt + 1 < nkt) step(kt + 1, sb, sa);
-    }
+    };
+    for (int kt = 0; kt < nfull; ++kt) tile(kt, std::false_type{});
+    if (nfull < nkt) tile(nfull, std::true_type{});
 
     // finalize: lane (query l31, half hh) holds O^T rows d = 32*db + 8g + 4hh + r in register 4g + r
     float l;
