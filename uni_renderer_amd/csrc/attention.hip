@@ -511,8 +511,7 @@ __global__ void __launch_bounds__(256) attention32_kernel(const ur_attn_desc p) 
             for (int i = 0; i < DB; ++i) acc_o[i] *= alpha;
         }
         vec8 pf[2][2];  // [kb][s]: keys 32kb + 16s + 8hh + (0..7) of this lane's query
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+        auto make_p = [&](int kb) {
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 float t[8];
@@ -526,8 +525,8 @@ __global__ void __launch_bounds__(256) attention32_kernel(const ur_attn_desc p) 
                 for (int i = 0; i < 8; ++i) pv[i] = (T)t[i];
                 pf[kb][s2] = pv;
             }
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+        };
+        auto pv_mfma = [&](int kb) {
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
@@ -535,6 +534,11 @@ __global__ void __launch_bounds__(256) attention32_kernel(const ur_attn_desc p) 
                     const vec8 vf = *reinterpret_cast<const vec8*>(vs_ + (db * 32 + l31) * 128 + (((kb * 4 + s2 * 2 + hh) ^ vswz) << 4));
                     acc_o[db] = mfma32(vf, pf[kb][s2], acc_o[db]);
                 }
+        };
+        make_p(0);
+        make_p(1);
+        pv_mfma(0);
+        pv_mfma(1);
         __syncthreads();
     };
     for (int kt = 0; kt < nfull; ++kt) tile(kt, std::false_type{});
