@@ -19,7 +19,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from uni_renderer_amd import ops  # noqa: E402
 
-# (M per stream, N, K, taps, streams)
+# (M per stream, N, K, taps, streams); N >= 2560 are the feed-forward input GEMMs (GEGLU epilogue, no residual)
 PROBLEMS = [
     (16384, 320, 320, 1, 2), (16384, 320, 2880, 9, 2), (16384, 320, 5760, 9, 2), (16384, 2560, 320, 1, 2),
     (16384, 320, 1280, 1, 2), (16384, 640, 320, 1, 2),
@@ -36,6 +36,8 @@ def build(M, N, K, taps, S, dev, dt):
         x = torch.randn(S * M, K, generator=g).to(dev).to(dt)
         w = (torch.randn(S, N, K, generator=g) * K ** -0.5).to(dev).to(dt)
         b = torch.randn(S, N, generator=g).to(dev)
+        if N >= 2560:
+            return lambda tile, sk: ops.linear(x, w, b, act=ops.ACT_GEGLU, tile=tile, splitk=sk, streams=S)
         r = torch.randn(S * M, N, generator=g).to(dev).to(dt)
         return lambda tile, sk: ops.linear(x, w, b, res=r, tile=tile, splitk=sk, streams=S)
     cin = K // 9
@@ -77,6 +79,7 @@ def main():
     ap.add_argument("--sweep", action="store_true")
     ap.add_argument("--dtype", default="fp16")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--tiles", default="", help="comma-separated tile ids for --sweep (default: all)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     dt = torch.float16 if args.dtype == "fp16" else torch.bfloat16
@@ -87,7 +90,7 @@ def main():
         fl = 2.0 * M * N * K * S
         if args.sweep:
             res = {}
-            for tile in ops._TILES:
+            for tile in ([int(t) for t in args.tiles.split(",")] if args.tiles else ops._TILES):
                 for sk in (1, 2, 4, 8):
                     if sk > 1 and K // 64 < 4 * sk:
                         continue
@@ -102,6 +105,8 @@ def main():
             us = time_graph(lambda: fn(None, None))
         total += us
         rows.append(dict(M=M, N=N, K=K, taps=taps, z=S, cfg=cfg, us=round(us, 2), tflops=round(fl / us / 1e6, 1)))
+        if args.sweep:
+            rows[-1]["top"] = {f"{t},{k}": round(v, 2) for (t, k), v in sorted(res.items(), key=lambda kv: kv[1])[:6]}
         print(json.dumps(rows[-1]), flush=True)
     print(json.dumps(dict(lib=os.environ.get("UR_LIB_PATH", "default"), sum_us=round(total, 1))))
     if args.out:
