@@ -6,7 +6,8 @@ dual-stream step and write uni_renderer_amd/igemm_tuning.json (read by ops.plan_
 
 One eager step is run with ops.igemm intercepted to collect the call arguments (tensors kept alive); each unique
 (M, N, K, taps, zbatch) is then re-launched with every candidate configuration, timed with HIP events on the
-launch stream (median of 3 rounds x 8 launches).
+launch stream.  Default timing: the launch is captured 8x into a HIP graph and replayed (median of 3 replays) -- the
+regime the product runs in, free of host pacing; ``--eager`` times plain back-to-back launches instead.
 """
 import argparse
 import json
@@ -47,9 +48,13 @@ def collect(models, inputs, grouped=False):
     return calls
 
 
-def time_cfg(kw, tile, splitk, rounds=3, iters=8):
+_side = None
+
+
+def time_cfg(kw, tile, splitk, rounds=3, iters=8, graph=True):
     from uni_renderer_amd import ops
 
+    global _side
     kw = dict(kw)
     kw["tile"], kw["splitk"] = tile, splitk
     try:
@@ -58,6 +63,26 @@ def time_cfg(kw, tile, splitk, rounds=3, iters=8):
     except RuntimeError:
         return None
     ts = []
+    if graph:
+        if _side is None:
+            _side = torch.cuda.Stream()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(_side):
+            with torch.cuda.graph(g, stream=_side):
+                for _ in range(iters):
+                    ops.igemm(**kw)
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        for _ in range(rounds):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            g.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1) / iters)
+        del g
+        return statistics.median(ts)
     for _ in range(rounds):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -75,6 +100,7 @@ def main():
     ap.add_argument("--latent", type=int, default=64)
     ap.add_argument("--dtype", default="fp16")
     ap.add_argument("--also", default="", help='extra "batch,latent" pairs separated by ;')
+    ap.add_argument("--eager", action="store_true", help="time eager launches instead of graph replays")
     ap.add_argument("--only-missing", action="store_true", help="tune only problems absent from the existing table")
     ap.add_argument("--out", default=os.path.join(ROOT, "uni_renderer_amd", "igemm_tuning.json"))
     ap.add_argument("--report", default=os.path.join(ROOT, "gpurun_out", "tune_report.json"))
@@ -106,7 +132,7 @@ def main():
                 for sk in (1, 2, 4, 8):
                     if sk > 1 and (zb > 4 or K // 64 < 4 * sk):
                         continue
-                    t = time_cfg(kw, tile, sk)
+                    t = time_cfg(kw, tile, sk, graph=not args.eager)
                     if t is not None:
                         res[(tile, sk)] = t
             best = min(res, key=res.get)
