@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Micro-benchmarks of the non-GEMM device ops at the shapes of the headline step (B=4, 64x64 latent), timed with
-HIP events on the launch stream (median of 5 rounds x 20 launches).  Used to choose launch heuristics.
+"""Micro-benchmarks of the non-GEMM device ops at the shapes of the headline step (B=4, 64x64 latent), timed as
+HIP-graph replays of 20 launches (median of 5 replays).  Used to choose launch heuristics.
 
     python tools/bench_ops.py [--what gn,ln,attn] > gpurun_out/bench_ops.jsonl
 """
@@ -17,14 +17,24 @@ sys.path.insert(0, ROOT)
 
 
 def timeit(fn, rounds=5, iters=20):
+    """median us per launch over `rounds` replays of a HIP graph holding `iters` launches (no host pacing)."""
     fn()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        fn()
+        with torch.cuda.graph(g, stream=side):
+            for _ in range(iters):
+                fn()
+    torch.cuda.synchronize()
+    g.replay()
     torch.cuda.synchronize()
     ts = []
     for _ in range(rounds):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(iters):
-            fn()
+        g.replay()
         e1.record()
         torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1) / iters * 1e3)

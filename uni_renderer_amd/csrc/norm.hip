@@ -11,13 +11,16 @@ namespace ur {
 // sample b over all channels and writes partial[b][chunk][g] = (sum, sumsq).
 // Thread mapping: a thread owns one 8-channel vector (fixed) and strides over rows, so consecutive
 // threads read consecutive 16-B pieces of a row and, because NHWC rows are contiguous, of the next row.
+// Eight row loads are always in flight per thread (rows past the chunk are clamped and weighted 0), a
+// thread folds its 8 channels into the (at most two) groups they belong to, and every group is then
+// summed by four threads over a few LDS entries -- all in a fixed order (deterministic).
 // ------------------------------------------------------------------------------------------
 template <typename T>
 __global__ void __launch_bounds__(256) gn_stats_kernel(const T* __restrict__ x0, const T* __restrict__ x1, int c0,
                                                        int c1, int rows, int groups, int nchunks,
                                                        float* __restrict__ partial) {
-    __shared__ float2 chs[2048];  // per-(row-subset, channel) sums of the current pass
-    __shared__ float2 gacc[64];
+    __shared__ float4 tpart[256];  // per thread: (sum, sumsq) of its channels in group gA, and in group gA + 1
+    __shared__ float2 chs[2048];   // cpg < 8 only (tiny test configurations): per-(row-subset, channel) sums
     const int C = c0 + c1, nvec = C >> 3, cpg = C / groups;
     const int b = blockIdx.y, chunk = blockIdx.x;
     const int rpc = (rows + nchunks - 1) / nchunks;
@@ -27,73 +30,96 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(const T* __restrict__ x0,
     const int rs = 256 / tpr;
     const int rsub = t / tpr, cvl = t - rsub * tpr;
     const int nv0 = c0 >> 3;
-    float gs = 0.f, gss = 0.f;  // thread g < groups accumulates its group over the passes
+    float gs = 0.f, gss = 0.f;  // threads 4g .. 4g+3 accumulate group g over the passes
     for (int cvb = 0; cvb < nvec; cvb += tpr) {
         const int cv = cvb + cvl;
         float s[8], ss[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) { s[i] = 0.f; ss[i] = 0.f; }
-        if (rsub < rs && cv < nvec) {
+        const bool active = rsub < rs && cv < nvec && rbeg < rend;
+        if (active) {
             const T* base;
             int64_t ld;
             int co;
             if (cv < nv0) { base = x0 + (int64_t)b * rows * c0; ld = c0; co = cv * 8; }
             else { base = x1 + (int64_t)b * rows * c1; ld = c1; co = (cv - nv0) * 8; }
-            int r = rbeg + rsub;
-            for (; r + 7 * rs < rend; r += 8 * rs) {  // 8 independent 16-byte loads in flight per thread
+            for (int r = rbeg + rsub; r < rend; r += 8 * rs) {  // 8 independent 16-byte loads in flight per thread
                 typename Vec8<T>::type raw[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u)
-                    raw[u] = *reinterpret_cast<const typename Vec8<T>::type*>(base + (int64_t)(r + u * rs) * ld + co);
+                    raw[u] = *reinterpret_cast<const typename Vec8<T>::type*>(base + (int64_t)min(r + u * rs, rend - 1) * ld + co);
 #pragma unroll
-                for (int u = 0; u < 8; ++u)
+                for (int u = 0; u < 8; ++u) {
+                    const float w = (r + u * rs < rend) ? 1.f : 0.f;
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
-                        const float v = (float)raw[u][i];
+                        const float v = (float)raw[u][i] * w;
                         s[i] += v;
                         ss[i] += v * v;
                     }
-            }
-            for (; r + 1 * rs < rend; r += 2 * rs) {
-                float v0[8], v1[8];
-                load8(base + (int64_t)r * ld + co, v0);
-                load8(base + (int64_t)(r + rs) * ld + co, v1);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    s[i] += v0[i] + v1[i];
-                    ss[i] += v0[i] * v0[i] + v1[i] * v1[i];
                 }
             }
-            for (; r < rend; r += rs) {
-                float v[8];
-                load8(base + (int64_t)r * ld + co, v);
+        }
+        if (cpg < 8) {
+            // narrow groups (a vector spans more than two): per-channel sums through LDS, one thread per group
+            __syncthreads();
+            if (rsub < rs) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) { s[i] += v[i]; ss[i] += v[i] * v[i]; }
+                for (int i = 0; i < 8; ++i) chs[rsub * (tpr * 8) + cvl * 8 + i] = active ? make_float2(s[i], ss[i]) : make_float2(0.f, 0.f);
             }
+            __syncthreads();
+            if ((t & 3) == 0 && (t >> 2) < groups) {
+                const int g = t >> 2;
+                const int pb = cvb * 8, pe = min(C, pb + tpr * 8);
+                const int cb = max(pb, g * cpg), ce = min(pe, (g + 1) * cpg);
+                for (int c = cb; c < ce; ++c)
+                    for (int k = 0; k < rs; ++k) {
+                        const float2 a = chs[k * (tpr * 8) + (c - pb)];
+                        gs += a.x;
+                        gss += a.y;
+                    }
+            }
+            continue;
+        }
+        // fold the 8 channels into their (at most two: cpg >= 8) groups
+        const int ca = cv * 8, ga = ca / cpg, split = (ga + 1) * cpg - ca;  // channels i < split belong to ga
+        float4 tp = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (i < split) { tp.x += s[i]; tp.y += ss[i]; }
+            else { tp.z += s[i]; tp.w += ss[i]; }
         }
         __syncthreads();  // previous pass fully consumed
-        if (rsub < rs) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) chs[rsub * (tpr * 8) + cvl * 8 + i] = make_float2(s[i], ss[i]);
-        }
+        tpart[t] = active ? tp : make_float4(0.f, 0.f, 0.f, 0.f);
         __syncthreads();
-        if (t < groups) {
-            // channels of this pass: [cvb*8, cvb*8 + tpr*8) intersected with the group's range
-            const int pb = cvb * 8, pe = min(C, pb + tpr * 8);
-            const int cb = max(pb, t * cpg), ce = min(pe, (t + 1) * cpg);
-            for (int c = cb; c < ce; ++c)
-                for (int k = 0; k < rs; ++k) {
-                    float2 a = chs[k * (tpr * 8) + (c - pb)];
-                    gs += a.x;
-                    gss += a.y;
+        {   // group g = t / 4 (needs groups <= 64), quarter q = t & 3 of its contributing (vector, row-subset) entries
+            const int g = t >> 2, q = t & 3;
+            float a = 0.f, a2 = 0.f;
+            if (g < groups) {
+                // vectors of THIS pass touching group g: cv in [first, last]
+                const int first = max(cvb, (g * cpg) >> 3), last = min(min(cvb + tpr, nvec) - 1, ((g + 1) * cpg - 1) >> 3);
+                const int nv = last - first + 1;
+                for (int e = q; e < nv * rs; e += 4) {
+                    const int k = e / nv, cvv = first + (e - k * nv);
+                    const float4 v = tpart[k * tpr + (cvv - cvb)];
+                    const int gav = (cvv * 8) / cpg;
+                    if (gav == g) { a += v.x; a2 += v.y; }
+                    else if (gav + 1 == g) { a += v.z; a2 += v.w; }
                 }
+            }
+            gs += a;
+            gss += a2;
         }
     }
-    if (t < groups) {
-        float2* dst = reinterpret_cast<float2*>(partial) + ((int64_t)b * nchunks + chunk) * groups + t;
+    // combine the four quarter sums of a group (lanes 4g .. 4g+3 of one wave), fixed order
+    gs += __shfl_xor(gs, 1, 64);
+    gss += __shfl_xor(gss, 1, 64);
+    gs += __shfl_xor(gs, 2, 64);
+    gss += __shfl_xor(gss, 2, 64);
+    if ((t & 3) == 0 && (t >> 2) < groups) {
+        float2* dst = reinterpret_cast<float2*>(partial) + ((int64_t)b * nchunks + chunk) * groups + (t >> 2);
         *dst = make_float2(gs, gss);
     }
-    (void)gacc;
 }
 
 template <typename T>
@@ -104,12 +130,12 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const T* __restrict__ x0,
                                                        const float* __restrict__ beta, float eps, int silu,
                                                        int bper, int pstride, T* __restrict__ out) {
     __shared__ float2 stat[64];  // (mean, rstd) per group
-    __shared__ float2 red[8][64];
+    __shared__ float2 red[4][64];
     const int C = c0 + c1, nvec = C >> 3, cpg = C / groups;
     const int b = blockIdx.y, chunk = blockIdx.x;
     const int t = threadIdx.x;
-    {   // reduce the stats partials of sample b: 8 thread-slices x groups, fixed order (deterministic)
-        const int g = t & 63, j = t >> 6;  // 4 slices of up to 64 groups
+    {   // reduce the stats partials of sample b: 4 thread-slices x groups, fixed order (deterministic)
+        const int g = t & 63, j = t >> 6;
         float s = 0.f, ss = 0.f;
         if (g < groups) {
             const float2* src = reinterpret_cast<const float2*>(partial) + (int64_t)b * nstat * groups + g;
@@ -137,16 +163,24 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const T* __restrict__ x0,
     const int rs = 256 / tpr;
     const int rsub = t / tpr, cvl = t - rsub * tpr;
     const int nv0 = c0 >> 3;
-    if (rsub >= rs) return;
+    if (rsub >= rs || rbeg >= rend) return;
     const int poff = bper > 0 ? (b / bper) * pstride : 0;  // per-stream affine parameters (grouped execution)
     for (int cv = cvl; cv < nvec; cv += tpr) {
         float a[8], sh[8];
+        {
+            const float4* g4 = reinterpret_cast<const float4*>(gamma + poff + cv * 8);
+            const float4* b4 = reinterpret_cast<const float4*>(beta + poff + cv * 8);
+            const float4 g0 = g4[0], g1 = g4[1], b0 = b4[0], b1 = b4[1];
+            const float gm[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+            const float bt[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+            const int ca = cv * 8, ga = ca / cpg, split = (ga + 1) * cpg - ca;
+            const float2 sa = stat[ga], sb = stat[min(ga + 1, groups - 1)];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int c = cv * 8 + i;
-            const float2 st = stat[c / cpg];
-            a[i] = st.y * gamma[poff + c];
-            sh[i] = beta[poff + c] - st.x * a[i];
+            for (int i = 0; i < 8; ++i) {
+                const float2 st = (cpg < 8) ? stat[(ca + i) / cpg] : ((i < split) ? sa : sb);
+                a[i] = st.y * gm[i];
+                sh[i] = bt[i] - st.x * a[i];
+            }
         }
         const T* base;
         int64_t ld;
@@ -154,90 +188,97 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const T* __restrict__ x0,
         if (cv < nv0) { base = x0 + (int64_t)b * rows * c0; ld = c0; co = cv * 8; }
         else { base = x1 + (int64_t)b * rows * c1; ld = c1; co = (cv - nv0) * 8; }
         T* ob = out + (int64_t)b * rows * C + cv * 8;
-        int r = rbeg + rsub;
-        for (; r + 3 * rs < rend; r += 4 * rs) {  // 4 loads in flight, then normalise + store
+        for (int r = rbeg + rsub; r < rend; r += 4 * rs) {  // 4 loads in flight (clamped rows), then normalise + store
             typename Vec8<T>::type raw[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-                raw[u] = *reinterpret_cast<const typename Vec8<T>::type*>(base + (int64_t)(r + u * rs) * ld + co);
+                raw[u] = *reinterpret_cast<const typename Vec8<T>::type*>(base + (int64_t)min(r + u * rs, rend - 1) * ld + co);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                float v[8];
+                if (r + u * rs < rend) {
+                    float v[8];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const float y = (float)raw[u][i] * a[i] + sh[i];
-                    v[i] = silu ? silu_f(y) : y;
+                    for (int i = 0; i < 8; ++i) {
+                        const float y = (float)raw[u][i] * a[i] + sh[i];
+                        v[i] = silu ? silu_f(y) : y;
+                    }
+                    store8(ob + (int64_t)(r + u * rs) * C, v);
                 }
-                store8(ob + (int64_t)(r + u * rs) * C, v);
             }
-        }
-        for (; r < rend; r += rs) {
-            float v[8];
-            load8(base + (int64_t)r * ld + co, v);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const float y = v[i] * a[i] + sh[i];
-                v[i] = silu ? silu_f(y) : y;
-            }
-            store8(ob + (int64_t)r * C, v);
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// LayerNorm: one wave per row, values held in registers (one read, exact two-pass variance).
+// LayerNorm: one wave owns R consecutive rows, all held in registers (one read, exact two-pass variance).
+// R rows per wave keep R independent 16-byte loads in flight per lane -- the kernel is latency-bound: with one
+// row per wave a C = 320 row is a single 640-byte request per wave.
 // ------------------------------------------------------------------------------------------
-template <typename T, int MAXV>
+template <typename T, int MAXV, int R>
 __global__ void __launch_bounds__(256) layernorm_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps, int rows, int C,
                                                         int rows_per_set, int pstride, T* __restrict__ out) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const int poff = rows_per_set > 0 ? (row / rows_per_set) * pstride : 0;  // per-stream affine parameters
-    gamma += poff;
-    beta += poff;
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+    if (row0 >= rows) return;
     const int nvec = C >> 3;
-    const T* xr = x + (int64_t)row * C;
-    float v[MAXV][8];
-    float s = 0.f;
+    float v[R][MAXV][8];
+    float s[R];
 #pragma unroll
-    for (int k = 0; k < MAXV; ++k) {
-        const int cv = lane + k * 64;
-        if (cv < nvec) {
-            load8(xr + cv * 8, v[k]);
+    for (int r = 0; r < R; ++r) {
+        s[r] = 0.f;
+        const T* xr = x + (int64_t)min(row0 + r, rows - 1) * C;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) s += v[k][i];
+        for (int k = 0; k < MAXV; ++k) {
+            const int cv = lane + k * 64;
+            if (cv < nvec) load8(xr + cv * 8, v[r][k]);
         }
     }
-    const float mean = wave_sum(s) / (float)C;
-    float ss = 0.f;
 #pragma unroll
-    for (int k = 0; k < MAXV; ++k) {
-        const int cv = lane + k * 64;
-        if (cv < nvec) {
+    for (int r = 0; r < R; ++r)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const float d = v[k][i] - mean;
-                ss += d * d;
+        for (int k = 0; k < MAXV; ++k)
+            if (lane + k * 64 < nvec) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) s[r] += v[r][k][i];
             }
-        }
+    float mean[R], ss[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) mean[r] = wave_sum(s[r]) / (float)C;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        ss[r] = 0.f;
+#pragma unroll
+        for (int k = 0; k < MAXV; ++k)
+            if (lane + k * 64 < nvec) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float d = v[r][k][i] - mean[r];
+                    ss[r] += d * d;
+                }
+            }
     }
-    const float rstd = rsqrtf(wave_sum(ss) / (float)C + eps);
-    T* orow = out + (int64_t)row * C;
 #pragma unroll
-    for (int k = 0; k < MAXV; ++k) {
-        const int cv = lane + k * 64;
-        if (cv < nvec) {
-            float o[8];
-            const float4* g4 = reinterpret_cast<const float4*>(gamma + cv * 8);
-            const float4* b4 = reinterpret_cast<const float4*>(beta + cv * 8);
-            const float4 g0 = g4[0], g1 = g4[1], b0 = b4[0], b1 = b4[1];
-            const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-            const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+    for (int r = 0; r < R; ++r) {
+        const int row = row0 + r;
+        const float rstd = rsqrtf(wave_sum(ss[r]) / (float)C + eps);
+        if (row >= rows) continue;
+        const int poff = rows_per_set > 0 ? (row / rows_per_set) * pstride : 0;  // per-stream affine parameters
+        T* orow = out + (int64_t)row * C;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) o[i] = (v[k][i] - mean) * rstd * g[i] + bb[i];
-            store8(orow + cv * 8, o);
+        for (int k = 0; k < MAXV; ++k) {
+            const int cv = lane + k * 64;
+            if (cv < nvec) {
+                float o[8];
+                const float4* g4 = reinterpret_cast<const float4*>(gamma + poff + cv * 8);
+                const float4* b4 = reinterpret_cast<const float4*>(beta + poff + cv * 8);
+                const float4 g0 = g4[0], g1 = g4[1], b0 = b4[0], b1 = b4[1];
+                const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+                const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o[i] = (v[r][k][i] - mean[r]) * rstd * g[i] + bb[i];
+                store8(orow + cv * 8, o);
+            }
         }
     }
 }
@@ -291,29 +332,28 @@ extern "C" int ur_groupnorm_apply(const void* x0, const void* x1, int c0, int c1
     return e == hipSuccess ? 0 : -(int)e;
 }
 
+template <typename T>
+static void launch_ln(const void* x, const float* gamma, const float* beta, float eps, int rows, int C, int rows_per_set,
+                      int pstride, void* out, hipStream_t s) {
+    // rows per wave chosen so that a wave keeps >= 4 16-byte loads per lane in flight and the grid still fills the chip
+#define UR_LN(MAXV, R)                                                                                              \
+    hipLaunchKernelGGL((layernorm_kernel<T, MAXV, R>), dim3((rows + 4 * R - 1) / (4 * R)), dim3(256), 0, s,          \
+                       (const T*)x, gamma, beta, eps, rows, C, rows_per_set, pstride, (T*)out)
+    const bool big = rows >= 8192;  // enough rows to give every CU several workgroups even at R = 4
+    if (C <= 512) { if (big) UR_LN(1, 4); else UR_LN(1, 1); }
+    else if (C <= 1024) { if (big) UR_LN(2, 2); else UR_LN(2, 1); }
+    else if (C <= 2048) { if (big) UR_LN(4, 2); else UR_LN(4, 1); }
+    else UR_LN(8, 1);
+#undef UR_LN
+}
+
 extern "C" int ur_layernorm(const void* x, const float* gamma, const float* beta, float eps, int rows, int C,
                             int rows_per_set, int pstride, void* out, int dtype, void* stream) {
     if (!x || !gamma || !beta || !out || rows <= 0 || C <= 0 || (C & 7) || C > 4096) return UR_E_BADARG;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    dim3 grid((rows + 3) / 4);
-    const bool small = C <= 2048;
-    if (dtype == UR_DT_F16) {
-        if (small)
-            hipLaunchKernelGGL((layernorm_kernel<f16, 4>), grid, dim3(256), 0, s, (const f16*)x, gamma, beta, eps, rows,
-                               C, rows_per_set, pstride, (f16*)out);
-        else
-            hipLaunchKernelGGL((layernorm_kernel<f16, 8>), grid, dim3(256), 0, s, (const f16*)x, gamma, beta, eps, rows,
-                               C, rows_per_set, pstride, (f16*)out);
-    } else if (dtype == UR_DT_BF16) {
-        if (small)
-            hipLaunchKernelGGL((layernorm_kernel<bf16, 4>), grid, dim3(256), 0, s, (const bf16*)x, gamma, beta, eps,
-                               rows, C, rows_per_set, pstride, (bf16*)out);
-        else
-            hipLaunchKernelGGL((layernorm_kernel<bf16, 8>), grid, dim3(256), 0, s, (const bf16*)x, gamma, beta, eps,
-                               rows, C, rows_per_set, pstride, (bf16*)out);
-    } else {
-        return UR_E_BADARG;
-    }
+    if (dtype == UR_DT_F16) launch_ln<f16>(x, gamma, beta, eps, rows, C, rows_per_set, pstride, out, s);
+    else if (dtype == UR_DT_BF16) launch_ln<bf16>(x, gamma, beta, eps, rows, C, rows_per_set, pstride, out, s);
+    else return UR_E_BADARG;
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : -(int)e;
 }

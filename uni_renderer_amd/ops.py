@@ -261,11 +261,12 @@ def vt_proj(x, wv, streams=1, shared_x=False):
 # norms, attention, glue
 # ---------------------------------------------------------------------------------------------
 def _gn_chunks_bytes(B: int, rows: int, C: int, esize: int = 2):
-    """Chunking by BYTES per workgroup: a stats workgroup streams ~32 KB, an apply workgroup ~8 KB in + 8 KB out;
-    never fewer than 2 rows per chunk, stats partials capped at 64 per sample (the apply prologue re-reduces them)."""
+    """Chunking by BYTES per workgroup (measured on MI355X with tools/bench_ops.py --what gn): a stats workgroup
+    streams ~64 KB, an apply workgroup ~20 KB in + 20 KB out; never fewer than 2 rows per chunk, stats partials capped
+    at 32 per sample (every apply workgroup re-reduces them in its prologue)."""
     sample_bytes = rows * C * esize
-    nstat = max(1, min(sample_bytes // (32 << 10), rows // 2, 64))
-    napply = max(1, min(sample_bytes // (8 << 10), rows // 2, 512, max(1, 4096 // max(B, 1))))
+    nstat = max(1, min(sample_bytes // (64 << 10), rows // 2, 32))
+    napply = max(1, min(sample_bytes // (20 << 10), rows // 2, 512, max(1, 4096 // max(B, 1))))
     return int(nstat), int(napply)
 
 
