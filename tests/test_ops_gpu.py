@@ -191,6 +191,20 @@ def test_layernorm(dev, dtype, C):
     assert rel_l2(y, ref) < TOL[dtype]
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("C", [64, 512, 1024, 2048, 320])
+def test_layernorm_many_rows_and_streams(dev, dtype, C):
+    """rows >= 8192 selects the several-rows-per-wave launch; streams=2 the per-stream affine parameters."""
+    from uni_renderer_amd import ops
+    x = _rand((2, 4101, C), dtype, dev, seed=2) * 2 - 0.5
+    g = torch.randn(2, C, generator=torch.Generator().manual_seed(5)).to(dev)
+    b = torch.randn(2, C, generator=torch.Generator().manual_seed(6)).to(dev)
+    y = ops.layernorm(x, g, b, 1e-5, streams=2)
+    for s in range(2):
+        ref = F.layer_norm(x[s].float().cpu(), (C,), g[s].cpu(), b[s].cpu(), 1e-5)
+        assert rel_l2(y[s], ref) < TOL[dtype]
+
+
 def _attn_ref(q, k, v, H):
     B, Tq, C = q.shape
     d = C // H

@@ -283,6 +283,58 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const T* __restrict__ x,
     }
 }
 
+// LayerNorm for the SD channel counts C = 320 / 640 / 1280 (C / 8 = 5 * L vectors, L = 8 / 16 / 32): L lanes share a
+// row, every lane holds five 16-byte vectors, so all 64 lanes are busy (a C = 320 row only fills 40 lanes of the
+// one-row-per-wave kernel), five loads are in flight per lane and the reductions run over L lanes only.
+template <typename T, int L>
+__global__ void __launch_bounds__(256) layernorm5_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float eps, int rows, int C,
+                                                         int rows_per_set, int pstride, T* __restrict__ out) {
+    constexpr int RPW = 64 / L;  // rows per wave
+    const int lane = threadIdx.x & 63, sub = lane % L;
+    const int row = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + lane / L;
+    const bool valid = row < rows;
+    const T* xr = x + (int64_t)min(row, rows - 1) * C;
+    float v[5][8];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) load8(xr + (sub + k * L) * 8, v[k]);
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += v[k][i];
+#pragma unroll
+    for (int o = L / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s / (float)C;
+    float ss = 0.f;
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float d = v[k][i] - mean;
+            ss += d * d;
+        }
+#pragma unroll
+    for (int o = L / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    const float rstd = rsqrtf(ss / (float)C + eps);
+    if (!valid) return;
+    const int poff = rows_per_set > 0 ? (row / rows_per_set) * pstride : 0;  // per-stream affine parameters
+    T* orow = out + (int64_t)row * C;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const int cv = sub + k * L;
+        float o[8];
+        const float4* g4 = reinterpret_cast<const float4*>(gamma + poff + cv * 8);
+        const float4* b4 = reinterpret_cast<const float4*>(beta + poff + cv * 8);
+        const float4 g0 = g4[0], g1 = g4[1], b0 = b4[0], b1 = b4[1];
+        const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+        const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = (v[k][i] - mean) * rstd * g[i] + bb[i];
+        store8(orow + cv * 8, o);
+    }
+}
+
 }  // namespace ur
 
 using namespace ur;
@@ -339,6 +391,13 @@ static void launch_ln(const void* x, const float* gamma, const float* beta, floa
 #define UR_LN(MAXV, R)                                                                                              \
     hipLaunchKernelGGL((layernorm_kernel<T, MAXV, R>), dim3((rows + 4 * R - 1) / (4 * R)), dim3(256), 0, s,          \
                        (const T*)x, gamma, beta, eps, rows, C, rows_per_set, pstride, (T*)out)
+#define UR_LN5(LL)                                                                                                   \
+    hipLaunchKernelGGL((layernorm5_kernel<T, LL>), dim3((rows + 4 * (64 / LL) - 1) / (4 * (64 / LL))), dim3(256), 0, s, \
+                       (const T*)x, gamma, beta, eps, rows, C, rows_per_set, pstride, (T*)out)
+    if (C == 320) { UR_LN5(8); return; }
+    if (C == 640) { UR_LN5(16); return; }
+    if (C == 1280) { UR_LN5(32); return; }
+#undef UR_LN5
     const bool big = rows >= 8192;  // enough rows to give every CU several workgroups even at R = 4
     if (C <= 512) { if (big) UR_LN(1, 4); else UR_LN(1, 1); }
     else if (C <= 1024) { if (big) UR_LN(2, 2); else UR_LN(2, 1); }
