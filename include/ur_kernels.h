@@ -30,6 +30,8 @@
  *                   (controlnet.py:1078-1087, 1114-1115).
  *   ur_timestep_embedding   diffusers Timesteps (controlnet.py:285, 909-914).
  *   ur_nchw_to_nhwc / ur_nhwc_to_nchw   layout glue at the module boundary (the reference is NCHW).
+ *   ur_ddim_update / ur_sampler_advance   the per-group scheduler `.step()` calls and the timestep bookkeeping between
+ *                   two denoise steps of the sampling loops (models/pipeline.py:2691-2730, 1645-1649), on the device.
  */
 #ifndef UR_KERNELS_H
 #define UR_KERNELS_H
@@ -191,6 +193,22 @@ int ur_nchw_to_nhwc(const void* src, int src_dtype, int B, int C, int H, int W, 
                     void* stream);
 int ur_nhwc_to_nchw(const void* src, int dtype, int B, int C, int H, int W, void* dst, int dst_dtype,
                     void* stream);
+
+/*
+ * Sampler glue between two denoise steps, graph-capturable: no host value is baked in.
+ * ur_ddim_update: DDIM (eta 0) update for an x0-predicting model over C latent channels,
+ *     eps = (x - c[0]*x0) / c[1];  x <- c[2]*x0 + c[3]*eps,   c = coef + 4 * min(*step, nsteps-1)
+ *     (c = sqrt(a_t), sqrt(1-a_t), sqrt(a_prev), sqrt(1-a_prev)), evaluated in fp32 without FMA contraction.
+ *     pred: NHWC [B][HW][pred_ld], channels pred_c0 .. pred_c0+C (a network output);
+ *     lat:  NCHW [B][C][HW], sample b at lat + b*lat_bstride (a channel slice of the next step's input), in place.
+ *     master: NULL, or the sampler's own contiguous fp32 [B][C][HW] copy of the latents: then x is read from it,
+ *     the result is stored there (rounded through the storage dtype first if round_master) and its rounding in lat.
+ * ur_sampler_advance: *step += 1; t_out[0..B) = tsteps[min(*step, nsteps-1)] (t_out may be NULL; B <= 256).
+ */
+int ur_ddim_update(const void* pred, int pred_ld, int pred_c0, void* lat, int64_t lat_bstride, int C, int B, int HW,
+                   const float* coef, const int* step, int nsteps, float* master, int round_master, int dtype,
+                   void* stream);
+int ur_sampler_advance(int* step, const float* tsteps, int nsteps, float* t_out, int B, void* stream);
 
 /* Library self-description. */
 int ur_abi_version(void);

@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""End-to-end sampling loops (latents in, latents out; VAE / CLIP outside): wall time of the 50-step
+inverse-rendering loop (UniRendererPipeline.real_image2mask_3mod_albedo) and the rendering loop
+(mask2image_3mod_albedo) against 50 x the bare graph-replayed denoise step."""
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from uni_renderer_amd.pipeline import UniRendererPipeline  # noqa: E402
+
+
+def main():
+    dev, dt = torch.device("cuda:0"), torch.float16
+    B, L, steps = int(os.environ.get("B", 4)), 64, 50
+    unet, enc, dec = bench.build_models(dev, dt)
+    pipe = UniRendererPipeline(unet=unet, controlnet=enc, controldec=dec)
+    g = torch.Generator(device=dev).manual_seed(3)
+    img = torch.randn(B, 4, L, L, device=dev, generator=g).to(dt)
+    msk = torch.randn(B, 4, L, L, device=dev, generator=g).to(dt)
+    ehs = (torch.randn(B, 77, 768, device=dev, generator=g) * 0.5).to(dt)
+    attr = torch.randn(B, 28, L, L, device=dev, generator=g).to(dt)
+    res = {}
+    for name, fn in (
+        ("inverse_50", lambda: pipe.real_image2mask_3mod_albedo(prompt_embeds=ehs, image_latents=img, mask_latents=msk,
+                                                               num_inference_steps=steps, guidance_scale=0.0,
+                                                               output_type="latent")),
+        ("render_50", lambda: pipe.mask2image_3mod_albedo(prompt_embeds=ehs, attr_latents=attr,
+                                                          num_inference_steps=steps, guidance_scale=0.0,
+                                                          output_type="latent")),
+    ):
+        fn()  # capture + warm
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        res[name] = dict(ms_total=round(min(ts) * 1e3, 2), ms_per_step=round(min(ts) * 1e3 / steps, 3))
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()

@@ -32,7 +32,7 @@ def klass(name: str):
         st = -int(st[1:]) if st.startswith("n") else int(st)
         t = TILE.get((bm, bn, wm, wn, st), f"{bm}x{bn}s{st}w{wm * wn}")
         return f"igemm_{t}_{'conv3x3' if m.group(6) == '1' else 'gemm'}"
-    m = re.search(r"attention_kernelID(?:F16_|F16b)Li(\d+)", name)
+    m = re.search(r"attention(?:32)?_kernelID(?:F16_|F16b)Li(\d+)", name)
     if m:
         return f"attention_d{m.group(1)}"
     for k, v in (("gn_stats_kernel", "gn_stats"), ("gn_apply_kernel", "gn_apply"), ("layernorm_kernel", "layernorm"),

@@ -163,6 +163,78 @@ extern "C" int ur_nhwc_to_nchw(const void* src, int dtype, int B, int C, int H, 
     return UR_E_BADARG;
 }
 
+// ------------------------------------------------------------------------------------------
+// On-device sampler update: the DDIM (eta = 0) step of models/pipeline.py:2691-2730 /
+// 1645-1649 for a model that predicts x0 ("sample"), applied to C latent channels at once, with the per-step
+// scalars read from a device table indexed by a device-side step counter -- so a whole sampling loop is graph
+// replays with no host round trip.  Same operation order as the scheduler's fp32 torch expression (no FMA
+// contraction), so the fused loop reproduces the unfused one bit for bit:
+//     eps  = (x - sqrt(a_t) * x0) / sqrt(1 - a_t);   x' = sqrt(a_prev) * x0 + sqrt(1 - a_prev) * eps
+// pred: NHWC [B][HW][pred_ld], channels pred_c0 .. pred_c0 + C.   lat: NCHW [B][C][HW] with batch stride lat_bs.
+// master (optional, contiguous fp32 [B][C][HW]): the sampler's own copy of the latents -- the reference keeps them
+// in the caller's dtype (fp32 in eval) between steps and only the network input is rounded to fp16/bf16.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) ddim_update_kernel(const T* __restrict__ pred, int pred_ld, int pred_c0,
+                                                          T* __restrict__ lat, int64_t lat_bs, int C, int B, int HW,
+                                                          const float* __restrict__ coef, const int* __restrict__ step,
+                                                          int nsteps, float* __restrict__ master, int round_master) {
+#pragma clang fp contract(off)
+    const int st = min(*step, nsteps - 1);
+    const float s_at = coef[4 * st + 0], s_1mat = coef[4 * st + 1], s_ap = coef[4 * st + 2], s_1map = coef[4 * st + 3];
+    const int64_t total = (int64_t)B * C * HW;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int p = (int)(i % HW);
+        const int64_t bc = i / HW;
+        const int c = (int)(bc % C), b = (int)(bc / C);
+        T* xp = lat + (int64_t)b * lat_bs + (int64_t)c * HW + p;
+        const float x = master ? master[i] : (float)*xp;
+        const float x0 = (float)pred[((int64_t)b * HW + p) * pred_ld + pred_c0 + c];
+        const float eps = (x - s_at * x0) / s_1mat;
+        const float a = s_ap * x0;
+        const float e = s_1map * eps;
+        const float v = a + e;
+        *xp = (T)v;
+        if (master) master[i] = round_master ? (float)(T)v : v;
+    }
+}
+
+// step += 1; t_out[0..B) = tsteps[step] (the timestep the NEXT replay denoises at)
+__global__ void sampler_advance_kernel(int* step, const float* __restrict__ tsteps, int nsteps, float* t_out, int B) {
+    const int st = *step + 1;
+    if (threadIdx.x == 0) *step = st;
+    if (t_out && (int)threadIdx.x < B) t_out[threadIdx.x] = tsteps[min(st, nsteps - 1)];
+}
+
+extern "C" int ur_ddim_update(const void* pred, int pred_ld, int pred_c0, void* lat, int64_t lat_bstride, int C, int B,
+                              int HW, const float* coef, const int* step, int nsteps, float* master, int round_master,
+                              int dtype, void* stream) {
+    if (!pred || !lat || !coef || !step || C <= 0 || B <= 0 || HW <= 0 || nsteps <= 0 || pred_c0 < 0 ||
+        pred_c0 + C > pred_ld)
+        return UR_E_BADARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int64_t total = (int64_t)B * C * HW;
+    const int grid = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+    if (dtype == UR_DT_F16)
+        hipLaunchKernelGGL((ddim_update_kernel<f16>), dim3(grid), dim3(256), 0, s, (const f16*)pred, pred_ld, pred_c0,
+                           (f16*)lat, lat_bstride, C, B, HW, coef, step, nsteps, master, round_master);
+    else if (dtype == UR_DT_BF16)
+        hipLaunchKernelGGL((ddim_update_kernel<bf16>), dim3(grid), dim3(256), 0, s, (const bf16*)pred, pred_ld, pred_c0,
+                           (bf16*)lat, lat_bstride, C, B, HW, coef, step, nsteps, master, round_master);
+    else
+        return UR_E_BADARG;
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : -(int)e;
+}
+
+extern "C" int ur_sampler_advance(int* step, const float* tsteps, int nsteps, float* t_out, int B, void* stream) {
+    if (!step || !tsteps || nsteps <= 0 || B < 0 || B > 256) return UR_E_BADARG;
+    hipLaunchKernelGGL(sampler_advance_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), step, tsteps,
+                       nsteps, t_out, B);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : -(int)e;
+}
+
 extern "C" int ur_abi_version(void) { return UR_ABI_VERSION; }
 extern "C" const char* ur_build_info(void) { return "liburhip gfx950 (hipcc, MFMA 16x16x32, LDS-DMA) abi 1"; }
 extern "C" int ur_sizeof_igemm_desc(void) { return (int)sizeof(ur_igemm_desc); }

@@ -127,6 +127,20 @@ class GraphedDualStreamStep:
         return self
 
     @torch.no_grad()
+    def capture_with(self, post_fn):
+        """A second graph over the same static buffers: the step followed by ``post_fn(out)`` -- e.g. the on-device
+        sampler update that turns the prediction into the next step's input (pipeline.py), so that a sampling loop is
+        nothing but replays.  Returns ``(graph, out)``."""
+        if self.graph is None:
+            self.capture()  # warm-up, weight packing
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = self._run()
+            post_fn(out)
+        torch.cuda.synchronize()
+        return g, out
+
+    @torch.no_grad()
     def step(self, x_t=None, cond=None, ehs=None, t_img=None, t_attr=None):
         if self.graph is None:
             self.capture()

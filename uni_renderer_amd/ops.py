@@ -334,6 +334,32 @@ def attention(q, k, vt, *, B, H, Tq, Tk, d, ldq, ldk, q_off=0, k_off=0, scale=No
     return o
 
 
+def ddim_update(pred_nhwc, c0: int, lat_nchw, coef, step, nsteps: int, master=None, round_master: bool = False):
+    """In-place DDIM (x0-prediction) update of the NCHW latent slice ``lat_nchw`` [B, C, H, W] (batch stride free,
+    channel planes contiguous) from channels c0.. of the NHWC prediction ``pred_nhwc`` [B, H, W, Cp]; the four step
+    scalars come from the device table ``coef`` [nsteps, 4] at the device counter ``step`` (include/ur_kernels.h).
+    ``master``: optional contiguous fp32 [B, C, H, W] copy that carries the latents between steps."""
+    _require_gpu(pred_nhwc)
+    lib = _lib.load()
+    B, Cc, H, W = lat_nchw.shape
+    if lat_nchw.stride(3) != 1 or lat_nchw.stride(2) != W or lat_nchw.stride(1) != H * W:
+        raise RuntimeError("ddim_update: latent slice must have contiguous channel planes")
+    if pred_nhwc.dtype != lat_nchw.dtype or coef.dtype != torch.float32 or step.dtype != torch.int32:
+        raise RuntimeError("ddim_update: dtype mismatch")
+    if master is not None and (master.dtype != torch.float32 or not master.is_contiguous() or master.shape != lat_nchw.shape):
+        raise RuntimeError("ddim_update: master must be a contiguous fp32 tensor of the latent's shape")
+    check(lib.ur_ddim_update(pred_nhwc.data_ptr(), pred_nhwc.shape[-1], c0, lat_nchw.data_ptr(), lat_nchw.stride(0), Cc,
+                             B, H * W, coef.data_ptr(), step.data_ptr(), nsteps, _ptr(master), int(round_master),
+                             DT[lat_nchw.dtype], _stream()),
+          "ur_ddim_update")
+
+
+def sampler_advance(step, tsteps, nsteps: int, t_out=None):
+    lib = _lib.load()
+    check(lib.ur_sampler_advance(step.data_ptr(), tsteps.data_ptr(), nsteps, _ptr(t_out),
+                                 (t_out.numel() if t_out is not None else 0), _stream()), "ur_sampler_advance")
+
+
 def add(a, b, alpha: float = 1.0):
     _require_gpu(a)
     lib = _lib.load()

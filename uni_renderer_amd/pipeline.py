@@ -24,6 +24,7 @@ from typing import Any, Callable, Dict, List, Optional, Sequence, Tuple, Union
 import torch
 
 from .controlnet import AttributeDecoderModel, AttributeEncoderModel, UNet2DConditionModel
+from . import ops
 from .graph import GraphedDualStreamStep, dual_stream_step
 from .schedulers import DDIMScheduler, retrieve_timesteps
 
@@ -42,6 +43,8 @@ class UniRendererPipeline:
             setattr(self, f"scheduler_{n}", scheduler if (scheduler is not None and n == "img") else DDIMScheduler())
         self.vae_scale_factor = 8
         self.use_hip_graph = True
+        self.use_fused_sampler = True  # whole sampling loop on the device when the configuration allows (_fusable)
+        self._sample_graphs: Dict[Any, Any] = {}
         self._graphs: Dict[Tuple, GraphedDualStreamStep] = {}
         self._progress_kwargs: Dict[str, Any] = {}
         self._guidance_scale = 0.0
@@ -182,6 +185,94 @@ class UniRendererPipeline:
         return [Image.fromarray((a * 255).round().astype("uint8")) for a in arr]
 
     # ---- one denoise step of the three networks ----------------------------------------------------------
+    # ---- on-device sampling loop -------------------------------------------------------------
+    def _fusable(self, scheds, device, cond_scale, callback) -> bool:
+        """The fused loop covers what eval needs: our DDIM (x0 prediction) on every latent group with one common
+        schedule, no classifier-free guidance, no per-step callback, HIP graph on.  Anything else takes the
+        step-by-step loop below (identical results: tests/test_pipeline_gpu.py)."""
+        from .schedulers import DDIMScheduler
+
+        if not (self.use_fused_sampler and self.use_hip_graph and torch.device(device).type == "cuda"):
+            return False
+        if self.do_classifier_free_guidance or callback is not None or cond_scale != 1.0:
+            return False
+        s0 = scheds[0]
+        for s in scheds:
+            if type(s) is not DDIMScheduler or s.prediction_type != "sample":
+                return False
+            if s.num_inference_steps != s0.num_inference_steps or not torch.equal(s.timesteps.cpu(), s0.timesteps.cpu()):
+                return False
+            if not torch.equal(s.alphas_cumprod, s0.alphas_cumprod) or float(s.final_alpha_cumprod) != float(s0.final_alpha_cumprod):
+                return False
+        return True
+
+    @staticmethod
+    def _ddim_tables(sched, timesteps):
+        """[n, 4] fp32 rows sqrt(a_t), sqrt(1-a_t), sqrt(a_prev), sqrt(1-a_prev) -- the same fp32 torch expressions as
+        DDIMScheduler.step -- and the timestep values as floats."""
+        rows = []
+        ts = [int(t) for t in timesteps.cpu().tolist()]
+        for t in ts:
+            prev_t = t - sched.num_train_timesteps // (sched.num_inference_steps or sched.num_train_timesteps)
+            a_t = sched._alpha(t, "cpu")
+            a_prev = sched._alpha(prev_t, "cpu") if prev_t >= 0 else sched.final_alpha_cumprod.to("cpu")
+            rows.append(torch.stack([a_t.sqrt(), (1 - a_t).sqrt(), a_prev.sqrt(), (1 - a_prev).sqrt()]).float())
+        return torch.stack(rows), torch.tensor(ts, dtype=torch.float32)
+
+    def _graph_for(self, x_img, cond28, ehs, run_decoder):
+        B, _, h, w = x_img.shape
+        dt = self.unet.dtype
+        key = (B, h, w, ehs.shape[1], ehs.shape[2], run_decoder, dt)
+        g = self._graphs.get(key)
+        if g is None:
+            g = GraphedDualStreamStep(self.unet, self.controlnet, self.controldec, B, (h, w), ehs.shape[2], dtype=dt,
+                                      device=x_img.device, run_decoder=run_decoder, cond_channels=cond28.shape[1],
+                                      img_channels=x_img.shape[1], ctx_len=ehs.shape[1])
+            g.load_inputs(x_img, cond28, ehs, 0, 0)
+            g.capture()
+            self._graphs[key] = g
+        return key, g
+
+    def _fused_loop(self, x_img, cond28, ehs, timesteps, sched, run_decoder: bool, lat_dtype=torch.float32):
+        """All denoise steps as replays of ONE graph = step + ur_ddim_update (prediction -> next input, in the
+        graph's static input buffer) + ur_sampler_advance (step counter, next timestep).  Inverse direction: the 24
+        attribute channels of ``cond`` evolve at t_attr, the image latent is clean (t_img = 0); rendering direction:
+        the 4 image channels of ``x_t`` evolve at t_img, the attributes are clean."""
+        n = len(timesteps)
+        key, g = self._graph_for(x_img, cond28, ehs, run_decoder)
+        t0 = float(timesteps[0])
+        g.load_inputs(x_img, cond28, ehs, 0.0 if run_decoder else t0, t0 if run_decoder else 0.0)
+        coef, tvals = self._ddim_tables(sched, timesteps)
+        skey = key + (n, lat_dtype)
+        st = self._sample_graphs.get(skey)
+        if st is None:
+            dev = x_img.device
+            evolving = g.cond[:, 4:] if run_decoder else g.x_t
+            st = dict(step=torch.zeros(1, dtype=torch.int32, device=dev), coef=torch.zeros(n, 4, device=dev),
+                      tvals=torch.zeros(n, device=dev), master=torch.zeros(evolving.shape, dtype=torch.float32, device=dev),
+                      round_master=lat_dtype != torch.float32)
+
+            def post(out):
+                if run_decoder:
+                    ops.ddim_update(out["attr_pred"].permute(0, 2, 3, 1), 4, g.cond[:, 4:], st["coef"], st["step"], n,
+                                    master=st["master"], round_master=st["round_master"])
+                    ops.sampler_advance(st["step"], st["tvals"], n, g.t_attr)
+                else:
+                    ops.ddim_update(out["img_pred"].permute(0, 2, 3, 1), 0, g.x_t, st["coef"], st["step"], n,
+                                    master=st["master"], round_master=st["round_master"])
+                    ops.sampler_advance(st["step"], st["tvals"], n, g.t_img)
+
+            st["graph"], st["out"] = g.capture_with(post)
+            self._sample_graphs[skey] = st
+            g.load_inputs(x_img, cond28, ehs, 0.0 if run_decoder else t0, t0 if run_decoder else 0.0)  # capture ran no kernel, but be explicit
+        st["step"].zero_()
+        st["coef"].copy_(coef)
+        st["tvals"].copy_(tvals)
+        st["master"].copy_(cond28[:, 4:] if run_decoder else x_img)  # the caller's latents at their own precision
+        for _ in range(n):
+            st["graph"].replay()
+        return st["master"].to(lat_dtype)
+
     def _step(self, x_img, cond28, ehs, t_img, t_attr, run_decoder: bool, cond_scale: float = 1.0):
         B, _, h, w = x_img.shape
         dt = self.unet.dtype
@@ -251,6 +342,14 @@ class UniRendererPipeline:
         x_mask = self.scheduler_img.scale_model_input(dup(mask_latents), 0)
         cond_scale = float(controlnet_conditioning_scale)
 
+        group_scheds = [getattr(self, f"scheduler_{n}") for n in ATTR_GROUPS]
+        if self._fusable([self.scheduler_attr] + group_scheds, device, cond_scale, callback_on_step_end):
+            cat = torch.cat([lat[n] for n in ATTR_GROUPS], dim=1)
+            cond28 = torch.cat((x_mask.to(cat.dtype), cat), dim=1)
+            fin = self._fused_loop(x_img, cond28, prompt_embeds, timesteps_attr, group_scheds[0], run_decoder=True,
+                                   lat_dtype=cat.dtype)
+            lat = {n: fin[:, 4 * k:4 * k + 4].to(lat[n].dtype) for k, n in enumerate(ATTR_GROUPS)}
+            timesteps_img = timesteps_attr = []  # loop below is skipped
         with self.progress_bar(total=num_inference_steps) as bar:
             for i, (t_img, t_attr) in enumerate(zip(timesteps_img, timesteps_attr)):
                 cat = torch.cat([dup(lat[n]) for n in ATTR_GROUPS], dim=1)
@@ -323,6 +422,10 @@ class UniRendererPipeline:
         cfg = self.do_classifier_free_guidance
         dup = (lambda t: torch.cat([t, t])) if cfg else (lambda t: t)
         cond28 = dup(self.scheduler_img.scale_model_input(attr_latents, 0))
+        if self._fusable([self.scheduler_img], device, float(controlnet_conditioning_scale), None):
+            latents_img = self._fused_loop(latents_img, cond28, prompt_embeds, timesteps, self.scheduler_img,
+                                           run_decoder=False, lat_dtype=latents_img.dtype)
+            timesteps = timesteps[:0]  # loop below is skipped
         with self.progress_bar(total=num_inference_steps) as bar:
             for i in range(len(timesteps)):
                 t_img, t_attr = timesteps[i], timesteps_attr[i]
