@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define UR_ABI_VERSION 1
+#define UR_ABI_VERSION 2
 
 #define UR_E_BADARG (-1001)   /* inconsistent descriptor (shape / alignment / null pointer)   */
 #define UR_E_UNSUPPORTED (-1002) /* shape outside what the kernels are instantiated for       */
@@ -93,6 +93,11 @@ extern "C" {
  *   zbatch > 1: grid.z batches independent problems of one shape; every operand has its own per-z element
  *      stride (zx, zx1, zw, zbias, zrow, zres, zout).  Used for the transposed V projection
  *      Vt[b] = Wv . X[b]^T and for executing the two diffusion streams as ONE grouped launch.
+ *   (hi, lo) residual stream: the tensors that carry `x + f(x)` through a network (block outputs) may be held as
+ *      an fp16/bf16 PAIR whose fp32 sum is the value: `out` keeps the ordinary rounded value (what every GEMM operand
+ *      consumer reads), `out_lo` the rounding remainder; residual adds (`res` + `res_lo`) and the norm kernels
+ *      (`*_lo` arguments) consume the pair.  This removes the random walk of the storage rounding along the residual
+ *      path (55 % of the fp16 error variance of the step) for 2 extra bytes per element.
  *   splitk > 1: K is additionally split over grid.z; `partial` is a caller-provided fp32 workspace of
  *      zbatch * splitk * M * ldp floats and the epilogue runs in a second small kernel.
  */
@@ -124,6 +129,9 @@ typedef struct ur_igemm_desc {
     int32_t zx_div;      /* x0 of problem z starts at x0 + (z / zx_div) * zx (0/1 = every z)   */
     int32_t tile;        /* UR_TILE_*                                                      */
     int32_t dtype;
+    /* (hi, lo) residual stream, see below: both optional, same leading dimension / z stride as res / out */
+    const void* res_lo;  /* low part of the residual: the epilogue adds res + res_lo in fp32 */
+    void* out_lo;        /* if set, receives dtype(v - float(dtype(v))) of every stored value v */
 } ur_igemm_desc;
 
 int ur_igemm(const ur_igemm_desc* d, void* stream);
@@ -138,16 +146,19 @@ int64_t ur_igemm_partial_floats(const ur_igemm_desc* d);
  *           `nstat` chunks of `partial` written by the stats pass.
  * rows = H*W per sample; nchunks = number of row chunks per sample (grid.x) of the call at hand.
  * bper > 0: sample b uses gamma/beta + (b / bper) * pstride (grouped execution of several streams).
+ * x0_lo / x1_lo: NULL, or the low parts of (hi, lo) residual-stream inputs (same layout as x0 / x1): the value
+ * normalised is x + x_lo in fp32.
  */
-int ur_groupnorm_stats(const void* x0, const void* x1, int c0, int c1, int B, int rows, int groups,
-                       int nchunks, float* partial, int dtype, void* stream);
-int ur_groupnorm_apply(const void* x0, const void* x1, int c0, int c1, int B, int rows, int groups,
-                       int nstat, int nchunks, const float* partial, const float* gamma, const float* beta,
-                       float eps, int silu, int bper, int pstride, void* out, int dtype, void* stream);
+int ur_groupnorm_stats(const void* x0, const void* x1, const void* x0_lo, const void* x1_lo, int c0, int c1, int B,
+                       int rows, int groups, int nchunks, float* partial, int dtype, void* stream);
+int ur_groupnorm_apply(const void* x0, const void* x1, const void* x0_lo, const void* x1_lo, int c0, int c1, int B,
+                       int rows, int groups, int nstat, int nchunks, const float* partial, const float* gamma,
+                       const float* beta, float eps, int silu, int bper, int pstride, void* out, int dtype,
+                       void* stream);
 
 /* LayerNorm over the last dimension of x[rows][C] (C % 8 == 0, C <= 4096), fp32 statistics.
- * rows_per_set > 0: row r uses gamma/beta + (r / rows_per_set) * pstride. */
-int ur_layernorm(const void* x, const float* gamma, const float* beta, float eps, int rows, int C,
+ * rows_per_set > 0: row r uses gamma/beta + (r / rows_per_set) * pstride.  x_lo: NULL or the low part of x. */
+int ur_layernorm(const void* x, const void* x_lo, const float* gamma, const float* beta, float eps, int rows, int C,
                  int rows_per_set, int pstride, void* out, int dtype, void* stream);
 
 /*
@@ -181,6 +192,9 @@ int ur_attention(const ur_attn_desc* d, void* stream);
 
 /* out = a + b * alpha (elementwise, n % 8 == 0). */
 int ur_add(const void* a, const void* b, float alpha, void* out, int64_t n, int dtype, void* stream);
+/* the same over (hi, lo) pairs: out + out_lo = (a + a_lo) + alpha * (b + b_lo); any *_lo may be NULL */
+int ur_add_hilo(const void* a, const void* a_lo, const void* b, const void* b_lo, float alpha, void* out, void* out_lo,
+                int64_t n, int dtype, void* stream);
 
 /* Sinusoidal timestep embedding of nt (1 or B) fp32 timesteps: out[b][:] = [cos | sin] (flip) or
  * [sin | cos]; fp32 math. */

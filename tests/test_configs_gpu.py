@@ -55,17 +55,40 @@ def test_cfg3_inverse_512_fp16(dev, sd):
     unet, enc, dec = product(torch.float16)
     x, c, ehs, ti, ta = O.make_inputs(2, 64, 768, seed=8, t_img=0)
     ref = O.dual_stream_step(*oracle, x, c, ehs, ti, ta)
+    # the same oracle holding exactly the parameter values the product holds (fp32 arithmetic on fp16-rounded weights):
+    # separates the arithmetic error of the kernels from the quantisation of the checkpoint
+    import copy
+    oracle_q = copy.deepcopy(oracle)
+    for m in oracle_q:
+        for p_ in m.parameters():
+            p_.data = p_.data.to(torch.float16).to(torch.float32)
+    ref_q = O.dual_stream_step(*oracle_q, x, c, ehs, ti, ta)
+    del oracle_q
     g = [t.to(dev) for t in (x, c, ehs, ti, ta)]
     with torch.no_grad():
         mod = product_step(unet, enc, dec, *g)
-        grp = GroupedDualStreamStep(unet, enc, dec)(*g)
+        grp = GroupedDualStreamStep(unet, enc, dec, precise_residual=True)(*g)
+        plain = GroupedDualStreamStep(unet, enc, dec, precise_residual=False)(*g)
     errs = dict(cfg=3, dtype="f16",
                 img_modules=rel_l2(mod["img_pred"], ref["img_pred"]), attr_modules=rel_l2(mod["attr_pred"], ref["attr_pred"]),
                 img_grouped=rel_l2(grp["img_pred"], ref["img_pred"]), attr_grouped=rel_l2(grp["attr_pred"], ref["attr_pred"]),
-                raw_mid_unet=rel_l2(mod["raw_mid_unet"], ref["raw_mid_unet"]))
+                img_grouped_plain=rel_l2(plain["img_pred"], ref["img_pred"]),
+                attr_grouped_plain=rel_l2(plain["attr_pred"], ref["attr_pred"]),
+                raw_mid_unet=rel_l2(mod["raw_mid_unet"], ref["raw_mid_unet"]),
+                same_weights=dict(img_grouped=rel_l2(grp["img_pred"], ref_q["img_pred"]),
+                                  attr_grouped=rel_l2(grp["attr_pred"], ref_q["attr_pred"]),
+                                  img_grouped_plain=rel_l2(plain["img_pred"], ref_q["img_pred"]),
+                                  attr_grouped_plain=rel_l2(plain["attr_pred"], ref_q["attr_pred"]),
+                                  img_modules=rel_l2(mod["img_pred"], ref_q["img_pred"]),
+                                  attr_modules=rel_l2(mod["attr_pred"], ref_q["attr_pred"]),
+                                  oracle_fp16w_vs_fp32w_img=rel_l2(ref_q["img_pred"], ref["img_pred"]),
+                                  oracle_fp16w_vs_fp32w_attr=rel_l2(ref_q["attr_pred"], ref["attr_pred"])))
     print(json.dumps(errs))
-    # measured round 1: 1.2e-3 .. 1.5e-3 (random-init weights); bound = measured + margin, see DESIGN.md section 5
-    assert max(errs["img_modules"], errs["attr_modules"], errs["img_grouped"], errs["attr_grouped"]) < 2e-3
+    # module-by-module path and the grouped executor with a plain fp16 residual stream: 1.2e-3 .. 1.5e-3 measured
+    # (random-init weights), bound = measured + margin
+    assert max(errs["img_modules"], errs["attr_modules"], errs["img_grouped_plain"], errs["attr_grouped_plain"]) < 2e-3
+    # default executor ((hi, lo) residual stream) against the oracle on the SAME parameter values: north_star's tolerance
+    assert max(errs["same_weights"]["img_grouped"], errs["same_weights"]["attr_grouped"]) < 1e-3
 
 
 def test_cfg5_relighting_1024_bs1_fp16(dev, sd):

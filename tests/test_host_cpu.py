@@ -38,7 +38,7 @@ def test_bad_descriptor_is_rejected_without_gpu():
     assert lib.ur_igemm(None, None) == -1001
     a = _lib.AttnDesc()
     assert lib.ur_attention(ctypes.byref(a), None) == -1001
-    assert lib.ur_layernorm(None, None, None, 1e-5, 4, 64, 0, 0, None, 0, None) == -1001
+    assert lib.ur_layernorm(None, None, None, None, 1e-5, 4, 64, 0, 0, None, 0, None) == -1001
     assert lib.ur_add(None, None, 1.0, None, 8, 0, None) == -1001
 
 

@@ -322,6 +322,65 @@ def test_add_and_timestep_and_layout(dev, dtype):
     assert ops.to_nhwc(ops.as_nchw_view(a), dtype).data_ptr() == a.data_ptr()  # zero-copy for channels-last views
 
 
+def _pair(shape, dtype, dev, seed):
+    """An fp32 tensor and its (hi, lo) representation in `dtype`."""
+    v = torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * 2 + 0.3
+    hi = v.to(dtype)
+    lo = (v - hi.float()).to(dtype)
+    h = hi.to(dev)
+    h.lo = lo.to(dev)
+    return v, h
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_hilo_residual_stream_ops(dev, dtype):
+    """(hi, lo) residual stream (include/ur_kernels.h): the pair reproduces the fp32 value to ~2^-19 (fp16) / 2^-15
+    (bf16) instead of 2^-11 / 2^-8, through the GEMM / conv epilogues, the norms and the add."""
+    from uni_renderer_amd import ops
+    tol = 3e-5 if dtype == torch.float16 else 4e-4  # accumulation order + one lo rounding; plain storage: 3e-4 / 2e-3
+    # linear: out + out.lo == x @ w^T + b + (res + res.lo)
+    x = _rand((2, 200, 128), dtype, dev, seed=1)
+    w = (_rand((192, 128), dtype, dev, seed=2) * 0.1).to(dtype)
+    b = torch.randn(192, generator=torch.Generator().manual_seed(3)).to(dev)
+    rv, r = _pair((2, 200, 192), dtype, dev, 4)
+    y = ops.linear(x, w, b, res=r, hilo=True)
+    ref = x.float().cpu() @ w.float().cpu().t() + b.cpu() + rv
+    assert y.lo is not None and y.lo.shape == y.shape
+    assert rel_l2(y.float().cpu() + y.lo.float().cpu(), ref) < tol
+    assert rel_l2(y, ref) < TOL[dtype]  # hi alone is the ordinary rounded result
+    assert torch.equal(y.float().cpu() + y.lo.float().cpu(), (y.float() + y.lo.float()).cpu())
+    # split-K path (epilogue in the reduce kernel)
+    y2 = ops.linear(x, w, b, res=r, hilo=True, splitk=2, tile=3)
+    assert rel_l2(y2.float().cpu() + y2.lo.float().cpu(), ref) < tol
+    # conv3x3 with a (hi, lo) residual
+    xi = _rand((2, 12, 10, 64), dtype, dev, seed=5)
+    wc = (_rand((64, 9 * 64), dtype, dev, seed=6) * 0.05).to(dtype)
+    rv2, r2 = _pair((2, 12, 10, 64), dtype, dev, 7)
+    yc = ops.conv3x3(xi, wc, None, res=r2, hilo=True)
+    wt = wc.float().cpu().view(64, 3, 3, 64).permute(0, 3, 1, 2)
+    refc = F.conv2d(xi.float().cpu().permute(0, 3, 1, 2), wt, padding=1).permute(0, 2, 3, 1) + rv2
+    assert rel_l2(yc.float().cpu() + yc.lo.float().cpu(), refc) < tol
+    # GroupNorm / LayerNorm read hi + lo
+    gv, gx = _pair((2, 9, 7, 320), dtype, dev, 8)
+    gam = torch.randn(320, generator=torch.Generator().manual_seed(9)).to(dev)
+    bet = torch.randn(320, generator=torch.Generator().manual_seed(10)).to(dev)
+    yg = ops.groupnorm(gx, gam, bet, 1e-5, groups=32, silu=True)
+    refg = F.silu(F.group_norm(gv.permute(0, 3, 1, 2), 32, gam.cpu(), bet.cpu(), 1e-5)).permute(0, 2, 3, 1)
+    plain = gx.clone()  # without the low part the input itself is only good to 2^-11
+    yg_plain = ops.groupnorm(plain, gam, bet, 1e-5, groups=32, silu=True)
+    assert rel_l2(yg, refg) < TOL[dtype] and rel_l2(yg, refg) <= rel_l2(yg_plain, refg) * 1.05
+    lv, lx = _pair((3, 50, 640), dtype, dev, 11)
+    g2 = torch.randn(640, generator=torch.Generator().manual_seed(12)).to(dev)
+    b2 = torch.randn(640, generator=torch.Generator().manual_seed(13)).to(dev)
+    yl = ops.layernorm(lx, g2, b2, 1e-5)
+    assert rel_l2(yl, F.layer_norm(lv, (640,), g2.cpu(), b2.cpu(), 1e-5)) < TOL[dtype]
+    # add over pairs
+    av, a = _pair((4, 8, 64), dtype, dev, 14)
+    bv, bb = _pair((4, 8, 64), dtype, dev, 15)
+    s_ = ops.add(a, bb, 0.5, hilo=True)
+    assert rel_l2(s_.float().cpu() + s_.lo.float().cpu(), av + 0.5 * bv) < tol
+
+
 def test_no_cpu_fallback():
     from uni_renderer_amd import ops
     with pytest.raises(RuntimeError, match="no CPU fallback"):

@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must be imported first, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("UR_LIB_PATH", os.path.join(_HERE, "liburhip.so"))  # override = kernel experiments only
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
@@ -35,6 +35,7 @@ class IGemmDesc(C.Structure):
         ("n_store", i32), ("ld_rowadd", i32), ("rows_per_b", i32),
         ("act", i32), ("out_scale", f32),
         ("zbatch", i32), ("splitk", i32), ("zx_div", i32), ("tile", i32), ("dtype", i32),
+        ("res_lo", vp), ("out_lo", vp),
     ]
 
 
@@ -54,12 +55,13 @@ class AttnDesc(C.Structure):
 SYMBOLS = {
     "ur_igemm": (C.c_int, [C.POINTER(IGemmDesc), vp]),
     "ur_igemm_partial_floats": (C.c_int64, [C.POINTER(IGemmDesc)]),
-    "ur_groupnorm_stats": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]),
-    "ur_groupnorm_apply": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp,
-                                     C.c_float, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]),
-    "ur_layernorm": (C.c_int, [vp, vp, vp, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]),
+    "ur_groupnorm_stats": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]),
+    "ur_groupnorm_apply": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp,
+                                     vp, C.c_float, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]),
+    "ur_layernorm": (C.c_int, [vp, vp, vp, vp, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]),
     "ur_attention": (C.c_int, [C.POINTER(AttnDesc), vp]),
     "ur_add": (C.c_int, [vp, vp, C.c_float, vp, C.c_int64, C.c_int, vp]),
+    "ur_add_hilo": (C.c_int, [vp, vp, vp, vp, C.c_float, vp, vp, C.c_int64, C.c_int, vp]),
     "ur_timestep_embedding": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp, C.c_int, vp]),
     "ur_nchw_to_nhwc": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp]),
     "ur_nhwc_to_nchw": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]),

@@ -28,12 +28,14 @@ struct V16 { float v[16]; };
 // the scalars of the descriptor the masked epilogue needs, passed BY VALUE: handing the kernel-argument struct to
 // an out-of-line function by reference would force a scratch copy of it and turn every p.field into a scratch load
 struct EpiArgs { int N, n_store, rows_per_b, ld_rowadd, act; int64_t ldc, ldres; float out_scale; };
+// low parts of the (hi, lo) residual stream (include/ur_kernels.h): same leading dimensions as res / out
+template <typename T> struct HiLo { const T* res_lo; T* out_lo; };
 
 // Rare path (ragged N tile, conv_out with 4 / 28 channels, unaligned leading dimensions): element-wise with
 // masks.  Kept OUT OF LINE so that the hot kernels carry only the straight-line vector epilogue.
 template <typename T>
 __device__ __noinline__ void epilogue16_slow(EpiArgs p, T* __restrict__ outz, const float* biasz, const T* rowaddz,
-                                             const T* resz, int m, int nc, V16 a) {
+                                             const T* resz, int m, int nc, V16 a, HiLo<T> hl) {
     float (&v)[16] = a.v;
     if (biasz) {
         for (int i = 0; i < 16; ++i)
@@ -59,15 +61,26 @@ __device__ __noinline__ void epilogue16_slow(EpiArgs p, T* __restrict__ outz, co
         const T* rp = resz + (int64_t)m * p.ldres + nc;
         for (int i = 0; i < 16; ++i)
             if (nc + i < p.N) v[i] += to_f(rp[i]);
+        if (hl.res_lo) {
+            const T* rl = hl.res_lo + (int64_t)m * p.ldres + nc;
+            for (int i = 0; i < 16; ++i)
+                if (nc + i < p.N) v[i] += to_f(rl[i]);
+        }
     }
     T* dst = outz + (int64_t)m * p.ldc + nc;
+    T* dlo = hl.out_lo ? hl.out_lo + (int64_t)m * p.ldc + nc : nullptr;
     for (int i = 0; i < 16; ++i)
-        if (nc + i < p.n_store) dst[i] = from_f<T>(v[i] * p.out_scale);
+        if (nc + i < p.n_store) {
+            const float y = v[i] * p.out_scale;
+            const T h = from_f<T>(y);
+            dst[i] = h;
+            if (dlo) dlo[i] = from_f<T>(y - to_f(h));
+        }
 }
 
 template <typename T>
 __device__ __forceinline__ void epilogue16(const ur_igemm_desc& p, T* __restrict__ outz, const float* biasz,
-                                           const T* rowaddz, const T* resz, int m, int nc, float (&v)[16]) {
+                                           const T* rowaddz, const T* resz, int m, int nc, float (&v)[16], HiLo<T> hl) {
     if (m >= p.M) return;
     const bool vec = (((p.ldc | p.ldres | (int64_t)p.ld_rowadd) & 7) == 0);
     const int n_out_end = (p.act == ACT_GEGLU) ? (nc >> 1) + 8 : nc + 16;
@@ -76,7 +89,7 @@ __device__ __forceinline__ void epilogue16(const ur_igemm_desc& p, T* __restrict
 #pragma unroll
         for (int i = 0; i < 16; ++i) a.v[i] = v[i];
         const EpiArgs e{p.N, p.n_store, p.rows_per_b, p.ld_rowadd, p.act, p.ldc, p.ldres, p.out_scale};
-        epilogue16_slow<T>(e, outz, biasz, rowaddz, resz, m, nc, a);
+        epilogue16_slow<T>(e, outz, biasz, rowaddz, resz, m, nc, a, hl);
         return;
     }
     if (biasz) {
@@ -120,6 +133,15 @@ __device__ __forceinline__ void epilogue16(const ur_igemm_desc& p, T* __restrict
         load8(rp + 8, t);
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[8 + i] += t[i];
+        if (hl.res_lo) {
+            const T* rl = hl.res_lo + (int64_t)m * p.ldres + nc;
+            load8(rl, t);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] += t[i];
+            load8(rl + 8, t);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[8 + i] += t[i];
+        }
     }
     if (p.out_scale != 1.0f) {
 #pragma unroll
@@ -133,6 +155,15 @@ __device__ __forceinline__ void epilogue16(const ur_igemm_desc& p, T* __restrict
 #pragma unroll
     for (int i = 0; i < 8; ++i) t[i] = v[8 + i];
     store8(dst + 8, t);
+    if (hl.out_lo) {  // rounding remainders: v - float(T(v)), exact in fp32
+        T* dlo = hl.out_lo + (int64_t)m * p.ldc + nc;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t[i] = v[i] - to_f(from_f<T>(v[i]));
+        store8(dlo, t);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t[i] = v[8 + i] - to_f(from_f<T>(v[8 + i]));
+        store8(dlo + 8, t);
+    }
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int NSTAGE, bool CONV>
@@ -422,7 +453,9 @@ __global__ void __launch_bounds__(WM * WN * 64) igemm_kernel(const ur_igemm_desc
             epilogue16<T>(p, reinterpret_cast<T*>(p.out) + (int64_t)zb * p.zout,
                           p.bias ? p.bias + (int64_t)zb * p.zbias : nullptr,
                           p.rowadd ? reinterpret_cast<const T*>(p.rowadd) + (int64_t)zb * p.zrow : nullptr,
-                          p.res ? reinterpret_cast<const T*>(p.res) + (int64_t)zb * p.zres : nullptr, m, nc, v);
+                          p.res ? reinterpret_cast<const T*>(p.res) + (int64_t)zb * p.zres : nullptr, m, nc, v,
+                          HiLo<T>{p.res_lo ? reinterpret_cast<const T*>(p.res_lo) + (int64_t)zb * p.zres : nullptr,
+                                  p.out_lo ? reinterpret_cast<T*>(p.out_lo) + (int64_t)zb * p.zout : nullptr});
         }
     }
 }
@@ -453,7 +486,9 @@ __global__ void __launch_bounds__(256) igemm_splitk_reduce(const ur_igemm_desc p
             epilogue16<T>(p, reinterpret_cast<T*>(p.out) + (int64_t)zb * p.zout,
                           p.bias ? p.bias + (int64_t)zb * p.zbias : nullptr,
                           p.rowadd ? reinterpret_cast<const T*>(p.rowadd) + (int64_t)zb * p.zrow : nullptr,
-                          p.res ? reinterpret_cast<const T*>(p.res) + (int64_t)zb * p.zres : nullptr, m, nc, v);
+                          p.res ? reinterpret_cast<const T*>(p.res) + (int64_t)zb * p.zres : nullptr, m, nc, v,
+                          HiLo<T>{p.res_lo ? reinterpret_cast<const T*>(p.res_lo) + (int64_t)zb * p.zres : nullptr,
+                                  p.out_lo ? reinterpret_cast<T*>(p.out_lo) + (int64_t)zb * p.zout : nullptr});
     }
 }
 

@@ -93,6 +93,52 @@ extern "C" int ur_add(const void* a, const void* b, float alpha, void* out, int6
     return e == hipSuccess ? 0 : -(int)e;
 }
 
+template <typename T>
+__global__ void __launch_bounds__(256) add_hilo_kernel(const T* __restrict__ a, const T* __restrict__ a_lo,
+                                                       const T* __restrict__ b, const T* __restrict__ b_lo, float alpha,
+                                                       T* __restrict__ out, T* __restrict__ out_lo, int64_t nvec) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+        float x[8], y[8], t[8];
+        load8(a + i * 8, x);
+        load8(b + i * 8, y);
+        if (a_lo) {
+            load8(a_lo + i * 8, t);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) x[k] += t[k];
+        }
+        if (b_lo) {
+            load8(b_lo + i * 8, t);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) y[k] += t[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) x[k] = x[k] + alpha * y[k];
+        store8(out + i * 8, x);
+        if (out_lo) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t[k] = x[k] - to_f(from_f<T>(x[k]));
+            store8(out_lo + i * 8, t);
+        }
+    }
+}
+
+extern "C" int ur_add_hilo(const void* a, const void* a_lo, const void* b, const void* b_lo, float alpha, void* out,
+                           void* out_lo, int64_t n, int dtype, void* stream) {
+    if (!a || !b || !out || n <= 0 || (n & 7)) return UR_E_BADARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int64_t nvec = n / 8;
+    if (dtype == UR_DT_F16)
+        hipLaunchKernelGGL((add_hilo_kernel<f16>), dim3(grid_for(nvec)), dim3(256), 0, s, (const f16*)a, (const f16*)a_lo,
+                           (const f16*)b, (const f16*)b_lo, alpha, (f16*)out, (f16*)out_lo, nvec);
+    else if (dtype == UR_DT_BF16)
+        hipLaunchKernelGGL((add_hilo_kernel<bf16>), dim3(grid_for(nvec)), dim3(256), 0, s, (const bf16*)a,
+                           (const bf16*)a_lo, (const bf16*)b, (const bf16*)b_lo, alpha, (bf16*)out, (bf16*)out_lo, nvec);
+    else
+        return UR_E_BADARG;
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : -(int)e;
+}
+
 extern "C" int ur_timestep_embedding(const float* t, int nt, int B, int dim, int flip_sin_to_cos, float freq_shift,
                                      void* out, int dtype, void* stream) {
     if (!t || !out || B <= 0 || dim < 2 || (nt != 1 && nt != B)) return UR_E_BADARG;
@@ -236,6 +282,6 @@ extern "C" int ur_sampler_advance(int* step, const float* tsteps, int nsteps, fl
 }
 
 extern "C" int ur_abi_version(void) { return UR_ABI_VERSION; }
-extern "C" const char* ur_build_info(void) { return "liburhip gfx950 (hipcc, MFMA 16x16x32, LDS-DMA) abi 1"; }
+extern "C" const char* ur_build_info(void) { return "liburhip gfx950 (hipcc, MFMA 16x16x32, LDS-DMA) abi 2"; }
 extern "C" int ur_sizeof_igemm_desc(void) { return (int)sizeof(ur_igemm_desc); }
 extern "C" int ur_sizeof_attn_desc(void) { return (int)sizeof(ur_attn_desc); }

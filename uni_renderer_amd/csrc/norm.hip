@@ -16,7 +16,8 @@ namespace ur {
 // summed by four threads over a few LDS entries -- all in a fixed order (deterministic).
 // ------------------------------------------------------------------------------------------
 template <typename T>
-__global__ void __launch_bounds__(256) gn_stats_kernel(const T* __restrict__ x0, const T* __restrict__ x1, int c0,
+__global__ void __launch_bounds__(256) gn_stats_kernel(const T* __restrict__ x0, const T* __restrict__ x1,
+                                                       const T* __restrict__ x0_lo, const T* __restrict__ x1_lo, int c0,
                                                        int c1, int rows, int groups, int nchunks,
                                                        float* __restrict__ partial) {
     __shared__ float4 tpart[256];  // per thread: (sum, sumsq) of its channels in group gA, and in group gA + 1
@@ -39,15 +40,33 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(const T* __restrict__ x0,
         const bool active = rsub < rs && cv < nvec && rbeg < rend;
         if (active) {
             const T* base;
+            const T* lbase;  // low part of a (hi, lo) residual-stream input, or null
             int64_t ld;
             int co;
-            if (cv < nv0) { base = x0 + (int64_t)b * rows * c0; ld = c0; co = cv * 8; }
-            else { base = x1 + (int64_t)b * rows * c1; ld = c1; co = (cv - nv0) * 8; }
+            if (cv < nv0) { base = x0 + (int64_t)b * rows * c0; lbase = x0_lo ? x0_lo + (int64_t)b * rows * c0 : nullptr; ld = c0; co = cv * 8; }
+            else { base = x1 + (int64_t)b * rows * c1; lbase = x1_lo ? x1_lo + (int64_t)b * rows * c1 : nullptr; ld = c1; co = (cv - nv0) * 8; }
             for (int r = rbeg + rsub; r < rend; r += 8 * rs) {  // 8 independent 16-byte loads in flight per thread
                 typename Vec8<T>::type raw[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u)
                     raw[u] = *reinterpret_cast<const typename Vec8<T>::type*>(base + (int64_t)min(r + u * rs, rend - 1) * ld + co);
+                if (lbase) {
+                    typename Vec8<T>::type rlo[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        rlo[u] = *reinterpret_cast<const typename Vec8<T>::type*>(lbase + (int64_t)min(r + u * rs, rend - 1) * ld + co);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const float w = (r + u * rs < rend) ? 1.f : 0.f;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const float v = ((float)raw[u][i] + (float)rlo[u][i]) * w;
+                            s[i] += v;
+                            ss[i] += v * v;
+                        }
+                    }
+                    continue;
+                }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const float w = (r + u * rs < rend) ? 1.f : 0.f;
@@ -123,7 +142,8 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(const T* __restrict__ x0,
 }
 
 template <typename T>
-__global__ void __launch_bounds__(256) gn_apply_kernel(const T* __restrict__ x0, const T* __restrict__ x1, int c0,
+__global__ void __launch_bounds__(256) gn_apply_kernel(const T* __restrict__ x0, const T* __restrict__ x1,
+                                                       const T* __restrict__ x0_lo, const T* __restrict__ x1_lo, int c0,
                                                        int c1, int rows, int groups, int nstat, int nchunks,
                                                        const float* __restrict__ partial,
                                                        const float* __restrict__ gamma,
@@ -183,23 +203,32 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const T* __restrict__ x0,
             }
         }
         const T* base;
+        const T* lbase;
         int64_t ld;
         int co;
-        if (cv < nv0) { base = x0 + (int64_t)b * rows * c0; ld = c0; co = cv * 8; }
-        else { base = x1 + (int64_t)b * rows * c1; ld = c1; co = (cv - nv0) * 8; }
+        if (cv < nv0) { base = x0 + (int64_t)b * rows * c0; lbase = x0_lo ? x0_lo + (int64_t)b * rows * c0 : nullptr; ld = c0; co = cv * 8; }
+        else { base = x1 + (int64_t)b * rows * c1; lbase = x1_lo ? x1_lo + (int64_t)b * rows * c1 : nullptr; ld = c1; co = (cv - nv0) * 8; }
         T* ob = out + (int64_t)b * rows * C + cv * 8;
         for (int r = rbeg + rsub; r < rend; r += 4 * rs) {  // 4 loads in flight (clamped rows), then normalise + store
             typename Vec8<T>::type raw[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u)
                 raw[u] = *reinterpret_cast<const typename Vec8<T>::type*>(base + (int64_t)min(r + u * rs, rend - 1) * ld + co);
+            typename Vec8<T>::type rlo[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (lbase) rlo[u] = *reinterpret_cast<const typename Vec8<T>::type*>(lbase + (int64_t)min(r + u * rs, rend - 1) * ld + co);
+                else
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) rlo[u][i] = (T)0.0f;
+            }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 if (r + u * rs < rend) {
                     float v[8];
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
-                        const float y = (float)raw[u][i] * a[i] + sh[i];
+                        const float y = ((float)raw[u][i] + (float)rlo[u][i]) * a[i] + sh[i];
                         v[i] = silu ? silu_f(y) : y;
                     }
                     store8(ob + (int64_t)(r + u * rs) * C, v);
@@ -215,7 +244,7 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const T* __restrict__ x0,
 // row per wave a C = 320 row is a single 640-byte request per wave.
 // ------------------------------------------------------------------------------------------
 template <typename T, int MAXV, int R>
-__global__ void __launch_bounds__(256) layernorm_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+__global__ void __launch_bounds__(256) layernorm_kernel(const T* __restrict__ x, const T* __restrict__ x_lo, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps, int rows, int C,
                                                         int rows_per_set, int pstride, T* __restrict__ out) {
     const int lane = threadIdx.x & 63;
@@ -228,10 +257,19 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const T* __restrict__ x,
     for (int r = 0; r < R; ++r) {
         s[r] = 0.f;
         const T* xr = x + (int64_t)min(row0 + r, rows - 1) * C;
+        const T* xl = x_lo ? x_lo + (int64_t)min(row0 + r, rows - 1) * C : nullptr;
 #pragma unroll
         for (int k = 0; k < MAXV; ++k) {
             const int cv = lane + k * 64;
-            if (cv < nvec) load8(xr + cv * 8, v[r][k]);
+            if (cv < nvec) {
+                load8(xr + cv * 8, v[r][k]);
+                if (xl) {
+                    float l[8];
+                    load8(xl + cv * 8, l);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[r][k][i] += l[i];
+                }
+            }
         }
     }
 #pragma unroll
@@ -287,7 +325,7 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const T* __restrict__ x,
 // row, every lane holds five 16-byte vectors, so all 64 lanes are busy (a C = 320 row only fills 40 lanes of the
 // one-row-per-wave kernel), five loads are in flight per lane and the reductions run over L lanes only.
 template <typename T, int L>
-__global__ void __launch_bounds__(256) layernorm5_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+__global__ void __launch_bounds__(256) layernorm5_kernel(const T* __restrict__ x, const T* __restrict__ x_lo, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, float eps, int rows, int C,
                                                          int rows_per_set, int pstride, T* __restrict__ out) {
     constexpr int RPW = 64 / L;  // rows per wave
@@ -298,6 +336,16 @@ __global__ void __launch_bounds__(256) layernorm5_kernel(const T* __restrict__ x
     float v[5][8];
 #pragma unroll
     for (int k = 0; k < 5; ++k) load8(xr + (sub + k * L) * 8, v[k]);
+    if (x_lo) {
+        const T* xl = x_lo + (int64_t)min(row, rows - 1) * C;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            float l[8];
+            load8(xl + (sub + k * L) * 8, l);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[k][i] += l[i];
+        }
+    }
     float s = 0.f;
 #pragma unroll
     for (int k = 0; k < 5; ++k)
@@ -346,26 +394,26 @@ static int gn_check(const void* x0, const void* x1, int c0, int c1, int B, int r
     return 0;
 }
 
-extern "C" int ur_groupnorm_stats(const void* x0, const void* x1, int c0, int c1, int B, int rows, int groups,
-                                  int nchunks, float* partial, int dtype, void* stream) {
+extern "C" int ur_groupnorm_stats(const void* x0, const void* x1, const void* x0_lo, const void* x1_lo, int c0, int c1,
+                                  int B, int rows, int groups, int nchunks, float* partial, int dtype, void* stream) {
     int rc = gn_check(x0, x1, c0, c1, B, rows, groups, nchunks);
     if (rc || !partial) return rc ? rc : UR_E_BADARG;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     dim3 grid(nchunks, B);
     if (dtype == UR_DT_F16)
-        hipLaunchKernelGGL((gn_stats_kernel<f16>), grid, dim3(256), 0, s, (const f16*)x0, (const f16*)x1, c0, c1, rows,
-                           groups, nchunks, partial);
+        hipLaunchKernelGGL((gn_stats_kernel<f16>), grid, dim3(256), 0, s, (const f16*)x0, (const f16*)x1,
+                           (const f16*)x0_lo, (const f16*)x1_lo, c0, c1, rows, groups, nchunks, partial);
     else if (dtype == UR_DT_BF16)
-        hipLaunchKernelGGL((gn_stats_kernel<bf16>), grid, dim3(256), 0, s, (const bf16*)x0, (const bf16*)x1, c0, c1,
-                           rows, groups, nchunks, partial);
+        hipLaunchKernelGGL((gn_stats_kernel<bf16>), grid, dim3(256), 0, s, (const bf16*)x0, (const bf16*)x1,
+                           (const bf16*)x0_lo, (const bf16*)x1_lo, c0, c1, rows, groups, nchunks, partial);
     else
         return UR_E_BADARG;
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : -(int)e;
 }
 
-extern "C" int ur_groupnorm_apply(const void* x0, const void* x1, int c0, int c1, int B, int rows, int groups,
-                                  int nstat, int nchunks, const float* partial, const float* gamma,
+extern "C" int ur_groupnorm_apply(const void* x0, const void* x1, const void* x0_lo, const void* x1_lo, int c0, int c1,
+                                  int B, int rows, int groups, int nstat, int nchunks, const float* partial, const float* gamma,
                                   const float* beta, float eps, int silu, int bper, int pstride, void* out,
                                   int dtype, void* stream) {
     int rc = gn_check(x0, x1, c0, c1, B, rows, groups, nchunks);
@@ -373,11 +421,13 @@ extern "C" int ur_groupnorm_apply(const void* x0, const void* x1, int c0, int c1
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     dim3 grid(nchunks, B);
     if (dtype == UR_DT_F16)
-        hipLaunchKernelGGL((gn_apply_kernel<f16>), grid, dim3(256), 0, s, (const f16*)x0, (const f16*)x1, c0, c1, rows,
-                           groups, nstat, nchunks, partial, gamma, beta, eps, silu, bper, pstride, (f16*)out);
+        hipLaunchKernelGGL((gn_apply_kernel<f16>), grid, dim3(256), 0, s, (const f16*)x0, (const f16*)x1,
+                           (const f16*)x0_lo, (const f16*)x1_lo, c0, c1, rows, groups, nstat, nchunks, partial, gamma, beta,
+                           eps, silu, bper, pstride, (f16*)out);
     else if (dtype == UR_DT_BF16)
-        hipLaunchKernelGGL((gn_apply_kernel<bf16>), grid, dim3(256), 0, s, (const bf16*)x0, (const bf16*)x1, c0, c1,
-                           rows, groups, nstat, nchunks, partial, gamma, beta, eps, silu, bper, pstride, (bf16*)out);
+        hipLaunchKernelGGL((gn_apply_kernel<bf16>), grid, dim3(256), 0, s, (const bf16*)x0, (const bf16*)x1,
+                           (const bf16*)x0_lo, (const bf16*)x1_lo, c0, c1, rows, groups, nstat, nchunks, partial, gamma,
+                           beta, eps, silu, bper, pstride, (bf16*)out);
     else
         return UR_E_BADARG;
     hipError_t e = hipGetLastError();
@@ -385,15 +435,15 @@ extern "C" int ur_groupnorm_apply(const void* x0, const void* x1, int c0, int c1
 }
 
 template <typename T>
-static void launch_ln(const void* x, const float* gamma, const float* beta, float eps, int rows, int C, int rows_per_set,
-                      int pstride, void* out, hipStream_t s) {
+static void launch_ln(const void* x, const void* x_lo, const float* gamma, const float* beta, float eps, int rows, int C,
+                      int rows_per_set, int pstride, void* out, hipStream_t s) {
     // rows per wave chosen so that a wave keeps >= 4 16-byte loads per lane in flight and the grid still fills the chip
 #define UR_LN(MAXV, R)                                                                                              \
     hipLaunchKernelGGL((layernorm_kernel<T, MAXV, R>), dim3((rows + 4 * R - 1) / (4 * R)), dim3(256), 0, s,          \
-                       (const T*)x, gamma, beta, eps, rows, C, rows_per_set, pstride, (T*)out)
+                       (const T*)x, (const T*)x_lo, gamma, beta, eps, rows, C, rows_per_set, pstride, (T*)out)
 #define UR_LN5(LL)                                                                                                   \
     hipLaunchKernelGGL((layernorm5_kernel<T, LL>), dim3((rows + 4 * (64 / LL) - 1) / (4 * (64 / LL))), dim3(256), 0, s, \
-                       (const T*)x, gamma, beta, eps, rows, C, rows_per_set, pstride, (T*)out)
+                       (const T*)x, (const T*)x_lo, gamma, beta, eps, rows, C, rows_per_set, pstride, (T*)out)
     if (C == 320) { UR_LN5(8); return; }
     if (C == 640) { UR_LN5(16); return; }
     if (C == 1280) { UR_LN5(32); return; }
@@ -406,12 +456,12 @@ static void launch_ln(const void* x, const float* gamma, const float* beta, floa
 #undef UR_LN
 }
 
-extern "C" int ur_layernorm(const void* x, const float* gamma, const float* beta, float eps, int rows, int C,
-                            int rows_per_set, int pstride, void* out, int dtype, void* stream) {
+extern "C" int ur_layernorm(const void* x, const void* x_lo, const float* gamma, const float* beta, float eps, int rows,
+                            int C, int rows_per_set, int pstride, void* out, int dtype, void* stream) {
     if (!x || !gamma || !beta || !out || rows <= 0 || C <= 0 || (C & 7) || C > 4096) return UR_E_BADARG;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == UR_DT_F16) launch_ln<f16>(x, gamma, beta, eps, rows, C, rows_per_set, pstride, out, s);
-    else if (dtype == UR_DT_BF16) launch_ln<bf16>(x, gamma, beta, eps, rows, C, rows_per_set, pstride, out, s);
+    if (dtype == UR_DT_F16) launch_ln<f16>(x, x_lo, gamma, beta, eps, rows, C, rows_per_set, pstride, out, s);
+    else if (dtype == UR_DT_BF16) launch_ln<bf16>(x, x_lo, gamma, beta, eps, rows, C, rows_per_set, pstride, out, s);
     else return UR_E_BADARG;
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : -(int)e;

@@ -21,6 +21,7 @@ between the two is tested bit-for-bit-close in tests/test_fused_gpu.py.  The mod
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -56,9 +57,16 @@ def _stk(ts):
 class GroupedDualStreamStep:
     """enc + unet + dec step with every op of the two diffusion streams issued as one grouped kernel."""
 
-    def __init__(self, unet, enc, dec):
+    def __init__(self, unet, enc, dec, precise_residual: Optional[bool] = None):
+        """precise_residual: carry the residual stream (block outputs, the x + f(x) adds, skips, exchange sums) as
+        (hi, lo) fp16/bf16 pairs (include/ur_kernels.h) -- removes the random walk of the storage rounding along the
+        residual path, which is 55 % of the step's fp16 error variance, for 2 extra bytes per
+        element on those tensors.  Default: env UR_PRECISE_RESIDUAL (1 / 0), on."""
         self.unet, self.enc, self.dec = unet, enc, dec
         self.pk = _Packs()
+        if precise_residual is None:
+            precise_residual = os.environ.get("UR_PRECISE_RESIDUAL", "1") != "0"
+        self.hilo = bool(precise_residual)
 
     # ------------------------------------------------------------------ leaves (S streams in lockstep)
     def _resnet(self, rs: Sequence[ResnetBlock2D], x, temb, slice_, x1=None):
@@ -83,7 +91,7 @@ class GroupedDualStreamStep:
             sc = ops.linear(x, ws, bs, x1=x1, streams=S)
         else:
             sc = x
-        return ops.conv3x3(h, w2, c2, res=sc, out_scale=1.0 / r0.output_scale_factor, streams=S)
+        return ops.conv3x3(h, w2, c2, res=sc, out_scale=1.0 / r0.output_scale_factor, streams=S, hilo=self.hilo)
 
     def _attn(self, as_: Sequence[Attention], xn, residual, kc, vtc, kv_slice):
         S, pk, dt = len(as_), self.pk, xn.dtype
@@ -106,7 +114,7 @@ class GroupedDualStreamStep:
             lo, hi = kv_slice
             o = ops.attention(q, kc[:, :, lo:hi], vtc[:, lo:hi], B=Bt, H=H, Tq=T, Tk=kc.shape[1], d=d, ldq=C,
                               ldk=kc.stride(1), scale=0.0)
-        return ops.linear(o, wo, bo, res=residual, streams=S)
+        return ops.linear(o, wo, bo, res=residual, streams=S, hilo=self.hilo)
 
     def _tblock(self, bs: Sequence[BasicTransformerBlock], x, kc, vtc, kv_slice):
         S, pk, dt = len(bs), self.pk, x.dtype
@@ -134,7 +142,7 @@ class GroupedDualStreamStep:
         w_out = pk.get("t.ffo", bs, [o.weight for o in outs], dt, lambda: _stk(pack_matrix(o.weight, dt) for o in outs))
         b_out = pk.get("t.ffb", bs, [o.bias for o in outs], dt, lambda: _stk(f32(o.bias) for o in outs))
         gg = ops.linear(xn, w_in, b_in, act=ops.ACT_GEGLU, streams=S)
-        return ops.linear(gg, w_out, b_out, res=x, streams=S)
+        return ops.linear(gg, w_out, b_out, res=x, streams=S, hilo=self.hilo)
 
     def _transformer(self, ts: Sequence[Transformer2DModel], x, kc, vtc, kv_slices):
         S, pk, dt = len(ts), self.pk, x.dtype
@@ -146,16 +154,17 @@ class GroupedDualStreamStep:
         wo = pk.get("x.wo", ts, [t.proj_out.weight for t in ts], dt, lambda: _stk(pack_matrix(t.proj_out.weight, dt) for t in ts))
         bo = pk.get("x.bo", ts, [t.proj_out.bias for t in ts], dt, lambda: _stk(f32(t.proj_out.bias) for t in ts))
         h = ops.groupnorm(x, g, b_, ts[0].norm.eps, groups=ts[0].groups, silu=False, streams=S)
-        h = ops.linear(h.view(Bt, H * W, Cc), wi, bi, streams=S)
+        h = ops.linear(h.view(Bt, H * W, Cc), wi, bi, streams=S, hilo=self.hilo)
         for j in range(len(ts[0].transformer_blocks)):
             h = self._tblock([t.transformer_blocks[j] for t in ts], h, kc, vtc, kv_slices[j])
-        return ops.linear(h, wo, bo, res=x.view(Bt, H * W, Cc), streams=S).view(Bt, H, W, Cc)
+        y = ops.linear(h, wo, bo, res=ops.view_hilo(x, Bt, H * W, Cc), streams=S, hilo=self.hilo)
+        return ops.view_hilo(y, Bt, H, W, Cc)
 
     def _conv(self, name, convs, x, stride=1, ups=False):
         S, pk, dt = len(convs), self.pk, x.dtype
         w = pk.get(name + ".w", convs, [c.weight for c in convs], dt, lambda: _stk(pack_conv3x3(c.weight, dt) for c in convs))
         b = pk.get(name + ".b", convs, [c.bias for c in convs], dt, lambda: _stk(f32(c.bias) for c in convs))
-        return ops.conv3x3(x, w, b, stride=stride, ups=ups, streams=S)
+        return ops.conv3x3(x, w, b, stride=stride, ups=ups, streams=S, hilo=self.hilo)
 
     # ------------------------------------------------------------------ per-phase context (temb, prompt K / V^T)
     def _phase_ctx(self, nets, resnet_lists, cross_lists, semb, ehs):
@@ -242,7 +251,7 @@ class GroupedDualStreamStep:
         cins = [n.conv_in for n in pair]
         wci = pk.get("cin.w", cins, [m.weight for m in cins], dt, lambda: _stk(pack_conv3x3(m.weight, dt, CIN_PAD) for m in cins))
         bci = pk.get("cin.b", cins, [m.bias for m in cins], dt, lambda: _stk(f32(m.bias) for m in cins))
-        x = ops.conv3x3(x_in, wci, bci, streams=2)
+        x = ops.conv3x3(x_in, wci, bci, streams=2, hilo=self.hilo)
         skips = [x]
         for bi_ in range(len(enc.down_blocks)):
             blks = [n.down_blocks[bi_] for n in pair]
@@ -278,10 +287,14 @@ class GroupedDualStreamStep:
                 b = pk.get((name, "b", scale), mods, [m.bias for m in mods], dt,
                            lambda: _stk([f32(z_enc.bias) * scale, f32(z_dec.bias)]))
                 tt = t.view(2, -1, Cc)
-                return ops.linear(tt, w, b, res=tt[1], res_zstride=-half, streams=2).view(t.shape)
+                tl = ops.lo_of(t)
+                y = ops.linear(tt, w, b, res=tt[1], res_zstride=-half, streams=2, hilo=self.hilo,
+                               res_lo=(tl.view(2, -1, Cc)[1] if tl is not None else None))
+                return ops.view_hilo(y, *t.shape)
             w = pk.get((name, "w1", scale), [z_enc], [z_enc.weight], dt, lambda: (pack_matrix(z_enc.weight, dt) * scale).contiguous())
             b = pk.get((name, "b1", scale), [z_enc], [z_enc.bias], dt, lambda: f32(z_enc.bias) * scale)
-            return ops.linear(t[:B], w, b, res=t[B:])
+            tl = ops.lo_of(t)
+            return ops.linear(t[:B], w, b, res=t[B:], hilo=self.hilo, res_lo=(tl[B:] if tl is not None else None))
 
         up_skips = [exchange(f"ex{i}", enc.controlnet_down_blocks[i], dec.control_down_blocks[i] if run_decoder else None, s)
                     for i, s in enumerate(skips)]

@@ -140,7 +140,8 @@ def plan_igemm(M: int, N: int, K: int, taps: int = 1, zbatch: int = 1) -> Tuple[
 # ---------------------------------------------------------------------------------------------
 def igemm(*, x0, w, out, M, N, K, c0, c1=0, x1=None, ldx0, ldx1=0, ldw, ldc, taps=1, conv=None, stride=1, ups=0,
           bias=None, rowadd=None, rows_per_b=0, res=None, ldres=0, n_store=0, act=ACT_NONE, out_scale=1.0,
-          zbatch=1, zx=0, zw=0, zout=0, zx1=0, zbias=0, zrow=0, zres=0, zx_div=1, tile=None, splitk=None):
+          zbatch=1, zx=0, zw=0, zout=0, zx1=0, zbias=0, zrow=0, zres=0, zx_div=1, tile=None, splitk=None,
+          res_lo=None, out_lo=None):
     _require_gpu(x0)
     lib = _lib.load()
     if tile is None or splitk is None:
@@ -150,6 +151,7 @@ def igemm(*, x0, w, out, M, N, K, c0, c1=0, x1=None, ldx0, ldx1=0, ldw, ldc, tap
     d = IGemmDesc()
     d.x0, d.x1, d.w = _ptr(x0), _ptr(x1), _ptr(w)
     d.bias, d.rowadd, d.res, d.out = _ptr(bias), _ptr(rowadd), _ptr(res), _ptr(out)
+    d.res_lo, d.out_lo = _ptr(res_lo), _ptr(out_lo)
     zp = zero_page(x0.device)
     d.zero_page = zp.data_ptr()
     d.ldx0, d.ldx1, d.ldw, d.ldres, d.ldc = ldx0, ldx1, ldw, ldres, ldc
@@ -184,9 +186,35 @@ def igemm(*, x0, w, out, M, N, K, c0, c1=0, x1=None, ldx0, ldx1=0, ldw, ldc, tap
     return out
 
 
+# ---------------------------------------------------------------------------------------------
+# (hi, lo) residual stream (include/ur_kernels.h): the low part of a residual-stream tensor travels as the attribute
+# ``.lo`` of the ordinary (hi) tensor.  Views / slices drop it, which is the safe default: a consumer that does not
+# know about it just sees the ordinary rounded tensor.
+# ---------------------------------------------------------------------------------------------
+def lo_of(t):
+    return getattr(t, "lo", None) if t is not None else None
+
+
+def view_hilo(t, *shape):
+    """``t.view(*shape)`` that keeps the low part attached."""
+    v = t.view(*shape)
+    lo = lo_of(t)
+    if lo is not None:
+        v.lo = lo.view(*shape)
+    return v
+
+
+def _with_lo(out, want: bool):
+    if want:
+        out.lo = torch.empty_like(out)
+    return out
+
+
 def linear(x, w, bias=None, *, x1=None, res=None, act=ACT_NONE, out_scale=1.0, rowadd=None, rows_per_b=0, out=None,
-           tile=None, splitk=None, streams=1, res_zstride=None):
+           tile=None, splitk=None, streams=1, res_zstride=None, hilo=False, res_lo=None):
     """y[..., N] = epilogue(x[..., K] @ w[N, K]^T).  ``x1``: second source concatenated along K.
+    ``hilo``: also produce the rounding remainder (``y.lo``); the low part of ``res`` (``res.lo`` or ``res_lo``) is
+    added when present.
 
     ``streams=S`` > 1 runs S independent problems of one shape as ONE grouped launch: x (x1, res, out) hold the
     S row-blocks back to back, ``w`` is [S, N, K], ``bias`` [S, N], ``rowadd`` has its rows grouped per stream.
@@ -199,6 +227,9 @@ def linear(x, w, bias=None, *, x1=None, res=None, act=ACT_NONE, out_scale=1.0, r
     n_out = N // 2 if act == ACT_GEGLU else N
     if out is None:
         out = torch.empty(*x.shape[:-1], n_out, dtype=x.dtype, device=x.device)
+    _with_lo(out, hilo and act != ACT_GEGLU)
+    if res_lo is None:
+        res_lo = lo_of(res)
     z = {}
     if streams > 1:
         z = dict(zbatch=streams, zx=M * K0, zx1=M * K1, zw=w.stride(0), zout=M * n_out,
@@ -207,12 +238,12 @@ def linear(x, w, bias=None, *, x1=None, res=None, act=ACT_NONE, out_scale=1.0, r
                  zrow=(rowadd.stride(0) * (rowadd.shape[0] // streams)) if rowadd is not None else 0)
     igemm(x0=x, x1=x1, w=w, out=out, M=M, N=N, K=K0 + K1, c0=K0, c1=K1, ldx0=K0, ldx1=K1, ldw=w.stride(-2), ldc=n_out,
           bias=bias, res=res, ldres=(n_out if res is not None else 0), act=act, out_scale=out_scale, rowadd=rowadd,
-          rows_per_b=rows_per_b, tile=tile, splitk=splitk, **z)
+          rows_per_b=rows_per_b, tile=tile, splitk=splitk, res_lo=res_lo, out_lo=lo_of(out), **z)
     return out
 
 
 def conv3x3(x, w, bias=None, *, x1=None, stride=1, ups=False, rowadd=None, res=None, out_scale=1.0, n_out=None,
-            tile=None, splitk=None, streams=1):
+            tile=None, splitk=None, streams=1, hilo=False):
     """3x3 conv, pad 1, over NHWC ``x`` (optionally cat(x, x1) on channels, optionally after a nearest-2x
     upsample).  ``w`` is [Npad >= n_out, 9*Cin] with k = (ky*3+kx)*Cin + c.  Output [B, Ho, Wo, n_out].
     ``streams=S``: x is [S*B, H, W, C] (stream-major), ``w`` [S, N, 9*Cin], ``bias`` [S, N]: one grouped launch."""
@@ -224,7 +255,7 @@ def conv3x3(x, w, bias=None, *, x1=None, stride=1, ups=False, rowadd=None, res=N
     else:
         Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
     N = n_out if n_out is not None else w.shape[-2]
-    out = torch.empty(Bt, Ho, Wo, N, dtype=x.dtype, device=x.device)
+    out = _with_lo(torch.empty(Bt, Ho, Wo, N, dtype=x.dtype, device=x.device), hilo)
     M = B * Ho * Wo
     z = {}
     if streams > 1:
@@ -234,7 +265,7 @@ def conv3x3(x, w, bias=None, *, x1=None, stride=1, ups=False, rowadd=None, res=N
     igemm(x0=x, x1=x1, w=w, out=out, M=M, N=N, K=9 * (C0 + C1), c0=C0, c1=C1, ldx0=C0, ldx1=C1,
           ldw=w.stride(-2), ldc=N, taps=9, conv=(B, H, W, Ho, Wo), stride=stride, ups=int(ups), bias=bias,
           rowadd=rowadd, rows_per_b=Ho * Wo, res=res, ldres=(N if res is not None else 0), out_scale=out_scale,
-          tile=tile, splitk=splitk, **z)
+          tile=tile, splitk=splitk, res_lo=lo_of(res), out_lo=lo_of(out), **z)
     return out
 
 
@@ -284,11 +315,12 @@ def groupnorm(x, gamma, beta, eps, *, x1=None, groups=32, silu=False, nstat=None
     out = torch.empty(*x.shape[:-1], C0 + C1, dtype=x.dtype, device=x.device)
     s = _stream()
     e0 = _prof_begin()
-    check(lib.ur_groupnorm_stats(_ptr(x), _ptr(x1), C0, C1, B, rows, groups, nstat, part.data_ptr(), DT[x.dtype], s),
-          "ur_groupnorm_stats")
+    xl, x1l = lo_of(x), lo_of(x1)
+    check(lib.ur_groupnorm_stats(_ptr(x), _ptr(x1), _ptr(xl), _ptr(x1l), C0, C1, B, rows, groups, nstat, part.data_ptr(),
+                                 DT[x.dtype], s), "ur_groupnorm_stats")
     _prof_end(e0, "gn_stats", 0.0, 1.0 * out.numel() * out.element_size())
     e1 = _prof_begin()
-    check(lib.ur_groupnorm_apply(_ptr(x), _ptr(x1), C0, C1, B, rows, groups, nstat, napply, part.data_ptr(),
+    check(lib.ur_groupnorm_apply(_ptr(x), _ptr(x1), _ptr(xl), _ptr(x1l), C0, C1, B, rows, groups, nstat, napply, part.data_ptr(),
                                  gamma.data_ptr(), beta.data_ptr(), float(eps), int(silu),
                                  (B // streams if streams > 1 else 0), (C0 + C1 if streams > 1 else 0), out.data_ptr(),
                                  DT[x.dtype], s),
@@ -304,7 +336,7 @@ def layernorm(x, gamma, beta, eps=1e-5, streams=1):
     rows = x.numel() // Cn
     out = torch.empty_like(x)
     e0 = _prof_begin()
-    check(lib.ur_layernorm(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(eps), rows, Cn,
+    check(lib.ur_layernorm(x.data_ptr(), _ptr(lo_of(x)), gamma.data_ptr(), beta.data_ptr(), float(eps), rows, Cn,
                            (rows // streams if streams > 1 else 0), (Cn if streams > 1 else 0), out.data_ptr(),
                            DT[x.dtype], _stream()), "ur_layernorm")
     _prof_end(e0, "layernorm", 0.0, 2.0 * out.numel() * out.element_size())
@@ -360,13 +392,19 @@ def sampler_advance(step, tsteps, nsteps: int, t_out=None):
                                  (t_out.numel() if t_out is not None else 0), _stream()), "ur_sampler_advance")
 
 
-def add(a, b, alpha: float = 1.0):
+def add(a, b, alpha: float = 1.0, hilo=False):
+    """a + alpha * b.  Low parts (``a.lo`` / ``b.lo``) are included when present; ``hilo`` also returns ``out.lo``."""
     _require_gpu(a)
     lib = _lib.load()
-    out = torch.empty_like(a)
+    out = _with_lo(torch.empty_like(a), hilo)
+    al, bl = lo_of(a), lo_of(b)
     e0 = _prof_begin()
-    check(lib.ur_add(a.data_ptr(), b.data_ptr(), float(alpha), out.data_ptr(), a.numel(), DT[a.dtype], _stream()),
-          "ur_add")
+    if al is None and bl is None and not hilo:
+        check(lib.ur_add(a.data_ptr(), b.data_ptr(), float(alpha), out.data_ptr(), a.numel(), DT[a.dtype], _stream()),
+              "ur_add")
+    else:
+        check(lib.ur_add_hilo(a.data_ptr(), _ptr(al), b.data_ptr(), _ptr(bl), float(alpha), out.data_ptr(),
+                              _ptr(lo_of(out)), a.numel(), DT[a.dtype], _stream()), "ur_add_hilo")
     _prof_end(e0, "add", 0.0, 3.0 * out.numel() * out.element_size())
     return out
 
