@@ -76,7 +76,15 @@ def test_rendering_direction_and_scalar_timesteps(dev):
 
 def test_structural_invariants_on_gpu(dev):
     """Reference invariants: enc ignores `sample`; with zero-init exchange convs the unet
-    output does not depend on the enc residuals and dec does not depend on the unet features."""
+    output does not depend on the enc residuals and dec does not depend on the unet features.  With the (hi, lo)
+    residual stream an added zero re-splits the pair: hi + lo is unchanged (checked bit for bit below), but hi itself
+    can move by one ulp where lo sits at half an ulp, and that re-rounding propagates like any other fp16 rounding
+    -- the no-op then holds to the fp16 noise floor (the bound used between executors), not bit for bit."""
+    from uni_renderer_amd import ops
+
+    def same(p, q):
+        return torch.equal(p, q) if not ops.PRECISE_RESIDUAL else rel_l2(p, q) < 3e-3
+
     unet_o, enc_o, dec_o = O.build_triplet(O.TINY_CONFIG, seed=3, exchange_std=0.0)
     unet, enc, dec = build_product_from_oracle(unet_o, enc_o, dec_o, torch.float16, dev)
     x, c, ehs, ti, ta = [t.to(dev) for t in O.make_inputs(2, 16, 64, seed=11)]
@@ -88,13 +96,17 @@ def test_structural_invariants_on_gpu(dev):
         a = unet(x, ti, ehs, down_block_additional_residuals=r1[0], mid_block_additional_residual=r1[1],
                  return_dict=False)
         b = unet(x, ti, ehs, return_dict=False)
-        assert torch.equal(a[0], b[0])
+        assert same(a[0], b[0])
+        if ops.PRECISE_RESIDUAL:  # the pair's VALUE is invariant under adding zero
+            sk = ops.to_nhwc(b[1][3], torch.float16)
+            z = ops.add(sk, torch.zeros_like(sk), hilo=True)
+            assert torch.equal(sk.float() + ops.lo_of(sk).float(), z.float() + z.lo.float())
         d1 = dec(r1[3], r1[2], ta, ehs, down_block_additional_residuals=a[1], mid_block_additional_residual=a[2],
                  return_dict=False)
         zeros = tuple(torch.zeros_like(t) for t in a[1])
         d2 = dec(r1[3], r1[2], ta, ehs, down_block_additional_residuals=zeros,
                  mid_block_additional_residual=torch.zeros_like(a[2]), return_dict=False)
-        assert torch.equal(d1, d2)
+        assert same(d1, d2)
         assert unet(x, ti, ehs).sample.shape == (2, 4, 16, 16)  # return_dict=True surface
 
 

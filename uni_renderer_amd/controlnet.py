@@ -118,7 +118,7 @@ class _DenoiserBase(ConfigModelMixin, nn.Module):
         b = self._pk.get("cin_b", [self.conv_in.bias], dt, lambda: f32(self.conv_in.bias))
         if x_nchw.shape[1] > CIN_PAD:
             raise NotImplementedError("conv_in with more than 64 input channels")
-        return ops.conv3x3(ops.to_nhwc(x_nchw, dt, CIN_PAD), w, b)
+        return ops.conv3x3(ops.to_nhwc(x_nchw, dt, CIN_PAD), w, b, hilo=ops.PRECISE_RESIDUAL)
 
     def _conv_out(self, x: torch.Tensor, ctx: Ctx) -> torch.Tensor:
         dt = ctx.dtype
@@ -133,7 +133,7 @@ class _DenoiserBase(ConfigModelMixin, nn.Module):
         dt = ctx.dtype
         w = self._pk.get(name + "_w", [conv.weight], dt, lambda: pack_matrix(conv.weight, dt))
         b = self._pk.get(name + "_b", [conv.bias], dt, lambda: f32(conv.bias))
-        return ops.linear(x, w, b, res=res, out_scale=scale)
+        return ops.linear(x, w, b, res=res, out_scale=scale, hilo=ops.PRECISE_RESIDUAL and res is not None)
 
 
 def _exchange_channels(block_out_channels, layers_per_block):
@@ -313,8 +313,9 @@ class UNet2DConditionModel(_DenoiserBase):
         if down_block_additional_residuals is not None and not is_controlnet:
             raise NotImplementedError("T2I-adapter style down_block_additional_residuals without a mid residual")
         if is_controlnet:  # ref 1078-1087: 12 exchange adds; ref 1114-1115: mid
-            skips = tuple(ops.add(s, ops.to_nhwc(e, dt)) for s, e in zip(skips, down_block_additional_residuals))
-            x = ops.add(x, ops.to_nhwc(mid_block_additional_residual, dt))
+            hl = ops.PRECISE_RESIDUAL
+            skips = tuple(ops.add(s, ops.to_nhwc(e, dt), hilo=hl) for s, e in zip(skips, down_block_additional_residuals))
+            x = ops.add(x, ops.to_nhwc(mid_block_additional_residual, dt), hilo=hl)
         up_res = (x,)
         for i, blk in enumerate(self.up_blocks):
             nres = len(blk.resnets)

@@ -173,7 +173,7 @@ class ResnetBlock2D(nn.Module):
             if x1 is not None:
                 raise RuntimeError("concat input requires a conv_shortcut (in_channels != out_channels)")
             sc = x
-        return ops.conv3x3(h, w2, cb2, res=sc, out_scale=1.0 / self.output_scale_factor)
+        return ops.conv3x3(h, w2, cb2, res=sc, out_scale=1.0 / self.output_scale_factor, hilo=ops.PRECISE_RESIDUAL)
 
 
 class Attention(nn.Module):
@@ -211,7 +211,7 @@ class Attention(nn.Module):
             q = ops.linear(xn, wq, out_scale=cs)
             o = ops.attention(q, ctx.kc[:, :, lo:hi], ctx.vtc[:, lo:hi], B=B, H=H, Tq=T, Tk=ctx.kc.shape[1], d=d,
                               ldq=C, ldk=ctx.kc.stride(1), scale=0.0)
-            return ops.linear(o, wo, bo, res=residual)
+            return ops.linear(o, wo, bo, res=residual, hilo=ops.PRECISE_RESIDUAL)
         wv = pk.get("wv", [self.to_v.weight], dt, lambda: pack_matrix(self.to_v.weight, dt))
         if not self.is_cross:
             wqk = pk.get("wqk", [self.to_q.weight, self.to_k.weight], dt,
@@ -228,7 +228,7 @@ class Attention(nn.Module):
             k = ops.linear(ehs, wk)                        # [B,Tk,C]
             vt = ops.vt_proj(ehs, wv)                      # [B,C,ceil64(Tk)]
             o = ops.attention(q, k, vt, B=B, H=H, Tq=T, Tk=Tk, d=d, ldq=C, ldk=C, scale=0.0)
-        return ops.linear(o, wo, bo, res=residual)
+        return ops.linear(o, wo, bo, res=residual, hilo=ops.PRECISE_RESIDUAL)
 
 
 class GEGLU(nn.Module):
@@ -259,7 +259,7 @@ class FeedForward(nn.Module):
         w_out = pk.get("wout", [out.weight], dt, lambda: pack_matrix(out.weight, dt))
         b_out = pk.get("bout", [out.bias], dt, lambda: f32(out.bias))
         g = ops.linear(xn, w_in, b_in, act=ops.ACT_GEGLU)   # [B,T,4C]
-        return ops.linear(g, w_out, b_out, res=residual)
+        return ops.linear(g, w_out, b_out, res=residual, hilo=ops.PRECISE_RESIDUAL)
 
 
 class BasicTransformerBlock(nn.Module):
@@ -312,11 +312,11 @@ class Transformer2DModel(nn.Module):
         wo = pk.get("wo", [self.proj_out.weight], dt, lambda: pack_matrix(self.proj_out.weight, dt))
         bo = pk.get("bo", [self.proj_out.bias], dt, lambda: f32(self.proj_out.bias))
         h = ops.groupnorm(x, g, b, self.norm.eps, groups=self.groups, silu=False)
-        h = ops.linear(h.view(B, H * W, Cc), wi, bi)
+        h = ops.linear(h.view(B, H * W, Cc), wi, bi, hilo=ops.PRECISE_RESIDUAL)
         for blk in self.transformer_blocks:
             h = blk(h, ctx)
-        out = ops.linear(h, wo, bo, res=x.view(B, H * W, Cc))
-        return out.view(B, H, W, Cc)
+        out = ops.linear(h, wo, bo, res=ops.view_hilo(x, B, H * W, Cc), hilo=ops.PRECISE_RESIDUAL)
+        return ops.view_hilo(out, B, H, W, Cc)
 
 
 class Downsample2D(nn.Module):
@@ -333,7 +333,7 @@ class Downsample2D(nn.Module):
         dt = x.dtype
         w = self._pk.get("w", [self.conv.weight], dt, lambda: pack_conv3x3(self.conv.weight, dt))
         b = self._pk.get("b", [self.conv.bias], dt, lambda: f32(self.conv.bias))
-        return ops.conv3x3(x, w, b, stride=2)
+        return ops.conv3x3(x, w, b, stride=2, hilo=ops.PRECISE_RESIDUAL)
 
 
 class Upsample2D(nn.Module):
@@ -350,7 +350,7 @@ class Upsample2D(nn.Module):
         dt = x.dtype
         w = self._pk.get("w", [self.conv.weight], dt, lambda: pack_conv3x3(self.conv.weight, dt))
         b = self._pk.get("b", [self.conv.bias], dt, lambda: f32(self.conv.bias))
-        return ops.conv3x3(x, w, b, ups=True)
+        return ops.conv3x3(x, w, b, ups=True, hilo=ops.PRECISE_RESIDUAL)
 
 
 def zero_module(m: nn.Module) -> nn.Module:

@@ -191,6 +191,9 @@ def igemm(*, x0, w, out, M, N, K, c0, c1=0, x1=None, ldx0, ldx1=0, ldw, ldc, tap
 # ``.lo`` of the ordinary (hi) tensor.  Views / slices drop it, which is the safe default: a consumer that does not
 # know about it just sees the ordinary rounded tensor.
 # ---------------------------------------------------------------------------------------------
+PRECISE_RESIDUAL = os.environ.get("UR_PRECISE_RESIDUAL", "1") != "0"  # default of the ``hilo`` producers below
+
+
 def lo_of(t):
     return getattr(t, "lo", None) if t is not None else None
 
@@ -425,7 +428,11 @@ def to_nhwc(x_nchw: torch.Tensor, dtype, cpad: Optional[int] = None) -> torch.Te
     B, Cc, H, W = x_nchw.shape
     cpad = Cc if cpad is None else cpad
     if cpad == Cc and x_nchw.dtype == dtype and x_nchw.permute(0, 2, 3, 1).is_contiguous():
-        return x_nchw.permute(0, 2, 3, 1)  # already channels-last memory: zero copy
+        v = x_nchw.permute(0, 2, 3, 1)  # already channels-last memory: zero copy
+        lo = lo_of(x_nchw)  # a (hi, lo) residual-stream tensor handed back by the caller keeps its low part
+        if lo is not None and lo.shape == x_nchw.shape and lo.permute(0, 2, 3, 1).is_contiguous():
+            v.lo = lo.permute(0, 2, 3, 1)
+        return v
     lib = _lib.load()
     src = x_nchw.contiguous()
     out = torch.empty(B, H, W, cpad, dtype=dtype, device=src.device)
@@ -447,5 +454,10 @@ def to_nchw(x_nhwc: torch.Tensor, dtype=None) -> torch.Tensor:
 
 
 def as_nchw_view(x_nhwc: torch.Tensor) -> torch.Tensor:
-    """Zero-copy logical-NCHW view of an NHWC tensor (channels_last strides)."""
-    return x_nhwc.permute(0, 3, 1, 2)
+    """Zero-copy logical-NCHW view of an NHWC tensor (channels_last strides); the low part of a (hi, lo) pair stays
+    attached (as the same kind of view)."""
+    v = x_nhwc.permute(0, 3, 1, 2)
+    lo = lo_of(x_nhwc)
+    if lo is not None:
+        v.lo = lo.permute(0, 3, 1, 2)
+    return v
