@@ -271,9 +271,11 @@ def main():
                                                       "concurrent": "hipGraph replay, 2 concurrent branches (enc || unet.down, dec || unet.up)",
                                                       "serial": "hipGraph replay, serial"}[runner.mode],
                 "algorithmic_tflop_per_step": round(1.623 * args.batch * (args.latent / 64) ** 2, 3),
+                "residual_stream": ("(hi, lo) pairs (parity <= 1e-3, DESIGN.md section 5)"
+                                    if os.environ.get("UR_PRECISE_RESIDUAL", "1") != "0" else "plain (UR_PRECISE_RESIDUAL=0)"),
             },
         }
-        if not args.no_roofline and world == 1:
+        if not args.no_roofline:  # rank 0 only (this block), at every N: the kernels are the same on every rank
             side, runner.side = runner.side, None  # serial launches for per-kernel timing
             roof, table, total_ms = measure_roofline(runner._run)
             out["roofline"] = roof
@@ -289,8 +291,9 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             del runner
             out["cpu_baseline"] = cpu_baseline(args.batch, args.latent)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
+        torch.distributed.barrier()  # rank 0 may still have been in its roofline leg
         torch.distributed.destroy_process_group()
 
 
