@@ -185,6 +185,8 @@ def main():
     ap.add_argument("--batch", type=int, default=4, help="per-GPU batch (headline: 4)")
     ap.add_argument("--latent", type=int, default=64, help="latent side (headline: 64 = 512x512 image)")
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"])
+    ap.add_argument("--direction", default="inverse", choices=["inverse", "render"],
+                    help="inverse: enc+unet+dec (headline, cfg 3/5); render: enc+unet only (cfg 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="time eager launches instead of the HIP graph")
@@ -217,12 +219,14 @@ def main():
     models = build_models(dev, dtype)
     inputs = make_inputs(args.batch, args.latent, dev, dtype, seed=100 + rank)
     runner = GraphedDualStreamStep(*models, batch=args.batch, latent_hw=args.latent, cross_dim=768, dtype=dtype,
-                                   device=dev, run_decoder=True, concurrent=not args.no_concurrent, mode=args.mode)
+                                   device=dev, run_decoder=(args.direction == "inverse"),
+                                   concurrent=not args.no_concurrent, mode=args.mode)
     runner.load_inputs(*inputs)
     if args.eager:
         def one():
             with torch.no_grad():
-                dual_stream_step(*models, runner.x_t, runner.cond, runner.ehs, runner.t_img, runner.t_attr)
+                dual_stream_step(*models, runner.x_t, runner.cond, runner.ehs, runner.t_img, runner.t_attr,
+                                 run_decoder=(args.direction == "inverse"))
         one()
     else:
         runner.capture()
@@ -262,15 +266,19 @@ def main():
             "dtype": "f16" if dtype == torch.float16 else "bf16",
             "data": "synthetic",
             "config": {
-                "workload": f"inverse-rendering denoise step: AttributeEncoderModel + UNet2DConditionModel + "
-                            f"AttributeDecoderModel forward (SD-1.x size, 1.74 G params, random init), "
+                "workload": ("inverse-rendering denoise step: AttributeEncoderModel + UNet2DConditionModel + "
+                             "AttributeDecoderModel forward (SD-1.x size, 1.74 G params, random init), "
+                             if args.direction == "inverse" else
+                             "rendering denoise step: AttributeEncoderModel + UNet2DConditionModel forward (SD-1.x size, "
+                             "random init), ") +
                             f"{args.latent * 8}x{args.latent * 8} image = {args.latent}x{args.latent} latent, 28-channel "
                             f"attribute latent, 77x768 prompt embedding, batch {args.batch} per GPU",
                 "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
                 "launch": "eager" if args.eager else {"grouped": "hipGraph replay; enc||unet.down and unet.up||dec issued as grouped (zbatch=2) launches",
                                                       "concurrent": "hipGraph replay, 2 concurrent branches (enc || unet.down, dec || unet.up)",
                                                       "serial": "hipGraph replay, serial"}[runner.mode],
-                "algorithmic_tflop_per_step": round(1.623 * args.batch * (args.latent / 64) ** 2, 3),
+                "algorithmic_tflop_per_step": round((1.623 if args.direction == "inverse" else 1.074) * args.batch
+                                                    * (args.latent / 64) ** 2, 3),  # unet .804 + enc .27 + dec .55
                 "residual_stream": ("(hi, lo) pairs (parity <= 1e-3, DESIGN.md section 5)"
                                     if os.environ.get("UR_PRECISE_RESIDUAL", "1") != "0" else "plain (UR_PRECISE_RESIDUAL=0)"),
             },

@@ -21,7 +21,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def collect(models, inputs, grouped=False):
+def collect(models, inputs, grouped=False, run_decoder=True):
     from uni_renderer_amd import ops
     from uni_renderer_amd.fused import GroupedDualStreamStep
     from uni_renderer_amd.graph import dual_stream_step
@@ -39,9 +39,9 @@ def collect(models, inputs, grouped=False):
     try:
         with torch.no_grad():
             if grouped:
-                GroupedDualStreamStep(*models)(*inputs)
+                GroupedDualStreamStep(*models)(*inputs, run_decoder=run_decoder)
             else:
-                dual_stream_step(*models, *inputs)
+                dual_stream_step(*models, *inputs, run_decoder=run_decoder)
         torch.cuda.synchronize()
     finally:
         ops.igemm = orig
@@ -120,8 +120,9 @@ def main():
             table.update(json.load(open(pth)))
     for (B, L) in shapes:
         calls = collect(models, bench.make_inputs(B, L, dev, dtype, seed=7))
-        calls_g = collect(models, bench.make_inputs(B, L, dev, dtype, seed=7), grouped=True)
-        calls.update({k: v for k, v in calls_g.items() if k not in calls})
+        for grouped, dec in ((True, True), (True, False)):  # the rendering direction runs the up path ungrouped (z = 1)
+            extra = collect(models, bench.make_inputs(B, L, dev, dtype, seed=7), grouped=grouped, run_decoder=dec)
+            calls.update({k: v for k, v in extra.items() if k not in calls})
         if args.only_missing:
             calls = {k: v for k, v in calls.items() if f"{k[0]},{k[1]},{k[2]},{k[3]},{k[4]}" not in table}
         print(f"[tune] batch {B} latent {L}: {len(calls)} distinct problems", flush=True)
