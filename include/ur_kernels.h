@@ -217,11 +217,14 @@ int ur_nhwc_to_nchw(const void* src, int dtype, int B, int C, int H, int W, void
  *     lat:  NCHW [B][C][HW], sample b at lat + b*lat_bstride (a channel slice of the next step's input), in place.
  *     master: NULL, or the sampler's own contiguous fp32 [B][C][HW] copy of the latents: then x is read from it,
  *     the result is stored there (rounded through the storage dtype first if round_master) and its rounding in lat.
+ *     cfg != 0: classifier-free guidance (pipeline.py:2695-2721, 1642-1644): pred and lat hold 2B samples (cond
+ *     [0,B), uncond [B,2B)); channels c < cfg_channels use x0 = p_uncond + guidance * (p_cond - p_uncond) evaluated in
+ *     the prediction's dtype like the reference, the others p_cond; the new latent is written to both halves of lat.
  * ur_sampler_advance: *step += 1; t_out[0..B) = tsteps[min(*step, nsteps-1)] (t_out may be NULL; B <= 256).
  */
 int ur_ddim_update(const void* pred, int pred_ld, int pred_c0, void* lat, int64_t lat_bstride, int C, int B, int HW,
-                   const float* coef, const int* step, int nsteps, float* master, int round_master, int dtype,
-                   void* stream);
+                   const float* coef, const int* step, int nsteps, float* master, int round_master, int cfg,
+                   float guidance, int cfg_channels, int dtype, void* stream);
 int ur_sampler_advance(int* step, const float* tsteps, int nsteps, float* t_out, int B, void* stream);
 
 /* Library self-description. */

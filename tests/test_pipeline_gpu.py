@@ -68,7 +68,8 @@ def test_inverse_rendering_loop_matches_oracle_loop(dev, guidance):
         assert rel_l2(o, ref[n]) < 1e-2, n
 
 
-def test_fused_on_device_loop_equals_step_by_step_loop(dev):
+@pytest.mark.parametrize("guidance", [0.0, 2.5])
+def test_fused_on_device_loop_equals_step_by_step_loop(dev, guidance):
     """The whole-loop-on-device path (one graph = step + ur_ddim_update + ur_sampler_advance, replayed) against the
     step-by-step loop with host-side schedulers: same arithmetic in the same order.  The network sees bit-identical
     inputs as long as the fp32 latents agree to the last ulp; torch's own fp32 division kernel is not bit-reproducible
@@ -76,7 +77,7 @@ def test_fused_on_device_loop_equals_step_by_step_loop(dev):
     the bound is a small rel-L2 (a wrong coefficient or timestep would be off by orders of magnitude)."""
     pipe, _, img, mask, ehs, noise = _setup(dev, seed=23)
     kw = dict(prompt_embeds=ehs.to(dev).half(), image_latents=img.to(dev), mask_latents=mask.to(dev), latents=noise,
-              num_inference_steps=5, guidance_scale=0.0, output_type="latent")
+              num_inference_steps=5, guidance_scale=guidance, output_type="latent")
     pipe.use_fused_sampler = True
     a = pipe.real_image2mask_3mod_albedo(**kw)
     assert len(pipe._sample_graphs) == 1
@@ -85,16 +86,31 @@ def test_fused_on_device_loop_equals_step_by_step_loop(dev):
     b = pipe.real_image2mask_3mod_albedo(**kw)
     for x, y, z in zip(a, a2, b):
         assert torch.equal(x, y)
-        assert rel_l2(x, z) < 2e-3
+        assert rel_l2(x, z) < (2e-3 if guidance == 0 else 6e-3)  # guidance amplifies the flipped roundings
+    # ONE step: no feedback through the network yet, so the update formula (incl. the guidance arithmetic in the
+    # prediction's dtype) must agree to fp32 rounding
+    kw1 = dict(kw, num_inference_steps=1)
+    pipe.use_fused_sampler = True
+    a1 = pipe.real_image2mask_3mod_albedo(**kw1)
+    pipe.use_fused_sampler = False
+    b1 = pipe.real_image2mask_3mod_albedo(**kw1)
+    for x, z in zip(a1, b1):
+        assert rel_l2(x, z) < 1e-6
     g = torch.Generator().manual_seed(11)
     attr = torch.randn(2, 28, 16, 16, generator=g).to(dev)
     kw = dict(prompt_embeds=ehs.to(dev).half(), attr_latents=attr, latents=noise, num_inference_steps=4,
-              guidance_scale=0.0, output_type="latent")
+              guidance_scale=guidance, output_type="latent")
     pipe.use_fused_sampler = True
     c = pipe.mask2image_3mod_albedo(**kw)
     pipe.use_fused_sampler = False
     d = pipe.mask2image_3mod_albedo(**kw)
-    assert rel_l2(c, d) < 2e-3
+    assert rel_l2(c, d) < (2e-3 if guidance == 0 else 6e-3)
+    kw1 = dict(kw, num_inference_steps=1)
+    pipe.use_fused_sampler = True
+    c1 = pipe.mask2image_3mod_albedo(**kw1)
+    pipe.use_fused_sampler = False
+    d1 = pipe.mask2image_3mod_albedo(**kw1)
+    assert rel_l2(c1, d1) < 1e-6
 
 
 def test_graph_replay_equals_eager(dev):

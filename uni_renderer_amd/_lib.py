@@ -66,7 +66,7 @@ SYMBOLS = {
     "ur_nchw_to_nhwc": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp]),
     "ur_nhwc_to_nchw": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]),
     "ur_ddim_update": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int64, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp,
-                                 C.c_int, C.c_int, vp]),
+                                 C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, vp]),
     "ur_sampler_advance": (C.c_int, [vp, vp, C.c_int, vp, C.c_int, vp]),
     "ur_abi_version": (C.c_int, []),
     "ur_build_info": (C.c_char_p, []),

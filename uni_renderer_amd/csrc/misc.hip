@@ -224,7 +224,8 @@ template <typename T>
 __global__ void __launch_bounds__(256) ddim_update_kernel(const T* __restrict__ pred, int pred_ld, int pred_c0,
                                                           T* __restrict__ lat, int64_t lat_bs, int C, int B, int HW,
                                                           const float* __restrict__ coef, const int* __restrict__ step,
-                                                          int nsteps, float* __restrict__ master, int round_master) {
+                                                          int nsteps, float* __restrict__ master, int round_master,
+                                                          int cfg, float guidance, int cfg_channels) {
 #pragma clang fp contract(off)
     const int st = min(*step, nsteps - 1);
     const float s_at = coef[4 * st + 0], s_1mat = coef[4 * st + 1], s_ap = coef[4 * st + 2], s_1map = coef[4 * st + 3];
@@ -235,12 +236,22 @@ __global__ void __launch_bounds__(256) ddim_update_kernel(const T* __restrict__ 
         const int c = (int)(bc % C), b = (int)(bc / C);
         T* xp = lat + (int64_t)b * lat_bs + (int64_t)c * HW + p;
         const float x = master ? master[i] : (float)*xp;
-        const float x0 = (float)pred[((int64_t)b * HW + p) * pred_ld + pred_c0 + c];
+        T x0t = pred[((int64_t)b * HW + p) * pred_ld + pred_c0 + c];
+        if (cfg && c < cfg_channels) {
+            // classifier-free guidance as the reference's loop evaluates it in the prediction's dtype (every
+            // operation rounded): pred = p_uncond + g * (p_cond - p_uncond), cond = samples [0, B), uncond = [B, 2B)
+            const T pu = pred[((int64_t)(b + B) * HW + p) * pred_ld + pred_c0 + c];
+            const T d = (T)((float)x0t - (float)pu);
+            const T m = (T)((float)d * guidance);
+            x0t = (T)((float)pu + (float)m);
+        }
+        const float x0 = (float)x0t;
         const float eps = (x - s_at * x0) / s_1mat;
         const float a = s_ap * x0;
         const float e = s_1map * eps;
         const float v = a + e;
         *xp = (T)v;
+        if (cfg) xp[(int64_t)B * lat_bs] = (T)v;  // the uncond half of the next input is the same latent
         if (master) master[i] = round_master ? (float)(T)v : v;
     }
 }
@@ -254,7 +265,7 @@ __global__ void sampler_advance_kernel(int* step, const float* __restrict__ tste
 
 extern "C" int ur_ddim_update(const void* pred, int pred_ld, int pred_c0, void* lat, int64_t lat_bstride, int C, int B,
                               int HW, const float* coef, const int* step, int nsteps, float* master, int round_master,
-                              int dtype, void* stream) {
+                              int cfg, float guidance, int cfg_channels, int dtype, void* stream) {
     if (!pred || !lat || !coef || !step || C <= 0 || B <= 0 || HW <= 0 || nsteps <= 0 || pred_c0 < 0 ||
         pred_c0 + C > pred_ld)
         return UR_E_BADARG;
@@ -263,10 +274,12 @@ extern "C" int ur_ddim_update(const void* pred, int pred_ld, int pred_c0, void* 
     const int grid = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
     if (dtype == UR_DT_F16)
         hipLaunchKernelGGL((ddim_update_kernel<f16>), dim3(grid), dim3(256), 0, s, (const f16*)pred, pred_ld, pred_c0,
-                           (f16*)lat, lat_bstride, C, B, HW, coef, step, nsteps, master, round_master);
+                           (f16*)lat, lat_bstride, C, B, HW, coef, step, nsteps, master, round_master, cfg, guidance,
+                           cfg_channels);
     else if (dtype == UR_DT_BF16)
         hipLaunchKernelGGL((ddim_update_kernel<bf16>), dim3(grid), dim3(256), 0, s, (const bf16*)pred, pred_ld, pred_c0,
-                           (bf16*)lat, lat_bstride, C, B, HW, coef, step, nsteps, master, round_master);
+                           (bf16*)lat, lat_bstride, C, B, HW, coef, step, nsteps, master, round_master, cfg, guidance,
+                           cfg_channels);
     else
         return UR_E_BADARG;
     hipError_t e = hipGetLastError();

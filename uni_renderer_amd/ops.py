@@ -371,23 +371,32 @@ def attention(q, k, vt, *, B, H, Tq, Tk, d, ldq, ldk, q_off=0, k_off=0, scale=No
     return o
 
 
-def ddim_update(pred_nhwc, c0: int, lat_nchw, coef, step, nsteps: int, master=None, round_master: bool = False):
+def ddim_update(pred_nhwc, c0: int, lat_nchw, coef, step, nsteps: int, master=None, round_master: bool = False,
+                guidance: Optional[float] = None, cfg_channels: int = 0):
     """In-place DDIM (x0-prediction) update of the NCHW latent slice ``lat_nchw`` [B, C, H, W] (batch stride free,
     channel planes contiguous) from channels c0.. of the NHWC prediction ``pred_nhwc`` [B, H, W, Cp]; the four step
     scalars come from the device table ``coef`` [nsteps, 4] at the device counter ``step`` (include/ur_kernels.h).
-    ``master``: optional contiguous fp32 [B, C, H, W] copy that carries the latents between steps."""
+    ``master``: optional contiguous fp32 [B, C, H, W] copy that carries the latents between steps.
+    ``guidance`` (classifier-free): pred / lat hold 2B samples (cond, uncond), ``master`` B; the first ``cfg_channels``
+    channels are guided."""
     _require_gpu(pred_nhwc)
     lib = _lib.load()
     B, Cc, H, W = lat_nchw.shape
+    cfg = guidance is not None
+    if cfg:
+        if B % 2 or pred_nhwc.shape[0] != B:
+            raise RuntimeError("ddim_update: guidance needs cond + uncond halves")
+        B //= 2
     if lat_nchw.stride(3) != 1 or lat_nchw.stride(2) != W or lat_nchw.stride(1) != H * W:
         raise RuntimeError("ddim_update: latent slice must have contiguous channel planes")
     if pred_nhwc.dtype != lat_nchw.dtype or coef.dtype != torch.float32 or step.dtype != torch.int32:
         raise RuntimeError("ddim_update: dtype mismatch")
-    if master is not None and (master.dtype != torch.float32 or not master.is_contiguous() or master.shape != lat_nchw.shape):
-        raise RuntimeError("ddim_update: master must be a contiguous fp32 tensor of the latent's shape")
+    if master is not None and (master.dtype != torch.float32 or not master.is_contiguous()
+                               or tuple(master.shape) != (B, Cc, H, W)):
+        raise RuntimeError("ddim_update: master must be a contiguous fp32 [B, C, H, W] tensor")
     check(lib.ur_ddim_update(pred_nhwc.data_ptr(), pred_nhwc.shape[-1], c0, lat_nchw.data_ptr(), lat_nchw.stride(0), Cc,
                              B, H * W, coef.data_ptr(), step.data_ptr(), nsteps, _ptr(master), int(round_master),
-                             DT[lat_nchw.dtype], _stream()),
+                             int(cfg), float(guidance or 0.0), int(cfg_channels), DT[lat_nchw.dtype], _stream()),
           "ur_ddim_update")
 
 

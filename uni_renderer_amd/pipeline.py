@@ -188,13 +188,13 @@ class UniRendererPipeline:
     # ---- on-device sampling loop -------------------------------------------------------------
     def _fusable(self, scheds, device, cond_scale, callback) -> bool:
         """The fused loop covers what eval needs: our DDIM (x0 prediction) on every latent group with one common
-        schedule, no classifier-free guidance, no per-step callback, HIP graph on.  Anything else takes the
-        step-by-step loop below (identical results: tests/test_pipeline_gpu.py)."""
+        schedule, with or without classifier-free guidance, no per-step callback, HIP graph on.  Anything else takes
+        the step-by-step loop below (identical results: tests/test_pipeline_gpu.py)."""
         from .schedulers import DDIMScheduler
 
         if not (self.use_fused_sampler and self.use_hip_graph and torch.device(device).type == "cuda"):
             return False
-        if self.do_classifier_free_guidance or callback is not None or cond_scale != 1.0:
+        if callback is not None or cond_scale != 1.0:
             return False
         s0 = scheds[0]
         for s in scheds:
@@ -233,33 +233,41 @@ class UniRendererPipeline:
             self._graphs[key] = g
         return key, g
 
-    def _fused_loop(self, x_img, cond28, ehs, timesteps, sched, run_decoder: bool, lat_dtype=torch.float32):
+    def _fused_loop(self, x_img, cond28, ehs, timesteps, sched, run_decoder: bool, lat_dtype=torch.float32,
+                    guidance: Optional[float] = None):
         """All denoise steps as replays of ONE graph = step + ur_ddim_update (prediction -> next input, in the
         graph's static input buffer) + ur_sampler_advance (step counter, next timestep).  Inverse direction: the 24
         attribute channels of ``cond`` evolve at t_attr, the image latent is clean (t_img = 0); rendering direction:
-        the 4 image channels of ``x_t`` evolve at t_img, the attributes are clean."""
+        the 4 image channels of ``x_t`` evolve at t_img, the attributes are clean.  ``guidance``: classifier-free
+        guidance -- the inputs hold cond + uncond halves (2B samples); the inverse direction guides the material group
+        only (pipeline.py:2695-2721), the rendering direction the whole image prediction (1642-1644)."""
         n = len(timesteps)
+        cfg = guidance is not None
+        nb = x_img.shape[0] // 2 if cfg else x_img.shape[0]  # distinct latents
         key, g = self._graph_for(x_img, cond28, ehs, run_decoder)
         t0 = float(timesteps[0])
         g.load_inputs(x_img, cond28, ehs, 0.0 if run_decoder else t0, t0 if run_decoder else 0.0)
         coef, tvals = self._ddim_tables(sched, timesteps)
-        skey = key + (n, lat_dtype)
+        skey = key + (n, lat_dtype, guidance)
         st = self._sample_graphs.get(skey)
         if st is None:
             dev = x_img.device
             evolving = g.cond[:, 4:] if run_decoder else g.x_t
             st = dict(step=torch.zeros(1, dtype=torch.int32, device=dev), coef=torch.zeros(n, 4, device=dev),
-                      tvals=torch.zeros(n, device=dev), master=torch.zeros(evolving.shape, dtype=torch.float32, device=dev),
+                      tvals=torch.zeros(n, device=dev),
+                      master=torch.zeros((nb,) + tuple(evolving.shape[1:]), dtype=torch.float32, device=dev),
                       round_master=lat_dtype != torch.float32)
 
             def post(out):
                 if run_decoder:
                     ops.ddim_update(out["attr_pred"].permute(0, 2, 3, 1), 4, g.cond[:, 4:], st["coef"], st["step"], n,
-                                    master=st["master"], round_master=st["round_master"])
+                                    master=st["master"], round_master=st["round_master"], guidance=guidance,
+                                    cfg_channels=4)  # the material group is channels 4..7 of the 28
                     ops.sampler_advance(st["step"], st["tvals"], n, g.t_attr)
                 else:
                     ops.ddim_update(out["img_pred"].permute(0, 2, 3, 1), 0, g.x_t, st["coef"], st["step"], n,
-                                    master=st["master"], round_master=st["round_master"])
+                                    master=st["master"], round_master=st["round_master"], guidance=guidance,
+                                    cfg_channels=g.x_t.shape[1])
                     ops.sampler_advance(st["step"], st["tvals"], n, g.t_img)
 
             st["graph"], st["out"] = g.capture_with(post)
@@ -268,7 +276,7 @@ class UniRendererPipeline:
         st["step"].zero_()
         st["coef"].copy_(coef)
         st["tvals"].copy_(tvals)
-        st["master"].copy_(cond28[:, 4:] if run_decoder else x_img)  # the caller's latents at their own precision
+        st["master"].copy_((cond28[:nb, 4:] if run_decoder else x_img[:nb]))  # the caller's latents at their own precision
         for _ in range(n):
             st["graph"].replay()
         return st["master"].to(lat_dtype)
@@ -344,10 +352,10 @@ class UniRendererPipeline:
 
         group_scheds = [getattr(self, f"scheduler_{n}") for n in ATTR_GROUPS]
         if self._fusable([self.scheduler_attr] + group_scheds, device, cond_scale, callback_on_step_end):
-            cat = torch.cat([lat[n] for n in ATTR_GROUPS], dim=1)
+            cat = torch.cat([dup(lat[n]) for n in ATTR_GROUPS], dim=1)
             cond28 = torch.cat((x_mask.to(cat.dtype), cat), dim=1)
             fin = self._fused_loop(x_img, cond28, prompt_embeds, timesteps_attr, group_scheds[0], run_decoder=True,
-                                   lat_dtype=cat.dtype)
+                                   lat_dtype=cat.dtype, guidance=(float(self.guidance_scale) if cfg else None))
             lat = {n: fin[:, 4 * k:4 * k + 4].to(lat[n].dtype) for k, n in enumerate(ATTR_GROUPS)}
             timesteps_img = timesteps_attr = []  # loop below is skipped
         with self.progress_bar(total=num_inference_steps) as bar:
@@ -423,8 +431,9 @@ class UniRendererPipeline:
         dup = (lambda t: torch.cat([t, t])) if cfg else (lambda t: t)
         cond28 = dup(self.scheduler_img.scale_model_input(attr_latents, 0))
         if self._fusable([self.scheduler_img], device, float(controlnet_conditioning_scale), None):
-            latents_img = self._fused_loop(latents_img, cond28, prompt_embeds, timesteps, self.scheduler_img,
-                                           run_decoder=False, lat_dtype=latents_img.dtype)
+            latents_img = self._fused_loop(dup(latents_img), cond28, prompt_embeds, timesteps, self.scheduler_img,
+                                           run_decoder=False, lat_dtype=latents_img.dtype,
+                                           guidance=(float(self.guidance_scale) if cfg else None))
             timesteps = timesteps[:0]  # loop below is skipped
         with self.progress_bar(total=num_inference_steps) as bar:
             for i in range(len(timesteps)):
