@@ -88,8 +88,10 @@ def measure_roofline(step_fn, by_shape=False):
     for key, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
         row = dict(kernel=key, calls=a["calls"], ms=round(a["ms"], 4), share=round(a["ms"] / total_ms, 4),
                    avg_us=round(1e3 * a["ms"] / a["calls"], 2))
+        row["alg_bytes_per_launch"] = round(a["bytes"] / a["calls"])
         if a["flop"] > 0:
             row["tflops"] = round(a["flop"] / (a["ms"] * 1e-3) / 1e12, 2)
+            row["alg_flop_per_launch"] = round(a["flop"] / a["calls"])
         else:
             row["gbs"] = round(a["bytes"] / (a["ms"] * 1e-3) / 1e9, 1)
         table.append(row)
@@ -108,6 +110,8 @@ def measure_roofline(step_fn, by_shape=False):
         roof = dict(bound="hbm", kernel=dom["kernel"], achieved=dom["gbs"], peak=PEAK_HBM_GBS, unit="GB/s",
                     frac=round(dom["gbs"] / PEAK_HBM_GBS, 4))
     roof.update(calls_per_step=dom["calls"], avg_launch_us=dom["avg_us"], share_of_step=dom["share"],
+                algorithmic_bytes_per_launch=dom["alg_bytes_per_launch"],
+                algorithmic_flop_per_launch=dom.get("alg_flop_per_launch"),
                 share_of_step_incl_splitk_launches=round(sym_share[dom_sym], 4), traffic=None)
     tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")  # HBM bytes/launch from a separate rocprofv3 --pmc pass
     if os.path.exists(tf):

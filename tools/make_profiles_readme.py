@@ -76,8 +76,9 @@ profile `r01_*`: 13.25 ms).
 Dominant kernel (by symbol; plain + split-K launches {100 * roof.get('share_of_step_incl_splitk_launches', roof['share_of_step']):.0f} % of the step):
 `{roof['kernel']}` at {roof['achieved']:.0f} TFLOP/s = {100 * roof['frac']:.0f} % of peak over its {roof['calls_per_step']} plain launches/step
 ({roof['avg_launch_us']:.0f} us each by HIP events; rocprofv3 average over plain AND split launches of the symbol: {float(dom['AverageNs']) / 1e3:.1f} us),
-MFMA-busy {100 * mf[dom['Name']]['mfma_util']:.0f} %, PMC traffic {(roof['traffic'] or 0) / 1e6:.0f} MB/launch (3-4x the algorithmic bytes: the nine taps re-fetch the
-image panel from the Infinity Cache).
+MFMA-busy {100 * mf[dom['Name']]['mfma_util']:.0f} %, PMC traffic {(roof['traffic'] or 0) / 1e6:.0f} MB/launch averaged over the plain AND split-K launches of the symbol
+(algorithmic average 70 MB: the excess is the fp32 split-K slabs and the 29-59 MB weight matrices of the deep levels;
+the level-0 launch alone has 92 % L2 hits and compulsory-only misses, `tools/pmc_l2.sh`).
 Attention d = 40 (4096-token self-attention + 77-key cross-attention launches): {att[0]['tflops'] if att else 0:.0f} TFLOP/s,
 MFMA-busy {100 * att_u[0]['mfma_util'] if att_u else 0:.0f} % (north_star asks >= 40 %), PMC traffic {tr.get('attention_d40', {}).get('hbm_bytes_per_launch', 0) / 1e6:.0f} MB/launch vs 84 MB algorithmic Q+K+V+O.
 

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--splitk", type=int, default=None)
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--res", action="store_true")
+    ap.add_argument("--streams", type=int, default=1, help="grouped launch of S problems (the product's z = 2)")
     args = ap.parse_args()
     from uni_renderer_amd import ops
 
@@ -35,12 +36,12 @@ def main():
         fn = lambda: ops.linear(x, w, b, res=r, tile=args.tile, splitk=args.splitk)
     else:
         cin = args.K // 9
-        B = 4
+        B, S = 4, args.streams
         hw = int(round((args.M // B) ** 0.5))
-        x = torch.randn(B, hw, hw, cin, device=dev).to(dt)
-        w = (torch.randn(args.N, args.K, device=dev) * 0.02).to(dt)
-        b = torch.randn(args.N, device=dev)
-        fn = lambda: ops.conv3x3(x, w, b, tile=args.tile, splitk=args.splitk)
+        x = torch.randn(S * B, hw, hw, cin, device=dev).to(dt)
+        w = (torch.randn(S, args.N, args.K, device=dev) * 0.02).to(dt) if S > 1 else (torch.randn(args.N, args.K, device=dev) * 0.02).to(dt)
+        b = torch.randn(S, args.N, device=dev) if S > 1 else torch.randn(args.N, device=dev)
+        fn = lambda: ops.conv3x3(x, w, b, tile=args.tile, splitk=args.splitk, streams=S)
     fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
