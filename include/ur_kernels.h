@@ -49,6 +49,7 @@ extern "C" {
 
 #define UR_DT_F16 0
 #define UR_DT_BF16 1
+#define UR_DT_F32 2   /* accepted only where a function says so (layout glue, ur_colsum) */
 
 #define UR_ACT_NONE 0
 #define UR_ACT_SILU 1
@@ -226,6 +227,40 @@ int ur_ddim_update(const void* pred, int pred_ld, int pred_c0, void* lat, int64_
                    const float* coef, const int* step, int nsteps, float* master, int round_master, int cfg,
                    float guidance, int cfg_channels, int dtype, void* stream);
 int ur_sampler_advance(int* step, const float* tsteps, int nsteps, float* t_out, int B, void* stream);
+
+/*
+ * Backward building blocks (device op 11; csrc/backward.hip).  The GEMM-shaped gradients run on
+ * ur_igemm over transposed operands (dX = dY.W: x0 = dY, w = W^T; dW = dY^T.X: x0 = dY^T, w = X^T; conv dX = conv3x3
+ * of dY with rotated weights; conv dW: x0 = dY^T, w = im2col(X)^T); these entry points are what that needs around
+ * the GEMM plus the backward of the memory-bound ops.  Deterministic (fixed-order) reductions, fp32 sums.
+ *
+ * ur_transpose2d   dst[b][c][r] = src[b][r][c]; R, C, leading dims and batch strides multiples of 8.
+ * ur_im2col3x3_t   out[(tap*C + c)][p] = x[pixel(p, tap)][c] of a 3x3 / pad 1 / stride 1|2 conv over NHWC x
+ *                  (p = (b, oy, ox) row-major, ld_out >= P, columns P .. ld_out written as zeros).
+ * ur_colsum        out[g][n] = sum of x[m][n] over the rows of group g (rows_per_group rows each; 0 = one group);
+ *                  fp32 out; dtype may be UR_DT_F32 (one group only).
+ * ur_silu_backward dx = dy * d/dx(x * sigmoid(x)).
+ * ur_geglu_forward / ur_geglu_backward   the reference's GEGLU layout h = [value | gate] (2D columns):
+ *                  y = value * gelu(gate) (erf);  dh = [dy * gelu(gate) | dy * value * gelu'(gate)].
+ * ur_groupnorm_backward   dx of y = act(GN(x) * gamma + beta) (act = SiLU if silu) from the forward statistics
+ *                  partials (ur_groupnorm_stats, nstat chunks); chan_part[b][nchunks][C][2] (fp32, caller provided)
+ *                  receives per-channel partial (sum dz, sum dz*xhat): their sums over (b, chunk) are dbeta and dgamma.
+ * ur_layernorm_backward   dx per row; part[wave][2][C] (fp32, waves = ceil(rows / rows_per_wave)) receives the
+ *                  per-wave partial (dgamma, dbeta); C <= 2048.
+ */
+int ur_transpose2d(const void* src, int64_t ld_src, int64_t bs_src, void* dst, int64_t ld_dst, int64_t bs_dst, int R,
+                   int C, int batch, int dtype, void* stream);
+int ur_im2col3x3_t(const void* x, int B, int H, int W, int C, int stride, void* out, int64_t ld_out, int dtype,
+                   void* stream);
+int ur_colsum(const void* x, int64_t ldx, int M, int N, int rows_per_group, float* out, int dtype, void* stream);
+int ur_silu_backward(const void* x, const void* dy, void* dx, int64_t n, int dtype, void* stream);
+int ur_geglu_forward(const void* h, void* y, int64_t M, int D, int dtype, void* stream);
+int ur_geglu_backward(const void* h, const void* dy, void* dh, int64_t M, int D, int dtype, void* stream);
+int ur_groupnorm_backward(const void* x, const void* dy, int C, int B, int rows, int groups, int nstat,
+                          const float* partial, const float* gamma, const float* beta, float eps, int silu, int nchunks,
+                          float* chan_part, void* dx, int dtype, void* stream);
+int ur_layernorm_backward(const void* x, const void* dy, const float* gamma, float eps, int rows, int C,
+                          int rows_per_wave, void* dx, float* part, int dtype, void* stream);
 
 /* Library self-description. */
 int ur_abi_version(void);

@@ -1,0 +1,170 @@
+"""Backward building blocks of the hot path (device op 11) -- the gradients of every leaf op of
+the denoise step, each on the MI355X:
+
+  * GEMM-shaped gradients run on the forward implicit-GEMM kernel (``ur_igemm``) over transposed operands
+    (``ur_transpose2d``, ``ur_im2col3x3_t``):  dX = dY.W,  dW = dY^T.X,  conv dX = conv3x3(dY, rot180(W)^T),
+    conv dW = dY^T . im2col(X);
+  * bias / time-embedding gradients are column sums (``ur_colsum``);
+  * SiLU, GEGLU, GroupNorm(+SiLU), LayerNorm backward are HIP kernels of their own (csrc/backward.hip).
+
+These are op-level functions with parity tests against autograd (tests/test_backward_gpu.py); the autograd wiring of
+the modules and the training step (cfg 4: train/train.py:1258-1427) are not assembled yet.
+Reference semantics: ``nn.Linear`` / ``nn.Conv2d`` / ``nn.GroupNorm`` / ``nn.LayerNorm`` / ``F.silu`` / diffusers
+``GEGLU`` as used by models/unet_2d_blocks.py:1100-1126.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib, ops
+from ._lib import check
+from .ops import DT, _ptr, _require_gpu, _stream
+
+
+def transpose2d(x: torch.Tensor) -> torch.Tensor:
+    """[..., R, C] -> [..., C, R] (contiguous), batch = product of the leading dims."""
+    _require_gpu(x)
+    lib = _lib.load()
+    x = x.contiguous()
+    R, Cc = x.shape[-2:]
+    batch = x.numel() // (R * Cc)
+    out = torch.empty(*x.shape[:-2], Cc, R, dtype=x.dtype, device=x.device)
+    check(lib.ur_transpose2d(x.data_ptr(), Cc, R * Cc, out.data_ptr(), R, R * Cc, R, Cc, batch, DT[x.dtype], _stream()),
+          "ur_transpose2d")
+    return out
+
+
+def colsum(x: torch.Tensor, rows_per_group: int = 0) -> torch.Tensor:
+    """fp32 column sums of the 2-D view [M, N] of ``x``; with ``rows_per_group`` one sum per group of rows."""
+    _require_gpu(x)
+    lib = _lib.load()
+    N = x.shape[-1]
+    M = x.numel() // N
+    groups = 1 if rows_per_group <= 0 else (M + rows_per_group - 1) // rows_per_group
+    out = torch.empty(groups, N, dtype=torch.float32, device=x.device)
+    dt = 2 if x.dtype == torch.float32 else DT[x.dtype]
+    check(lib.ur_colsum(x.data_ptr(), N, M, N, rows_per_group, out.data_ptr(), dt, _stream()), "ur_colsum")
+    return out if rows_per_group > 0 else out[0]
+
+
+def _pad_rows64(t: torch.Tensor) -> torch.Tensor:
+    """zero-pad the last (contraction) dim of a [R, M] matrix to a multiple of 64 (ur_igemm's K granularity)."""
+    M = t.shape[-1]
+    if M % 64 == 0:
+        return t
+    out = torch.zeros(*t.shape[:-1], (M + 63) // 64 * 64, dtype=t.dtype, device=t.device)
+    out[..., :M] = t
+    return out
+
+
+def linear_backward(x: torch.Tensor, w: torch.Tensor, dy: torch.Tensor, need_bias: bool = True
+                    ) -> Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]:
+    """y = x @ w^T + b  (x [..., K], w [N, K] in the compute dtype, dy [..., N])  ->  (dx, dw, db).
+    dx = dy @ w, dw = dy^T @ x (both through ``ur_igemm``), db = column sums of dy (fp32)."""
+    K, N = x.shape[-1], w.shape[0]
+    x2, dy2 = x.reshape(-1, K), dy.reshape(-1, N)
+    wt = transpose2d(w)                                   # [K, N]
+    dx = ops.linear(dy2, wt).view(x.shape)                # [M, N] @ [K, N]^T
+    dyt, xt = _pad_rows64(transpose2d(dy2)), _pad_rows64(transpose2d(x2))   # [N, M], [K, M]
+    dw = ops.linear(dyt, xt)                              # [N, M] @ [K, M]^T = [N, K]
+    db = colsum(dy2) if need_bias else None
+    return dx, dw, db
+
+
+def _rot_weights(w_packed: torch.Tensor, cin: int) -> torch.Tensor:
+    """forward conv weights [N][(ky,kx,c)] -> the dgrad conv's [C][(ky',kx',n)] with ky' = 2-ky, kx' = 2-kx."""
+    N = w_packed.shape[0]
+    w4 = w_packed.view(N, 3, 3, cin)
+    return w4.flip(1, 2).permute(3, 1, 2, 0).reshape(cin, 9 * N).contiguous()
+
+
+def conv3x3_backward(x: torch.Tensor, w_packed: torch.Tensor, dy: torch.Tensor, need_bias: bool = True
+                     ) -> Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]:
+    """3x3 / pad 1 / stride 1 conv over NHWC x [B,H,W,C] with packed weights [N][(ky,kx,c)], dy [B,H,W,N]
+    ->  (dx [B,H,W,C], dw [N][(ky,kx,c)], db [N] fp32).
+    dx is the same implicit-GEMM conv applied to dy with the rotated / channel-transposed weights; dw contracts dy^T with
+    the transposed im2col of x over the B*H*W pixels."""
+    lib = _lib.load()
+    B, H, W, Cc = x.shape
+    N = w_packed.shape[0]
+    if N % 64 or Cc % 64:
+        raise RuntimeError("conv3x3_backward: channel counts must be multiples of 64")
+    dx = ops.conv3x3(dy.contiguous(), _rot_weights(w_packed, Cc))
+    P = B * H * W
+    Pp = (P + 63) // 64 * 64
+    xcol_t = torch.empty(9 * Cc, Pp, dtype=x.dtype, device=x.device)
+    check(lib.ur_im2col3x3_t(x.contiguous().data_ptr(), B, H, W, Cc, 1, xcol_t.data_ptr(), Pp, DT[x.dtype], _stream()),
+          "ur_im2col3x3_t")
+    dyt = _pad_rows64(transpose2d(dy.reshape(P, N)))      # [N, Pp]
+    dw = ops.linear(dyt, xcol_t)                          # [N, Pp] @ [9C, Pp]^T = [N, 9C]
+    db = colsum(dy.reshape(P, N)) if need_bias else None
+    return dx, dw, db
+
+
+def silu_backward(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    dx = torch.empty_like(x)
+    check(lib.ur_silu_backward(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), x.numel(), DT[x.dtype], _stream()),
+          "ur_silu_backward")
+    return dx
+
+
+def geglu_forward(h: torch.Tensor) -> torch.Tensor:
+    """h [..., 2D] = [value | gate] (the reference's chunk(2, -1)) -> value * gelu(gate)."""
+    lib = _lib.load()
+    D = h.shape[-1] // 2
+    M = h.numel() // (2 * D)
+    y = torch.empty(*h.shape[:-1], D, dtype=h.dtype, device=h.device)
+    check(lib.ur_geglu_forward(h.data_ptr(), y.data_ptr(), M, D, DT[h.dtype], _stream()), "ur_geglu_forward")
+    return y
+
+
+def geglu_backward(h: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    D = h.shape[-1] // 2
+    M = h.numel() // (2 * D)
+    dh = torch.empty_like(h)
+    check(lib.ur_geglu_backward(h.data_ptr(), dy.data_ptr(), dh.data_ptr(), M, D, DT[h.dtype], _stream()),
+          "ur_geglu_backward")
+    return dh
+
+
+def groupnorm_backward(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float,
+                       groups: int = 32, silu: bool = False) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """x, dy NHWC [B,H,W,C]; y = act(GN(x)*gamma + beta).  -> (dx, dgamma, dbeta) (the last two fp32).
+    The forward statistics are recomputed with ``ur_groupnorm_stats`` (one read of x) instead of being saved."""
+    _require_gpu(x)
+    lib = _lib.load()
+    B, Cc = x.shape[0], x.shape[-1]
+    rows = x.numel() // (B * Cc)
+    nstat, nchunks = ops._gn_chunks_bytes(B, rows, Cc, x.element_size())
+    part = torch.empty(B * nstat * groups * 2, dtype=torch.float32, device=x.device)
+    s = _stream()
+    check(lib.ur_groupnorm_stats(x.data_ptr(), None, None, None, Cc, 0, B, rows, groups, nstat, part.data_ptr(), DT[x.dtype],
+                                 s), "ur_groupnorm_stats")
+    chan_part = torch.empty(B * nchunks, Cc, 2, dtype=torch.float32, device=x.device)
+    dx = torch.empty_like(x)
+    check(lib.ur_groupnorm_backward(x.data_ptr(), dy.data_ptr(), Cc, B, rows, groups, nstat, part.data_ptr(),
+                                    gamma.data_ptr(), beta.data_ptr(), float(eps), int(silu), nchunks,
+                                    chan_part.data_ptr(), dx.data_ptr(), DT[x.dtype], s), "ur_groupnorm_backward")
+    sums = colsum(chan_part.view(B * nchunks, 2 * Cc)).view(Cc, 2)  # (sum dz, sum dz*xhat) per channel
+    return dx, sums[:, 1].contiguous(), sums[:, 0].contiguous()
+
+
+def layernorm_backward(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, eps: float = 1e-5
+                       ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """x, dy [..., C] -> (dx, dgamma, dbeta) (fp32 parameter gradients)."""
+    _require_gpu(x)
+    lib = _lib.load()
+    Cc = x.shape[-1]
+    rows = x.numel() // Cc
+    rpw = max(1, min(64, rows // 2048))  # rows per wave: enough waves to fill the chip, few partial rows
+    waves = (rows + rpw - 1) // rpw
+    part = torch.zeros(waves, 2, Cc, dtype=torch.float32, device=x.device)
+    dx = torch.empty_like(x)
+    check(lib.ur_layernorm_backward(x.data_ptr(), dy.data_ptr(), gamma.data_ptr(), float(eps), rows, Cc, rpw, dx.data_ptr(),
+                                    part.data_ptr(), DT[x.dtype], _stream()), "ur_layernorm_backward")
+    sums = colsum(part.view(waves, 2 * Cc)).view(2, Cc)
+    return dx, sums[0].contiguous(), sums[1].contiguous()

@@ -1,0 +1,568 @@
+// Building blocks of the backward pass (device op 11) for gfx950.  The FLOP-heavy gradients are
+// GEMM-shaped and run on the forward implicit-GEMM kernel (ur_igemm) over transposed operands:
+//     dX = dY . W            -> ur_igemm(x0 = dY [M][N],   w = W^T [K][N])
+//     dW = dY^T . X          -> ur_igemm(x0 = dY^T [N][M], w = X^T [K][M])          (contraction over the M rows)
+//     conv dX                -> ur_igemm conv3x3 of dY with the 180-degree rotated, channel-transposed weights
+//     conv dW                -> ur_igemm(x0 = dY^T [N][P], w = im2col(X)^T [9C][P])
+// This file holds what that needs around the GEMM -- an LDS-tiled transpose, the transposed im2col gather, column
+// sums (bias / time-embedding gradients) -- and the backward of the memory-bound ops: SiLU, GEGLU, GroupNorm(+SiLU),
+// LayerNorm.  All reductions are fixed-order (deterministic), statistics and sums in fp32.
+#include "ur_common.h"
+#include "../../include/ur_kernels.h"
+
+namespace ur {
+
+// ---------------------------------------------------------------------------------------------------------------
+// dst[b][c][r] = src[b][r][c]   (R x C tiles of 64 x 64 through LDS, both sides in 16-byte vectors)
+// rowmap != null: source row r is rowmap-free here; the im2col variant below gathers rows instead.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) transpose2d_kernel(const T* __restrict__ src, int64_t ld_src, int64_t bs_src,
+                                                          T* __restrict__ dst, int64_t ld_dst, int64_t bs_dst, int R,
+                                                          int C) {
+    __shared__ T tile[64][64 + 8];
+    const int t = threadIdx.x;
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    src += (int64_t)blockIdx.z * bs_src;
+    dst += (int64_t)blockIdx.z * bs_dst;
+    typedef typename Vec8<T>::type vec8;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int r = pass * 32 + (t >> 3), cv = (t & 7) * 8;
+        vec8 v;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (T)0.0f;
+        if (r0 + r < R && c0 + cv < C) v = *reinterpret_cast<const vec8*>(src + (int64_t)(r0 + r) * ld_src + c0 + cv);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) tile[r][cv + i] = v[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int c = pass * 32 + (t >> 3), rv = (t & 7) * 8;
+        if (c0 + c < C && r0 + rv < R) {
+            vec8 v;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = tile[rv + i][c];
+            *reinterpret_cast<vec8*>(dst + (int64_t)(c0 + c) * ld_dst + r0 + rv) = v;
+        }
+    }
+}
+
+// Transposed im2col of a 3x3 / pad 1 convolution: out[(tap*C + c)][p] = x[pixel(p, tap)][c] (0 outside the image),
+// p = (b, oy, ox) row-major; columns p >= P (padding to ld_out) are written as zeros by the caller's memset.
+template <typename T>
+__global__ void __launch_bounds__(256) im2col3x3_t_kernel(const T* __restrict__ x, int B, int H, int W, int C, int Ho,
+                                                          int Wo, int stride, T* __restrict__ out, int64_t ld_out) {
+    __shared__ T tile[64][64 + 8];
+    const int t = threadIdx.x;
+    const int P = B * Ho * Wo;
+    const int p0 = blockIdx.y * 64, c0 = blockIdx.x * 64, tap = blockIdx.z;
+    const int dy = tap / 3, dx = tap - dy * 3;
+    typedef typename Vec8<T>::type vec8;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int r = pass * 32 + (t >> 3), cv = (t & 7) * 8;
+        const int p = p0 + r;
+        vec8 v;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (T)0.0f;
+        if (p < P && c0 + cv < C) {
+            const int b = p / (Ho * Wo), rem = p - b * (Ho * Wo);
+            const int oy = rem / Wo, ox = rem - oy * Wo;
+            const int iy = oy * stride - 1 + dy, ix = ox * stride - 1 + dx;
+            if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+                v = *reinterpret_cast<const vec8*>(x + (((int64_t)b * H + iy) * W + ix) * C + c0 + cv);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) tile[r][cv + i] = v[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int c = pass * 32 + (t >> 3), rv = (t & 7) * 8;
+        if (c0 + c < C && p0 + rv < (int)ld_out) {
+            vec8 v;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = tile[rv + i][c];
+            *reinterpret_cast<vec8*>(out + ((int64_t)tap * C + c0 + c) * ld_out + p0 + rv) = v;
+        }
+    }
+}
+
+// out[g][n] = sum over the rows m in [g*rpg, (g+1)*rpg) of x[m][n] (fp32).  grid = (N/64 column blocks, groups).
+template <typename T>
+__global__ void __launch_bounds__(256) colsum_kernel(const T* __restrict__ x, int64_t ldx, int M, int N, int rpg,
+                                                     float* __restrict__ out) {
+    __shared__ float red[32][64];
+    const int t = threadIdx.x, cv = (t & 7) * 8, rl = t >> 3;  // 8 vector columns x 32 row lanes
+    const int n0 = blockIdx.x * 64, g = blockIdx.y;
+    const int mbeg = g * rpg, mend = min(M, mbeg + rpg);
+    float s[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s[i] = 0.f;
+    if (n0 + cv < N) {
+        for (int m = mbeg + rl; m < mend; m += 32) {
+            float v[8];
+            load8(x + (int64_t)m * ldx + n0 + cv, v);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s[i] += v[i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) red[rl][cv + i] = s[i];
+    __syncthreads();
+    if (t < 64 && n0 + t < N) {
+        float a = 0.f;
+        for (int k = 0; k < 32; ++k) a += red[k][t];  // fixed order
+        out[(int64_t)g * N + n0 + t] = a;
+    }
+}
+
+// the same over fp32 input (partials of the norm backward kernels)
+__global__ void __launch_bounds__(256) colsum_f32_kernel(const float* __restrict__ x, int64_t ldx, int M, int N,
+                                                         float* __restrict__ out) {
+    __shared__ float red[4][64];
+    const int t = threadIdx.x, c = t & 63, rl = t >> 6;
+    const int n = blockIdx.x * 64 + c;
+    float a = 0.f;
+    if (n < N)
+        for (int m = rl; m < M; m += 4) a += x[(int64_t)m * ldx + n];
+    red[rl][c] = a;
+    __syncthreads();
+    if (t < 64 && n < N) out[n] = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+}
+
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float silu_grad_f(float x) {  // d/dx x*sigmoid(x)
+    const float s = sigmoid_f(x);
+    return s * (1.0f + x * (1.0f - s));
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) silu_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                       T* __restrict__ dx, int64_t nvec) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+        float a[8], g[8];
+        load8(x + i * 8, a);
+        load8(dy + i * 8, g);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a[k] = g[k] * silu_grad_f(a[k]);
+        store8(dx + i * 8, a);
+    }
+}
+
+// GEGLU in the reference's layout (diffusers GEGLU: hidden, gate = proj(x).chunk(2, -1)): h[m][0..D) values,
+// h[m][D..2D) gates; forward y = value * gelu(gate) (erf), backward dvalue = dy*gelu(gate), dgate = dy*value*gelu'(gate).
+template <typename T>
+__global__ void __launch_bounds__(256) geglu_fwd_kernel(const T* __restrict__ h, T* __restrict__ y, int64_t M, int D) {
+    const int dv = D >> 3;
+    const int64_t total = M * dv;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = i / dv;
+        const int c = (int)(i - m * dv) * 8;
+        float a[8], g[8];
+        load8(h + m * 2 * D + c, a);
+        load8(h + m * 2 * D + D + c, g);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a[k] = a[k] * (0.5f * g[k] * (1.0f + erff(g[k] * 0.70710678118654752f)));
+        store8(y + m * D + c, a);
+    }
+}
+template <typename T>
+__global__ void __launch_bounds__(256) geglu_bwd_kernel(const T* __restrict__ h, const T* __restrict__ dy,
+                                                        T* __restrict__ dh, int64_t M, int D) {
+    const int dv = D >> 3;
+    const int64_t total = M * dv;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = i / dv;
+        const int c = (int)(i - m * dv) * 8;
+        float a[8], g[8], d[8], da[8], dg[8];
+        load8(h + m * 2 * D + c, a);
+        load8(h + m * 2 * D + D + c, g);
+        load8(dy + m * D + c, d);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float phi = 0.5f * (1.0f + erff(g[k] * 0.70710678118654752f));             // Phi(g)
+            const float pdf = 0.3989422804014327f * __expf(-0.5f * g[k] * g[k]);             // phi(g)
+            da[k] = d[k] * g[k] * phi;
+            dg[k] = d[k] * a[k] * (phi + g[k] * pdf);
+        }
+        store8(dh + m * 2 * D + c, da);
+        store8(dh + m * 2 * D + D + c, dg);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// GroupNorm(+SiLU) backward.  y = act(xhat * gamma + beta), xhat = (x - mean) * rstd per (sample, group).
+//   pass 1 (grid = (nchunks, B)): per channel partial sums over the chunk's rows of dz and dz * xhat
+//           (dz = dy * act'(z)) -> chan_part[b][chunk][C] (float2).  Their sum over (b, chunk) is (dbeta, dgamma).
+//   pass 2 (grid = (nchunks, B)): per group A = sum_c gamma_c * sum dz / n, Bg = sum_c gamma_c * sum dz*xhat / n
+//           (reduced from pass 1's partials in the prologue), dx = rstd * (dz * gamma - A - xhat * Bg).
+// mean / rstd come from the forward statistics partials (ur_groupnorm_stats), reduced in fixed order.
+// Thread mapping as in the forward kernels: a thread owns one 8-channel vector and strides over rows.  C <= 2048.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void gn_stat_reduce(const float* __restrict__ partial, int b, int nstat, int groups, int rows,
+                                               int cpg, float eps, float2* stat, float2 (*red)[64], int t) {
+    const int g = t & 63, j = t >> 6;
+    float s = 0.f, ss = 0.f;
+    if (g < groups) {
+        const float2* src = reinterpret_cast<const float2*>(partial) + (int64_t)b * nstat * groups + g;
+        for (int k = j; k < nstat; k += 4) {
+            float2 a = src[(int64_t)k * groups];
+            s += a.x;
+            ss += a.y;
+        }
+    }
+    red[j][g] = make_float2(s, ss);
+    __syncthreads();
+    if (t < groups) {
+        float2 a0 = red[0][t], a1 = red[1][t], a2 = red[2][t], a3 = red[3][t];
+        const float sum = (a0.x + a1.x) + (a2.x + a3.x), sq = (a0.y + a1.y) + (a2.y + a3.y);
+        const float n = (float)rows * (float)cpg;
+        const float mean = sum / n;
+        const float var = fmaxf(sq / n - mean * mean, 0.f);
+        stat[t] = make_float2(mean, rsqrtf(var + eps));
+    }
+    __syncthreads();
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) gn_bwd_reduce_kernel(const T* __restrict__ x, const T* __restrict__ dy, int C,
+                                                            int rows, int groups, int nstat, int nchunks,
+                                                            const float* __restrict__ partial,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float eps, int silu,
+                                                            float* __restrict__ chan_part) {
+    __shared__ float2 stat[64];
+    __shared__ float2 red[4][64];
+    __shared__ float2 acc[256];  // one entry per thread = (row lane, vector column), folded per channel below
+    const int nvec = C >> 3, cpg = C / groups;
+    const int b = blockIdx.y, chunk = blockIdx.x, t = threadIdx.x;
+    gn_stat_reduce<T>(partial, b, nstat, groups, rows, cpg, eps, stat, red, t);
+    const int rpc = (rows + nchunks - 1) / nchunks;
+    const int rbeg = chunk * rpc, rend = min(rows, rbeg + rpc);
+    const int tpr = min(nvec, 256), rs = 256 / tpr;
+    const int rsub = t / tpr, cvl = t - rsub * tpr;
+    const T* xb = x + (int64_t)b * rows * C;
+    const T* db = dy + (int64_t)b * rows * C;
+    float2* outp = reinterpret_cast<float2*>(chan_part) + ((int64_t)b * nchunks + chunk) * C;
+    for (int cvb = 0; cvb < nvec; cvb += tpr) {
+        const int cv = cvb + cvl;
+        float sd[8], sx[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { sd[i] = 0.f; sx[i] = 0.f; }
+        if (rsub < rs && cv < nvec) {
+            float gm[8], bt[8], mu[8], rsd[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int c = cv * 8 + i;
+                const float2 st = stat[c / cpg];
+                gm[i] = gamma[c]; bt[i] = beta[c]; mu[i] = st.x; rsd[i] = st.y;
+            }
+            for (int r = rbeg + rsub; r < rend; r += rs) {
+                float xv[8], dv[8];
+                load8(xb + (int64_t)r * C + cv * 8, xv);
+                load8(db + (int64_t)r * C + cv * 8, dv);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float xh = (xv[i] - mu[i]) * rsd[i];
+                    const float dz = silu ? dv[i] * silu_grad_f(xh * gm[i] + bt[i]) : dv[i];
+                    sd[i] += dz;
+                    sx[i] += dz * xh;
+                }
+            }
+        }
+        // fold the row lanes (fixed order) and write the per-channel partials of this chunk
+        for (int i = 0; i < 8; ++i) {
+            __syncthreads();
+            acc[t] = make_float2(sd[i], sx[i]);
+            __syncthreads();
+            if (rsub == 0 && cv < nvec) {
+                float a = 0.f, a2 = 0.f;
+                for (int k = 0; k < rs; ++k) { a += acc[k * tpr + cvl].x; a2 += acc[k * tpr + cvl].y; }
+                outp[cv * 8 + i] = make_float2(a, a2);
+            }
+        }
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy, int C,
+                                                           int rows, int groups, int nstat, int nred, int nchunks,
+                                                           const float* __restrict__ partial,
+                                                           const float* __restrict__ chan_part,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float eps, int silu,
+                                                           T* __restrict__ dx) {
+    __shared__ float2 stat[64];
+    __shared__ float2 red[4][64];
+    __shared__ float2 gsum[64];  // per group: (A, Bg)
+    __shared__ float2 gpart[256];
+    const int nvec = C >> 3, cpg = C / groups;
+    const int b = blockIdx.y, chunk = blockIdx.x, t = threadIdx.x;
+    gn_stat_reduce<T>(partial, b, nstat, groups, rows, cpg, eps, stat, red, t);
+    {   // per group sums of gamma_c * (sum dz, sum dz*xhat): 4 threads per group over its channels and the nred chunks
+        const int g = t >> 2, q = t & 3;
+        float a = 0.f, a2 = 0.f;
+        if (g < groups) {
+            const float2* src = reinterpret_cast<const float2*>(chan_part) + (int64_t)b * nred * C;
+            for (int e = q; e < cpg * nred; e += 4) {
+                const int k = e / cpg, c = g * cpg + (e - k * cpg);
+                const float2 v = src[(int64_t)k * C + c];
+                a += gamma[c] * v.x;
+                a2 += gamma[c] * v.y;
+            }
+        }
+        gpart[t] = make_float2(a, a2);
+        __syncthreads();
+        if (t < groups) {
+            const float2 p0 = gpart[4 * t], p1 = gpart[4 * t + 1], p2 = gpart[4 * t + 2], p3 = gpart[4 * t + 3];
+            const float n = (float)rows * (float)cpg;
+            gsum[t] = make_float2(((p0.x + p1.x) + (p2.x + p3.x)) / n, ((p0.y + p1.y) + (p2.y + p3.y)) / n);
+        }
+        __syncthreads();
+    }
+    const int rpc = (rows + nchunks - 1) / nchunks;
+    const int rbeg = chunk * rpc, rend = min(rows, rbeg + rpc);
+    const int tpr = min(nvec, 256), rs = 256 / tpr;
+    const int rsub = t / tpr, cvl = t - rsub * tpr;
+    if (rsub >= rs) return;
+    const T* xb = x + (int64_t)b * rows * C;
+    const T* db = dy + (int64_t)b * rows * C;
+    T* ob = dx + (int64_t)b * rows * C;
+    for (int cv = cvl; cv < nvec; cv += tpr) {
+        float gm[8], bt[8], mu[8], rsd[8], A[8], Bg[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = cv * 8 + i, g = c / cpg;
+            const float2 st = stat[g], gs = gsum[g];
+            gm[i] = gamma[c]; bt[i] = beta[c]; mu[i] = st.x; rsd[i] = st.y; A[i] = gs.x; Bg[i] = gs.y;
+        }
+        for (int r = rbeg + rsub; r < rend; r += rs) {
+            float xv[8], dv[8];
+            load8(xb + (int64_t)r * C + cv * 8, xv);
+            load8(db + (int64_t)r * C + cv * 8, dv);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float xh = (xv[i] - mu[i]) * rsd[i];
+                const float dz = silu ? dv[i] * silu_grad_f(xh * gm[i] + bt[i]) : dv[i];
+                xv[i] = rsd[i] * (dz * gm[i] - A[i] - xh * Bg[i]);
+            }
+            store8(ob + (int64_t)r * C + cv * 8, xv);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// LayerNorm backward: one wave per row block of RPW rows; dx per row, and per-wave partial (dgamma, dbeta) rows
+// part[wave][2][C] (fp32) that a column sum reduces.  C <= 2048 (MAXV vectors of 8 per lane).
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T, int MAXV>
+__global__ void __launch_bounds__(256) ln_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                     const float* __restrict__ gamma, float eps, int rows, int C,
+                                                     int rpw, T* __restrict__ dx, float* __restrict__ part) {
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nvec = C >> 3;
+    float dg[MAXV][8], dbt[MAXV][8];
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { dg[k][i] = 0.f; dbt[k][i] = 0.f; }
+    const int rbeg = wave * rpw, rend = min(rows, rbeg + rpw);
+    for (int row = rbeg; row < rend; ++row) {
+        float xv[MAXV][8], dv[MAXV][8];
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < MAXV; ++k) {
+            const int cv = lane + k * 64;
+            if (cv < nvec) {
+                load8(x + (int64_t)row * C + cv * 8, xv[k]);
+                load8(dy + (int64_t)row * C + cv * 8, dv[k]);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) s += xv[k][i];
+            }
+        }
+        const float mean = wave_sum(s) / (float)C;
+        float ss = 0.f;
+#pragma unroll
+        for (int k = 0; k < MAXV; ++k)
+            if (lane + k * 64 < nvec) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float d = xv[k][i] - mean;
+                    ss += d * d;
+                }
+            }
+        const float rstd = rsqrtf(wave_sum(ss) / (float)C + eps);
+        float a = 0.f, b2 = 0.f;  // sum dxhat, sum dxhat * xhat
+#pragma unroll
+        for (int k = 0; k < MAXV; ++k) {
+            const int cv = lane + k * 64;
+            if (cv < nvec) {
+                const float4* g4 = reinterpret_cast<const float4*>(gamma + cv * 8);
+                const float4 g0 = g4[0], g1 = g4[1];
+                const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float xh = (xv[k][i] - mean) * rstd;
+                    dg[k][i] += dv[k][i] * xh;
+                    dbt[k][i] += dv[k][i];
+                    const float dxh = dv[k][i] * g[i];
+                    a += dxh;
+                    b2 += dxh * xh;
+                    xv[k][i] = xh;      // keep xhat
+                    dv[k][i] = dxh;     // keep dxhat
+                }
+            }
+        }
+        a = wave_sum(a) / (float)C;
+        b2 = wave_sum(b2) / (float)C;
+#pragma unroll
+        for (int k = 0; k < MAXV; ++k) {
+            const int cv = lane + k * 64;
+            if (cv < nvec) {
+                float o[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o[i] = rstd * (dv[k][i] - a - xv[k][i] * b2);
+                store8(dx + (int64_t)row * C + cv * 8, o);
+            }
+        }
+    }
+    if (rbeg < rows) {
+        float* pg = part + (int64_t)wave * 2 * C;
+#pragma unroll
+        for (int k = 0; k < MAXV; ++k) {
+            const int cv = lane + k * 64;
+            if (cv < nvec) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    pg[cv * 8 + i] = dg[k][i];
+                    pg[C + cv * 8 + i] = dbt[k][i];
+                }
+            }
+        }
+    }
+}
+
+static inline int grid_for(int64_t n) {
+    int64_t g = (n + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+}
+
+}  // namespace ur
+
+using namespace ur;
+
+#define UR_DISPATCH(dtype, CALL)                          \
+    if ((dtype) == UR_DT_F16) { typedef f16 T; CALL; }    \
+    else if ((dtype) == UR_DT_BF16) { typedef bf16 T; CALL; } \
+    else return UR_E_BADARG;
+
+static int last_error() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : -(int)e;
+}
+
+extern "C" int ur_transpose2d(const void* src, int64_t ld_src, int64_t bs_src, void* dst, int64_t ld_dst, int64_t bs_dst,
+                              int R, int C, int batch, int dtype, void* stream) {
+    if (!src || !dst || R <= 0 || C <= 0 || batch <= 0 || (R & 7) || (C & 7) || (ld_src & 7) || (ld_dst & 7) ||
+        (bs_src & 7) || (bs_dst & 7))
+        return UR_E_BADARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    dim3 grid((C + 63) / 64, (R + 63) / 64, batch);
+    UR_DISPATCH(dtype, hipLaunchKernelGGL((transpose2d_kernel<T>), grid, dim3(256), 0, s, (const T*)src, ld_src, bs_src,
+                                          (T*)dst, ld_dst, bs_dst, R, C));
+    return last_error();
+}
+
+extern "C" int ur_im2col3x3_t(const void* x, int B, int H, int W, int C, int stride, void* out, int64_t ld_out, int dtype,
+                              void* stream) {
+    if (!x || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 7) || (stride != 1 && stride != 2) || (ld_out & 7))
+        return UR_E_BADARG;
+    const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+    if (ld_out < (int64_t)B * Ho * Wo) return UR_E_BADARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    dim3 grid((C + 63) / 64, (int)((ld_out + 63) / 64), 9);
+    UR_DISPATCH(dtype, hipLaunchKernelGGL((im2col3x3_t_kernel<T>), grid, dim3(256), 0, s, (const T*)x, B, H, W, C, Ho, Wo,
+                                          stride, (T*)out, ld_out));
+    return last_error();
+}
+
+extern "C" int ur_colsum(const void* x, int64_t ldx, int M, int N, int rows_per_group, float* out, int dtype, void* stream) {
+    if (!x || !out || M <= 0 || N <= 0 || (N & 7) || (ldx & 7)) return UR_E_BADARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == UR_DT_F32) {
+        if (rows_per_group > 0 && rows_per_group < M) return UR_E_UNSUPPORTED;
+        hipLaunchKernelGGL(colsum_f32_kernel, dim3((N + 63) / 64), dim3(256), 0, s, (const float*)x, ldx, M, N, out);
+        return last_error();
+    }
+    const int rpg = rows_per_group > 0 ? rows_per_group : M;
+    dim3 grid((N + 63) / 64, (M + rpg - 1) / rpg);
+    UR_DISPATCH(dtype, hipLaunchKernelGGL((colsum_kernel<T>), grid, dim3(256), 0, s, (const T*)x, ldx, M, N, rpg, out));
+    return last_error();
+}
+
+extern "C" int ur_silu_backward(const void* x, const void* dy, void* dx, int64_t n, int dtype, void* stream) {
+    if (!x || !dy || !dx || n <= 0 || (n & 7)) return UR_E_BADARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    UR_DISPATCH(dtype, hipLaunchKernelGGL((silu_bwd_kernel<T>), dim3(grid_for(n / 8)), dim3(256), 0, s, (const T*)x,
+                                          (const T*)dy, (T*)dx, n / 8));
+    return last_error();
+}
+
+extern "C" int ur_geglu_forward(const void* h, void* y, int64_t M, int D, int dtype, void* stream) {
+    if (!h || !y || M <= 0 || D <= 0 || (D & 7)) return UR_E_BADARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    UR_DISPATCH(dtype, hipLaunchKernelGGL((geglu_fwd_kernel<T>), dim3(grid_for(M * (D / 8))), dim3(256), 0, s, (const T*)h,
+                                          (T*)y, M, D));
+    return last_error();
+}
+
+extern "C" int ur_geglu_backward(const void* h, const void* dy, void* dh, int64_t M, int D, int dtype, void* stream) {
+    if (!h || !dy || !dh || M <= 0 || D <= 0 || (D & 7)) return UR_E_BADARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    UR_DISPATCH(dtype, hipLaunchKernelGGL((geglu_bwd_kernel<T>), dim3(grid_for(M * (D / 8))), dim3(256), 0, s, (const T*)h,
+                                          (const T*)dy, (T*)dh, M, D));
+    return last_error();
+}
+
+extern "C" int ur_groupnorm_backward(const void* x, const void* dy, int C, int B, int rows, int groups, int nstat,
+                                     const float* partial, const float* gamma, const float* beta, float eps, int silu,
+                                     int nchunks, float* chan_part, void* dx, int dtype, void* stream) {
+    if (!x || !dy || !partial || !gamma || !beta || !chan_part || !dx) return UR_E_BADARG;
+    if (C <= 0 || (C & 7) || C > 2048 || B <= 0 || rows <= 0 || groups <= 0 || groups > 64 || (C % groups) || nstat <= 0 ||
+        nchunks <= 0 || nchunks > 65535)
+        return UR_E_BADARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    dim3 grid(nchunks, B);
+    UR_DISPATCH(dtype, {
+        hipLaunchKernelGGL((gn_bwd_reduce_kernel<T>), grid, dim3(256), 0, s, (const T*)x, (const T*)dy, C, rows, groups, nstat,
+                           nchunks, partial, gamma, beta, eps, silu, chan_part);
+        hipLaunchKernelGGL((gn_bwd_apply_kernel<T>), grid, dim3(256), 0, s, (const T*)x, (const T*)dy, C, rows, groups, nstat,
+                           nchunks, nchunks, partial, chan_part, gamma, beta, eps, silu, (T*)dx);
+    });
+    return last_error();
+}
+
+extern "C" int ur_layernorm_backward(const void* x, const void* dy, const float* gamma, float eps, int rows, int C,
+                                     int rows_per_wave, void* dx, float* part, int dtype, void* stream) {
+    if (!x || !dy || !gamma || !dx || !part || rows <= 0 || C <= 0 || (C & 7) || C > 2048 || rows_per_wave <= 0)
+        return UR_E_BADARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int waves = (rows + rows_per_wave - 1) / rows_per_wave;
+    dim3 grid((waves + 3) / 4);
+    if (C <= 512) {
+        UR_DISPATCH(dtype, hipLaunchKernelGGL((ln_bwd_kernel<T, 1>), grid, dim3(256), 0, s, (const T*)x, (const T*)dy, gamma,
+                                              eps, rows, C, rows_per_wave, (T*)dx, part));
+    } else if (C <= 1024) {
+        UR_DISPATCH(dtype, hipLaunchKernelGGL((ln_bwd_kernel<T, 2>), grid, dim3(256), 0, s, (const T*)x, (const T*)dy, gamma,
+                                              eps, rows, C, rows_per_wave, (T*)dx, part));
+    } else {
+        UR_DISPATCH(dtype, hipLaunchKernelGGL((ln_bwd_kernel<T, 4>), grid, dim3(256), 0, s, (const T*)x, (const T*)dy, gamma,
+                                              eps, rows, C, rows_per_wave, (T*)dx, part));
+    }
+    return last_error();
+}
