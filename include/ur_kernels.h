@@ -261,6 +261,18 @@ int ur_groupnorm_backward(const void* x, const void* dy, int C, int B, int rows,
                           float* chan_part, void* dx, int dtype, void* stream);
 int ur_layernorm_backward(const void* x, const void* dy, const float* gamma, float eps, int rows, int C,
                           int rows_per_wave, void* dx, float* part, int dtype, void* stream);
+/* Attention backward helpers: P = softmax(Q K^T * scale) is recomputed and materialised per (batch, head); the five
+ * GEMMs of the gradient (S, dV = P^T dO, dP = dO V^T, dQ = dS K, dK = dS^T Q) run z-batched on ur_igemm.
+ * ur_split_heads: x [B][T][ld], head h at columns off + h*d  ->  out [B*H][Tp][dp] (zero padded rows / columns);
+ * ur_merge_heads: the inverse; ur_softmax_rows: in place over the first ncols columns of [rows][ld] (padding
+ * columns become 0); ur_softmax_backward_rows: dp <- p * (dp - sum_k dp*p) * scale. */
+int ur_split_heads(const void* x, int64_t ld, int off, int B, int T, int H, int d, void* out, int Tp, int dp, int dtype,
+                   void* stream);
+int ur_merge_heads(const void* g, int Tp, int dp, int B, int T, int H, int d, void* out, int64_t ld, int off, int dtype,
+                   void* stream);
+int ur_softmax_rows(void* s, int64_t ld, int64_t rows, int ncols, int dtype, void* stream);
+int ur_softmax_backward_rows(const void* p, void* dp, int64_t ld, int64_t rows, int ncols, float scale, int dtype,
+                             void* stream);
 
 /* Library self-description. */
 int ur_abi_version(void);

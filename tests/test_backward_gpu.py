@@ -117,3 +117,22 @@ def test_layernorm_backward(dev, dtype, C):
     assert rel_l2(dx, xr.grad) < TOL[dtype] * 2
     assert rel_l2(dg, gr.grad) < TOL[dtype]
     assert rel_l2(db, br.grad) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(2, 2, 40, 128, 128), (1, 8, 40, 200, 77), (2, 4, 80, 64, 64), (1, 2, 160, 96, 96)])
+def test_attention_backward(dev, dtype, shape):
+    from uni_renderer_amd import backward as bw
+    B, H, d, Tq, Tk = shape
+    C = H * d
+    q = _rand((B, Tq, C), dtype, dev, 1)
+    k = _rand((B, Tk, C), dtype, dev, 2)
+    v = _rand((B, Tk, C), dtype, dev, 3)
+    do = _rand((B, Tq, C), dtype, dev, 4)
+    dq, dk, dv = bw.attention_backward(q, k, v, do, H)
+    qr, kr, vr = (t.float().cpu().requires_grad_() for t in (q, k, v))
+    o = F.scaled_dot_product_attention(qr.view(B, Tq, H, d).transpose(1, 2), kr.view(B, Tk, H, d).transpose(1, 2),
+                                       vr.view(B, Tk, H, d).transpose(1, 2)).transpose(1, 2).reshape(B, Tq, C)
+    (o * do.float().cpu()).sum().backward()
+    tol = TOL[dtype] * 2  # P and dS are materialised in the compute dtype
+    assert rel_l2(dq, qr.grad) < tol and rel_l2(dk, kr.grad) < tol and rel_l2(dv, vr.grad) < tol

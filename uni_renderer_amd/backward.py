@@ -168,3 +168,54 @@ def layernorm_backward(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, e
                                     part.data_ptr(), DT[x.dtype], _stream()), "ur_layernorm_backward")
     sums = colsum(part.view(waves, 2 * Cc)).view(2, Cc)
     return dx, sums[0].contiguous(), sums[1].contiguous()
+
+
+def _split_heads(x: torch.Tensor, H: int, d: int, Tp: int, dp: int, off: int = 0) -> torch.Tensor:
+    lib = _lib.load()
+    B, T = x.shape[0], x.shape[1]
+    out = torch.empty(B * H, Tp, dp, dtype=x.dtype, device=x.device)
+    check(lib.ur_split_heads(x.data_ptr(), x.stride(1), off, B, T, H, d, out.data_ptr(), Tp, dp, DT[x.dtype], _stream()),
+          "ur_split_heads")
+    return out
+
+
+def _merge_heads(g: torch.Tensor, B: int, T: int, H: int, d: int) -> torch.Tensor:
+    lib = _lib.load()
+    out = torch.empty(B, T, H * d, dtype=g.dtype, device=g.device)
+    check(lib.ur_merge_heads(g.data_ptr(), g.shape[1], g.shape[2], B, T, H, d, out.data_ptr(), H * d, 0, DT[g.dtype],
+                             _stream()), "ur_merge_heads")
+    return out
+
+
+def attention_backward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, do: torch.Tensor, H: int,
+                       scale: Optional[float] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """Gradients of o = softmax(q k^T * scale) v per head (q, do [B,Tq,H*d]; k, v [B,Tk,H*d]) -> (dq, dk, dv).
+    The forward keeps nothing but q, k, v (flash kernel); here P is recomputed and materialised per (batch, head)
+    ([B*H, Tq, Tk] in the compute dtype) and the five GEMMs run z-batched on ``ur_igemm``:
+        S = Q K^T,  dV = P^T dO,  dP = dO V^T,  dS = P (dP - rowsum(dP P)) scale,  dQ = dS K,  dK = dS^T Q."""
+    lib = _lib.load()
+    B, Tq, Cc = q.shape
+    Tk = k.shape[1]
+    d = Cc // H
+    scale = float(d ** -0.5 if scale is None else scale)
+    dp = (d + 63) // 64 * 64
+    Tqp, Tkp = (Tq + 63) // 64 * 64, (Tk + 63) // 64 * 64
+    S = B * H
+    qp, dop = _split_heads(q, H, d, Tqp, dp), _split_heads(do, H, d, Tqp, dp)       # [S, Tqp, dp]
+    kp, vp = _split_heads(k, H, d, Tkp, dp), _split_heads(v, H, d, Tkp, dp)         # [S, Tkp, dp]
+    s_ = _stream()
+    # P = softmax(Q K^T * scale): rows = queries (padded rows are all-zero q -> uniform rows, masked out below by dO = 0)
+    P = ops.linear(qp, kp, out_scale=scale, streams=S)                              # [S*Tqp, Tkp] viewed [S, Tqp, Tkp]
+    P = P.view(S, Tqp, Tkp)
+    check(lib.ur_softmax_rows(P.data_ptr(), Tkp, S * Tqp, Tk, DT[P.dtype], s_), "ur_softmax_rows")
+    dP = ops.linear(dop, vp, streams=S).view(S, Tqp, Tkp)                           # dO V^T
+    Pt, dot_ = transpose2d(P), transpose2d(dop)                                     # [S, Tkp, Tqp], [S, dp, Tqp]
+    dV = ops.linear(Pt.view(S * Tkp, Tqp), dot_, streams=S).view(S, Tkp, dp)        # P^T dO
+    check(lib.ur_softmax_backward_rows(P.data_ptr(), dP.data_ptr(), Tkp, S * Tqp, Tk, scale, DT[P.dtype], s_),
+          "ur_softmax_backward_rows")                                                 # dP now holds dS
+    dS = dP
+    kpt, qpt = transpose2d(kp), transpose2d(qp)                                     # [S, dp, Tkp], [S, dp, Tqp]
+    dQ = ops.linear(dS.view(S * Tqp, Tkp), kpt, streams=S).view(S, Tqp, dp)         # dS K
+    dSt = transpose2d(dS)                                                           # [S, Tkp, Tqp]
+    dK = ops.linear(dSt.view(S * Tkp, Tqp), qpt, streams=S).view(S, Tkp, dp)        # dS^T Q
+    return _merge_heads(dQ, B, Tq, H, d), _merge_heads(dK, B, Tk, H, d), _merge_heads(dV, B, Tk, H, d)

@@ -447,6 +447,113 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const T* __restrict__ x, co
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Attention backward helpers (the P = softmax(Q K^T) matrix is recomputed and materialised per (batch, head); the
+// five GEMMs of the gradient run on ur_igemm, z-batched over batch*heads).
+//   split_heads: x [B][T][ld] (head h at columns off + h*d) -> out [B*H][Tp][dp], zero padded rows / columns
+//   merge_heads: the inverse (accumulating nothing: plain store of the d real columns)
+//   softmax_rows / softmax_bwd_rows: row-wise over the first ncols columns of [rows][ld], fp32 inside, in place
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) split_heads_kernel(const T* __restrict__ x, int64_t ld, int off, int B, int T_,
+                                                          int H, int d, T* __restrict__ out, int Tp, int dp) {
+    const int dv = dp >> 3;
+    const int64_t total = (int64_t)B * H * Tp * dv;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % dv) * 8;
+        const int64_t r = i / dv;
+        const int t = (int)(r % Tp);
+        const int bh = (int)(r / Tp), b = bh / H, h = bh - b * H;
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = 0.f;
+        if (t < T_ && c < d) load8(x + ((int64_t)b * T_ + t) * ld + off + h * d + c, v);
+        store8(out + i * 8, v);
+    }
+}
+template <typename T>
+__global__ void __launch_bounds__(256) merge_heads_kernel(const T* __restrict__ g, int Tp, int dp, int B, int T_, int H,
+                                                          int d, T* __restrict__ out, int64_t ld, int off) {
+    const int dv = d >> 3;
+    const int64_t total = (int64_t)B * H * T_ * dv;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % dv) * 8;
+        const int64_t r = i / dv;
+        const int t = (int)(r % T_);
+        const int bh = (int)(r / T_), b = bh / H, h = bh - b * H;
+        float v[8];
+        load8(g + ((int64_t)bh * Tp + t) * dp + c, v);
+        store8(out + ((int64_t)b * T_ + t) * ld + off + h * d + c, v);
+    }
+}
+
+// one wave per row; columns in 16-byte vectors; three passes over the row (max, sum, write) out of L2
+template <typename T>
+__global__ void __launch_bounds__(256) softmax_rows_kernel(T* __restrict__ s, int64_t ld, int64_t rows, int ncols) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    T* p = s + row * ld;
+    const int nv = (ncols + 7) >> 3;
+    float mx = -3.0e38f;
+    for (int cv = lane; cv < nv; cv += 64) {
+        float v[8];
+        load8(p + cv * 8, v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (cv * 8 + k < ncols) mx = fmaxf(mx, v[k]);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int cv = lane; cv < nv; cv += 64) {
+        float v[8];
+        load8(p + cv * 8, v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (cv * 8 + k < ncols) sum += __expf(v[k] - mx);
+    }
+    const float inv = 1.0f / wave_sum(sum);
+    const int nvl = (int)(ld >> 3);
+    for (int cv = lane; cv < nvl; cv += 64) {  // padding columns become exact zeros
+        float v[8];
+        load8(p + cv * 8, v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = (cv * 8 + k < ncols) ? __expf(v[k] - mx) * inv : 0.f;
+        store8(p + cv * 8, v);
+    }
+}
+
+// dS = P * (dP - sum_k dP*P) * scale, written over dP
+template <typename T>
+__global__ void __launch_bounds__(256) softmax_bwd_rows_kernel(const T* __restrict__ pm, T* __restrict__ dp, int64_t ld,
+                                                               int64_t rows, int ncols, float scale) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const T* p = pm + row * ld;
+    T* g = dp + row * ld;
+    const int nv = (ncols + 7) >> 3;
+    float dot = 0.f;
+    for (int cv = lane; cv < nv; cv += 64) {
+        float a[8], b[8];
+        load8(p + cv * 8, a);
+        load8(g + cv * 8, b);
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (cv * 8 + k < ncols) dot += a[k] * b[k];
+    }
+    dot = wave_sum(dot);
+    const int nvl = (int)(ld >> 3);
+    for (int cv = lane; cv < nvl; cv += 64) {
+        float a[8], b[8];
+        load8(p + cv * 8, a);
+        load8(g + cv * 8, b);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) b[k] = (cv * 8 + k < ncols) ? a[k] * (b[k] - dot) * scale : 0.f;
+        store8(g + cv * 8, b);
+    }
+}
+
 static inline int grid_for(int64_t n) {
     int64_t g = (n + 255) / 256;
     return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
@@ -564,5 +671,44 @@ extern "C" int ur_layernorm_backward(const void* x, const void* dy, const float*
         UR_DISPATCH(dtype, hipLaunchKernelGGL((ln_bwd_kernel<T, 4>), grid, dim3(256), 0, s, (const T*)x, (const T*)dy, gamma,
                                               eps, rows, C, rows_per_wave, (T*)dx, part));
     }
+    return last_error();
+}
+
+extern "C" int ur_split_heads(const void* x, int64_t ld, int off, int B, int T_, int H, int d, void* out, int Tp, int dp,
+                              int dtype, void* stream) {
+    if (!x || !out || B <= 0 || T_ <= 0 || H <= 0 || d <= 0 || (d & 7) || (dp & 7) || dp < d || Tp < T_ || (ld & 7) || (off & 7))
+        return UR_E_BADARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int64_t total = (int64_t)B * H * Tp * (dp / 8);
+    UR_DISPATCH(dtype, hipLaunchKernelGGL((split_heads_kernel<T>), dim3(grid_for(total)), dim3(256), 0, s, (const T*)x, ld, off,
+                                          B, T_, H, d, (T*)out, Tp, dp));
+    return last_error();
+}
+
+extern "C" int ur_merge_heads(const void* g, int Tp, int dp, int B, int T_, int H, int d, void* out, int64_t ld, int off,
+                              int dtype, void* stream) {
+    if (!g || !out || B <= 0 || T_ <= 0 || H <= 0 || d <= 0 || (d & 7) || (dp & 7) || dp < d || Tp < T_ || (ld & 7) || (off & 7))
+        return UR_E_BADARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int64_t total = (int64_t)B * H * T_ * (d / 8);
+    UR_DISPATCH(dtype, hipLaunchKernelGGL((merge_heads_kernel<T>), dim3(grid_for(total)), dim3(256), 0, s, (const T*)g, Tp, dp, B,
+                                          T_, H, d, (T*)out, ld, off));
+    return last_error();
+}
+
+extern "C" int ur_softmax_rows(void* s_, int64_t ld, int64_t rows, int ncols, int dtype, void* stream) {
+    if (!s_ || rows <= 0 || ncols <= 0 || (ld & 7) || ld < ncols) return UR_E_BADARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    UR_DISPATCH(dtype, hipLaunchKernelGGL((softmax_rows_kernel<T>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, (T*)s_, ld,
+                                          rows, ncols));
+    return last_error();
+}
+
+extern "C" int ur_softmax_backward_rows(const void* p, void* dp, int64_t ld, int64_t rows, int ncols, float scale, int dtype,
+                                        void* stream) {
+    if (!p || !dp || rows <= 0 || ncols <= 0 || (ld & 7) || ld < ncols) return UR_E_BADARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    UR_DISPATCH(dtype, hipLaunchKernelGGL((softmax_bwd_rows_kernel<T>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s,
+                                          (const T*)p, (T*)dp, ld, rows, ncols, scale));
     return last_error();
 }
