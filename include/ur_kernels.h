@@ -273,6 +273,11 @@ int ur_merge_heads(const void* g, int Tp, int dp, int B, int T, int H, int d, vo
 int ur_softmax_rows(void* s, int64_t ld, int64_t rows, int ncols, int dtype, void* stream);
 int ur_softmax_backward_rows(const void* p, void* dp, int64_t ld, int64_t rows, int ncols, float scale, int dtype,
                              void* stream);
+/* Training-path glue: SiLU forward (unfused, the pre-activation is kept for the backward), and 2x resampling of NHWC
+ * tensors -- mode 0 nearest upsample (forward of Upsample2D), 1 2x2 sum pooling (its backward), 2 zero insertion
+ * (dgrad of the stride-2 Downsample2D conv = stride-1 conv of the zero-inserted dY with the rotated weights). */
+int ur_silu_forward(const void* x, void* y, int64_t n, int dtype, void* stream);
+int ur_resample2x(const void* in, void* out, int B, int Hout, int Wout, int C, int mode, int dtype, void* stream);
 
 /* Library self-description. */
 int ur_abi_version(void);

@@ -136,3 +136,86 @@ def test_attention_backward(dev, dtype, shape):
     (o * do.float().cpu()).sum().backward()
     tol = TOL[dtype] * 2  # P and dS are materialised in the compute dtype
     assert rel_l2(dq, qr.grad) < tol and rel_l2(dk, kr.grad) < tol and rel_l2(dv, vr.grad) < tol
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_autograd_functions_conv_variants(dev, dtype):
+    """Conv3x3 Function: stride 2 (zero-insertion dgrad), nearest-2x + conv, fused bias / time-embedding row add /
+    residual, and a 28-channel output (conv_out), against nn.functional autograd."""
+    from uni_renderer_amd import autograd_ops as A
+    B, H, W, Ci, Co = 2, 8, 8, 64, 128
+    x = _rand((B, H, W, Ci), dtype, dev, 1).requires_grad_()
+    w = (_rand((Co, Ci, 3, 3), torch.float32, dev, 2, 0.05)).requires_grad_()
+    b = _rand((Co,), torch.float32, dev, 3).requires_grad_()
+    row = _rand((B, Co), dtype, dev, 4).requires_grad_()
+    res = _rand((B, H, W, Co), dtype, dev, 5).requires_grad_()
+    dy = _rand((B, H, W, Co), dtype, dev, 6)
+    y = A.conv3x3(x, A.pack_conv_weight(w, dtype), b, res=res, rowadd=row)
+    (y.float() * dy.float()).sum().backward()
+    xr = x.detach().float().cpu().permute(0, 3, 1, 2).requires_grad_()
+    wr = w.detach().to(dtype).float().cpu().requires_grad_()
+    br = b.detach().cpu().requires_grad_()
+    rr, sr = row.detach().float().cpu().requires_grad_(), res.detach().float().cpu().requires_grad_()
+    yr = F.conv2d(xr, wr, br, padding=1) + rr[:, :, None, None] + sr.permute(0, 3, 1, 2)
+    (yr * dy.float().cpu().permute(0, 3, 1, 2)).sum().backward()
+    assert rel_l2(y, yr.permute(0, 2, 3, 1)) < TOL[dtype]
+    assert rel_l2(x.grad, xr.grad.permute(0, 2, 3, 1)) < TOL[dtype]
+    assert rel_l2(w.grad, wr.grad) < TOL[dtype]
+    assert rel_l2(b.grad, br.grad) < 1e-3 and rel_l2(row.grad, rr.grad) < TOL[dtype] and rel_l2(res.grad, sr.grad) < 1e-6
+    # stride 2 and upsample + conv, 28 output channels
+    for mode in ("s2", "up"):
+        x2 = _rand((B, H, W, Ci), dtype, dev, 7).requires_grad_()
+        w2 = (_rand((28, Ci, 3, 3), torch.float32, dev, 8, 0.05)).requires_grad_()
+        if mode == "s2":
+            y2 = A.conv3x3(x2, A.pack_conv_weight(w2, dtype), None, stride=2)
+        else:
+            y2 = A.conv3x3(A.Up2x.apply(x2), A.pack_conv_weight(w2, dtype), None)
+        g2 = _rand(tuple(y2.shape), dtype, dev, 9)
+        (y2.float() * g2.float()).sum().backward()
+        x2r = x2.detach().float().cpu().permute(0, 3, 1, 2).requires_grad_()
+        w2r = w2.detach().to(dtype).float().cpu().requires_grad_()
+        if mode == "s2":
+            y2r = F.conv2d(x2r, w2r, None, stride=2, padding=1)
+        else:
+            y2r = F.conv2d(F.interpolate(x2r, scale_factor=2.0, mode="nearest"), w2r, None, padding=1)
+        (y2r * g2.float().cpu().permute(0, 3, 1, 2)).sum().backward()
+        assert rel_l2(y2, y2r.permute(0, 2, 3, 1)) < TOL[dtype], mode
+        assert rel_l2(x2.grad, x2r.grad.permute(0, 2, 3, 1)) < TOL[dtype], mode
+        assert rel_l2(w2.grad, w2r.grad) < TOL[dtype], mode
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_autograd_functions_chain(dev, dtype):
+    """LayerNorm -> q/k/v Linear -> Attention -> Linear(+res) -> GroupNorm(+SiLU) chained through autograd."""
+    from uni_renderer_amd import autograd_ops as A
+    B, T, C, H = 2, 64, 128, 2
+    x = _rand((B, T, C), dtype, dev, 1).requires_grad_()
+    par = {n: (_rand(s, torch.float32, dev, i + 10, sc)).requires_grad_() for i, (n, s, sc) in enumerate(
+        [("lg", (C,), 1.0), ("lb", (C,), 1.0), ("wq", (C, C), 0.1), ("wk", (C, C), 0.1), ("wv", (C, C), 0.1), ("wo", (C, C), 0.1),
+         ("bo", (C,), 1.0), ("gg", (C,), 1.0), ("gb", (C,), 1.0)])}
+    dy = _rand((B, 8, 8, C), dtype, dev, 30)
+
+    def run(x, p, hip):
+        if hip:
+            xn = A.LayerNorm.apply(x, p["lg"], p["lb"], 1e-5)
+            q, k, v = (A.linear(xn, p[n].to(dtype)) for n in ("wq", "wk", "wv"))
+            o = A.Attention.apply(q, k, v, H)
+            y = A.linear(o, p["wo"].to(dtype), p["bo"], res=x)
+            return A.GroupNorm.apply(y.view(B, 8, 8, C), p["gg"], p["gb"], 1e-5, 32, True)
+        xn = F.layer_norm(x, (C,), p["lg"], p["lb"], 1e-5)
+        q, k, v = (F.linear(xn, p[n]) for n in ("wq", "wk", "wv"))
+        sp = lambda t: t.view(B, T, H, C // H).transpose(1, 2)
+        o = F.scaled_dot_product_attention(sp(q), sp(k), sp(v)).transpose(1, 2).reshape(B, T, C)
+        y = F.linear(o, p["wo"], p["bo"]) + x
+        return F.silu(F.group_norm(y.view(B, 8, 8, C).permute(0, 3, 1, 2), 32, p["gg"], p["gb"], 1e-5)).permute(0, 2, 3, 1)
+
+    out = run(x, par, True)
+    (out.float() * dy.float()).sum().backward()
+    xr = x.detach().float().cpu().requires_grad_()
+    pr = {n: (t.detach().to(dtype).float().cpu() if t.dim() == 2 else t.detach().cpu()).requires_grad_() for n, t in par.items()}
+    outr = run(xr, pr, False)
+    (outr * dy.float().cpu()).sum().backward()
+    assert rel_l2(out, outr) < TOL[dtype] * 2
+    assert rel_l2(x.grad, xr.grad) < TOL[dtype] * 4
+    for n in par:
+        assert rel_l2(par[n].grad, pr[n].grad) < TOL[dtype] * 4, n

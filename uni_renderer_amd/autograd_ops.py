@@ -1,0 +1,173 @@
+"""torch.autograd Functions over the HIP ops: forward = the forward kernels of ``ops``, backward = the building blocks
+of ``backward`` (device op 11).  They let the training step (train_step.py; reference
+train/train.py:1258-1427) be written as an ordinary forward pass -- autograd only does the graph bookkeeping (skip
+connections, concatenations, dtype casts of the fp32 master parameters); every gradient is computed by this package's
+kernels.  All tensors are NHWC / token matrices in the compute dtype (bf16 or fp16); biases and norm parameters fp32.
+"""
+from __future__ import annotations
+
+import torch
+from torch.autograd import Function
+
+from . import _lib, backward as bw, ops
+from ._lib import check
+from .ops import DT, _stream
+
+
+class Linear(Function):
+    """y = x @ w^T (+ b) (+ rowadd[m // rows_per_b]) (+ res).  x [..., K], w [N, K], b fp32 [N], rowadd [B, N]."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, res, rowadd, rows_per_b):
+        ctx.save_for_backward(x, w)
+        ctx.flags = (b is not None, res is not None, rowadd is not None, int(rows_per_b))
+        return ops.linear(x, w, b, res=res, rowadd=rowadd, rows_per_b=rows_per_b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        has_b, has_res, has_row, rpb = ctx.flags
+        dy = dy.contiguous()
+        dx, dw, db = bw.linear_backward(x, w, dy, need_bias=has_b)
+        drow = bw.colsum(dy, rows_per_group=rpb).to(dy.dtype) if has_row else None
+        return dx, dw, db, (dy if has_res else None), drow, None
+
+
+class Conv3x3(Function):
+    """3x3 / pad 1 conv over NHWC x with packed weights [N][(ky,kx,c)] (+ b) (+ rowadd per sample) (+ res)."""
+
+    @staticmethod
+    def forward(ctx, x, wp, b, res, rowadd, stride):
+        ctx.save_for_backward(x, wp)
+        ctx.flags = (b is not None, res is not None, rowadd is not None, int(stride))
+        return ops.conv3x3(x, wp, b, stride=stride, rowadd=rowadd, res=res)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wp = ctx.saved_tensors
+        has_b, has_res, has_row, stride = ctx.flags
+        dy = dy.contiguous()
+        dx, dw, db = bw.conv3x3_backward(x, wp, dy, need_bias=has_b, stride=stride, need_dx=ctx.needs_input_grad[0])
+        drow = None
+        if has_row:
+            drow = bw.colsum(bw._pad_cols64(dy), rows_per_group=dy.shape[1] * dy.shape[2])[:, : dy.shape[-1]].to(dy.dtype)
+        return dx, dw, db, (dy if has_res else None), drow, None
+
+
+class Up2x(Function):
+    """nearest 2x upsample (F.interpolate of Upsample2D, unet_2d_blocks.py:2501); backward = 2x2 sum pooling."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return bw.resample2x(x, 0)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return bw.resample2x(dy.contiguous(), 1)
+
+
+class GroupNorm(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, groups, silu):
+        ctx.save_for_backward(x, gamma, beta)
+        ctx.cfg = (float(eps), int(groups), bool(silu))
+        return ops.groupnorm(x, gamma, beta, eps, groups=groups, silu=silu)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta = ctx.saved_tensors
+        eps, groups, silu = ctx.cfg
+        dx, dg, db = bw.groupnorm_backward(x, dy.contiguous(), gamma, beta, eps, groups=groups, silu=silu)
+        return dx, dg, db, None, None, None
+
+
+class LayerNorm(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        ctx.save_for_backward(x, gamma)
+        ctx.eps = float(eps)
+        return ops.layernorm(x, gamma, beta, eps)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma = ctx.saved_tensors
+        dx, dg, db = bw.layernorm_backward(x, dy.contiguous(), gamma, ctx.eps)
+        return dx, dg, db, None
+
+
+class Attention(Function):
+    """softmax(q k^T / sqrt(d)) v per head; q [B,Tq,H*d], k / v [B,Tk,H*d].  Forward: the flash kernel (nothing but
+    q, k, v is kept); backward: backward.attention_backward."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, heads):
+        B, Tq, Cc = q.shape
+        Tk = k.shape[1]
+        d = Cc // heads
+        vt = bw._pad_rows64(bw.transpose2d(v.contiguous()))  # [B, C, Tk_pad]
+        ctx.save_for_backward(q, k, v)
+        ctx.heads = heads
+        return ops.attention(q.contiguous(), k.contiguous(), vt, B=B, H=heads, Tq=Tq, Tk=Tk, d=d, ldq=Cc, ldk=Cc)
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v = ctx.saved_tensors
+        dq, dk, dv = bw.attention_backward(q.contiguous(), k.contiguous(), v.contiguous(), do.contiguous(), ctx.heads)
+        return dq, dk, dv, None
+
+
+class GEGLU(Function):
+    """h = [value | gate] -> value * gelu(gate) (diffusers GEGLU)."""
+
+    @staticmethod
+    def forward(ctx, h):
+        ctx.save_for_backward(h)
+        return bw.geglu_forward(h.contiguous())
+
+    @staticmethod
+    def backward(ctx, dy):
+        (h,) = ctx.saved_tensors
+        return bw.geglu_backward(h.contiguous(), dy.contiguous())
+
+
+class SiLU(Function):
+    @staticmethod
+    def forward(ctx, x):
+        lib = _lib.load()
+        x = x.contiguous()
+        ctx.save_for_backward(x)
+        y = torch.empty_like(x)
+        check(lib.ur_silu_forward(x.data_ptr(), y.data_ptr(), x.numel(), DT[x.dtype], _stream()), "ur_silu_forward")
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return bw.silu_backward(x, dy.contiguous())
+
+
+class Add(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        return ops.add(a.contiguous(), b.contiguous())
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy
+
+
+def linear(x, w, b=None, res=None, rowadd=None, rows_per_b=0):
+    return Linear.apply(x, w, b, res, rowadd, rows_per_b)
+
+
+def conv3x3(x, wp, b=None, res=None, rowadd=None, stride=1):
+    return Conv3x3.apply(x, wp, b, res, rowadd, stride)
+
+
+def pack_conv_weight(weight: torch.Tensor, dtype, cin_pad=None) -> torch.Tensor:
+    """differentiable version of layers.pack_conv3x3: [Co, Ci, 3, 3] fp32 master -> [Co][(ky,kx,ci_pad)] compute dtype."""
+    co, ci = weight.shape[:2]
+    w = weight.permute(0, 2, 3, 1)
+    if cin_pad is not None and cin_pad != ci:
+        w = torch.nn.functional.pad(w, (0, cin_pad - ci))
+    return w.reshape(co, -1).to(dtype).contiguous()

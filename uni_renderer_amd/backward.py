@@ -80,26 +80,57 @@ def _rot_weights(w_packed: torch.Tensor, cin: int) -> torch.Tensor:
     return w4.flip(1, 2).permute(3, 1, 2, 0).reshape(cin, 9 * N).contiguous()
 
 
-def conv3x3_backward(x: torch.Tensor, w_packed: torch.Tensor, dy: torch.Tensor, need_bias: bool = True
-                     ) -> Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]:
-    """3x3 / pad 1 / stride 1 conv over NHWC x [B,H,W,C] with packed weights [N][(ky,kx,c)], dy [B,H,W,N]
-    ->  (dx [B,H,W,C], dw [N][(ky,kx,c)], db [N] fp32).
-    dx is the same implicit-GEMM conv applied to dy with the rotated / channel-transposed weights; dw contracts dy^T with
-    the transposed im2col of x over the B*H*W pixels."""
+def resample2x(x: torch.Tensor, mode: int) -> torch.Tensor:
+    """NHWC 2x resampling glue (include/ur_kernels.h): 0 nearest upsample, 1 2x2 sum pooling, 2 zero insertion."""
+    lib = _lib.load()
+    B, H, W, Cc = x.shape
+    Ho, Wo = (H // 2, W // 2) if mode == 1 else (2 * H, 2 * W)
+    out = torch.empty(B, Ho, Wo, Cc, dtype=x.dtype, device=x.device)
+    check(lib.ur_resample2x(x.contiguous().data_ptr(), out.data_ptr(), B, Ho, Wo, Cc, mode, DT[x.dtype], _stream()),
+          "ur_resample2x")
+    return out
+
+
+def _pad_cols64(t: torch.Tensor) -> torch.Tensor:
+    """zero-pad the channel (last) dim to a multiple of 64."""
+    n = t.shape[-1]
+    if n % 64 == 0:
+        return t.contiguous()
+    out = torch.zeros(*t.shape[:-1], (n + 63) // 64 * 64, dtype=t.dtype, device=t.device)
+    out[..., :n] = t
+    return out
+
+
+def conv3x3_backward(x: torch.Tensor, w_packed: torch.Tensor, dy: torch.Tensor, need_bias: bool = True, stride: int = 1,
+                     need_dx: bool = True) -> Tuple[Optional[torch.Tensor], torch.Tensor, Optional[torch.Tensor]]:
+    """3x3 / pad 1 / stride 1|2 conv over NHWC x [B,H,W,C] (C % 64 == 0) with packed weights [N][(ky,kx,c)],
+    dy [B,Ho,Wo,N]  ->  (dx [B,H,W,C], dw [N][(ky,kx,c)], db [N] fp32).
+    dx is the same implicit-GEMM conv applied to dy (zero-inserted for stride 2) with the rotated / channel-transposed
+    weights; dw contracts dy^T with the transposed im2col of x over the B*Ho*Wo output pixels.  N is zero-padded to a
+    multiple of 64 internally (conv_out has 4 / 28 channels)."""
     lib = _lib.load()
     B, H, W, Cc = x.shape
     N = w_packed.shape[0]
-    if N % 64 or Cc % 64:
-        raise RuntimeError("conv3x3_backward: channel counts must be multiples of 64")
-    dx = ops.conv3x3(dy.contiguous(), _rot_weights(w_packed, Cc))
-    P = B * H * W
+    Ho, Wo = dy.shape[1:3]
+    if Cc % 64:
+        raise RuntimeError("conv3x3_backward: input channels must be a multiple of 64")
+    dyp = _pad_cols64(dy)                                     # [B,Ho,Wo,Np]
+    Np = dyp.shape[-1]
+    dx = None
+    if need_dx:
+        wpad = w_packed if Np == N else torch.cat([w_packed, w_packed.new_zeros(Np - N, w_packed.shape[1])], 0)
+        src = dyp if stride == 1 else resample2x(dyp, 2)      # stride 2: zero insertion, then a stride-1 conv
+        dx = ops.conv3x3(src, _rot_weights(wpad, Cc))
+        if dx.shape[1] != H or dx.shape[2] != W:
+            raise RuntimeError("conv3x3_backward: odd input sizes are not supported with stride 2")
+    P = B * Ho * Wo
     Pp = (P + 63) // 64 * 64
     xcol_t = torch.empty(9 * Cc, Pp, dtype=x.dtype, device=x.device)
-    check(lib.ur_im2col3x3_t(x.contiguous().data_ptr(), B, H, W, Cc, 1, xcol_t.data_ptr(), Pp, DT[x.dtype], _stream()),
+    check(lib.ur_im2col3x3_t(x.contiguous().data_ptr(), B, H, W, Cc, stride, xcol_t.data_ptr(), Pp, DT[x.dtype], _stream()),
           "ur_im2col3x3_t")
-    dyt = _pad_rows64(transpose2d(dy.reshape(P, N)))      # [N, Pp]
-    dw = ops.linear(dyt, xcol_t)                          # [N, Pp] @ [9C, Pp]^T = [N, 9C]
-    db = colsum(dy.reshape(P, N)) if need_bias else None
+    dyt = _pad_rows64(transpose2d(dyp.reshape(P, Np)))        # [Np, Pp]
+    dw = ops.linear(dyt, xcol_t)[:N]                          # [Np, Pp] @ [9C, Pp]^T = [Np, 9C]
+    db = colsum(dyp.reshape(P, Np))[:N].contiguous() if need_bias else None
     return dx, dw, db
 
 

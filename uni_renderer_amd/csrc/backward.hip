@@ -554,6 +554,50 @@ __global__ void __launch_bounds__(256) softmax_bwd_rows_kernel(const T* __restri
     }
 }
 
+template <typename T>
+__global__ void __launch_bounds__(256) silu_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t nvec) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+        float a[8];
+        load8(x + i * 8, a);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a[k] = silu_f(a[k]);
+        store8(y + i * 8, a);
+    }
+}
+
+// Resampling glue of the training path over NHWC [B][H][W][C] (C % 8 == 0):
+//   mode 0  nearest 2x upsample        out[b][y][x] = in[b][y/2][x/2]                 (forward of Upsample2D)
+//   mode 1  2x2 sum pooling            out[b][y][x] = sum in[b][2y+i][2x+j]            (its backward)
+//   mode 2  zero insertion             out[b][2y][2x] = in[b][y][x], 0 elsewhere       (dgrad of the stride-2 conv)
+template <typename T>
+__global__ void __launch_bounds__(256) resample2x_kernel(const T* __restrict__ in, T* __restrict__ out, int B, int Ho,
+                                                         int Wo, int C, int mode) {
+    const int cv = C >> 3;
+    const int64_t total = (int64_t)B * Ho * Wo * cv;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cv) * 8;
+        const int64_t pix = i / cv;
+        const int x = (int)(pix % Wo), y = (int)((pix / Wo) % Ho), b = (int)(pix / ((int64_t)Wo * Ho));
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = 0.f;
+        if (mode == 0) {
+            load8(in + (((int64_t)b * (Ho / 2) + y / 2) * (Wo / 2) + x / 2) * C + c, v);
+        } else if (mode == 1) {
+            for (int dy = 0; dy < 2; ++dy)
+                for (int dx = 0; dx < 2; ++dx) {
+                    float t[8];
+                    load8(in + (((int64_t)b * (Ho * 2) + 2 * y + dy) * (Wo * 2) + 2 * x + dx) * C + c, t);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] += t[k];
+                }
+        } else if (((x | y) & 1) == 0) {
+            load8(in + (((int64_t)b * (Ho / 2) + y / 2) * (Wo / 2) + x / 2) * C + c, v);
+        }
+        store8(out + i * 8, v);
+    }
+}
+
 static inline int grid_for(int64_t n) {
     int64_t g = (n + 255) / 256;
     return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
@@ -640,7 +684,7 @@ extern "C" int ur_groupnorm_backward(const void* x, const void* dy, int C, int B
                                      const float* partial, const float* gamma, const float* beta, float eps, int silu,
                                      int nchunks, float* chan_part, void* dx, int dtype, void* stream) {
     if (!x || !dy || !partial || !gamma || !beta || !chan_part || !dx) return UR_E_BADARG;
-    if (C <= 0 || (C & 7) || C > 2048 || B <= 0 || rows <= 0 || groups <= 0 || groups > 64 || (C % groups) || nstat <= 0 ||
+    if (C <= 0 || (C & 7) || C > 4096 || B <= 0 || rows <= 0 || groups <= 0 || groups > 64 || (C % groups) || nstat <= 0 ||
         nchunks <= 0 || nchunks > 65535)
         return UR_E_BADARG;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -710,5 +754,22 @@ extern "C" int ur_softmax_backward_rows(const void* p, void* dp, int64_t ld, int
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     UR_DISPATCH(dtype, hipLaunchKernelGGL((softmax_bwd_rows_kernel<T>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s,
                                           (const T*)p, (T*)dp, ld, rows, ncols, scale));
+    return last_error();
+}
+
+extern "C" int ur_silu_forward(const void* x, void* y, int64_t n, int dtype, void* stream) {
+    if (!x || !y || n <= 0 || (n & 7)) return UR_E_BADARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    UR_DISPATCH(dtype, hipLaunchKernelGGL((silu_fwd_kernel<T>), dim3(grid_for(n / 8)), dim3(256), 0, s, (const T*)x, (T*)y, n / 8));
+    return last_error();
+}
+
+extern "C" int ur_resample2x(const void* in, void* out, int B, int Hout, int Wout, int C, int mode, int dtype, void* stream) {
+    if (!in || !out || B <= 0 || Hout <= 0 || Wout <= 0 || C <= 0 || (C & 7) || mode < 0 || mode > 2) return UR_E_BADARG;
+    if (mode != 1 && ((Hout | Wout) & 1)) return UR_E_BADARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int64_t total = (int64_t)B * Hout * Wout * (C / 8);
+    UR_DISPATCH(dtype, hipLaunchKernelGGL((resample2x_kernel<T>), dim3(grid_for(total)), dim3(256), 0, s, (const T*)in, (T*)out, B,
+                                          Hout, Wout, C, mode));
     return last_error();
 }
