@@ -234,7 +234,8 @@ int ur_sampler_advance(int* step, const float* tsteps, int nsteps, float* t_out,
  * of dY with rotated weights; conv dW: x0 = dY^T, w = im2col(X)^T); these entry points are what that needs around
  * the GEMM plus the backward of the memory-bound ops.  Deterministic (fixed-order) reductions, fp32 sums.
  *
- * ur_transpose2d   dst[b][c][r] = src[b][r][c]; R, C, leading dims and batch strides multiples of 8.
+ * ur_transpose2d   dst[b][c][r] = src[b][r][c]; C, leading dims and batch strides multiples of 8; columns R .. ceil8(R)
+ *                  of dst are written as zeros (ld_dst >= ceil8(R)).
  * ur_im2col3x3_t   out[(tap*C + c)][p] = x[pixel(p, tap)][c] of a 3x3 / pad 1 / stride 1|2 conv over NHWC x
  *                  (p = (b, oy, ox) row-major, ld_out >= P, columns P .. ld_out written as zeros).
  * ur_colsum        out[g][n] = sum of x[m][n] over the rows of group g (rows_per_group rows each; 0 = one group);

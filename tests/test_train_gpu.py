@@ -1,0 +1,93 @@
+"""The training step on the GPU (uni_renderer_amd/train_step.py; SURVEY section 8a device op 11, cfg 4) against the
+CPU oracle's autograd: same parameters, same inputs, same x0-prediction MSE losses -> loss value and the gradient of
+every parameter of the three networks; then a few optimisation steps must bring the loss down, and two ranks' worth
+of gradient buckets must equal the single-rank gradients (gloo collective on CPU tensors is covered in
+test_parallel_cpu.py; here the bucket list is built over the GPU modules)."""
+import pytest
+import torch
+
+from conftest import rel_l2
+from util_models import O, build_product_from_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_loss(models, x, c, ehs, ti, ta, tgt_img, tgt_attr):
+    """the call pattern of O.dual_stream_step (which runs under no_grad) with autograd on"""
+    unet, enc, dec = models
+    res, mid, raw_enc, raw_mid_enc = enc(x, ta, ehs, controlnet_cond=c)
+    img_pred, raw_unet, raw_mid_unet, _ = unet(x, ti, ehs, down_block_additional_residuals=res,
+                                               mid_block_additional_residual=mid)
+    attr_pred = dec(raw_mid_enc, raw_enc, ta, ehs, down_block_additional_residuals=raw_unet,
+                    mid_block_additional_residual=raw_mid_unet)
+    return torch.mean((img_pred - tgt_img) ** 2) + torch.mean((attr_pred - tgt_attr) ** 2)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 2e-2), (torch.bfloat16, 1.2e-1)])
+def test_train_step_loss_and_gradients_match_oracle_autograd(dev, dtype, tol):
+    from uni_renderer_amd.train_step import dual_stream_forward, mse_losses
+
+    oracle = O.build_triplet(O.TINY_CONFIG, seed=31)
+    x, c, ehs, ti, ta = O.make_inputs(2, 16, 64, seed=12)
+    g = torch.Generator().manual_seed(13)
+    tgt_img, tgt_attr = torch.randn(2, 4, 16, 16, generator=g), torch.randn(2, 28, 16, 16, generator=g)
+    for m in oracle:
+        m.requires_grad_(True)
+    loss_o = _oracle_loss(oracle, x, c, ehs, ti, ta, tgt_img, tgt_attr)
+    loss_o.backward()
+
+    unet, enc, dec = build_product_from_oracle(*oracle, torch.float32, dev)  # fp32 master parameters
+    for m in (unet, enc, dec):
+        m.train()
+        m.requires_grad_(True)
+    out = dual_stream_forward(unet, enc, dec, x.to(dev), c.to(dev), ehs.to(dev), ti.to(dev), ta.to(dev), dtype=dtype)
+    loss = mse_losses(out, tgt_img.to(dev), tgt_attr.to(dev))
+    loss.backward()
+    assert abs(float(loss) - float(loss_o)) / float(loss_o) < (3e-3 if dtype == torch.float16 else 2e-2)
+
+    worst, flat_p, flat_o, rows = ("", 0.0), [], [], []
+    for mo, mp in zip(oracle, (unet, enc, dec)):
+        po, pp = dict(mo.named_parameters()), dict(mp.named_parameters())
+        assert set(po) == set(pp)
+        for name, p in pp.items():
+            assert p.grad is not None, name
+            go = po[name].grad
+            if go is None or float(go.abs().max()) == 0.0:  # e.g. the encoder's unused branches
+                continue
+            e = rel_l2(p.grad, go)
+            flat_p.append(p.grad.float().cpu().reshape(-1))
+            flat_o.append(go.reshape(-1))
+            rows.append((name, e, float(go.norm()) / go.numel() ** 0.5,
+                         float((p.grad.float().cpu() - go).norm()) / go.numel() ** 0.5))
+    total = rel_l2(torch.cat(flat_p), torch.cat(flat_o))
+    rms_all = float(torch.cat(flat_o).norm()) / sum(t.numel() for t in flat_o) ** 0.5
+    # a parameter passes if its gradient is right relative to its own size, or -- for gradients that nearly cancel
+    # (e.g. the LayerNorm bias in front of a cross-attention query) -- if the absolute error is small against the
+    # typical gradient entry of the network
+    for name, e, rms_o, rms_err in rows:
+        if e > worst[1] and rms_err > 0.02 * rms_all:
+            worst = (name, e)
+    print({"dtype": str(dtype), "loss": float(loss), "loss_oracle": float(loss_o), "grad_rel_l2_all": total,
+           "worst_param": worst})
+    assert total < tol / 2 and worst[1] < tol * 3
+
+
+def test_few_optimizer_steps_reduce_the_loss(dev):
+    from uni_renderer_amd.parallel import GradientBuckets
+    from uni_renderer_amd.train_step import train_step
+
+    oracle = O.build_triplet(O.TINY_CONFIG, seed=32)
+    nets = build_product_from_oracle(*oracle, torch.float32, dev)
+    for m in nets:
+        m.train()
+        m.requires_grad_(True)
+    x, c, ehs, ti, ta = [t.to(dev) for t in O.make_inputs(2, 16, 64, seed=14)]
+    g = torch.Generator().manual_seed(15)
+    batch = dict(x_t=x, cond=c, ehs=ehs, t_img=ti, t_attr=ta, target_img=torch.randn(2, 4, 16, 16, generator=g).to(dev),
+                 target_attr=torch.randn(2, 28, 16, 16, generator=g).to(dev))
+    opt = torch.optim.AdamW([p for m in nets for p in m.parameters()], lr=2e-4)
+    buckets = GradientBuckets(nets)  # single rank: all_reduce_mean is a no-op, the bucket list must cover everything
+    assert sum(p.numel() for b in buckets.buckets for p in b) == sum(p.numel() for m in nets for p in m.parameters())
+    losses = [train_step(nets, batch, optimizer=opt, buckets=buckets, dtype=torch.bfloat16)["loss"] for _ in range(6)]
+    print({"losses": losses})
+    assert losses[-1] < losses[0] * 0.9 and all(l == l for l in losses)

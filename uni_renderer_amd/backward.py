@@ -24,14 +24,16 @@ from .ops import DT, _ptr, _require_gpu, _stream
 
 
 def transpose2d(x: torch.Tensor) -> torch.Tensor:
-    """[..., R, C] -> [..., C, R] (contiguous), batch = product of the leading dims."""
+    """[..., R, C] -> [..., C, ceil8(R)] (contiguous; the columns past R are zeros), batch = product of the leading
+    dims.  C must be a multiple of 8."""
     _require_gpu(x)
     lib = _lib.load()
     x = x.contiguous()
     R, Cc = x.shape[-2:]
+    Rp = (R + 7) // 8 * 8
     batch = x.numel() // (R * Cc)
-    out = torch.empty(*x.shape[:-2], Cc, R, dtype=x.dtype, device=x.device)
-    check(lib.ur_transpose2d(x.data_ptr(), Cc, R * Cc, out.data_ptr(), R, R * Cc, R, Cc, batch, DT[x.dtype], _stream()),
+    out = torch.empty(*x.shape[:-2], Cc, Rp, dtype=x.dtype, device=x.device)
+    check(lib.ur_transpose2d(x.data_ptr(), Cc, R * Cc, out.data_ptr(), Rp, Rp * Cc, R, Cc, batch, DT[x.dtype], _stream()),
           "ur_transpose2d")
     return out
 
@@ -65,9 +67,10 @@ def linear_backward(x: torch.Tensor, w: torch.Tensor, dy: torch.Tensor, need_bia
     dx = dy @ w, dw = dy^T @ x (both through ``ur_igemm``), db = column sums of dy (fp32)."""
     K, N = x.shape[-1], w.shape[0]
     x2, dy2 = x.reshape(-1, K), dy.reshape(-1, N)
+    dy2p = dy2  # transpose2d zero-pads the row count (M = batch rows in the time-embedding GEMMs) to a multiple of 8
     wt = transpose2d(w)                                   # [K, N]
     dx = ops.linear(dy2, wt).view(x.shape)                # [M, N] @ [K, N]^T
-    dyt, xt = _pad_rows64(transpose2d(dy2)), _pad_rows64(transpose2d(x2))   # [N, M], [K, M]
+    dyt, xt = _pad_rows64(transpose2d(dy2p)), _pad_rows64(transpose2d(x2))  # [N, M], [K, M]
     dw = ops.linear(dyt, xt)                              # [N, M] @ [K, M]^T = [N, K]
     db = colsum(dy2) if need_bias else None
     return dx, dw, db

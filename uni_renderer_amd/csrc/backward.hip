@@ -40,7 +40,7 @@ __global__ void __launch_bounds__(256) transpose2d_kernel(const T* __restrict__ 
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
         const int c = pass * 32 + (t >> 3), rv = (t & 7) * 8;
-        if (c0 + c < C && r0 + rv < R) {
+        if (c0 + c < C && r0 + rv < ((R + 7) & ~7)) {  // rows R .. ceil8(R) of the source read as zeros
             vec8 v;
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[i] = tile[rv + i][c];
@@ -619,8 +619,8 @@ static int last_error() {
 
 extern "C" int ur_transpose2d(const void* src, int64_t ld_src, int64_t bs_src, void* dst, int64_t ld_dst, int64_t bs_dst,
                               int R, int C, int batch, int dtype, void* stream) {
-    if (!src || !dst || R <= 0 || C <= 0 || batch <= 0 || (R & 7) || (C & 7) || (ld_src & 7) || (ld_dst & 7) ||
-        (bs_src & 7) || (bs_dst & 7))
+    if (!src || !dst || R <= 0 || C <= 0 || batch <= 0 || (C & 7) || (ld_src & 7) || (ld_dst & 7) || (bs_src & 7) ||
+        (bs_dst & 7) || ld_dst < ((R + 7) & ~7))
         return UR_E_BADARG;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     dim3 grid((C + 63) / 64, (R + 63) / 64, batch);

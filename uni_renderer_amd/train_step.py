@@ -1,0 +1,176 @@
+"""Training step of the dual-stream denoiser on the MI355X (SURVEY section 8a device op 11, cfg 4; reference
+train/train.py:1258-1427): the forward pass of AttributeEncoderModel -> UNet2DConditionModel -> AttributeDecoderModel
+written over the autograd Functions of ``autograd_ops`` (every forward AND backward kernel is this package's HIP code;
+torch.autograd only walks the graph), the reference's x0-prediction MSE losses, and the data-parallel gradient
+all-reduce of ``parallel.GradientBuckets`` (RCCL over xGMI, one flat bucket list for the three networks instead of the
+reference's three DDP wrappers, train.py:1140-1142).
+
+The modules hold the fp32 master parameters (as under the reference's autocast); they are cast to the compute dtype
+inside the graph, so gradients arrive in fp32 on ``param.grad``.  This path trades the inference path's fusions for
+differentiability: GEGLU is its own kernel, the q / k / v projections are separate GEMMs, the up-path concatenation is
+materialised, attention recomputes and materialises P in the backward.  It is a functional first version -- parity of
+loss and gradients against the CPU oracle's autograd is tested (tests/test_train_gpu.py); throughput work comes next.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from . import autograd_ops as A
+from . import ops
+from .controlnet import CIN_PAD
+
+
+def _w2(conv_or_lin, dt):
+    """[N, K] compute-dtype view of a Linear / 1x1-conv weight (differentiable)."""
+    w = conv_or_lin.weight
+    return w.reshape(w.shape[0], -1).to(dt)
+
+
+def _resnet(r, x, temb_act, dt, x1=None):
+    """models/unet_2d_blocks.py:1100-1111 (ResnetBlock2D, time_embedding_norm='default')."""
+    xin = torch.cat([x, x1], -1) if x1 is not None else x
+    h = A.GroupNorm.apply(xin, r.norm1.weight, r.norm1.bias, r.eps, r.groups, True)
+    t = A.linear(temb_act, _w2(r.time_emb_proj, dt), r.time_emb_proj.bias)
+    h = A.conv3x3(h, A.pack_conv_weight(r.conv1.weight, dt), r.conv1.bias, rowadd=t)
+    h = A.GroupNorm.apply(h, r.norm2.weight, r.norm2.bias, r.eps, r.groups, True)
+    sc = xin if r.conv_shortcut is None else A.linear(xin, _w2(r.conv_shortcut, dt), r.conv_shortcut.bias)
+    if r.output_scale_factor != 1.0:
+        raise NotImplementedError("output_scale_factor != 1 in the training path")
+    return A.conv3x3(h, A.pack_conv_weight(r.conv2.weight, dt), r.conv2.bias, res=sc)
+
+
+def _attn(a, xn, ctx_tokens, res, dt):
+    src = xn if ctx_tokens is None else ctx_tokens
+    q = A.linear(xn, _w2(a.to_q, dt))
+    k = A.linear(src, _w2(a.to_k, dt))
+    v = A.linear(src, _w2(a.to_v, dt))
+    o = A.Attention.apply(q, k, v, a.heads)
+    return A.linear(o, _w2(a.to_out[0], dt), a.to_out[0].bias, res=res)
+
+
+def _tblock(b, x, ehs, dt):
+    x = _attn(b.attn1, A.LayerNorm.apply(x, b.norm1.weight, b.norm1.bias, b.norm1.eps), None, x, dt)
+    x = _attn(b.attn2, A.LayerNorm.apply(x, b.norm2.weight, b.norm2.bias, b.norm2.eps), ehs, x, dt)
+    proj, out = b.ff.net[0].proj, b.ff.net[2]
+    h = A.linear(A.LayerNorm.apply(x, b.norm3.weight, b.norm3.bias, b.norm3.eps), _w2(proj, dt), proj.bias)
+    return A.linear(A.GEGLU.apply(h), _w2(out, dt), out.bias, res=x)
+
+
+def _transformer(t, x, ehs, dt):
+    B, H, W, Cc = x.shape
+    h = A.GroupNorm.apply(x, t.norm.weight, t.norm.bias, t.norm.eps, t.groups, False)
+    h = A.linear(h.view(B, H * W, Cc), _w2(t.proj_in, dt), t.proj_in.bias)
+    for blk in t.transformer_blocks:
+        h = _tblock(blk, h, ehs, dt)
+    return A.linear(h, _w2(t.proj_out, dt), t.proj_out.bias, res=x.view(B, H * W, Cc)).view(B, H, W, Cc)
+
+
+def _conv(m, x, dt, stride=1, cin_pad=None):
+    return A.conv3x3(x, A.pack_conv_weight(m.weight, dt, cin_pad), m.bias, stride=stride)
+
+
+def _time(net, timesteps, B, dt, dev):
+    t = torch.as_tensor(timesteps, device=dev, dtype=torch.float32).reshape(-1)
+    t = t.expand(B).contiguous() if t.numel() == 1 else t.contiguous()
+    c = net.config
+    t_emb = ops.timestep_embedding(t, B, c["block_out_channels"][0], c["flip_sin_to_cos"], c["freq_shift"], dt)
+    te = net.time_embedding
+    emb = A.linear(A.SiLU.apply(A.linear(t_emb, _w2(te.linear_1, dt), te.linear_1.bias)), _w2(te.linear_2, dt),
+                   te.linear_2.bias)
+    return A.SiLU.apply(emb)  # every resnet applies SiLU to the embedding before its projection
+
+
+def _down_mid(net, x, temb, ehs, dt):
+    skips = [x]
+    for blk in net.down_blocks:
+        for i, r in enumerate(blk.resnets):
+            x = _resnet(r, x, temb, dt)
+            if getattr(blk, "has_cross_attention", False):
+                x = _transformer(blk.attentions[i], x, ehs, dt)
+            skips.append(x)
+        if blk.downsamplers is not None:
+            x = _conv(blk.downsamplers[0].conv, x, dt, stride=2)
+            skips.append(x)
+    m = net.mid_block
+    x = _resnet(m.resnets[0], x, temb, dt)
+    for a, r in zip(m.attentions, m.resnets[1:]):
+        x = _resnet(r, _transformer(a, x, ehs, dt), temb, dt)
+    return x, skips
+
+
+def _up_out(net, x, skips: List[torch.Tensor], temb, ehs, dt):
+    skips = list(skips)
+    for blk in net.up_blocks:
+        for i, r in enumerate(blk.resnets):
+            x = _resnet(r, x, temb, dt, x1=skips.pop())
+            if getattr(blk, "has_cross_attention", False):
+                x = _transformer(blk.attentions[i], x, ehs, dt)
+        if blk.upsamplers is not None:
+            x = _conv(blk.upsamplers[0].conv, A.Up2x.apply(x), dt)
+    n = net.conv_norm_out
+    h = A.GroupNorm.apply(x, n.weight, n.bias, n.eps, n.num_groups, True)
+    return _conv(net.conv_out, h, dt)
+
+
+def dual_stream_forward(unet, enc, dec, x_t, cond, ehs, t_img, t_attr, dtype=torch.bfloat16, run_decoder: bool = True
+                        ) -> Dict[str, torch.Tensor]:
+    """Differentiable dual-stream step (the call pattern of train.py:1324-1354): NCHW inputs, NHWC predictions
+    ``img_pred`` [B,H,W,4] / ``attr_pred`` [B,H,W,28] in the compute dtype."""
+    dev, B = x_t.device, x_t.shape[0]
+    dt = dtype
+    ehs = ehs.to(dt).contiguous()
+    if ehs.shape[0] == 1 and B > 1:
+        ehs = ehs.expand(B, -1, -1).contiguous()
+    # ---- encoder: conv_in(cond), down, mid, 12 + 1 zero convs (controlnet.py:1657-1778)
+    te = _time(enc, t_attr, B, dt, dev)
+    xe = _conv(enc.conv_in, ops.to_nhwc(cond, dt, CIN_PAD), dt, cin_pad=CIN_PAD)
+    raw_mid_enc, raw_enc = _down_mid(enc, xe, te, ehs, dt)
+    res = [A.linear(s, _w2(z, dt), z.bias) for s, z in zip(raw_enc, enc.controlnet_down_blocks)]
+    mid_res = A.linear(raw_mid_enc, _w2(enc.controlnet_mid_block, dt), enc.controlnet_mid_block.bias)
+    # ---- unet with the encoder's residuals (controlnet.py:781-1166)
+    tu = _time(unet, t_img, B, dt, dev)
+    xu = _conv(unet.conv_in, ops.to_nhwc(x_t, dt, CIN_PAD), dt, cin_pad=CIN_PAD)
+    raw_mid_unet, raw_unet = _down_mid(unet, xu, tu, ehs, dt)
+    skips = [A.Add.apply(s, r) for s, r in zip(raw_unet, res)]
+    img = _up_out(unet, A.Add.apply(raw_mid_unet, mid_res), skips, tu, ehs, dt)
+    out = {"img_pred": img}
+    if run_decoder:
+        # ---- decoder: exchange skip_enc + conv1x1(skip_unet), up path on its own weights (controlnet.py:2342-2527)
+        td = _time(dec, t_attr, B, dt, dev)
+        dskips = [A.linear(u, _w2(z, dt), z.bias, res=e) for u, e, z in zip(raw_unet, raw_enc, dec.control_down_blocks)]
+        xd = A.linear(raw_mid_unet, _w2(dec.control_mid_block, dt), dec.control_mid_block.bias, res=raw_mid_enc)
+        out["attr_pred"] = _up_out(dec, xd, dskips, td, ehs, dt)
+    return out
+
+
+def mse_losses(out: Dict[str, torch.Tensor], target_img: torch.Tensor, target_attr: Optional[torch.Tensor]) -> torch.Tensor:
+    """The x0-prediction losses of train.py:1356-1365: mean squared error of both predictions against the clean
+    latents (targets NCHW fp32)."""
+    loss = torch.mean((out["img_pred"].float() - target_img.permute(0, 2, 3, 1).float()) ** 2)
+    if "attr_pred" in out and target_attr is not None:
+        loss = loss + torch.mean((out["attr_pred"].float() - target_attr.permute(0, 2, 3, 1).float()) ** 2)
+    return loss
+
+
+def train_step(nets: Sequence[torch.nn.Module], batch: Dict[str, torch.Tensor], optimizer=None, buckets=None,
+               dtype=torch.bfloat16, max_grad_norm: Optional[float] = 1.0) -> Dict[str, float]:
+    """One optimisation step: forward, losses, backward (HIP kernels), gradient all-reduce (``buckets``: a
+    parallel.GradientBuckets, no-op on one rank), clipping (train.py:1422-1424), optimizer step."""
+    unet, enc, dec = nets
+    out = dual_stream_forward(unet, enc, dec, batch["x_t"], batch["cond"], batch["ehs"], batch["t_img"], batch["t_attr"],
+                              dtype=dtype)
+    loss = mse_losses(out, batch["target_img"], batch["target_attr"])
+    if optimizer is not None:
+        optimizer.zero_grad(set_to_none=True)
+    loss.backward()
+    if buckets is not None:
+        buckets.all_reduce_mean()
+    stats = {"loss": float(loss.detach())}
+    if max_grad_norm is not None:
+        params = [p for n in nets for p in n.parameters() if p.grad is not None]
+        stats["grad_norm"] = float(torch.nn.utils.clip_grad_norm_(params, max_grad_norm))
+    if optimizer is not None:
+        optimizer.step()
+    return stats
