@@ -91,3 +91,39 @@ def test_few_optimizer_steps_reduce_the_loss(dev):
     losses = [train_step(nets, batch, optimizer=opt, buckets=buckets, dtype=torch.bfloat16)["loss"] for _ in range(6)]
     print({"losses": losses})
     assert losses[-1] < losses[0] * 0.9 and all(l == l for l in losses)
+
+
+def test_train_step_gradients_sd_size(dev):
+    """SD-1.x-size networks (1.74 G parameters), 128x128 image = 16x16 latent, batch 1, bf16 compute with fp32 master
+    parameters (cfg 4's arithmetic): loss and the gradient of all parameters against the CPU oracle's autograd."""
+    from uni_renderer_amd.train_step import dual_stream_forward, mse_losses
+
+    oracle = O.build_triplet(O.SD15_CONFIG, seed=41)
+    x, c, ehs, ti, ta = O.make_inputs(1, 16, 768, seed=16)
+    g = torch.Generator().manual_seed(17)
+    tgt_img, tgt_attr = torch.randn(1, 4, 16, 16, generator=g), torch.randn(1, 28, 16, 16, generator=g)
+    for m in oracle:
+        m.requires_grad_(True)
+    loss_o = _oracle_loss(oracle, x, c, ehs, ti, ta, tgt_img, tgt_attr)
+    loss_o.backward()
+    nets = build_product_from_oracle(*oracle, torch.float32, dev)
+    for m in nets:
+        m.train()
+        m.requires_grad_(True)
+    out = dual_stream_forward(*nets, x.to(dev), c.to(dev), ehs.to(dev), ti.to(dev), ta.to(dev), dtype=torch.bfloat16)
+    loss = mse_losses(out, tgt_img.to(dev), tgt_attr.to(dev))
+    loss.backward()
+    num = den = 0.0
+    for mo, mp in zip(oracle, nets):
+        po = dict(mo.named_parameters())
+        for name, p in mp.named_parameters():
+            go = po[name].grad
+            if go is None:
+                continue
+            d = p.grad.float().cpu() - go
+            num += float((d * d).sum())
+            den += float((go * go).sum())
+    err = (num / den) ** 0.5
+    print({"sd_size_bf16": True, "loss": float(loss.detach()), "loss_oracle": float(loss_o.detach()), "grad_rel_l2_all": err})
+    assert abs(float(loss.detach()) - float(loss_o.detach())) / float(loss_o.detach()) < 2e-2
+    assert err < 8e-2

@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Training-step timing (cfg 4 of BASELINE.json: 512x512, per-GPU batch 4, bf16 compute, fp32 master parameters, AdamW,
+batch-sharded data parallel with one flat gradient all-reduce over RCCL).  NOT the headline metric (bench.py is);
+this reports where the first functional training path stands.
+
+    python tools/train_bench.py [--batch 4] [--latent 64] [--steps 3]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/train_bench.py
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from uni_renderer_amd.parallel import GradientBuckets  # noqa: E402
+from uni_renderer_amd.train_step import train_step  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=4)
+    ap.add_argument("--latent", type=int, default=64)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--dtype", default="bf16")
+    args = ap.parse_args()
+    world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.distributed.init_process_group("nccl", device_id=dev)
+    dt = torch.bfloat16 if args.dtype == "bf16" else torch.float16
+    nets = bench.build_models(dev, torch.float32)  # fp32 master parameters
+    for m in nets:
+        m.train()
+        m.requires_grad_(True)
+    B, L = args.batch, args.latent
+    g = torch.Generator(device=dev).manual_seed(7 + rank)
+    mk = lambda *s: torch.randn(*s, device=dev, generator=g)
+    batch = dict(x_t=mk(B, 4, L, L), cond=mk(B, 28, L, L), ehs=mk(B, 77, 768) * 0.5,
+                 t_img=torch.randint(0, 1000, (B,), device=dev, generator=g),
+                 t_attr=torch.randint(0, 1000, (B,), device=dev, generator=g),
+                 target_img=mk(B, 4, L, L), target_attr=mk(B, 28, L, L))
+    opt = torch.optim.AdamW([p for m in nets for p in m.parameters()], lr=1e-5)
+    buckets = GradientBuckets(nets, comm_dtype=torch.bfloat16) if world > 1 else None
+    stats = train_step(nets, batch, optimizer=opt, buckets=buckets, dtype=dt)  # warm-up (packs nothing: weights change)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        stats = train_step(nets, batch, optimizer=opt, buckets=buckets, dtype=dt)
+    torch.cuda.synchronize()
+    dtm = (time.perf_counter() - t0) / args.steps
+    if world > 1:
+        t = torch.tensor([dtm], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dtm = float(t.item())
+    if rank == 0:
+        print(json.dumps(dict(metric="train-steps/sec (dual-UNet, 512^2, per-GPU batch %d)" % B, value=round(world / dtm, 4),
+                              ms_per_step=round(dtm * 1e3, 1), n_gpus=world, dtype=args.dtype, loss=stats["loss"],
+                              grad_norm=stats.get("grad_norm"), peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2**30, 1))))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
