@@ -127,3 +127,64 @@ def test_train_step_gradients_sd_size(dev):
     print({"sd_size_bf16": True, "loss": float(loss.detach()), "loss_oracle": float(loss_o.detach()), "grad_rel_l2_all": err})
     assert abs(float(loss.detach()) - float(loss_o.detach())) / float(loss_o.detach()) < 2e-2
     assert err < 8e-2
+
+
+@pytest.mark.parametrize("inverse", [True, False])
+def test_reference_losses_match_oracle_autograd(dev, inverse):
+    """The objectives of train/train.py:1356-1413 -- inverse rendering with the cycle-consistency pass (the decoder's
+    prediction is fed back, differentiably, as the encoder's condition) and rendering with the contrastive term --
+    loss value and all parameter gradients against the same computation on the CPU oracle."""
+    from uni_renderer_amd.train_step import reference_losses
+
+    F = torch.nn.functional
+    oracle = O.build_triplet(O.TINY_CONFIG, seed=33)
+    unet_o, enc_o, dec_o = oracle
+    x, c, ehs, ti, ta = O.make_inputs(2, 16, 64, seed=18)
+    g = torch.Generator().manual_seed(19)
+    tgt_img, tgt_attr = torch.randn(2, 4, 16, 16, generator=g), torch.randn(2, 24, 16, 16, generator=g)
+    x_c, ti_c = torch.randn(2, 4, 16, 16, generator=g), torch.randint(0, 1000, (2,), generator=g)
+    for m in oracle:
+        m.requires_grad_(True)
+    # ---- oracle (NCHW, fp32), literally the reference's step body
+    res, mid, raw_enc, raw_mid_enc = enc_o(x, ta, ehs, controlnet_cond=c)
+    img_pred, raw_unet, raw_mid_unet, _ = unet_o(x, ti, ehs, down_block_additional_residuals=res,
+                                                 mid_block_additional_residual=mid)
+    mask_pred = dec_o(raw_mid_enc, raw_enc, ta, ehs, down_block_additional_residuals=raw_unet,
+                      mid_block_additional_residual=raw_mid_unet)[:, 4:]
+    loss_img, loss_mask = F.mse_loss(img_pred, tgt_img), F.mse_loss(mask_pred, tgt_attr)
+    if inverse:
+        cond_c = torch.cat((c[:, :4], mask_pred), dim=1)
+        res, mid, _, _ = enc_o(x_c, torch.zeros(2).long(), ehs, controlnet_cond=cond_c)
+        img_c = unet_o(x_c, ti_c, ehs, down_block_additional_residuals=res, mid_block_additional_residual=mid)[0]
+        loss_o = loss_img + loss_mask + 0.8 * F.mse_loss(img_c, tgt_img)
+    else:
+        cos = lambda a: F.cosine_similarity(a[0].reshape(-1), a[1].reshape(-1), dim=0) / 0.1
+        pos = torch.exp(cos(mask_pred[:, 8:12]))
+        neg = pos + torch.exp(cos(mask_pred[:, :4])) + torch.exp(cos(mask_pred[:, 12:16]))
+        loss_o = loss_img + loss_mask * 10.0 - torch.log(pos / neg) * 0.01
+    loss_o.backward()
+    # ---- product
+    nets = build_product_from_oracle(*oracle, torch.float32, dev)
+    for m in nets:
+        m.train()
+        m.requires_grad_(True)
+    batch = dict(x_t=x.to(dev), cond=c.to(dev), ehs=ehs.to(dev), t_img=ti.to(dev), t_attr=ta.to(dev),
+                 target_img=tgt_img.to(dev), target_attr=tgt_attr.to(dev), x_t_c=x_c.to(dev), t_img_c=ti_c.to(dev))
+    loss = reference_losses(nets, batch, dtype=torch.float16, inverse=inverse)["loss"]
+    loss.backward()
+    assert abs(float(loss.detach()) - float(loss_o.detach())) / abs(float(loss_o.detach())) < 5e-3
+    num = den = 0.0
+    for mo, mp in zip(oracle, nets):
+        po = dict(mo.named_parameters())
+        for name, p in mp.named_parameters():
+            go = po[name].grad
+            if go is None:
+                assert p.grad is None or float(p.grad.abs().max()) == 0.0, name  # e.g. the decoder in no branch
+                continue
+            assert p.grad is not None, name
+            d = p.grad.float().cpu() - go
+            num += float((d * d).sum())
+            den += float((go * go).sum())
+    err = (num / den) ** 0.5
+    print({"inverse": inverse, "loss": float(loss.detach()), "loss_oracle": float(loss_o.detach()), "grad_rel_l2_all": err})
+    assert err < 1.5e-2

@@ -114,10 +114,11 @@ def _up_out(net, x, skips: List[torch.Tensor], temb, ehs, dt):
     return _conv(net.conv_out, h, dt)
 
 
-def dual_stream_forward(unet, enc, dec, x_t, cond, ehs, t_img, t_attr, dtype=torch.bfloat16, run_decoder: bool = True
-                        ) -> Dict[str, torch.Tensor]:
+def dual_stream_forward(unet, enc, dec, x_t, cond, ehs, t_img, t_attr, dtype=torch.bfloat16, run_decoder: bool = True,
+                        cond_nhwc: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
     """Differentiable dual-stream step (the call pattern of train.py:1324-1354): NCHW inputs, NHWC predictions
-    ``img_pred`` [B,H,W,4] / ``attr_pred`` [B,H,W,28] in the compute dtype."""
+    ``img_pred`` [B,H,W,4] / ``attr_pred`` [B,H,W,28] in the compute dtype.  ``cond_nhwc`` ([B,H,W,28], compute dtype,
+    may require grad) replaces ``cond``: the cycle-consistency pass feeds the decoder's own prediction back in."""
     dev, B = x_t.device, x_t.shape[0]
     dt = dtype
     ehs = ehs.to(dt).contiguous()
@@ -125,7 +126,11 @@ def dual_stream_forward(unet, enc, dec, x_t, cond, ehs, t_img, t_attr, dtype=tor
         ehs = ehs.expand(B, -1, -1).contiguous()
     # ---- encoder: conv_in(cond), down, mid, 12 + 1 zero convs (controlnet.py:1657-1778)
     te = _time(enc, t_attr, B, dt, dev)
-    xe = _conv(enc.conv_in, ops.to_nhwc(cond, dt, CIN_PAD), dt, cin_pad=CIN_PAD)
+    if cond_nhwc is not None:
+        cin = torch.nn.functional.pad(cond_nhwc, (0, CIN_PAD - cond_nhwc.shape[-1])).contiguous()
+    else:
+        cin = ops.to_nhwc(cond, dt, CIN_PAD)
+    xe = _conv(enc.conv_in, cin, dt, cin_pad=CIN_PAD)
     raw_mid_enc, raw_enc = _down_mid(enc, xe, te, ehs, dt)
     res = [A.linear(s, _w2(z, dt), z.bias) for s, z in zip(raw_enc, enc.controlnet_down_blocks)]
     mid_res = A.linear(raw_mid_enc, _w2(enc.controlnet_mid_block, dt), enc.controlnet_mid_block.bias)
@@ -154,14 +159,58 @@ def mse_losses(out: Dict[str, torch.Tensor], target_img: torch.Tensor, target_at
     return loss
 
 
-def train_step(nets: Sequence[torch.nn.Module], batch: Dict[str, torch.Tensor], optimizer=None, buckets=None,
-               dtype=torch.bfloat16, max_grad_norm: Optional[float] = 1.0) -> Dict[str, float]:
-    """One optimisation step: forward, losses, backward (HIP kernels), gradient all-reduce (``buckets``: a
-    parallel.GradientBuckets, no-op on one rank), clipping (train.py:1422-1424), optimizer step."""
+def reference_losses(nets: Sequence[torch.nn.Module], batch: Dict[str, torch.Tensor], dtype=torch.bfloat16,
+                     inverse: bool = True) -> Dict[str, torch.Tensor]:
+    """The losses of train/train.py:1356-1413 on one micro-batch.
+
+    batch: ``x_t`` [B,4,h,w] noisy image latent, ``cond`` [B,28,h,w] = clean mask latent (4) | noisy attribute latents
+    (24), ``ehs``, ``t_img``, ``t_attr``, ``target_img`` [B,4,h,w], ``target_attr`` [B,24,h,w]; for the inverse-rendering
+    branch also ``x_t_c`` / ``t_img_c`` (a fresh noising of the image latent).
+
+    loss = mse(img) + 10 mse(attr) + 0.01 contrastive (albedo of samples 0 / 1 positive; material, specular negative), or
+    -- inverse rendering -- mse(img) + mse(attr) + 0.8 mse(img_c), where img_c is the UNet's prediction when the encoder
+    is conditioned on [mask | the decoder's OWN attribute prediction] at t_attr = 0 (gradient flows through it)."""
     unet, enc, dec = nets
+    F = torch.nn.functional
     out = dual_stream_forward(unet, enc, dec, batch["x_t"], batch["cond"], batch["ehs"], batch["t_img"], batch["t_attr"],
                               dtype=dtype)
-    loss = mse_losses(out, batch["target_img"], batch["target_attr"])
+    nhwc = lambda t: t.permute(0, 2, 3, 1).float()
+    mask_pred = out["attr_pred"][..., 4:]  # rule out the clean mask group (train.py:1354)
+    loss_img = F.mse_loss(out["img_pred"].float(), nhwc(batch["target_img"]))
+    loss_mask = F.mse_loss(mask_pred.float(), nhwc(batch["target_attr"]))
+    res = {"loss_img": loss_img, "loss_mask": loss_mask}
+    if not inverse:
+        cos = lambda a: F.cosine_similarity(a[0].reshape(-1).float(), a[1].reshape(-1).float(), dim=0) / 0.1
+        m_dis, a_dis, s_dis = cos(mask_pred[..., :4]), cos(mask_pred[..., 8:12]), cos(mask_pred[..., 12:16])
+        pos = torch.exp(a_dis)
+        res["contrastive"] = -torch.log(pos / (pos + torch.exp(m_dis) + torch.exp(s_dis)))
+        res["loss"] = loss_img + loss_mask * 10.0 + res["contrastive"] * 0.01
+        return res
+    mask_lat = batch["cond"][:, :4].permute(0, 2, 3, 1).to(dtype)
+    cond_c = torch.cat((mask_lat, mask_pred), dim=-1)
+    B = batch["x_t"].shape[0]
+    out_c = dual_stream_forward(unet, enc, dec, batch["x_t_c"], None, batch["ehs"], batch["t_img_c"],
+                                torch.zeros(B, device=batch["x_t"].device), dtype=dtype, run_decoder=False, cond_nhwc=cond_c)
+    res["loss_c"] = F.mse_loss(out_c["img_pred"].float(), nhwc(batch["target_img"]))
+    res["loss"] = loss_img + loss_mask + 0.8 * res["loss_c"]
+    return res
+
+
+def train_step(nets: Sequence[torch.nn.Module], batch: Dict[str, torch.Tensor], optimizer=None, buckets=None,
+               dtype=torch.bfloat16, max_grad_norm: Optional[float] = 1.0, inverse: Optional[bool] = None
+               ) -> Dict[str, float]:
+    """One optimisation step: forward, losses, backward (HIP kernels), gradient all-reduce (``buckets``: a
+    parallel.GradientBuckets, no-op on one rank), clipping (train.py:1422-1424), optimizer step.
+    ``inverse``: None = the plain two-stream MSE objective (mse_losses); True / False = the reference's inverse-rendering
+    (cycle consistency) / rendering (contrastive) objectives (reference_losses).  Ranks may pick different branches
+    (compute_t, train.py:445): parameters without a gradient contribute zeros to the buckets."""
+    unet, enc, dec = nets
+    if inverse is None:
+        out = dual_stream_forward(unet, enc, dec, batch["x_t"], batch["cond"], batch["ehs"], batch["t_img"],
+                                  batch["t_attr"], dtype=dtype)
+        loss = mse_losses(out, batch["target_img"], batch["target_attr"])
+    else:
+        loss = reference_losses(nets, batch, dtype=dtype, inverse=inverse)["loss"]
     if optimizer is not None:
         optimizer.zero_grad(set_to_none=True)
     loss.backward()
