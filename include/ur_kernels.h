@@ -239,13 +239,16 @@ int ur_sampler_advance(int* step, const float* tsteps, int nsteps, float* t_out,
  * ur_im2col3x3_t   out[(tap*C + c)][p] = x[pixel(p, tap)][c] of a 3x3 / pad 1 / stride 1|2 conv over NHWC x
  *                  (p = (b, oy, ox) row-major, ld_out >= P, columns P .. ld_out written as zeros).
  * ur_colsum        out[g][n] = sum of x[m][n] over the rows of group g (rows_per_group rows each; 0 = one group);
- *                  fp32 out; dtype may be UR_DT_F32 (one group only).
+ *                  fp32 out; dtype may be UR_DT_F32.  Tall inputs are summed in row slices into ``workspace``
+ *                  (ur_colsum_workspace_floats floats; may be null when that is 0) and folded in a fixed order.
  * ur_silu_backward dx = dy * d/dx(x * sigmoid(x)).
  * ur_geglu_forward / ur_geglu_backward   the reference's GEGLU layout h = [value | gate] (2D columns):
  *                  y = value * gelu(gate) (erf);  dh = [dy * gelu(gate) | dy * value * gelu'(gate)].
  * ur_groupnorm_backward   dx of y = act(GN(x) * gamma + beta) (act = SiLU if silu) from the forward statistics
- *                  partials (ur_groupnorm_stats, nstat chunks); chan_part[b][nchunks][C][2] (fp32, caller provided)
- *                  receives per-channel partial (sum dz, sum dz*xhat): their sums over (b, chunk) are dbeta and dgamma.
+ *                  partials (ur_groupnorm_stats, nstat chunks).  Three launches: per-channel partial (sum dz, sum dz*xhat)
+ *                  over nred row chunks into chan_part[b][nred][C][2] (fp32 workspace), their fixed-order fold into
+ *                  chan_sum[b][C][2] (fp32 output: summed over b these are dbeta and dgamma), and dx over nchunks
+ *                  row chunks per sample.
  * ur_layernorm_backward   dx per row; part[wave][2][C] (fp32, waves = ceil(rows / rows_per_wave)) receives the
  *                  per-wave partial (dgamma, dbeta); C <= 2048.
  */
@@ -253,13 +256,15 @@ int ur_transpose2d(const void* src, int64_t ld_src, int64_t bs_src, void* dst, i
                    int C, int batch, int dtype, void* stream);
 int ur_im2col3x3_t(const void* x, int B, int H, int W, int C, int stride, void* out, int64_t ld_out, int dtype,
                    void* stream);
-int ur_colsum(const void* x, int64_t ldx, int M, int N, int rows_per_group, float* out, int dtype, void* stream);
+int64_t ur_colsum_workspace_floats(int M, int N, int rows_per_group);
+int ur_colsum(const void* x, int64_t ldx, int M, int N, int rows_per_group, float* out, float* workspace, int dtype,
+              void* stream);
 int ur_silu_backward(const void* x, const void* dy, void* dx, int64_t n, int dtype, void* stream);
 int ur_geglu_forward(const void* h, void* y, int64_t M, int D, int dtype, void* stream);
 int ur_geglu_backward(const void* h, const void* dy, void* dh, int64_t M, int D, int dtype, void* stream);
 int ur_groupnorm_backward(const void* x, const void* dy, int C, int B, int rows, int groups, int nstat,
-                          const float* partial, const float* gamma, const float* beta, float eps, int silu, int nchunks,
-                          float* chan_part, void* dx, int dtype, void* stream);
+                          const float* partial, const float* gamma, const float* beta, float eps, int silu, int nred,
+                          float* chan_part, float* chan_sum, int nchunks, void* dx, int dtype, void* stream);
 int ur_layernorm_backward(const void* x, const void* dy, const float* gamma, float eps, int rows, int C,
                           int rows_per_wave, void* dx, float* part, int dtype, void* stream);
 /* Attention backward helpers: P = softmax(Q K^T * scale) is recomputed and materialised per (batch, head); the five

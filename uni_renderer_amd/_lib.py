@@ -70,12 +70,13 @@ SYMBOLS = {
     "ur_sampler_advance": (C.c_int, [vp, vp, C.c_int, vp, C.c_int, vp]),
     "ur_transpose2d": (C.c_int, [vp, C.c_int64, C.c_int64, vp, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "ur_im2col3x3_t": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int64, C.c_int, vp]),
-    "ur_colsum": (C.c_int, [vp, C.c_int64, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]),
+    "ur_colsum_workspace_floats": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
+    "ur_colsum": (C.c_int, [vp, C.c_int64, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp]),
     "ur_silu_backward": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int, vp]),
     "ur_geglu_forward": (C.c_int, [vp, vp, C.c_int64, C.c_int, C.c_int, vp]),
     "ur_geglu_backward": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int, C.c_int, vp]),
     "ur_groupnorm_backward": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_float,
-                                        C.c_int, C.c_int, vp, vp, C.c_int, vp]),
+                                        C.c_int, C.c_int, vp, vp, C.c_int, vp, C.c_int, vp]),
     "ur_layernorm_backward": (C.c_int, [vp, vp, vp, C.c_float, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp]),
     "ur_split_heads": (C.c_int, [vp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp]),
     "ur_merge_heads": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int64, C.c_int, C.c_int, vp]),

@@ -47,7 +47,10 @@ def colsum(x: torch.Tensor, rows_per_group: int = 0) -> torch.Tensor:
     groups = 1 if rows_per_group <= 0 else (M + rows_per_group - 1) // rows_per_group
     out = torch.empty(groups, N, dtype=torch.float32, device=x.device)
     dt = 2 if x.dtype == torch.float32 else DT[x.dtype]
-    check(lib.ur_colsum(x.data_ptr(), N, M, N, rows_per_group, out.data_ptr(), dt, _stream()), "ur_colsum")
+    nws = lib.ur_colsum_workspace_floats(M, N, rows_per_group)
+    ws = torch.empty(nws, dtype=torch.float32, device=x.device) if nws else None
+    check(lib.ur_colsum(x.data_ptr(), N, M, N, rows_per_group, out.data_ptr(), ws.data_ptr() if nws else None, dt,
+                        _stream()), "ur_colsum")
     return out if rows_per_group > 0 else out[0]
 
 
@@ -178,12 +181,14 @@ def groupnorm_backward(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, b
     s = _stream()
     check(lib.ur_groupnorm_stats(x.data_ptr(), None, None, None, Cc, 0, B, rows, groups, nstat, part.data_ptr(), DT[x.dtype],
                                  s), "ur_groupnorm_stats")
-    chan_part = torch.empty(B * nchunks, Cc, 2, dtype=torch.float32, device=x.device)
+    nred = max(1, min(nchunks, 512 // B))  # the reduction pass needs ~512 workgroups, not one per 20 KB
+    chan_part = torch.empty(B * nred, Cc, 2, dtype=torch.float32, device=x.device)
+    chan_sum = torch.empty(B, Cc, 2, dtype=torch.float32, device=x.device)
     dx = torch.empty_like(x)
     check(lib.ur_groupnorm_backward(x.data_ptr(), dy.data_ptr(), Cc, B, rows, groups, nstat, part.data_ptr(),
-                                    gamma.data_ptr(), beta.data_ptr(), float(eps), int(silu), nchunks,
-                                    chan_part.data_ptr(), dx.data_ptr(), DT[x.dtype], s), "ur_groupnorm_backward")
-    sums = colsum(chan_part.view(B * nchunks, 2 * Cc)).view(Cc, 2)  # (sum dz, sum dz*xhat) per channel
+                                    gamma.data_ptr(), beta.data_ptr(), float(eps), int(silu), nred, chan_part.data_ptr(),
+                                    chan_sum.data_ptr(), nchunks, dx.data_ptr(), DT[x.dtype], s), "ur_groupnorm_backward")
+    sums = (chan_sum[0] if B == 1 else colsum(chan_sum.view(B, 2 * Cc)).view(Cc, 2))  # (sum dz, sum dz*xhat) per channel
     return dx, sums[:, 1].contiguous(), sums[:, 0].contiguous()
 
 

@@ -16,37 +16,57 @@ namespace ur {
 // dst[b][c][r] = src[b][r][c]   (R x C tiles of 64 x 64 through LDS, both sides in 16-byte vectors)
 // rowmap != null: source row r is rowmap-free here; the im2col variant below gathers rows instead.
 // ---------------------------------------------------------------------------------------------------------------
+// Rows are packed in pairs on the way into LDS -- word (c, r/2) = (src[r][c], src[r+1][c]) -- so that the transposed
+// side leaves with one 16-byte LDS read per thread (8 b32 writes + 1 b128 read per 16 elements instead of 16 + 16
+// 2-byte accesses).  Word index inside a column is XOR-swizzled in 4-word groups to spread the banks.
+__device__ __forceinline__ int tp_word(int c, int r2) { return c * 32 + ((((r2 >> 2) ^ (c >> 3)) & 7) << 2 | (r2 & 3)); }
+
+template <typename T, typename LoadRow>
+__device__ __forceinline__ void transpose_tile_64x64(LoadRow load_row, uint32_t* tile, T* __restrict__ dst, int64_t ld_dst,
+                                                     int c_valid, int r_valid8, int t) {
+    typedef typename Vec8<T>::type vec8;
+    {   // thread = (row pair r2 = t >> 3, 8 columns cv): two 16-byte global loads, eight packed words
+        const int r2 = t >> 3, cv = (t & 7) * 8;
+        const vec8 a = load_row(2 * r2, cv), b = load_row(2 * r2 + 1, cv);
+        uint32_t ua[4], ub[4];  // (element 2j, element 2j+1) per word
+        __builtin_memcpy(ua, &a, 16);
+        __builtin_memcpy(ub, &b, 16);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            tile[tp_word(cv + 2 * j, r2)] = (ua[j] & 0xffffu) | (ub[j] << 16);
+            tile[tp_word(cv + 2 * j + 1, r2)] = (ua[j] >> 16) | (ub[j] & 0xffff0000u);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int c = pass * 32 + (t >> 3), g = t & 7;  // 8 destination elements = rows 8g .. 8g+7 of column c
+        if (c < c_valid && g * 8 < r_valid8) {
+            const uint4 v = *reinterpret_cast<const uint4*>(tile + c * 32 + (((g ^ (c >> 3)) & 7) << 2));
+            *reinterpret_cast<uint4*>(dst + (int64_t)c * ld_dst + g * 8) = v;
+        }
+    }
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256) transpose2d_kernel(const T* __restrict__ src, int64_t ld_src, int64_t bs_src,
                                                           T* __restrict__ dst, int64_t ld_dst, int64_t bs_dst, int R,
                                                           int C) {
-    __shared__ T tile[64][64 + 8];
+    __shared__ __attribute__((aligned(16))) uint32_t tile[64 * 32];
     const int t = threadIdx.x;
     const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
     src += (int64_t)blockIdx.z * bs_src;
     dst += (int64_t)blockIdx.z * bs_dst;
     typedef typename Vec8<T>::type vec8;
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-        const int r = pass * 32 + (t >> 3), cv = (t & 7) * 8;
+    auto load_row = [&](int r, int cv) {
         vec8 v;
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = (T)0.0f;
         if (r0 + r < R && c0 + cv < C) v = *reinterpret_cast<const vec8*>(src + (int64_t)(r0 + r) * ld_src + c0 + cv);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) tile[r][cv + i] = v[i];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-        const int c = pass * 32 + (t >> 3), rv = (t & 7) * 8;
-        if (c0 + c < C && r0 + rv < ((R + 7) & ~7)) {  // rows R .. ceil8(R) of the source read as zeros
-            vec8 v;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = tile[rv + i][c];
-            *reinterpret_cast<vec8*>(dst + (int64_t)(c0 + c) * ld_dst + r0 + rv) = v;
-        }
-    }
+        return v;
+    };
+    // rows R .. ceil8(R) of the source read as zeros
+    transpose_tile_64x64<T>(load_row, tile, dst + (int64_t)c0 * ld_dst + r0, ld_dst, C - c0, ((R + 7) & ~7) - r0, t);
 }
 
 // Transposed im2col of a 3x3 / pad 1 convolution: out[(tap*C + c)][p] = x[pixel(p, tap)][c] (0 outside the image),
@@ -54,15 +74,13 @@ __global__ void __launch_bounds__(256) transpose2d_kernel(const T* __restrict__ 
 template <typename T>
 __global__ void __launch_bounds__(256) im2col3x3_t_kernel(const T* __restrict__ x, int B, int H, int W, int C, int Ho,
                                                           int Wo, int stride, T* __restrict__ out, int64_t ld_out) {
-    __shared__ T tile[64][64 + 8];
+    __shared__ __attribute__((aligned(16))) uint32_t tile[64 * 32];
     const int t = threadIdx.x;
     const int P = B * Ho * Wo;
     const int p0 = blockIdx.y * 64, c0 = blockIdx.x * 64, tap = blockIdx.z;
     const int dy = tap / 3, dx = tap - dy * 3;
     typedef typename Vec8<T>::type vec8;
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-        const int r = pass * 32 + (t >> 3), cv = (t & 7) * 8;
+    auto load_row = [&](int r, int cv) {
         const int p = p0 + r;
         vec8 v;
 #pragma unroll
@@ -74,37 +92,48 @@ __global__ void __launch_bounds__(256) im2col3x3_t_kernel(const T* __restrict__ 
             if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
                 v = *reinterpret_cast<const vec8*>(x + (((int64_t)b * H + iy) * W + ix) * C + c0 + cv);
         }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) tile[r][cv + i] = v[i];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-        const int c = pass * 32 + (t >> 3), rv = (t & 7) * 8;
-        if (c0 + c < C && p0 + rv < (int)ld_out) {
-            vec8 v;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = tile[rv + i][c];
-            *reinterpret_cast<vec8*>(out + ((int64_t)tap * C + c0 + c) * ld_out + p0 + rv) = v;
-        }
-    }
+        return v;
+    };
+    transpose_tile_64x64<T>(load_row, tile, out + ((int64_t)tap * C + c0) * ld_out + p0, ld_out, C - c0, (int)ld_out - p0, t);
 }
 
-// out[g][n] = sum over the rows m in [g*rpg, (g+1)*rpg) of x[m][n] (fp32).  grid = (N/64 column blocks, groups).
+// out[g][n] = sum over the rows m in [g*rpg, (g+1)*rpg) of x[m][n] (fp32).  grid = (N/64 column blocks, slices, groups):
+// every group's rows are cut into ``slices`` contiguous pieces whose sums land in dst[(g*slices + s)][n]; with
+// slices > 1 dst is the caller's workspace and colsum_fold_kernel adds the pieces in a fixed order.
+template <typename T>
+__device__ __forceinline__ void load8f(const T* p, float (&v)[8]) { load8(p, v); }
+template <>
+__device__ __forceinline__ void load8f<float>(const float* p, float (&v)[8]) {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256) colsum_kernel(const T* __restrict__ x, int64_t ldx, int M, int N, int rpg,
-                                                     float* __restrict__ out) {
-    __shared__ float red[32][64];
+                                                     int slices, float* __restrict__ dst) {
+    __shared__ float red[32][64 + 1];
     const int t = threadIdx.x, cv = (t & 7) * 8, rl = t >> 3;  // 8 vector columns x 32 row lanes
-    const int n0 = blockIdx.x * 64, g = blockIdx.y;
-    const int mbeg = g * rpg, mend = min(M, mbeg + rpg);
+    const int n0 = blockIdx.x * 64, sl = blockIdx.y, g = blockIdx.z;
+    const int gbeg = g * rpg, gend = min(M, gbeg + rpg);
+    const int rps = (gend - gbeg + slices - 1) / slices;
+    const int mbeg = gbeg + sl * rps, mend = min(gend, mbeg + rps);
     float s[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) s[i] = 0.f;
     if (n0 + cv < N) {
-        for (int m = mbeg + rl; m < mend; m += 32) {
+        int m = mbeg + rl;
+        for (; m + 32 < mend; m += 64) {  // two rows in flight
+            float v[8], w[8];
+            load8f(x + (int64_t)m * ldx + n0 + cv, v);
+            load8f(x + (int64_t)(m + 32) * ldx + n0 + cv, w);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s[i] += v[i];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s[i] += w[i];
+        }
+        if (m < mend) {
             float v[8];
-            load8(x + (int64_t)m * ldx + n0 + cv, v);
+            load8f(x + (int64_t)m * ldx + n0 + cv, v);
 #pragma unroll
             for (int i = 0; i < 8; ++i) s[i] += v[i];
         }
@@ -115,22 +144,17 @@ __global__ void __launch_bounds__(256) colsum_kernel(const T* __restrict__ x, in
     if (t < 64 && n0 + t < N) {
         float a = 0.f;
         for (int k = 0; k < 32; ++k) a += red[k][t];  // fixed order
-        out[(int64_t)g * N + n0 + t] = a;
+        dst[((int64_t)g * slices + sl) * N + n0 + t] = a;
     }
 }
 
-// the same over fp32 input (partials of the norm backward kernels)
-__global__ void __launch_bounds__(256) colsum_f32_kernel(const float* __restrict__ x, int64_t ldx, int M, int N,
-                                                         float* __restrict__ out) {
-    __shared__ float red[4][64];
-    const int t = threadIdx.x, c = t & 63, rl = t >> 6;
-    const int n = blockIdx.x * 64 + c;
+__global__ void __launch_bounds__(256) colsum_fold_kernel(const float* __restrict__ ws, int N, int slices,
+                                                          float* __restrict__ out) {
+    const int n = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y;
+    if (n >= N) return;
     float a = 0.f;
-    if (n < N)
-        for (int m = rl; m < M; m += 4) a += x[(int64_t)m * ldx + n];
-    red[rl][c] = a;
-    __syncthreads();
-    if (t < 64 && n < N) out[n] = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+    for (int k = 0; k < slices; ++k) a += ws[((int64_t)g * slices + k) * N + n];
+    out[(int64_t)g * N + n] = a;
 }
 
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
@@ -286,6 +310,17 @@ __global__ void __launch_bounds__(256) gn_bwd_reduce_kernel(const T* __restrict_
             }
         }
     }
+}
+
+// chan_sum[b][c] = sum over the nred chunks of chan_part[b][chunk][c] (fixed order); one thread per (channel, component)
+__global__ void __launch_bounds__(256) gn_bwd_fold_kernel(const float* __restrict__ chan_part, int C2, int nred,
+                                                          float* __restrict__ chan_sum) {
+    const int e = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (e >= C2) return;
+    const float* src = chan_part + (int64_t)b * nred * C2 + e;
+    float a = 0.f;
+    for (int k = 0; k < nred; ++k) a += src[(int64_t)k * C2];
+    chan_sum[(int64_t)b * C2 + e] = a;
 }
 
 template <typename T>
@@ -642,17 +677,38 @@ extern "C" int ur_im2col3x3_t(const void* x, int B, int H, int W, int C, int str
     return last_error();
 }
 
-extern "C" int ur_colsum(const void* x, int64_t ldx, int M, int N, int rows_per_group, float* out, int dtype, void* stream) {
+static int colsum_slices(int M, int N, int rpg) {
+    // enough workgroups to fill the chip (>= ~1024) while a slice keeps >= 64 rows
+    const int groups = (M + rpg - 1) / rpg, cols = (N + 63) / 64;
+    int s = 1024 / (groups * cols);
+    const int max_s = (rpg < M ? rpg : M) / 64;
+    if (s > max_s) s = max_s;
+    return s < 1 ? 1 : s;
+}
+
+extern "C" int64_t ur_colsum_workspace_floats(int M, int N, int rows_per_group) {
+    if (M <= 0 || N <= 0) return 0;
+    const int rpg = rows_per_group > 0 ? rows_per_group : M;
+    const int sl = colsum_slices(M, N, rpg);
+    return sl > 1 ? (int64_t)((M + rpg - 1) / rpg) * sl * N : 0;
+}
+
+extern "C" int ur_colsum(const void* x, int64_t ldx, int M, int N, int rows_per_group, float* out, float* workspace,
+                         int dtype, void* stream) {
     if (!x || !out || M <= 0 || N <= 0 || (N & 7) || (ldx & 7)) return UR_E_BADARG;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == UR_DT_F32) {
-        if (rows_per_group > 0 && rows_per_group < M) return UR_E_UNSUPPORTED;
-        hipLaunchKernelGGL(colsum_f32_kernel, dim3((N + 63) / 64), dim3(256), 0, s, (const float*)x, ldx, M, N, out);
-        return last_error();
-    }
     const int rpg = rows_per_group > 0 ? rows_per_group : M;
-    dim3 grid((N + 63) / 64, (M + rpg - 1) / rpg);
-    UR_DISPATCH(dtype, hipLaunchKernelGGL((colsum_kernel<T>), grid, dim3(256), 0, s, (const T*)x, ldx, M, N, rpg, out));
+    const int groups = (M + rpg - 1) / rpg;
+    const int sl = colsum_slices(M, N, rpg);
+    if (sl > 1 && !workspace) return UR_E_BADARG;
+    float* dst = sl > 1 ? workspace : out;
+    dim3 grid((N + 63) / 64, sl, groups);
+    if (dtype == UR_DT_F32) {
+        hipLaunchKernelGGL((colsum_kernel<float>), grid, dim3(256), 0, s, (const float*)x, ldx, M, N, rpg, sl, dst);
+    } else {
+        UR_DISPATCH(dtype, hipLaunchKernelGGL((colsum_kernel<T>), grid, dim3(256), 0, s, (const T*)x, ldx, M, N, rpg, sl, dst));
+    }
+    if (sl > 1) hipLaunchKernelGGL(colsum_fold_kernel, dim3((N + 255) / 256, groups), dim3(256), 0, s, workspace, N, sl, out);
     return last_error();
 }
 
@@ -682,18 +738,19 @@ extern "C" int ur_geglu_backward(const void* h, const void* dy, void* dh, int64_
 
 extern "C" int ur_groupnorm_backward(const void* x, const void* dy, int C, int B, int rows, int groups, int nstat,
                                      const float* partial, const float* gamma, const float* beta, float eps, int silu,
-                                     int nchunks, float* chan_part, void* dx, int dtype, void* stream) {
-    if (!x || !dy || !partial || !gamma || !beta || !chan_part || !dx) return UR_E_BADARG;
+                                     int nred, float* chan_part, float* chan_sum, int nchunks, void* dx, int dtype,
+                                     void* stream) {
+    if (!x || !dy || !partial || !gamma || !beta || !chan_part || !chan_sum || !dx) return UR_E_BADARG;
     if (C <= 0 || (C & 7) || C > 4096 || B <= 0 || rows <= 0 || groups <= 0 || groups > 64 || (C % groups) || nstat <= 0 ||
-        nchunks <= 0 || nchunks > 65535)
+        nchunks <= 0 || nchunks > 65535 || nred <= 0 || nred > 65535)
         return UR_E_BADARG;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    dim3 grid(nchunks, B);
     UR_DISPATCH(dtype, {
-        hipLaunchKernelGGL((gn_bwd_reduce_kernel<T>), grid, dim3(256), 0, s, (const T*)x, (const T*)dy, C, rows, groups, nstat,
-                           nchunks, partial, gamma, beta, eps, silu, chan_part);
-        hipLaunchKernelGGL((gn_bwd_apply_kernel<T>), grid, dim3(256), 0, s, (const T*)x, (const T*)dy, C, rows, groups, nstat,
-                           nchunks, nchunks, partial, chan_part, gamma, beta, eps, silu, (T*)dx);
+        hipLaunchKernelGGL((gn_bwd_reduce_kernel<T>), dim3(nred, B), dim3(256), 0, s, (const T*)x, (const T*)dy, C, rows,
+                           groups, nstat, nred, partial, gamma, beta, eps, silu, chan_part);
+        hipLaunchKernelGGL(gn_bwd_fold_kernel, dim3((2 * C + 255) / 256, B), dim3(256), 0, s, chan_part, 2 * C, nred, chan_sum);
+        hipLaunchKernelGGL((gn_bwd_apply_kernel<T>), dim3(nchunks, B), dim3(256), 0, s, (const T*)x, (const T*)dy, C, rows,
+                           groups, nstat, 1, nchunks, partial, chan_sum, gamma, beta, eps, silu, (T*)dx);
     });
     return last_error();
 }

@@ -9,7 +9,7 @@ The modules hold the fp32 master parameters (as under the reference's autocast);
 inside the graph, so gradients arrive in fp32 on ``param.grad``.  This path trades the inference path's fusions for
 differentiability: GEGLU is its own kernel, the q / k / v projections are separate GEMMs, the up-path concatenation is
 materialised, attention recomputes and materialises P in the backward.  It is a functional first version -- parity of
-loss and gradients against the CPU oracle's autograd is tested (tests/test_train_gpu.py); throughput work comes next.
+loss and gradients against the CPU restatement of the reference under autograd is tested (tests/test_train_gpu.py); throughput work comes next.
 """
 from __future__ import annotations
 
