@@ -45,7 +45,7 @@ def main():
                  t_img=torch.randint(0, 1000, (B,), device=dev, generator=g),
                  t_attr=torch.randint(0, 1000, (B,), device=dev, generator=g),
                  target_img=mk(B, 4, L, L), target_attr=mk(B, 28, L, L))
-    opt = torch.optim.AdamW([p for m in nets for p in m.parameters()], lr=1e-5)
+    opt = torch.optim.AdamW([p for m in nets for p in m.parameters()], lr=1e-5, fused=True)
     buckets = GradientBuckets(nets, comm_dtype=torch.bfloat16) if world > 1 else None
     stats = train_step(nets, batch, optimizer=opt, buckets=buckets, dtype=dt)  # warm-up (packs nothing: weights change)
     torch.cuda.synchronize()

@@ -48,6 +48,42 @@ def collect(models, inputs, grouped=False, run_decoder=True):
     return calls
 
 
+def collect_train(B, L, dev, dtype):
+    """igemm problems of one training step (forward + backward, tools/train_bench.py's workload)."""
+    import bench
+    from uni_renderer_amd import ops
+    from uni_renderer_amd.train_step import train_step
+
+    nets = bench.build_models(dev, torch.float32)
+    for m in nets:
+        m.train()
+        m.requires_grad_(True)
+    g = torch.Generator(device=dev).manual_seed(7)
+    mk = lambda *s: torch.randn(*s, device=dev, generator=g)
+    batch = dict(x_t=mk(B, 4, L, L), cond=mk(B, 28, L, L), ehs=mk(B, 77, 768) * 0.5,
+                 t_img=torch.randint(0, 1000, (B,), device=dev, generator=g),
+                 t_attr=torch.randint(0, 1000, (B,), device=dev, generator=g),
+                 target_img=mk(B, 4, L, L), target_attr=mk(B, 28, L, L))
+    calls = {}
+    orig = ops.igemm
+
+    def spy(**kw):
+        key = (kw["M"], kw["N"], kw["K"], kw.get("taps", 1), kw.get("zbatch", 1))
+        if key not in calls:
+            calls[key] = dict(kw)
+        return orig(**kw)
+
+    ops.igemm = spy
+    try:
+        train_step(nets, batch, dtype=dtype)
+        torch.cuda.synchronize()
+    finally:
+        ops.igemm = orig
+    for m in nets:
+        m.zero_grad(set_to_none=True)
+    return calls
+
+
 _side = None
 
 
@@ -102,6 +138,8 @@ def main():
     ap.add_argument("--also", default="", help='extra "batch,latent" pairs separated by ;')
     ap.add_argument("--eager", action="store_true", help="time eager launches instead of graph replays")
     ap.add_argument("--only-missing", action="store_true", help="tune only problems absent from the existing table")
+    ap.add_argument("--train", action="store_true", help="tune the problems of a training step (forward + backward)")
+    ap.add_argument("--tiles", default="", help="comma-separated candidate tile ids (default: all)")
     ap.add_argument("--out", default=os.path.join(ROOT, "uni_renderer_amd", "igemm_tuning.json"))
     ap.add_argument("--report", default=os.path.join(ROOT, "gpurun_out", "tune_report.json"))
     args = ap.parse_args()
@@ -110,7 +148,8 @@ def main():
 
     dev = torch.device("cuda:0")
     dtype = torch.float16 if args.dtype == "fp16" else torch.bfloat16
-    models = bench.build_models(dev, dtype)
+    models = None if args.train else bench.build_models(dev, dtype)
+    tiles = [int(t) for t in args.tiles.split(",")] if args.tiles else list(ops._TILES)
     shapes = [(args.batch, args.latent)] + [tuple(int(v) for v in p.split(",")) for p in args.also.split(";") if p]
     ops.load_tuning_table("/nonexistent")  # start from the analytic planner
     table, report = {}, []
@@ -119,8 +158,8 @@ def main():
         if os.path.exists(pth):
             table.update(json.load(open(pth)))
     for (B, L) in shapes:
-        calls = collect(models, bench.make_inputs(B, L, dev, dtype, seed=7))
-        for grouped, dec in ((True, True), (True, False)):  # the rendering direction runs the up path ungrouped (z = 1)
+        calls = collect_train(B, L, dev, dtype) if args.train else collect(models, bench.make_inputs(B, L, dev, dtype, seed=7))
+        for grouped, dec in (() if args.train else ((True, True), (True, False))):  # the rendering direction runs the up path ungrouped (z = 1)
             extra = collect(models, bench.make_inputs(B, L, dev, dtype, seed=7), grouped=grouped, run_decoder=dec)
             calls.update({k: v for k, v in extra.items() if k not in calls})
         if args.only_missing:
@@ -129,7 +168,7 @@ def main():
         for key, kw in sorted(calls.items()):
             M, N, K, taps, zb = key
             res = {}
-            for tile in ops._TILES:
+            for tile in tiles:
                 for sk in (1, 2, 4, 8):
                     if sk > 1 and (zb > 4 or K // 64 < 4 * sk):
                         continue

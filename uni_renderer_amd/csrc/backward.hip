@@ -678,11 +678,12 @@ extern "C" int ur_im2col3x3_t(const void* x, int B, int H, int W, int C, int str
 }
 
 static int colsum_slices(int M, int N, int rpg) {
-    // enough workgroups to fill the chip (>= ~1024) while a slice keeps >= 64 rows
+    // enough workgroups to fill the chip (~512) while a slice keeps >= 64 rows; <= 32 slices keeps the fold short
     const int groups = (M + rpg - 1) / rpg, cols = (N + 63) / 64;
-    int s = 1024 / (groups * cols);
+    int s = 512 / (groups * cols);
     const int max_s = (rpg < M ? rpg : M) / 64;
     if (s > max_s) s = max_s;
+    if (s > 32) s = 32;
     return s < 1 ? 1 : s;
 }
 
