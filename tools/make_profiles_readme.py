@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Regenerate profiles/README.md from the committed summaries (profiles/<tag>_*.{json,csv}, profiles/pmc_traffic.json).
 
-    python tools/make_profiles_readme.py [tag=r01b]
+    python tools/make_profiles_readme.py [tag=r01c]
 """
 import csv
 import json
@@ -29,7 +29,7 @@ def pretty(n):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r01b"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r01c"
     rows = list(csv.DictReader(open(os.path.join(P, f"{tag}_kernel_stats.csv"))))
     d = json.loads(open(os.path.join(P, f"{tag}_bench_default.json")).read().strip().split("\n")[-1])
     mf = json.load(open(os.path.join(P, f"{tag}_pmc_mfma_util.json")))
@@ -67,8 +67,9 @@ rocprofv3 --kernel-trace --stats -d <out> -o {tag} --output-format csv -- python
 
 ## Headline (un-profiled, `{tag}_bench_default.json`)
 
-{d['value']:.2f} denoise-steps/s = {d['ms_per_step']:.2f} ms per dual-stream step (enc + unet + dec, SD-1.x size, B=4, 512x512, fp16) on
-one MI355X (boxes of the pool differ by +-4 %: 12.1 .. 12.9 ms were seen for this build); CPU oracle on the same host
+{d['value']:.2f} denoise-steps/s = {d['ms_per_step']:.2f} ms per dual-stream step (enc + unet + dec, SD-1.x size, B=4, 512x512, fp16,
+default (hi, lo) residual stream) on one MI355X (boxes of the pool differ by +-4 %: 13.0 .. 13.6 ms were seen for this
+build, 12.1 .. 12.9 ms with the plain fp16 residual stream `UR_PRECISE_RESIDUAL=0`); CPU oracle on the same host
 ({cpu['cores']}-core cgroup quota) {cpu['value']:.4f} steps/s.  6.49 TFLOP/step => {6.49 / d['ms_per_step']:.3f} PFLOP/s algorithmic =
 {100 * 6.49 / d['ms_per_step'] / 2.5:.0f} % of the dense fp16 MFMA roofline for the whole step (start of the round: 27.2 ms; first complete
 profile `r01_*`: 13.25 ms).
