@@ -15,7 +15,10 @@ from uni_renderer_amd import ops  # noqa: E402
 
 def main():
     dev, dt, S = torch.device("cuda:0"), torch.float16, 2
-    for (M, N, tile) in [(16384, 320, 9), (4096, 640, 5), (1024, 1280, 7), (256, 1280, 7), (16384, 320, 5)]:
+    cases = [(16384, 320, 9), (4096, 640, 5), (1024, 1280, 7), (256, 1280, 7), (16384, 320, 5)]
+    if len(sys.argv) > 1:  # e.g. "1024,1280,7;1024,1280,3"
+        cases = [tuple(int(v) for v in c.split(",")) for c in sys.argv[1].split(";")]
+    for (M, N, tile) in cases:
         rows = []
         for K in (64, 128, 320, 640, 1280, 2560):
             x = torch.randn(S * M, K, device=dev).to(dt)
