@@ -31,6 +31,8 @@ for k, v in agg.items():
 json.dump(out, open("$OUT/pmc_mfma_util.json", "w"), indent=1, sort_keys=True)
 for k, v in sorted(out.items(), key=lambda kv: -kv[1]["mfma_util"])[:12]: print(round(v["mfma_util"], 3), v["launches"], k[:90])
 PY
+bash $R/tools/pmc_l2_step.sh > $OUT/pmc_l2_step.log 2>&1; cp $R/gpurun_out/pmc_l2_step.json $OUT/pmc_l2_step.json
+cd $R
 # keep only the summaries (the raw kernel traces / counter dumps are tens of MB)
 cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
 rm -rf $OUT/stats $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_mfma

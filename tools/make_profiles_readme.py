@@ -34,6 +34,8 @@ def main():
     d = json.loads(open(os.path.join(P, f"{tag}_bench_default.json")).read().strip().split("\n")[-1])
     mf = json.load(open(os.path.join(P, f"{tag}_pmc_mfma_util.json")))
     tr = json.load(open(os.path.join(P, "pmc_traffic.json")))
+    l2p = os.path.join(P, f"{tag}_pmc_l2_step.json")
+    l2 = json.load(open(l2p)) if os.path.exists(l2p) else {}
     ours = [(pretty(r["Name"]), r) for r in rows if "_ZN2ur" in r["Name"]]
     tot = sum(float(r["TotalDurationNs"]) for _, r in ours)
     alltot = sum(float(r["TotalDurationNs"]) for r in rows)
@@ -60,6 +62,7 @@ complete collection of the round, kept for the history of the numbers; `{tag}_*`
 | `{tag}_bench_under_rocprofv3.json` | the bench line printed by that profiled run |
 | `{tag}_per_shape_eager_events.json` | per (kernel class, problem shape) table of one eager step, each launch bracketed by HIP events on the launch stream (`bench.py --shape-table`); eager launches of small kernels include launch latency |
 | `pmc_traffic.json` | HBM-side bytes per launch per kernel class from two separate PMC passes (`rocprofv3 --pmc FETCH_SIZE --kernel-trace`, `--pmc WRITE_SIZE --kernel-trace`, each around `bench.py --steps 3 --warmup 1`), reduced by `tools/pmc_traffic.py`: `FETCH_SIZE*2*1024 + WRITE_SIZE*1024` (KiB units; gfx950 FETCH_SIZE counts 128-B requests as 64 B — MI355X_MICROARCH.md §HBM).  `bench.py` reads it for `roofline.traffic`. |
+| `{tag}_pmc_l2_step.json` | a fourth PMC pass (`--pmc TCC_HIT TCC_MISS TCC_REQ --kernel-trace`, `tools/pmc_l2_step.sh`): L2 hit rate and miss bytes per launch per kernel class, in situ over whole steps |
 | `{tag}_pmc_mfma_util.json` | a third PMC pass (`--pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES --kernel-trace`): per kernel symbol `SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 1024 SIMDs)` summed over its launches (busy = 16 cycles per 16x16x32 MFMA, 32 per 32x32x16; calibrated with `tools/ubench/mfma_rate.hip`) |
 
 Commands (as the guide prescribes, counters in their own passes): `cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT &&
@@ -77,9 +80,16 @@ profile `r01_*`: 13.25 ms).
 Dominant kernel (by symbol; plain + split-K launches {100 * roof.get('share_of_step_incl_splitk_launches', roof['share_of_step']):.0f} % of the step):
 `{roof['kernel']}` at {roof['achieved']:.0f} TFLOP/s = {100 * roof['frac']:.0f} % of peak over its {roof['calls_per_step']} plain launches/step
 ({roof['avg_launch_us']:.0f} us each by HIP events; rocprofv3 average over plain AND split launches of the symbol: {float(dom['AverageNs']) / 1e3:.1f} us),
-MFMA-busy {100 * mf[dom['Name']]['mfma_util']:.0f} %, PMC traffic {(roof['traffic'] or 0) / 1e6:.0f} MB/launch averaged over the plain AND split-K launches of the symbol
-(algorithmic average 70 MB: the excess is the fp32 split-K slabs and the 29-59 MB weight matrices of the deep levels;
-the level-0 launch alone has 92 % L2 hits and compulsory-only misses, `tools/pmc_l2.sh`).
+MFMA-busy {100 * mf[dom['Name']]['mfma_util']:.0f} %.  PMC traffic of the plain launches {tr[roof['kernel']]['hbm_bytes_per_launch'] / 1e6:.0f} MB/launch
+({tr[roof['kernel']]['read_bytes'] / 1e6:.0f} read + {tr[roof['kernel']]['write_bytes'] / 1e6:.0f} written; split-K launches of the symbol {tr.get(roof['kernel'] + '_splitk', {}).get('hbm_bytes_per_launch', 0) / 1e6:.0f} MB incl. their fp32 partial
+slabs) against {roof['algorithmic_bytes_per_launch'] / 1e6:.0f} MB algorithmic: FETCH_SIZE / WRITE_SIZE count what leaves the XCD's L2, not what reaches
+HBM.  In situ the L2 hit rate of these launches is {100 * l2.get(roof['kernel'], {}).get('hit_rate', 0):.0f} % of {l2.get(roof['kernel'], {}).get('tcc_req', 0) * 128 / 1e6:.0f} MB of requests
+(`{tag}_pmc_l2_step.json`); replayed alone the level-0 problem has 92 % hits and 57 MB of misses (`tools/pmc_l2.sh`: its
+input slice stays in the same XCD's L2 from one replay to the next).  The in-situ excess is (a) the nine taps re-reading
+a 128-pixel panel whose XCD-wide footprint (32 workgroups x 166 KB + the weight chunks) exceeds the 4 MB L2 and (b)
+every XCD fetching the whole weight matrix of its z (29-59 MB at the 16x16 / 8x8 levels); both are served by the 256 MB
+Infinity Cache, and the launch takes the same time in situ as replayed alone (75.8 vs 76.3 us for M = 2x16384, N = 320,
+K = 2880), i.e. the K loop is not bound by this traffic.
 Attention d = 40 (4096-token self-attention + 77-key cross-attention launches): {att[0]['tflops'] if att else 0:.0f} TFLOP/s,
 MFMA-busy {100 * att_u[0]['mfma_util'] if att_u else 0:.0f} % (north_star asks >= 40 %), PMC traffic {tr.get('attention_d40', {}).get('hbm_bytes_per_launch', 0) / 1e6:.0f} MB/launch vs 84 MB algorithmic Q+K+V+O.
 

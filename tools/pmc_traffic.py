@@ -43,14 +43,25 @@ def klass(name: str):
 
 
 def per_class(path, counter):
+    """{class: [sum, launches]}.  A split-K launch shares its kernel symbol with the plain launches of the tile; it is
+    recognised by the ``igemm_splitk_reduce`` dispatch that immediately follows it (Dispatch_Id order) and filed under
+    ``<class>_splitk`` -- the same split bench.py's ``kernel_classes`` make."""
+    rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter]
     agg = collections.defaultdict(lambda: [0.0, 0])
-    for r in csv.DictReader(open(path)):
-        if r["Counter_Name"] != counter:
-            continue
+    if rows and "Dispatch_Id" in rows[0]:
+        rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+        names = {int(r["Dispatch_Id"]): r["Kernel_Name"] for r in rows}
+    else:
+        names = {}
+    for r in rows:
         k = klass(r["Kernel_Name"])
-        if k:
-            agg[k][0] += float(r["Counter_Value"])
-            agg[k][1] += 1
+        if not k:
+            continue
+        if names and k.startswith("igemm_") and k != "igemm_splitk_reduce" and \
+                "igemm_splitk_reduce" in names.get(int(r["Dispatch_Id"]) + 1, ""):
+            k += "_splitk"
+        agg[k][0] += float(r["Counter_Value"])
+        agg[k][1] += 1
     return agg
 
 
@@ -63,8 +74,8 @@ def main():
         rd = 2.0 * 1024.0 * f[0] / max(f[1], 1)  # gfx950: FETCH_SIZE counts 128-B requests as 64 B
         wr = 1024.0 * w[0] / max(w[1], 1)
         out[k] = dict(hbm_bytes_per_launch=round(rd + wr), read_bytes=round(rd), write_bytes=round(wr), launches=f[1],
-                      note="FETCH_SIZE*2*1024 + WRITE_SIZE*1024 (MI355X_MICROARCH.md HBM section); _splitk classes "
-                           "share the kernel symbol of the non-split launch")
+                      note="FETCH_SIZE*2*1024 + WRITE_SIZE*1024 (MI355X_MICROARCH.md HBM section); <class>_splitk = the "
+                           "launches of that kernel symbol followed by igemm_splitk_reduce (fp32 partial slabs)")
     dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json")
     if len(sys.argv) > 3:
         dst = sys.argv[3]

@@ -182,7 +182,12 @@ def igemm(*, x0, w, out, M, N, K, c0, c1=0, x1=None, ldx0, ldx1=0, ldw, ldc, tap
                + ("_splitk" if splitk > 1 else ""))
         if _prof_by_shape:
             key += f"|M{M}_N{N}_K{K}_z{z}_sk{splitk}"
-        _prof_end(e0, key, 2.0 * M * N * K * z, (M * K / taps + N * K + M * N) * el * z)
+        # algorithmic bytes: every operand once -- activations (the conv reads each input pixel once: M*stride^2/4^ups
+        # pixels), weights, output, plus the residual operand and the low parts of the (hi, lo) stream when present
+        in_rows = M * (stride * stride if taps == 9 else 1) / (4 ** ups if taps == 9 else 1)
+        n_out = N / 2 if act == ACT_GEGLU else N
+        extra = (res is not None) + (res_lo is not None) + (out_lo is not None)
+        _prof_end(e0, key, 2.0 * M * N * K * z, (in_rows * K / taps + N * K + M * n_out * (1 + extra)) * el * z)
     return out
 
 
