@@ -84,8 +84,7 @@ MFMA-busy {100 * mf[dom['Name']]['mfma_util']:.0f} %.  PMC traffic of the plain 
 ({tr[roof['kernel']]['read_bytes'] / 1e6:.0f} read + {tr[roof['kernel']]['write_bytes'] / 1e6:.0f} written; split-K launches of the symbol {tr.get(roof['kernel'] + '_splitk', {}).get('hbm_bytes_per_launch', 0) / 1e6:.0f} MB incl. their fp32 partial
 slabs) against {roof['algorithmic_bytes_per_launch'] / 1e6:.0f} MB algorithmic: FETCH_SIZE / WRITE_SIZE count what leaves the XCD's L2, not what reaches
 HBM.  In situ the L2 hit rate of these launches is {100 * l2.get(roof['kernel'], {}).get('hit_rate', 0):.0f} % of {l2.get(roof['kernel'], {}).get('tcc_req', 0) * 128 / 1e6:.0f} MB of requests
-(`{tag}_pmc_l2_step.json`); replayed alone the level-0 problem has 92 % hits and 57 MB of misses (`tools/pmc_l2.sh`: its
-input slice stays in the same XCD's L2 from one replay to the next).  The in-situ excess is (a) the nine taps re-reading
+(`{tag}_pmc_l2_step.json`); replayed alone the level-0 problem has 92 % hits and 57 MB of misses (`tools/pmc_l2.sh`).  The in-situ excess is (a) the nine taps re-reading
 a 128-pixel panel whose XCD-wide footprint (32 workgroups x 166 KB + the weight chunks) exceeds the 4 MB L2 and (b)
 every XCD fetching the whole weight matrix of its z (29-59 MB at the 16x16 / 8x8 levels); both are served by the 256 MB
 Infinity Cache, and the launch takes the same time in situ as replayed alone (75.8 vs 76.3 us for M = 2x16384, N = 320,
