@@ -162,7 +162,9 @@ def test_vt_proj(dev, dtype, T):
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("cfg", [(64, 0, 16), (320, 0, 64), (128, 64, 64), (1280, 1280, 16), (640, 320, 100)])
 @pytest.mark.parametrize("silu", [False, True])
-def test_groupnorm(dev, dtype, cfg, silu):
+@pytest.mark.parametrize("fused", [False, True])
+def test_groupnorm(dev, dtype, cfg, silu, fused):
+    """fused = the one-launch kernel of the 16x16 / 8x8 levels (ur_groupnorm_fused), else stats + apply."""
     from uni_renderer_amd import ops
     c0, c1, rows = cfg
     B = 3
@@ -171,7 +173,7 @@ def test_groupnorm(dev, dtype, cfg, silu):
     C = c0 + c1
     g = torch.randn(C, generator=torch.Generator().manual_seed(3)).to(dev)
     b = torch.randn(C, generator=torch.Generator().manual_seed(4)).to(dev)
-    y = ops.groupnorm(x0, g, b, 1e-5, x1=x1, groups=32, silu=silu)
+    y = ops.groupnorm(x0, g, b, 1e-5, x1=x1, groups=32, silu=silu, fused=fused)
     xc = torch.cat([x0, x1], -1) if c1 else x0
     ref = F.group_norm(xc.float().cpu().permute(0, 3, 1, 2), 32, g.cpu(), b.cpu(), 1e-5)
     if silu:

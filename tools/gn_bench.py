@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""GroupNorm(+SiLU) timing by level (graph replay of 20 calls, z = 2 grouped shapes of the headline step)."""
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ab_gemm import time_graph  # noqa: E402
+from uni_renderer_amd import ops  # noqa: E402
+
+
+def main():
+    dev, dt = torch.device("cuda:0"), torch.float16
+    hilo = os.environ.get("GN_LO", "1") != "0"
+    for (hw, c0, c1) in [(64, 320, 0), (64, 640, 320), (32, 640, 0), (32, 320, 0), (32, 1280, 640), (16, 1280, 0), (16, 640, 0),
+                         (16, 1280, 1280), (8, 1280, 0), (8, 1280, 1280)]:
+        B = 8
+        x = torch.randn(B, hw, hw, c0, device=dev).to(dt)
+        if hilo:
+            x.lo = (torch.randn(B, hw, hw, c0, device=dev) * 1e-4).to(dt)
+        x1 = torch.randn(B, hw, hw, c1, device=dev).to(dt) if c1 else None
+        C = c0 + c1
+        g, b = torch.randn(2 * C, device=dev), torch.randn(2 * C, device=dev)
+        us = time_graph(lambda: ops.groupnorm(x, g, b, 1e-5, x1=x1, silu=True, streams=2, fused=False))
+        usf = time_graph(lambda: ops.groupnorm(x, g, b, 1e-5, x1=x1, silu=True, streams=2, fused=True))
+        a = ops.groupnorm(x, g, b, 1e-5, x1=x1, silu=True, streams=2, fused=False).float()
+        f = ops.groupnorm(x, g, b, 1e-5, x1=x1, silu=True, streams=2, fused=True).float()
+        print(json.dumps(dict(hw=hw, c0=c0, c1=c1, hi_MB=round(B * hw * hw * C * 2 / 1e6, 1), two_launch_us=round(us, 2),
+                              fused_us=round(usf, 2), max_abs_diff=float((a - f).abs().max()))), flush=True)
+
+
+if __name__ == "__main__":
+    main()

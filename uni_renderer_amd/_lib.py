@@ -58,6 +58,8 @@ SYMBOLS = {
     "ur_groupnorm_stats": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]),
     "ur_groupnorm_apply": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp,
                                      vp, C.c_float, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]),
+    "ur_groupnorm_fused": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_float,
+                                     C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]),
     "ur_layernorm": (C.c_int, [vp, vp, vp, vp, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]),
     "ur_attention": (C.c_int, [C.POINTER(AttnDesc), vp]),
     "ur_add": (C.c_int, [vp, vp, C.c_float, vp, C.c_int64, C.c_int, vp]),

@@ -383,6 +383,154 @@ __global__ void __launch_bounds__(256) layernorm5_kernel(const T* __restrict__ x
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// One-launch GroupNorm(+SiLU) for the small maps (deep levels): one workgroup per (sample, group) makes two sweeps
+// over its [rows][cpg] strip -- sums over the hi parts, then normalise hi + lo -- the second sweep finds the strip in
+// this XCD's L2.  Replaces stats + apply (two launches, a partials round trip) where those are launch-bound: 12.6 us
+// for a 1.3 MB map against ~3 us of traffic.  A thread walks (row, piece) pairs, a piece = P channels (2 / 4 / 8
+// by the divisibility of the group width); the fixed-order block reduction keeps the result deterministic.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T, int P>
+__device__ __forceinline__ void load_piece(const T* p, float (&v)[P]) {
+    if constexpr (P == 8) {
+        load8(p, v);
+    } else if constexpr (P == 4) {
+        uint2 raw = *reinterpret_cast<const uint2*>(p);
+        T h[4];
+        __builtin_memcpy(h, &raw, 8);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = to_f(h[i]);
+    } else {
+        unsigned raw = *reinterpret_cast<const unsigned*>(p);
+        T h[2];
+        __builtin_memcpy(h, &raw, 4);
+        v[0] = to_f(h[0]);
+        v[1] = to_f(h[1]);
+    }
+}
+template <typename T, int P>
+__device__ __forceinline__ void store_piece(T* p, const float (&v)[P]) {
+    if constexpr (P == 8) {
+        store8(p, v);
+    } else {
+        T h[P];
+#pragma unroll
+        for (int i = 0; i < P; ++i) h[i] = from_f<T>(v[i]);
+        if constexpr (P == 4) {
+            uint2 raw;
+            __builtin_memcpy(&raw, h, 8);
+            *reinterpret_cast<uint2*>(p) = raw;
+        } else {
+            unsigned raw;
+            __builtin_memcpy(&raw, h, 4);
+            *reinterpret_cast<unsigned*>(p) = raw;
+        }
+    }
+}
+
+constexpr int GNF_THREADS = 1024;  // 16 waves: one round trip per sweep for the strips of the 16x16 / 8x8 levels
+
+template <typename T, int P>
+__global__ void __launch_bounds__(GNF_THREADS) gn_fused_kernel(const T* __restrict__ x0, const T* __restrict__ x1,
+                                                       const T* __restrict__ x0_lo, const T* __restrict__ x1_lo, int c0,
+                                                       int c1, int rows, int groups, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float eps, int silu, int bper,
+                                                       int pstride, T* __restrict__ out) {
+    __shared__ float2 red[GNF_THREADS / 64];
+    __shared__ __attribute__((aligned(16))) float2 aff[128];  // per channel of the group: (gamma * rstd, beta - mean * gamma * rstd)
+    const int t = threadIdx.x, g = blockIdx.x, b = blockIdx.y;
+    const int C = c0 + c1, cpg = C / groups, ppr = cpg / P;  // pieces per row
+    const int total = rows * ppr;
+    const int dr = GNF_THREADS / ppr, dp = GNF_THREADS - dr * ppr;  // (row, piece) step of i += GNF_THREADS
+    const int64_t row0 = (int64_t)b * rows;
+    constexpr int U = 4;  // independent loads in flight per thread
+
+    float s1 = 0.f, s2 = 0.f;
+    {
+        int r = t / ppr, pc = t - (t / ppr) * ppr;
+        for (int i = t; i < total; i += GNF_THREADS * U) {
+            float v[U][P];
+            int rr = r, pp = pc;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool ok = i + GNF_THREADS * u < total;
+                const int rc = ok ? rr : 0;
+                const int c = g * cpg + (ok ? pp : 0) * P;
+                const T* src = c < c0 ? x0 + (row0 + rc) * c0 + c : x1 + (row0 + rc) * c1 + (c - c0);
+                load_piece<T, P>(src, v[u]);
+                if (!ok) {
+#pragma unroll
+                    for (int k = 0; k < P; ++k) v[u][k] = 0.f;
+                }
+                rr += dr; pp += dp;
+                if (pp >= ppr) { pp -= ppr; rr += 1; }
+            }
+            r = rr; pc = pp;
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int k = 0; k < P; ++k) { s1 += v[u][k]; s2 += v[u][k] * v[u][k]; }
+        }
+    }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if ((t & 63) == 0) red[t >> 6] = make_float2(s1, s2);
+    __syncthreads();
+    const float n = (float)rows * (float)cpg;
+    float sum = 0.f, sq = 0.f;
+#pragma unroll
+    for (int w = 0; w < GNF_THREADS / 64; ++w) { sum += red[w].x; sq += red[w].y; }  // fixed order
+    const float mean = sum / n;
+    const float rstd = rsqrtf(fmaxf(sq / n - mean * mean, 0.f) + eps);
+    const int poff = bper > 0 ? (b / bper) * pstride : 0;  // per-stream affine parameters (grouped execution)
+    if (t < cpg) {
+        const float a = gamma[poff + g * cpg + t] * rstd;
+        aff[t] = make_float2(a, beta[poff + g * cpg + t] - mean * a);
+    }
+    __syncthreads();
+
+    int r = t / ppr, pc = t - (t / ppr) * ppr;
+    for (int i = t; i < total; i += GNF_THREADS * U) {
+        float v[U][P];
+        int cs[U], rs[U];
+        bool oks[U];
+        int rr = r, pp = pc;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool ok = i + GNF_THREADS * u < total;
+            const int rc = ok ? rr : 0;
+            const int c = g * cpg + (ok ? pp : 0) * P;
+            oks[u] = ok; cs[u] = c; rs[u] = rc;
+            const bool first = c < c0;
+            const int64_t off = first ? (row0 + rc) * c0 + c : (row0 + rc) * c1 + (c - c0);
+            load_piece<T, P>((first ? x0 : x1) + off, v[u]);
+            const T* lo = first ? x0_lo : x1_lo;
+            if (lo) {
+                float w[P];
+                load_piece<T, P>(lo + off, w);
+#pragma unroll
+                for (int k = 0; k < P; ++k) v[u][k] += w[k];
+            }
+            rr += dr; pp += dp;
+            if (pp >= ppr) { pp -= ppr; rr += 1; }
+        }
+        r = rr; pc = pp;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!oks[u]) continue;
+            float y[P];
+#pragma unroll
+            for (int k = 0; k < P; ++k) {
+                const float2 ab = aff[cs[u] - g * cpg + k];
+                float z = fmaf(v[u][k], ab.x, ab.y);
+                if (silu) z = silu_f(z);
+                y[k] = z;
+            }
+            store_piece<T, P>(out + (row0 + rs[u]) * C + cs[u], y);
+        }
+    }
+}
+
 }  // namespace ur
 
 using namespace ur;
@@ -432,6 +580,39 @@ extern "C" int ur_groupnorm_apply(const void* x0, const void* x1, const void* x0
         return UR_E_BADARG;
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : -(int)e;
+}
+
+// One launch: statistics + normalisation by one workgroup per (sample, group) (csrc comment at gn_fused_kernel).
+// Meant for maps up to a few tens of MB; larger ones are faster through ur_groupnorm_stats + ur_groupnorm_apply.
+template <typename T>
+static int launch_gn_fused(const void* x0, const void* x1, const void* x0_lo, const void* x1_lo, int c0, int c1, int B,
+                           int rows, int groups, const float* gamma, const float* beta, float eps, int silu, int bper,
+                           int pstride, void* out, hipStream_t s) {
+    const int cpg = (c0 + c1) / groups;
+    dim3 grid(groups, B);
+#define UR_GNF(PP)                                                                                                     \
+    hipLaunchKernelGGL((gn_fused_kernel<T, PP>), grid, dim3(GNF_THREADS), 0, s, (const T*)x0, (const T*)x1, (const T*)x0_lo,   \
+                       (const T*)x1_lo, c0, c1, rows, groups, gamma, beta, eps, silu, bper, pstride, (T*)out)
+    if (cpg % 8 == 0) UR_GNF(8);
+    else if (cpg % 4 == 0) UR_GNF(4);
+    else if (cpg % 2 == 0) UR_GNF(2);
+    else return UR_E_UNSUPPORTED;
+#undef UR_GNF
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : -(int)e;
+}
+
+extern "C" int ur_groupnorm_fused(const void* x0, const void* x1, const void* x0_lo, const void* x1_lo, int c0, int c1,
+                                  int B, int rows, int groups, const float* gamma, const float* beta, float eps, int silu,
+                                  int bper, int pstride, void* out, int dtype, void* stream) {
+    int rc = gn_check(x0, x1, c0, c1, B, rows, groups, 1);
+    if (rc || !gamma || !beta || !out) return rc ? rc : UR_E_BADARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == UR_DT_F16)
+        return launch_gn_fused<f16>(x0, x1, x0_lo, x1_lo, c0, c1, B, rows, groups, gamma, beta, eps, silu, bper, pstride, out, s);
+    if (dtype == UR_DT_BF16)
+        return launch_gn_fused<bf16>(x0, x1, x0_lo, x1_lo, c0, c1, B, rows, groups, gamma, beta, eps, silu, bper, pstride, out, s);
+    return UR_E_BADARG;
 }
 
 template <typename T>

@@ -309,14 +309,31 @@ def _gn_chunks_bytes(B: int, rows: int, C: int, esize: int = 2):
     return int(nstat), int(napply)
 
 
-def groupnorm(x, gamma, beta, eps, *, x1=None, groups=32, silu=False, nstat=None, napply=None, streams=1):
-    """GroupNorm over NHWC x (or over cat(x, x1)); returns one contiguous [B,H,W,C0+C1] tensor."""
+# maps of at most this many pixels per sample (16x16 and 8x8 levels) take the one-launch GroupNorm: measured 6-12 us
+# against 12-21 us for stats + apply; at 32x32 and above the two-launch path wins (tools/gn_bench.py)
+GN_FUSED_MAX_ROWS = int(os.environ.get("UR_GN_FUSED_MAX_ROWS", "256"))
+
+
+def groupnorm(x, gamma, beta, eps, *, x1=None, groups=32, silu=False, nstat=None, napply=None, streams=1, fused=None):
+    """GroupNorm over NHWC x (or over cat(x, x1)); returns one contiguous [B,H,W,C0+C1] tensor.
+    ``fused``: one launch (ur_groupnorm_fused) instead of stats + apply; default: maps of <= GN_FUSED_MAX_ROWS pixels."""
     _require_gpu(x)
     lib = _lib.load()
     B = x.shape[0]
     C0 = x.shape[-1]
     C1 = x1.shape[-1] if x1 is not None else 0
     rows = x.numel() // (B * C0)
+    if fused is None:
+        fused = nstat is None and napply is None and ((C0 + C1) // groups) % 2 == 0 and rows <= GN_FUSED_MAX_ROWS
+    if fused:
+        out = torch.empty(*x.shape[:-1], C0 + C1, dtype=x.dtype, device=x.device)
+        e0 = _prof_begin()
+        check(lib.ur_groupnorm_fused(_ptr(x), _ptr(x1), _ptr(lo_of(x)), _ptr(lo_of(x1)), C0, C1, B, rows, groups,
+                                     gamma.data_ptr(), beta.data_ptr(), float(eps), int(silu),
+                                     (B // streams if streams > 1 else 0), (C0 + C1 if streams > 1 else 0), out.data_ptr(),
+                                     DT[x.dtype], _stream()), "ur_groupnorm_fused")
+        _prof_end(e0, "gn_fused", 0.0, 2.0 * out.numel() * out.element_size())
+        return out
     _ns, _na = _gn_chunks_bytes(B, rows, C0 + C1, x.element_size())
     nstat, napply = (nstat or _ns), (napply or _na)
     part = torch.empty(B * nstat * groups * 2, dtype=torch.float32, device=x.device)
