@@ -80,18 +80,20 @@ def main():
     ap.add_argument("--dtype", default="fp16")
     ap.add_argument("--out", default=None)
     ap.add_argument("--tiles", default="", help="comma-separated tile ids for --sweep (default: all)")
+    ap.add_argument("--problems", default="", help='subset, e.g. "256,1280,11520,9,2;1024,1280,11520,9,2"')
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     dt = torch.float16 if args.dtype == "fp16" else torch.bfloat16
     total = 0.0
     rows = []
-    for (M, N, K, taps, S) in PROBLEMS:
+    problems = [tuple(int(v) for v in q.split(",")) for q in args.problems.split(";")] if args.problems else PROBLEMS
+    for (M, N, K, taps, S) in problems:
         fn = build(M, N, K, taps, S, dev, dt)
         fl = 2.0 * M * N * K * S
         if args.sweep:
             res = {}
             for tile in ([int(t) for t in args.tiles.split(",")] if args.tiles else ops._TILES):
-                for sk in (1, 2, 4, 8):
+                for sk in (1, 2, 4, 8, 16):
                     if sk > 1 and K // 64 < 4 * sk:
                         continue
                     try:
