@@ -159,7 +159,7 @@ int ur_groupnorm_apply(const void* x0, const void* x1, const void* x0_lo, const 
 
 /* The same GroupNorm in ONE launch (one workgroup per (sample, group), two sweeps over its strip; statistics over the
  * hi parts, normalisation of hi + lo): for the maps of the deep levels, where stats + apply are launch-bound.  Group
- * width (c0 + c1) / groups must be even (UR_E_UNSUPPORTED otherwise). */
+ * width (c0 + c1) / groups must be even and <= 128 (UR_E_UNSUPPORTED otherwise). */
 int ur_groupnorm_fused(const void* x0, const void* x1, const void* x0_lo, const void* x1_lo, int c0, int c1, int B,
                        int rows, int groups, const float* gamma, const float* beta, float eps, int silu, int bper,
                        int pstride, void* out, int dtype, void* stream);

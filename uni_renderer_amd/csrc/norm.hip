@@ -593,6 +593,7 @@ static int launch_gn_fused(const void* x0, const void* x1, const void* x0_lo, co
 #define UR_GNF(PP)                                                                                                     \
     hipLaunchKernelGGL((gn_fused_kernel<T, PP>), grid, dim3(GNF_THREADS), 0, s, (const T*)x0, (const T*)x1, (const T*)x0_lo,   \
                        (const T*)x1_lo, c0, c1, rows, groups, gamma, beta, eps, silu, bper, pstride, (T*)out)
+    if (cpg > 128) return UR_E_UNSUPPORTED;  // the group's affine pairs are staged in a 128-entry LDS table
     if (cpg % 8 == 0) UR_GNF(8);
     else if (cpg % 4 == 0) UR_GNF(4);
     else if (cpg % 2 == 0) UR_GNF(2);

@@ -324,7 +324,8 @@ def groupnorm(x, gamma, beta, eps, *, x1=None, groups=32, silu=False, nstat=None
     C1 = x1.shape[-1] if x1 is not None else 0
     rows = x.numel() // (B * C0)
     if fused is None:
-        fused = nstat is None and napply is None and ((C0 + C1) // groups) % 2 == 0 and rows <= GN_FUSED_MAX_ROWS
+        cpg = (C0 + C1) // groups
+        fused = nstat is None and napply is None and cpg % 2 == 0 and cpg <= 128 and rows <= GN_FUSED_MAX_ROWS
     if fused:
         out = torch.empty(*x.shape[:-1], C0 + C1, dtype=x.dtype, device=x.device)
         e0 = _prof_begin()
