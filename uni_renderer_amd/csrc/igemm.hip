@@ -315,6 +315,8 @@ __global__ void __launch_bounds__(WM * WN * 64) igemm_kernel(const ur_igemm_desc
     };
 
     // issue the LDS-DMA copies of the loader's current chunk into `buf`, then advance by one chunk
+    // (-DUR_ABLATE=1 builds a kernel without the copies, =2 one without the MFMAs: the two ablations behind the
+    // "MFMA time + loader time" model of DESIGN.md section 4; never defined in the product build)
     auto stage = [&](int buf) {
 #if defined(UR_ABLATE) && UR_ABLATE == 1
         if (buf >= 0) { seg_left -= 1; if (seg_left == 0) next_segment(); return; }
