@@ -211,6 +211,11 @@ int ur_timestep_embedding(const float* t, int nt, int B, int dim, int flip_sin_t
 
 /* Layout glue.  src_dtype/dst dtype: 0 f16, 1 bf16, 2 f32.  Channels >= C of the padded NHWC output
  * are written as zeros. */
+/* out[b][oy][ox][:] = in[b][sy][sx][:], PyTorch 'nearest': s = min(floor(o * (float)in / out), in - 1); NHWC, C % 8 == 0.
+ * The general F.interpolate(size=...) of Upsample2D (controlnet.py:1129-1130: latent side not a multiple of 8); the
+ * exact 2x case is fused into the conv gather (ur_igemm, ups = 1) instead. */
+int ur_resize_nearest(const void* in, void* out, int B, int Hin, int Win, int Hout, int Wout, int C, int dtype,
+                      void* stream);
 int ur_nchw_to_nhwc(const void* src, int src_dtype, int B, int C, int H, int W, void* dst, int Cpad, int dtype,
                     void* stream);
 int ur_nhwc_to_nchw(const void* src, int dtype, int B, int C, int H, int W, void* dst, int dst_dtype,

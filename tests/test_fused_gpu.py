@@ -59,3 +59,28 @@ def test_grouped_single_timestep_and_single_prompt_broadcast(dev):
     with torch.no_grad():
         out = GroupedDualStreamStep(unet, enc, dec)(x.to(dev), c.to(dev), ehs[:1].to(dev), 7, torch.tensor(500, device=dev))
     assert rel_l2(out["img_pred"], ref["img_pred"]) < 3e-3 and rel_l2(out["attr_pred"], ref["attr_pred"]) < 3e-3
+
+
+@pytest.mark.parametrize("hw", [(12, 12), (16, 24), (12, 20), (9, 14)])
+def test_odd_and_non_square_latents(dev, hw):
+    """Latent sides that are not multiples of 8 make the reference forward ``upsample_size`` (controlnet.py:869-883,
+    1129-1130: F.interpolate(size=skip size) instead of x2); non-square maps exercise every H != W index path.
+    Module path and grouped executor against the CPU oracle."""
+    from uni_renderer_amd.fused import GroupedDualStreamStep
+
+    oracle = O.build_triplet(O.TINY_CONFIG, seed=61)
+    unet, enc, dec = build_product_from_oracle(*oracle, torch.float16, dev)
+    g = torch.Generator().manual_seed(62)
+    H, W = hw
+    x, c = torch.randn(2, 4, H, W, generator=g), torch.randn(2, 28, H, W, generator=g)
+    ehs = torch.randn(2, 77, 64, generator=g) * 0.5
+    ti, ta = torch.tensor([3, 700]), torch.tensor([999, 0])
+    ref = O.dual_stream_step(*oracle, x, c, ehs, ti, ta)
+    d = [t.to(dev) for t in (x, c, ehs, ti, ta)]
+    with torch.no_grad():
+        mod = product_step(unet, enc, dec, *d)
+        grp = GroupedDualStreamStep(unet, enc, dec)(*d)
+    for out in (mod, grp):
+        assert out["img_pred"].shape == (2, 4, H, W) and out["attr_pred"].shape == (2, 28, H, W)
+        for k in ("img_pred", "attr_pred"):
+            assert rel_l2(out[k], ref[k]) < 3e-3, (hw, k, rel_l2(out[k], ref[k]))

@@ -73,6 +73,28 @@ static inline int grid_for(int64_t n) {
     return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
 }
 
+
+// out[b][oy][ox][:] = in[b][sy(oy)][sx(ox)][:] with PyTorch's 'nearest' rule: s(o) = min(floor(o * (float)in / out), in - 1)
+// (F.interpolate(size=...) of Upsample2D when the latent side is not a multiple of 8, controlnet.py:1129-1130).
+template <typename T>
+__global__ void __launch_bounds__(256) resize_nearest_kernel(const T* __restrict__ in, T* __restrict__ out, int B, int Hin,
+                                                             int Win, int Hout, int Wout, int C) {
+    const int nvec = C >> 3;
+    const int64_t total = (int64_t)B * Hout * Wout * nvec;
+    const float sh = (float)Hin / (float)Hout, sw = (float)Win / (float)Wout;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int cv = (int)(i % nvec);
+        const int64_t pix = i / nvec;
+        const int ox = (int)(pix % Wout);
+        const int oy = (int)((pix / Wout) % Hout);
+        const int b = (int)(pix / ((int64_t)Wout * Hout));
+        const int sy = min((int)floorf(oy * sh), Hin - 1), sx = min((int)floorf(ox * sw), Win - 1);
+        typedef typename Vec8<T>::type vec8;
+        *reinterpret_cast<vec8*>(out + pix * C + cv * 8) =
+            *reinterpret_cast<const vec8*>(in + (((int64_t)b * Hin + sy) * Win + sx) * C + cv * 8);
+    }
+}
+
 }  // namespace ur
 
 using namespace ur;
@@ -166,6 +188,23 @@ static int to_nhwc_src(const void* src, int B, int C, int H, int W, void* dst, i
     else if (dtype == UR_DT_BF16)
         hipLaunchKernelGGL((nchw_to_nhwc_kernel<S, bf16>), dim3(grid_for(total)), dim3(256), 0, s, (const S*)src, B, C, H,
                            W, (bf16*)dst, Cpad);
+    else
+        return UR_E_BADARG;
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : -(int)e;
+}
+
+extern "C" int ur_resize_nearest(const void* in, void* out, int B, int Hin, int Win, int Hout, int Wout, int C, int dtype,
+                                 void* stream) {
+    if (!in || !out || B <= 0 || Hin <= 0 || Win <= 0 || Hout <= 0 || Wout <= 0 || C <= 0 || (C & 7)) return UR_E_BADARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int64_t total = (int64_t)B * Hout * Wout * (C >> 3);
+    if (dtype == UR_DT_F16)
+        hipLaunchKernelGGL((resize_nearest_kernel<f16>), dim3(grid_for(total)), dim3(256), 0, s, (const f16*)in, (f16*)out, B,
+                           Hin, Win, Hout, Wout, C);
+    else if (dtype == UR_DT_BF16)
+        hipLaunchKernelGGL((resize_nearest_kernel<bf16>), dim3(grid_for(total)), dim3(256), 0, s, (const bf16*)in, (bf16*)out,
+                           B, Hin, Win, Hout, Wout, C);
     else
         return UR_E_BADARG;
     hipError_t e = hipGetLastError();

@@ -315,7 +315,12 @@ class GroupedDualStreamStep:
                     tsf = [b.attentions[li] for b in blks]
                     x = self._transformer(tsf, x, kc, vtc, self._kvs(tsf[0], ksl))
             if blks[0].upsamplers is not None:
-                x = self._conv("us", [b.upsamplers[0].conv for b in blks], x, ups=True)
+                ucs = [b.upsamplers[0].conv for b in blks]
+                tgt = tuple(up_skips[-1].shape[1:3])  # the reference's upsample_size (controlnet.py:1129-1130)
+                if tgt == (2 * x.shape[1], 2 * x.shape[2]):
+                    x = self._conv("us", ucs, x, ups=True)
+                else:  # latent side not a multiple of 8: general nearest resize, then the conv
+                    x = self._conv("us", ucs, ops.resize_nearest(x, tgt))
         norms = [n.conv_norm_out for n in pair]
         g = pk.get("out.g", norms, [m.weight for m in norms], dt, lambda: _stk(f32(m.weight) for m in norms))
         b_ = pk.get("out.b", norms, [m.bias for m in norms], dt, lambda: _stk(f32(m.bias) for m in norms))

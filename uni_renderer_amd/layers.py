@@ -345,11 +345,12 @@ class Upsample2D(nn.Module):
         self._pk = PackCache()
 
     def forward(self, x, output_size=None):
-        if output_size is not None and tuple(output_size) != (2 * x.shape[1], 2 * x.shape[2]):
-            raise NotImplementedError("upsample_size other than 2x (latent side not divisible by 8)")
         dt = x.dtype
         w = self._pk.get("w", [self.conv.weight], dt, lambda: pack_conv3x3(self.conv.weight, dt))
         b = self._pk.get("b", [self.conv.bias], dt, lambda: f32(self.conv.bias))
+        if output_size is not None and tuple(int(v) for v in output_size) != (2 * x.shape[1], 2 * x.shape[2]):
+            # latent side not a multiple of 8 (controlnet.py:869-883, 1129-1130): F.interpolate(size=...), then the conv
+            return ops.conv3x3(ops.resize_nearest(x, output_size), w, b, hilo=ops.PRECISE_RESIDUAL)
         return ops.conv3x3(x, w, b, ups=True, hilo=ops.PRECISE_RESIDUAL)
 
 

@@ -311,6 +311,17 @@ def _gn_chunks_bytes(B: int, rows: int, C: int, esize: int = 2):
 
 # maps of at most this many pixels per sample (16x16 and 8x8 levels) take the one-launch GroupNorm: measured 6-12 us
 # against 12-21 us for stats + apply; at 32x32 and above the two-launch path wins (tools/gn_bench.py)
+def resize_nearest(x, size):
+    """NHWC nearest-neighbour resize to ``size`` = (H, W) with F.interpolate's index rule."""
+    _require_gpu(x)
+    lib = _lib.load()
+    B, H, W, Cc = x.shape
+    out = torch.empty(B, int(size[0]), int(size[1]), Cc, dtype=x.dtype, device=x.device)
+    check(lib.ur_resize_nearest(x.data_ptr(), out.data_ptr(), B, H, W, int(size[0]), int(size[1]), Cc, DT[x.dtype], _stream()),
+          "ur_resize_nearest")
+    return out
+
+
 GN_FUSED_MAX_ROWS = int(os.environ.get("UR_GN_FUSED_MAX_ROWS", "256"))
 
 
