@@ -133,6 +133,11 @@ typedef struct ur_igemm_desc {
     /* (hi, lo) residual stream, see below: both optional, same leading dimension / z stride as res / out */
     const void* res_lo;  /* low part of the residual: the epilogue adds res + res_lo in fp32 */
     void* out_lo;        /* if set, receives dtype(v - float(dtype(v))) of every stored value v */
+    /* K order of a 3x3 conv.  0: k = tap * (c0 + c1) + c (tap outer).  > 0 (multiple of 64 dividing c0; one source,
+     * c1 == 0): channel blocks outer, k = (c / cblock) * 9 * cblock + tap * cblock + c % cblock -- a workgroup
+     * re-reads an input line after cblock / 64 chunks instead of c0 / 64, which keeps the nine taps of a wide input
+     * (c0 = 640 .. 2560) in the XCD's L2.  The weight matrix must be packed in the same order. */
+    int32_t cblock;
 } ur_igemm_desc;
 
 int ur_igemm(const ur_igemm_desc* d, void* stream);

@@ -387,3 +387,27 @@ def test_no_cpu_fallback():
     from uni_renderer_amd import ops
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ops.add(torch.zeros(8, dtype=torch.float16), torch.zeros(8, dtype=torch.float16))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", [(640, 320, 1, False, None), (960, 320, 1, False, 4), (640, 640, 2, False, None), (1280, 640, 1, True, 2)])
+def test_conv3x3_block_outer_k_order(dev, dtype, cfg):
+    """cblock > 0: K walks (block of 320 channels, tap) with weights packed to match -- same result as the tap-outer
+    order (bit-exact without split-K: the per-output sums run in a different order only across MFMA k-steps, so
+    compare within rounding), incl. stride 2, nearest-2x and split-K launches starting inside a block."""
+    from uni_renderer_amd import ops
+    from uni_renderer_amd.layers import pack_conv3x3
+    cin, cout, stride, ups, sk = cfg
+    x = _rand((2, 12, 10, cin), dtype, dev, seed=1)
+    w = _rand((cout, cin, 3, 3), torch.float32, dev, seed=2) * (cin * 9) ** -0.5
+    b = _rand((cout,), torch.float32, dev, seed=3)
+    cb = ops.conv_cblock(cin)
+    assert cb == 320
+    y0 = ops.conv3x3(x, pack_conv3x3(w, dtype), b, stride=stride, ups=ups, splitk=sk, tile=(None if sk is None else 2))
+    y1 = ops.conv3x3(x, pack_conv3x3(w, dtype, cblock=cb), b, stride=stride, ups=ups, cblock=cb, splitk=sk,
+                     tile=(None if sk is None else 2))
+    xin = x.float().cpu().permute(0, 3, 1, 2)
+    if ups:
+        xin = F.interpolate(xin, scale_factor=2.0, mode="nearest")
+    ref = F.conv2d(xin, w.to(dtype).float().cpu(), b.cpu(), stride=stride, padding=1).permute(0, 2, 3, 1)
+    assert rel_l2(y1, ref) < TOL[dtype] and rel_l2(y1, y0.float().cpu()) < TOL[dtype]

@@ -84,13 +84,13 @@ MFMA-busy {100 * mf[dom['Name']]['mfma_util']:.0f} %.  PMC traffic of the plain 
 ({tr[roof['kernel']]['read_bytes'] / 1e6:.0f} read + {tr[roof['kernel']]['write_bytes'] / 1e6:.0f} written; split-K launches of the symbol {tr.get(roof['kernel'] + '_splitk', {}).get('hbm_bytes_per_launch', 0) / 1e6:.0f} MB incl. their fp32 partial
 slabs) against {roof['algorithmic_bytes_per_launch'] / 1e6:.0f} MB algorithmic: FETCH_SIZE / WRITE_SIZE count what leaves the XCD's L2, not what reaches
 HBM.  In situ the L2 hit rate of these launches is {100 * l2.get(roof['kernel'], {}).get('hit_rate', 0):.0f} % of {l2.get(roof['kernel'], {}).get('tcc_req', 0) * 128 / 1e6:.0f} MB of requests
-(`{tag}_pmc_l2_step.json`); replayed alone the level-0 problem has 92 % hits and 57 MB of misses (`tools/pmc_l2.sh`).  The in-situ excess comes from the launches with wide inputs, not from the
-C = 320 ones: the K axis runs tap-outer, so a workgroup comes back to an input line after C/64 chunks of every
-co-resident workgroup -- 9 MB per XCD at C = 320 (half of the re-reads still hit the 4 MB L2) but 18-27 MB for the
-concatenated 640 / 960-channel inputs of the up path, where all nine taps miss (9 x 42-63 MB); and every XCD of a z
-fetches that z's whole weight matrix (4 x 29.5 MB at the 16x16 level).  Per launch that predicts (7 x 85 + 2 x 378 +
-567 + 150 + 425) / 13 = 192 MB, what the counters show.  The misses are served by the 256 MB Infinity Cache, and the launch takes the same time in situ as replayed alone (75.8 vs 76.3 us for M = 2x16384, N = 320,
-K = 2880), i.e. the K loop is not bound by this traffic (DESIGN.md section 4).
+(`{tag}_pmc_l2_step.json`); replayed alone the level-0 problem has 92 % hits and 57 MB of misses (`tools/pmc_l2.sh`).  With the K axis tap-outer these launches had 83 % hits and 205 MB of
+misses: a workgroup returns to an input line after C/64 chunks of every co-resident workgroup, 9 MB per XCD at C = 320
+but 18-27 MB for the 640 / 960-channel inputs of the up path, where all nine taps missed.  The channel-block-outer K
+order (`ur_igemm_desc.cblock = 320`: K walks (block of 320 channels, tap), weights packed to match) makes every conv
+re-read like the C = 320 one; what remains above the operand bytes is every XCD of a z fetching that z's whole weight
+matrix.  The step time did not change (+-0.3 %): the misses were served by the 256 MB Infinity Cache under an
+MFMA-issue-bound loop (DESIGN.md section 4).
 Attention d = 40 (4096-token self-attention + 77-key cross-attention launches): {att[0]['tflops'] if att else 0:.0f} TFLOP/s,
 MFMA-busy {100 * att_u[0]['mfma_util'] if att_u else 0:.0f} % (north_star asks >= 40 %), PMC traffic {tr.get('attention_d40', {}).get('hbm_bytes_per_launch', 0) / 1e6:.0f} MB/launch vs 84 MB algorithmic Q+K+V+O.
 

@@ -36,6 +36,7 @@ class IGemmDesc(C.Structure):
         ("act", i32), ("out_scale", f32),
         ("zbatch", i32), ("splitk", i32), ("zx_div", i32), ("tile", i32), ("dtype", i32),
         ("res_lo", vp), ("out_lo", vp),
+        ("cblock", i32),
     ]
 
 

@@ -255,17 +255,30 @@ __global__ void __launch_bounds__(WM * WN * 64) igemm_kernel(const ur_igemm_desc
         winc[it] = ok ? 128 : 0;
     }
 
-    // segment state of the loader (all wave-uniform)
+    // segment state of the loader (all wave-uniform).  Tap-outer order (cblock == 0): segments (tap, source) of
+    // c_src/64 chunks.  Block-outer order (cblock > 0, one source): segments (channel block, tap) of cblock/64 chunks.
     const int segs_per_tap = (p.c1 > 0) ? 2 : 1;
-    int seg_tap, seg_src, seg_left;
+    const int cblk = p.cblock;
+    int seg_tap, seg_src, seg_left, seg_coff = 0;  // seg_coff: first channel of the current block
     {
         const int Cin = p.c0 + p.c1;
         const int kglob = kbeg * BK;
-        seg_tap = kglob / Cin;
-        int cc = kglob - seg_tap * Cin;
-        seg_src = (cc >= p.c0) ? 1 : 0;
-        if (seg_src) cc -= p.c0;
-        seg_left = ((seg_src ? p.c1 : p.c0) - cc) / BK;
+        int cc;
+        if (cblk > 0) {
+            const int blk = kglob / (9 * cblk);
+            const int rem = kglob - blk * 9 * cblk;
+            seg_tap = rem / cblk;
+            cc = rem - seg_tap * cblk;
+            seg_src = 0;
+            seg_coff = blk * cblk;
+            seg_left = (cblk - cc) / BK;
+        } else {
+            seg_tap = kglob / Cin;
+            cc = kglob - seg_tap * Cin;
+            seg_src = (cc >= p.c0) ? 1 : 0;
+            if (seg_src) cc -= p.c0;
+            seg_left = ((seg_src ? p.c1 : p.c0) - cc) / BK;
+        }
         // pointers of the first segment, advanced to chunk cc
         const char* sb = seg_src ? x1 : x0;
         const int64_t ld = seg_src ? p.ldx1 : p.ldx0;
@@ -282,16 +295,22 @@ __global__ void __launch_bounds__(WM * WN * 64) igemm_kernel(const ur_igemm_desc
                 ok = xa[it] >= 0;
                 pix = xa[it];
             }
-            const int64_t off = ((int64_t)pix * ld + cc + js * 8) * (int64_t)sizeof(T);
+            const int64_t off = ((int64_t)pix * ld + seg_coff + cc + js * 8) * (int64_t)sizeof(T);
             xptr[it] = ok ? sb + off : zp;
             xinc[it] = ok ? 128 : 0;
         }
     }
 
     auto next_segment = [&]() {
-        seg_src += 1;
-        if (seg_src >= segs_per_tap) { seg_src = 0; seg_tap += 1; }
-        seg_left = (seg_src ? p.c1 : p.c0) / BK;
+        if (cblk > 0) {
+            seg_tap += 1;
+            if (seg_tap == 9) { seg_tap = 0; seg_coff += cblk; }
+            seg_left = cblk / BK;
+        } else {
+            seg_src += 1;
+            if (seg_src >= segs_per_tap) { seg_src = 0; seg_tap += 1; }
+            seg_left = (seg_src ? p.c1 : p.c0) / BK;
+        }
         const char* sb = seg_src ? x1 : x0;
         const int64_t ld = seg_src ? p.ldx1 : p.ldx0;
         const int dy = seg_tap / 3, dx = seg_tap - dy * 3;
@@ -307,7 +326,7 @@ __global__ void __launch_bounds__(WM * WN * 64) igemm_kernel(const ur_igemm_desc
                 ok = xa[it] >= 0;
                 pix = xa[it];
             }
-            const int64_t off = ((int64_t)pix * ld + js * 8) * (int64_t)sizeof(T);
+            const int64_t off = ((int64_t)pix * ld + seg_coff + js * 8) * (int64_t)sizeof(T);
             const char* cand = sb + off;
             xptr[it] = ok ? cand : zp;
             xinc[it] = ok ? 128 : 0;
@@ -621,6 +640,7 @@ extern "C" int ur_igemm(const ur_igemm_desc* din, void* stream) {
         if (d.M != d.B * d.Hout * d.Wout) return UR_E_BADARG;
         if (d.ups && d.stride != 1) return UR_E_BADARG;
     }
+    if (d.cblock < 0 || (d.cblock > 0 && (d.taps != 9 || (d.cblock % BK) || d.c1 != 0 || (d.c0 % d.cblock)))) return UR_E_BADARG;
     if (d.zbatch < 1) d.zbatch = 1;
     if (d.zx_div < 1) d.zx_div = 1;
     if (d.splitk < 1) d.splitk = 1;

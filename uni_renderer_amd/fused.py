@@ -76,13 +76,13 @@ class GroupedDualStreamStep:
         b1 = pk.get("r.b1", rs, [r.norm1.bias for r in rs], dt, lambda: _stk(f32(r.norm1.bias) for r in rs))
         g2 = pk.get("r.g2", rs, [r.norm2.weight for r in rs], dt, lambda: _stk(f32(r.norm2.weight) for r in rs))
         b2 = pk.get("r.b2", rs, [r.norm2.bias for r in rs], dt, lambda: _stk(f32(r.norm2.bias) for r in rs))
-        w1 = pk.get("r.w1", rs, [r.conv1.weight for r in rs], dt, lambda: _stk(pack_conv3x3(r.conv1.weight, dt) for r in rs))
+        w1 = pk.get("r.w1", rs, [r.conv1.weight for r in rs], dt, lambda: _stk(pack_conv3x3(r.conv1.weight, dt, cblock=ops.conv_cblock(r.conv1.weight.shape[1])) for r in rs))
         c1 = pk.get("r.c1", rs, [r.conv1.bias for r in rs], dt, lambda: _stk(f32(r.conv1.bias) for r in rs))
-        w2 = pk.get("r.w2", rs, [r.conv2.weight for r in rs], dt, lambda: _stk(pack_conv3x3(r.conv2.weight, dt) for r in rs))
+        w2 = pk.get("r.w2", rs, [r.conv2.weight for r in rs], dt, lambda: _stk(pack_conv3x3(r.conv2.weight, dt, cblock=ops.conv_cblock(r.conv2.weight.shape[1])) for r in rs))
         c2 = pk.get("r.c2", rs, [r.conv2.bias for r in rs], dt, lambda: _stk(f32(r.conv2.bias) for r in rs))
         lo, hi = slice_
         h = ops.groupnorm(x, g1, b1, r0.eps, x1=x1, groups=r0.groups, silu=True, streams=S)
-        h = ops.conv3x3(h, w1, c1, rowadd=temb[:, lo:hi], streams=S)
+        h = ops.conv3x3(h, w1, c1, rowadd=temb[:, lo:hi], streams=S, cblock=ops.conv_cblock(h.shape[-1]))
         h = ops.groupnorm(h, g2, b2, r0.eps, groups=r0.groups, silu=True, streams=S)
         if r0.conv_shortcut is not None:
             ws = pk.get("r.ws", rs, [r.conv_shortcut.weight for r in rs], dt,
@@ -91,7 +91,8 @@ class GroupedDualStreamStep:
             sc = ops.linear(x, ws, bs, x1=x1, streams=S)
         else:
             sc = x
-        return ops.conv3x3(h, w2, c2, res=sc, out_scale=1.0 / r0.output_scale_factor, streams=S, hilo=self.hilo)
+        return ops.conv3x3(h, w2, c2, res=sc, out_scale=1.0 / r0.output_scale_factor, streams=S, hilo=self.hilo,
+                           cblock=ops.conv_cblock(h.shape[-1]))
 
     def _attn(self, as_: Sequence[Attention], xn, residual, kc, vtc, kv_slice):
         S, pk, dt = len(as_), self.pk, xn.dtype
@@ -162,9 +163,9 @@ class GroupedDualStreamStep:
 
     def _conv(self, name, convs, x, stride=1, ups=False):
         S, pk, dt = len(convs), self.pk, x.dtype
-        w = pk.get(name + ".w", convs, [c.weight for c in convs], dt, lambda: _stk(pack_conv3x3(c.weight, dt) for c in convs))
+        w = pk.get(name + ".w", convs, [c.weight for c in convs], dt, lambda: _stk(pack_conv3x3(c.weight, dt, cblock=ops.conv_cblock(c.weight.shape[1])) for c in convs))
         b = pk.get(name + ".b", convs, [c.bias for c in convs], dt, lambda: _stk(f32(c.bias) for c in convs))
-        return ops.conv3x3(x, w, b, stride=stride, ups=ups, streams=S, hilo=self.hilo)
+        return ops.conv3x3(x, w, b, stride=stride, ups=ups, streams=S, hilo=self.hilo, cblock=ops.conv_cblock(x.shape[-1]))
 
     # ------------------------------------------------------------------ per-phase context (temb, prompt K / V^T)
     def _phase_ctx(self, nets, resnet_lists, cross_lists, semb, ehs):

@@ -71,13 +71,17 @@ class PackCache:
         return val
 
 
-def pack_conv3x3(weight: torch.Tensor, dtype, cin_pad: Optional[int] = None) -> torch.Tensor:
-    """[Co, Ci, 3, 3] -> [Co, 9 * Ci_pad] with k = (ky*3 + kx) * Ci_pad + c (zero padded channels)."""
+def pack_conv3x3(weight: torch.Tensor, dtype, cin_pad: Optional[int] = None, cblock: int = 0) -> torch.Tensor:
+    """[Co, Ci, 3, 3] -> [Co, 9 * Ci_pad] with k = (ky*3 + kx) * Ci_pad + c (zero padded channels), or with
+    ``cblock`` > 0 in the block-outer order k = (c // cblock) * 9 * cblock + (ky*3 + kx) * cblock + c % cblock
+    (``ops.conv_cblock``; the launch must pass the same ``cblock``)."""
     co, ci = weight.shape[:2]
     cp = ci if cin_pad is None else cin_pad
     w = weight.detach().permute(0, 2, 3, 1)  # [Co, ky, kx, Ci]
     if cp != ci:
         w = torch.nn.functional.pad(w, (0, cp - ci))
+    if cblock:
+        w = w.reshape(co, 9, cp // cblock, cblock).permute(0, 2, 1, 3)  # [Co, block, tap, c]
     return w.reshape(co, 9 * cp).to(dtype).contiguous()
 
 
@@ -157,13 +161,15 @@ class ResnetBlock2D(nn.Module):
         pk = self._pk
         g1, b1 = pk.get("n1", [self.norm1.weight, self.norm1.bias], dt, lambda: (f32(self.norm1.weight), f32(self.norm1.bias)))
         g2, b2 = pk.get("n2", [self.norm2.weight, self.norm2.bias], dt, lambda: (f32(self.norm2.weight), f32(self.norm2.bias)))
-        w1 = pk.get("w1", [self.conv1.weight], dt, lambda: pack_conv3x3(self.conv1.weight, dt))
+        w1 = pk.get("w1", [self.conv1.weight], dt,
+                    lambda: pack_conv3x3(self.conv1.weight, dt, cblock=ops.conv_cblock(self.conv1.weight.shape[1])))
         cb1 = pk.get("cb1", [self.conv1.bias], dt, lambda: f32(self.conv1.bias))
-        w2 = pk.get("w2", [self.conv2.weight], dt, lambda: pack_conv3x3(self.conv2.weight, dt))
+        w2 = pk.get("w2", [self.conv2.weight], dt,
+                    lambda: pack_conv3x3(self.conv2.weight, dt, cblock=ops.conv_cblock(self.conv2.weight.shape[1])))
         cb2 = pk.get("cb2", [self.conv2.bias], dt, lambda: f32(self.conv2.bias))
         lo, hi = self.temb_slice
         h = ops.groupnorm(x, g1, b1, self.eps, x1=x1, groups=self.groups, silu=True)
-        h = ops.conv3x3(h, w1, cb1, rowadd=ctx.temb[:, lo:hi])
+        h = ops.conv3x3(h, w1, cb1, rowadd=ctx.temb[:, lo:hi], cblock=ops.conv_cblock(h.shape[-1]))
         h = ops.groupnorm(h, g2, b2, self.eps, groups=self.groups, silu=True)
         if self.conv_shortcut is not None:
             ws = pk.get("ws", [self.conv_shortcut.weight], dt, lambda: pack_matrix(self.conv_shortcut.weight, dt))
@@ -173,7 +179,8 @@ class ResnetBlock2D(nn.Module):
             if x1 is not None:
                 raise RuntimeError("concat input requires a conv_shortcut (in_channels != out_channels)")
             sc = x
-        return ops.conv3x3(h, w2, cb2, res=sc, out_scale=1.0 / self.output_scale_factor, hilo=ops.PRECISE_RESIDUAL)
+        return ops.conv3x3(h, w2, cb2, res=sc, out_scale=1.0 / self.output_scale_factor, hilo=ops.PRECISE_RESIDUAL,
+                           cblock=ops.conv_cblock(h.shape[-1]))
 
 
 class Attention(nn.Module):
@@ -331,9 +338,10 @@ class Downsample2D(nn.Module):
 
     def forward(self, x):
         dt = x.dtype
-        w = self._pk.get("w", [self.conv.weight], dt, lambda: pack_conv3x3(self.conv.weight, dt))
+        w = self._pk.get("w", [self.conv.weight], dt,
+                         lambda: pack_conv3x3(self.conv.weight, dt, cblock=ops.conv_cblock(self.conv.weight.shape[1])))
         b = self._pk.get("b", [self.conv.bias], dt, lambda: f32(self.conv.bias))
-        return ops.conv3x3(x, w, b, stride=2, hilo=ops.PRECISE_RESIDUAL)
+        return ops.conv3x3(x, w, b, stride=2, hilo=ops.PRECISE_RESIDUAL, cblock=ops.conv_cblock(x.shape[-1]))
 
 
 class Upsample2D(nn.Module):
@@ -346,12 +354,13 @@ class Upsample2D(nn.Module):
 
     def forward(self, x, output_size=None):
         dt = x.dtype
-        w = self._pk.get("w", [self.conv.weight], dt, lambda: pack_conv3x3(self.conv.weight, dt))
+        w = self._pk.get("w", [self.conv.weight], dt,
+                         lambda: pack_conv3x3(self.conv.weight, dt, cblock=ops.conv_cblock(self.conv.weight.shape[1])))
         b = self._pk.get("b", [self.conv.bias], dt, lambda: f32(self.conv.bias))
         if output_size is not None and tuple(int(v) for v in output_size) != (2 * x.shape[1], 2 * x.shape[2]):
             # latent side not a multiple of 8 (controlnet.py:869-883, 1129-1130): F.interpolate(size=...), then the conv
-            return ops.conv3x3(ops.resize_nearest(x, output_size), w, b, hilo=ops.PRECISE_RESIDUAL)
-        return ops.conv3x3(x, w, b, ups=True, hilo=ops.PRECISE_RESIDUAL)
+            return ops.conv3x3(ops.resize_nearest(x, output_size), w, b, hilo=ops.PRECISE_RESIDUAL, cblock=ops.conv_cblock(x.shape[-1]))
+        return ops.conv3x3(x, w, b, ups=True, hilo=ops.PRECISE_RESIDUAL, cblock=ops.conv_cblock(x.shape[-1]))
 
 
 def zero_module(m: nn.Module) -> nn.Module:

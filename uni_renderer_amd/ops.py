@@ -141,7 +141,7 @@ def plan_igemm(M: int, N: int, K: int, taps: int = 1, zbatch: int = 1) -> Tuple[
 def igemm(*, x0, w, out, M, N, K, c0, c1=0, x1=None, ldx0, ldx1=0, ldw, ldc, taps=1, conv=None, stride=1, ups=0,
           bias=None, rowadd=None, rows_per_b=0, res=None, ldres=0, n_store=0, act=ACT_NONE, out_scale=1.0,
           zbatch=1, zx=0, zw=0, zout=0, zx1=0, zbias=0, zrow=0, zres=0, zx_div=1, tile=None, splitk=None,
-          res_lo=None, out_lo=None):
+          res_lo=None, out_lo=None, cblock=0):
     _require_gpu(x0)
     lib = _lib.load()
     if tile is None or splitk is None:
@@ -152,6 +152,7 @@ def igemm(*, x0, w, out, M, N, K, c0, c1=0, x1=None, ldx0, ldx1=0, ldw, ldc, tap
     d.x0, d.x1, d.w = _ptr(x0), _ptr(x1), _ptr(w)
     d.bias, d.rowadd, d.res, d.out = _ptr(bias), _ptr(rowadd), _ptr(res), _ptr(out)
     d.res_lo, d.out_lo = _ptr(res_lo), _ptr(out_lo)
+    d.cblock = cblock
     zp = zero_page(x0.device)
     d.zero_page = zp.data_ptr()
     d.ldx0, d.ldx1, d.ldw, d.ldres, d.ldc = ldx0, ldx1, ldw, ldres, ldc
@@ -250,10 +251,21 @@ def linear(x, w, bias=None, *, x1=None, res=None, act=ACT_NONE, out_scale=1.0, r
     return out
 
 
+CONV_CBLOCK = int(os.environ.get("UR_CONV_CBLOCK", "320"))
+
+
+def conv_cblock(cin: int) -> int:
+    """Channel-block size of the block-outer K order for a ``cin``-channel 3x3 conv (0 = tap-outer order): wide inputs
+    (640 .. 2560 channels) walk K as (block of 320 channels, tap) so that the nine taps of a block re-read their input
+    lines out of the XCD's L2 (include/ur_kernels.h, ``cblock``).  Weight packer and launch must agree."""
+    return CONV_CBLOCK if (CONV_CBLOCK > 0 and cin > CONV_CBLOCK and cin % CONV_CBLOCK == 0) else 0
+
+
 def conv3x3(x, w, bias=None, *, x1=None, stride=1, ups=False, rowadd=None, res=None, out_scale=1.0, n_out=None,
-            tile=None, splitk=None, streams=1, hilo=False):
+            tile=None, splitk=None, streams=1, hilo=False, cblock=0):
     """3x3 conv, pad 1, over NHWC ``x`` (optionally cat(x, x1) on channels, optionally after a nearest-2x
-    upsample).  ``w`` is [Npad >= n_out, 9*Cin] with k = (ky*3+kx)*Cin + c.  Output [B, Ho, Wo, n_out].
+    upsample).  ``w`` is [Npad >= n_out, 9*Cin] with k = (ky*3+kx)*Cin + c, or, with ``cblock`` > 0, in the
+    block-outer order k = (c // cblock)*9*cblock + (ky*3+kx)*cblock + c % cblock.  Output [B, Ho, Wo, n_out].
     ``streams=S``: x is [S*B, H, W, C] (stream-major), ``w`` [S, N, 9*Cin], ``bias`` [S, N]: one grouped launch."""
     Bt, H, W, C0 = x.shape
     B = Bt // streams
@@ -273,7 +285,7 @@ def conv3x3(x, w, bias=None, *, x1=None, stride=1, ups=False, rowadd=None, res=N
     igemm(x0=x, x1=x1, w=w, out=out, M=M, N=N, K=9 * (C0 + C1), c0=C0, c1=C1, ldx0=C0, ldx1=C1,
           ldw=w.stride(-2), ldc=N, taps=9, conv=(B, H, W, Ho, Wo), stride=stride, ups=int(ups), bias=bias,
           rowadd=rowadd, rows_per_b=Ho * Wo, res=res, ldres=(N if res is not None else 0), out_scale=out_scale,
-          tile=tile, splitk=splitk, res_lo=lo_of(res), out_lo=lo_of(out), **z)
+          tile=tile, splitk=splitk, res_lo=lo_of(res), out_lo=lo_of(out), cblock=cblock, **z)
     return out
 
 
