@@ -43,7 +43,7 @@ def test_train_step_loss_and_gradients_match_oracle_autograd(dev, dtype, tol):
     out = dual_stream_forward(unet, enc, dec, x.to(dev), c.to(dev), ehs.to(dev), ti.to(dev), ta.to(dev), dtype=dtype)
     loss = mse_losses(out, tgt_img.to(dev), tgt_attr.to(dev))
     loss.backward()
-    assert abs(float(loss) - float(loss_o)) / float(loss_o) < (3e-3 if dtype == torch.float16 else 2e-2)
+    assert abs(float(loss.detach()) - float(loss_o.detach())) / float(loss_o.detach()) < (3e-3 if dtype == torch.float16 else 2e-2)
 
     worst, flat_p, flat_o, rows = ("", 0.0), [], [], []
     for mo, mp in zip(oracle, (unet, enc, dec)):
