@@ -98,7 +98,10 @@ extern "C" {
  *      an fp16/bf16 PAIR whose fp32 sum is the value: `out` keeps the ordinary rounded value (what every GEMM operand
  *      consumer reads), `out_lo` the rounding remainder; residual adds (`res` + `res_lo`) and the norm kernels
  *      (`*_lo` arguments) consume the pair.  This removes the random walk of the storage rounding along the residual
- *      path (55 % of the fp16 error variance of the step) for 2 extra bytes per element.
+ *      path (55 % of the fp16 error variance of the step).  Storage of a low part: for fp16
+ *      streams ONE byte per element, e5m2 = the high byte of the fp16 encoding of the remainder, rounded to nearest
+ *      even (|lo| <= ulp(hi)/2, so three significant bits put the pair at 2^-14 relative); for bf16 streams a bf16.
+ *      Every `*_lo` pointer below is in that format, with the element strides of its hi tensor.
  *   splitk > 1: K is additionally split over grid.z; `partial` is a caller-provided fp32 workspace of
  *      zbatch * splitk * M * ldp floats and the epilogue runs in a second small kernel.
  */

@@ -100,7 +100,7 @@ def test_structural_invariants_on_gpu(dev):
         if ops.PRECISE_RESIDUAL:  # the pair's VALUE is invariant under adding zero
             sk = ops.to_nhwc(b[1][3], torch.float16)
             z = ops.add(sk, torch.zeros_like(sk), hilo=True)
-            assert torch.equal(sk.float() + ops.lo_of(sk).float(), z.float() + z.lo.float())
+            assert torch.equal(sk.float() + ops.lo_float(ops.lo_of(sk)), z.float() + ops.lo_float(z.lo))
         d1 = dec(r1[3], r1[2], ta, ehs, down_block_additional_residuals=a[1], mid_block_additional_residual=a[2],
                  return_dict=False)
         zeros = tuple(torch.zeros_like(t) for t in a[1])

@@ -20,7 +20,7 @@ def main():
         B = 8
         x = torch.randn(B, hw, hw, c0, device=dev).to(dt)
         if hilo:
-            x.lo = (torch.randn(B, hw, hw, c0, device=dev) * 1e-4).to(dt)
+            x.lo = ops.lo_encode(torch.randn(B, hw, hw, c0, device=dev) * 1e-4, dt)
         x1 = torch.randn(B, hw, hw, c1, device=dev).to(dt) if c1 else None
         C = c0 + c1
         g, b = torch.randn(2 * C, device=dev), torch.randn(2 * C, device=dev)

@@ -29,7 +29,7 @@ struct V16 { float v[16]; };
 // an out-of-line function by reference would force a scratch copy of it and turn every p.field into a scratch load
 struct EpiArgs { int N, n_store, rows_per_b, ld_rowadd, act; int64_t ldc, ldres; float out_scale; };
 // low parts of the (hi, lo) residual stream (include/ur_kernels.h): same leading dimensions as res / out
-template <typename T> struct HiLo { const T* res_lo; T* out_lo; };
+template <typename T> struct HiLo { const lo_t<T>* res_lo; lo_t<T>* out_lo; };  // low parts: e5m2 bytes (fp16) / bf16
 
 // Rare path (ragged N tile, conv_out with 4 / 28 channels, unaligned leading dimensions): element-wise with
 // masks.  Kept OUT OF LINE so that the hot kernels carry only the straight-line vector epilogue.
@@ -62,19 +62,19 @@ __device__ __noinline__ void epilogue16_slow(EpiArgs p, T* __restrict__ outz, co
         for (int i = 0; i < 16; ++i)
             if (nc + i < p.N) v[i] += to_f(rp[i]);
         if (hl.res_lo) {
-            const T* rl = hl.res_lo + (int64_t)m * p.ldres + nc;
+            const lo_t<T>* rl = hl.res_lo + (int64_t)m * p.ldres + nc;
             for (int i = 0; i < 16; ++i)
-                if (nc + i < p.N) v[i] += to_f(rl[i]);
+                if (nc + i < p.N) v[i] += lo_to_f(rl[i]);
         }
     }
     T* dst = outz + (int64_t)m * p.ldc + nc;
-    T* dlo = hl.out_lo ? hl.out_lo + (int64_t)m * p.ldc + nc : nullptr;
+    lo_t<T>* dlo = hl.out_lo ? hl.out_lo + (int64_t)m * p.ldc + nc : nullptr;
     for (int i = 0; i < 16; ++i)
         if (nc + i < p.n_store) {
             const float y = v[i] * p.out_scale;
             const T h = from_f<T>(y);
             dst[i] = h;
-            if (dlo) dlo[i] = from_f<T>(y - to_f(h));
+            if (dlo) dlo[i] = lo_from_f<lo_t<T>>(y - to_f(h));
         }
 }
 
@@ -134,11 +134,11 @@ __device__ __forceinline__ void epilogue16(const ur_igemm_desc& p, T* __restrict
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[8 + i] += t[i];
         if (hl.res_lo) {
-            const T* rl = hl.res_lo + (int64_t)m * p.ldres + nc;
-            load8(rl, t);
+            const lo_t<T>* rl = hl.res_lo + (int64_t)m * p.ldres + nc;
+            load_lo<8>(rl, t);
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[i] += t[i];
-            load8(rl + 8, t);
+            load_lo<8>(rl + 8, t);
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[8 + i] += t[i];
         }
@@ -155,14 +155,14 @@ __device__ __forceinline__ void epilogue16(const ur_igemm_desc& p, T* __restrict
 #pragma unroll
     for (int i = 0; i < 8; ++i) t[i] = v[8 + i];
     store8(dst + 8, t);
-    if (hl.out_lo) {  // rounding remainders: v - float(T(v)), exact in fp32
-        T* dlo = hl.out_lo + (int64_t)m * p.ldc + nc;
+    if (hl.out_lo) {  // rounding remainders v - float(T(v)) (exact in fp32), stored as e5m2 bytes / bf16
+        lo_t<T>* dlo = hl.out_lo + (int64_t)m * p.ldc + nc;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) t[i] = v[i] - to_f(from_f<T>(v[i]));
-        store8(dlo, t);
+        for (int i = 0; i < 8; ++i) t[i] = v[i];
+        store_lo8<T>(dlo, t);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) t[i] = v[8 + i] - to_f(from_f<T>(v[8 + i]));
-        store8(dlo + 8, t);
+        for (int i = 0; i < 8; ++i) t[i] = v[8 + i];
+        store_lo8<T>(dlo + 8, t);
     }
 }
 
@@ -475,8 +475,8 @@ __global__ void __launch_bounds__(WM * WN * 64) igemm_kernel(const ur_igemm_desc
                           p.bias ? p.bias + (int64_t)zb * p.zbias : nullptr,
                           p.rowadd ? reinterpret_cast<const T*>(p.rowadd) + (int64_t)zb * p.zrow : nullptr,
                           p.res ? reinterpret_cast<const T*>(p.res) + (int64_t)zb * p.zres : nullptr, m, nc, v,
-                          HiLo<T>{p.res_lo ? reinterpret_cast<const T*>(p.res_lo) + (int64_t)zb * p.zres : nullptr,
-                                  p.out_lo ? reinterpret_cast<T*>(p.out_lo) + (int64_t)zb * p.zout : nullptr});
+                          HiLo<T>{p.res_lo ? reinterpret_cast<const lo_t<T>*>(p.res_lo) + (int64_t)zb * p.zres : nullptr,
+                                  p.out_lo ? reinterpret_cast<lo_t<T>*>(p.out_lo) + (int64_t)zb * p.zout : nullptr});
         }
     }
 }
@@ -508,8 +508,8 @@ __global__ void __launch_bounds__(256) igemm_splitk_reduce(const ur_igemm_desc p
                           p.bias ? p.bias + (int64_t)zb * p.zbias : nullptr,
                           p.rowadd ? reinterpret_cast<const T*>(p.rowadd) + (int64_t)zb * p.zrow : nullptr,
                           p.res ? reinterpret_cast<const T*>(p.res) + (int64_t)zb * p.zres : nullptr, m, nc, v,
-                          HiLo<T>{p.res_lo ? reinterpret_cast<const T*>(p.res_lo) + (int64_t)zb * p.zres : nullptr,
-                                  p.out_lo ? reinterpret_cast<T*>(p.out_lo) + (int64_t)zb * p.zout : nullptr});
+                          HiLo<T>{p.res_lo ? reinterpret_cast<const lo_t<T>*>(p.res_lo) + (int64_t)zb * p.zres : nullptr,
+                                  p.out_lo ? reinterpret_cast<lo_t<T>*>(p.out_lo) + (int64_t)zb * p.zout : nullptr});
     }
 }
 

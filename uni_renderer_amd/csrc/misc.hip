@@ -116,31 +116,27 @@ extern "C" int ur_add(const void* a, const void* b, float alpha, void* out, int6
 }
 
 template <typename T>
-__global__ void __launch_bounds__(256) add_hilo_kernel(const T* __restrict__ a, const T* __restrict__ a_lo,
-                                                       const T* __restrict__ b, const T* __restrict__ b_lo, float alpha,
-                                                       T* __restrict__ out, T* __restrict__ out_lo, int64_t nvec) {
+__global__ void __launch_bounds__(256) add_hilo_kernel(const T* __restrict__ a, const lo_t<T>* __restrict__ a_lo,
+                                                       const T* __restrict__ b, const lo_t<T>* __restrict__ b_lo, float alpha,
+                                                       T* __restrict__ out, lo_t<T>* __restrict__ out_lo, int64_t nvec) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
         float x[8], y[8], t[8];
         load8(a + i * 8, x);
         load8(b + i * 8, y);
         if (a_lo) {
-            load8(a_lo + i * 8, t);
+            load_lo<8>(a_lo + i * 8, t);
 #pragma unroll
             for (int k = 0; k < 8; ++k) x[k] += t[k];
         }
         if (b_lo) {
-            load8(b_lo + i * 8, t);
+            load_lo<8>(b_lo + i * 8, t);
 #pragma unroll
             for (int k = 0; k < 8; ++k) y[k] += t[k];
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) x[k] = x[k] + alpha * y[k];
         store8(out + i * 8, x);
-        if (out_lo) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) t[k] = x[k] - to_f(from_f<T>(x[k]));
-            store8(out_lo + i * 8, t);
-        }
+        if (out_lo) store_lo8<T>(out_lo + i * 8, x);
     }
 }
 
@@ -150,11 +146,11 @@ extern "C" int ur_add_hilo(const void* a, const void* a_lo, const void* b, const
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int64_t nvec = n / 8;
     if (dtype == UR_DT_F16)
-        hipLaunchKernelGGL((add_hilo_kernel<f16>), dim3(grid_for(nvec)), dim3(256), 0, s, (const f16*)a, (const f16*)a_lo,
-                           (const f16*)b, (const f16*)b_lo, alpha, (f16*)out, (f16*)out_lo, nvec);
+        hipLaunchKernelGGL((add_hilo_kernel<f16>), dim3(grid_for(nvec)), dim3(256), 0, s, (const f16*)a, (const lo_t<f16>*)a_lo,
+                           (const f16*)b, (const lo_t<f16>*)b_lo, alpha, (f16*)out, (lo_t<f16>*)out_lo, nvec);
     else if (dtype == UR_DT_BF16)
         hipLaunchKernelGGL((add_hilo_kernel<bf16>), dim3(grid_for(nvec)), dim3(256), 0, s, (const bf16*)a,
-                           (const bf16*)a_lo, (const bf16*)b, (const bf16*)b_lo, alpha, (bf16*)out, (bf16*)out_lo, nvec);
+                           (const lo_t<bf16>*)a_lo, (const bf16*)b, (const lo_t<bf16>*)b_lo, alpha, (bf16*)out, (lo_t<bf16>*)out_lo, nvec);
     else
         return UR_E_BADARG;
     hipError_t e = hipGetLastError();

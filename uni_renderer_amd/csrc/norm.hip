@@ -17,7 +17,7 @@ namespace ur {
 // ------------------------------------------------------------------------------------------
 template <typename T>
 __global__ void __launch_bounds__(256) gn_stats_kernel(const T* __restrict__ x0, const T* __restrict__ x1,
-                                                       const T* __restrict__ x0_lo, const T* __restrict__ x1_lo, int c0,
+                                                       const lo_t<T>* __restrict__ x0_lo, const lo_t<T>* __restrict__ x1_lo, int c0,
                                                        int c1, int rows, int groups, int nchunks,
                                                        float* __restrict__ partial) {
     __shared__ float4 tpart[256];  // per thread: (sum, sumsq) of its channels in group gA, and in group gA + 1
@@ -40,7 +40,7 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(const T* __restrict__ x0,
         const bool active = rsub < rs && cv < nvec && rbeg < rend;
         if (active) {
             const T* base;
-            const T* lbase;  // low part of a (hi, lo) residual-stream input, or null
+            const lo_t<T>* lbase;  // low part of a (hi, lo) residual-stream input, or null
             int64_t ld;
             int co;
             if (cv < nv0) { base = x0 + (int64_t)b * rows * c0; lbase = x0_lo ? x0_lo + (int64_t)b * rows * c0 : nullptr; ld = c0; co = cv * 8; }
@@ -51,16 +51,15 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(const T* __restrict__ x0,
                 for (int u = 0; u < 8; ++u)
                     raw[u] = *reinterpret_cast<const typename Vec8<T>::type*>(base + (int64_t)min(r + u * rs, rend - 1) * ld + co);
                 if (lbase) {
-                    typename Vec8<T>::type rlo[8];
+                    float rlo[8][8];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u)
-                        rlo[u] = *reinterpret_cast<const typename Vec8<T>::type*>(lbase + (int64_t)min(r + u * rs, rend - 1) * ld + co);
+                    for (int u = 0; u < 8; ++u) load_lo<8>(lbase + (int64_t)min(r + u * rs, rend - 1) * ld + co, rlo[u]);
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
                         const float w = (r + u * rs < rend) ? 1.f : 0.f;
 #pragma unroll
                         for (int i = 0; i < 8; ++i) {
-                            const float v = ((float)raw[u][i] + (float)rlo[u][i]) * w;
+                            const float v = ((float)raw[u][i] + rlo[u][i]) * w;
                             s[i] += v;
                             ss[i] += v * v;
                         }
@@ -143,7 +142,7 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(const T* __restrict__ x0,
 
 template <typename T>
 __global__ void __launch_bounds__(256) gn_apply_kernel(const T* __restrict__ x0, const T* __restrict__ x1,
-                                                       const T* __restrict__ x0_lo, const T* __restrict__ x1_lo, int c0,
+                                                       const lo_t<T>* __restrict__ x0_lo, const lo_t<T>* __restrict__ x1_lo, int c0,
                                                        int c1, int rows, int groups, int nstat, int nchunks,
                                                        const float* __restrict__ partial,
                                                        const float* __restrict__ gamma,
@@ -203,7 +202,7 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const T* __restrict__ x0,
             }
         }
         const T* base;
-        const T* lbase;
+        const lo_t<T>* lbase;
         int64_t ld;
         int co;
         if (cv < nv0) { base = x0 + (int64_t)b * rows * c0; lbase = x0_lo ? x0_lo + (int64_t)b * rows * c0 : nullptr; ld = c0; co = cv * 8; }
@@ -214,13 +213,13 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const T* __restrict__ x0,
 #pragma unroll
             for (int u = 0; u < 4; ++u)
                 raw[u] = *reinterpret_cast<const typename Vec8<T>::type*>(base + (int64_t)min(r + u * rs, rend - 1) * ld + co);
-            typename Vec8<T>::type rlo[4];
+            float rlo[4][8];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                if (lbase) rlo[u] = *reinterpret_cast<const typename Vec8<T>::type*>(lbase + (int64_t)min(r + u * rs, rend - 1) * ld + co);
+                if (lbase) load_lo<8>(lbase + (int64_t)min(r + u * rs, rend - 1) * ld + co, rlo[u]);
                 else
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) rlo[u][i] = (T)0.0f;
+                    for (int i = 0; i < 8; ++i) rlo[u][i] = 0.f;
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -228,7 +227,7 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const T* __restrict__ x0,
                     float v[8];
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
-                        const float y = ((float)raw[u][i] + (float)rlo[u][i]) * a[i] + sh[i];
+                        const float y = ((float)raw[u][i] + rlo[u][i]) * a[i] + sh[i];
                         v[i] = silu ? silu_f(y) : y;
                     }
                     store8(ob + (int64_t)(r + u * rs) * C, v);
@@ -244,7 +243,7 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const T* __restrict__ x0,
 // row per wave a C = 320 row is a single 640-byte request per wave.
 // ------------------------------------------------------------------------------------------
 template <typename T, int MAXV, int R>
-__global__ void __launch_bounds__(256) layernorm_kernel(const T* __restrict__ x, const T* __restrict__ x_lo, const float* __restrict__ gamma,
+__global__ void __launch_bounds__(256) layernorm_kernel(const T* __restrict__ x, const lo_t<T>* __restrict__ x_lo, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps, int rows, int C,
                                                         int rows_per_set, int pstride, T* __restrict__ out) {
     const int lane = threadIdx.x & 63;
@@ -257,7 +256,7 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const T* __restrict__ x,
     for (int r = 0; r < R; ++r) {
         s[r] = 0.f;
         const T* xr = x + (int64_t)min(row0 + r, rows - 1) * C;
-        const T* xl = x_lo ? x_lo + (int64_t)min(row0 + r, rows - 1) * C : nullptr;
+        const lo_t<T>* xl = x_lo ? x_lo + (int64_t)min(row0 + r, rows - 1) * C : nullptr;
 #pragma unroll
         for (int k = 0; k < MAXV; ++k) {
             const int cv = lane + k * 64;
@@ -265,7 +264,7 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const T* __restrict__ x,
                 load8(xr + cv * 8, v[r][k]);
                 if (xl) {
                     float l[8];
-                    load8(xl + cv * 8, l);
+                    load_lo<8>(xl + cv * 8, l);
 #pragma unroll
                     for (int i = 0; i < 8; ++i) v[r][k][i] += l[i];
                 }
@@ -325,7 +324,7 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const T* __restrict__ x,
 // row, every lane holds five 16-byte vectors, so all 64 lanes are busy (a C = 320 row only fills 40 lanes of the
 // one-row-per-wave kernel), five loads are in flight per lane and the reductions run over L lanes only.
 template <typename T, int L>
-__global__ void __launch_bounds__(256) layernorm5_kernel(const T* __restrict__ x, const T* __restrict__ x_lo, const float* __restrict__ gamma,
+__global__ void __launch_bounds__(256) layernorm5_kernel(const T* __restrict__ x, const lo_t<T>* __restrict__ x_lo, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, float eps, int rows, int C,
                                                          int rows_per_set, int pstride, T* __restrict__ out) {
     constexpr int RPW = 64 / L;  // rows per wave
@@ -337,11 +336,11 @@ __global__ void __launch_bounds__(256) layernorm5_kernel(const T* __restrict__ x
 #pragma unroll
     for (int k = 0; k < 5; ++k) load8(xr + (sub + k * L) * 8, v[k]);
     if (x_lo) {
-        const T* xl = x_lo + (int64_t)min(row, rows - 1) * C;
+        const lo_t<T>* xl = x_lo + (int64_t)min(row, rows - 1) * C;
 #pragma unroll
         for (int k = 0; k < 5; ++k) {
             float l[8];
-            load8(xl + (sub + k * L) * 8, l);
+            load_lo<8>(xl + (sub + k * L) * 8, l);
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[k][i] += l[i];
         }
@@ -432,7 +431,7 @@ constexpr int GNF_THREADS = 1024;  // 16 waves: one round trip per sweep for the
 
 template <typename T, int P>
 __global__ void __launch_bounds__(GNF_THREADS) gn_fused_kernel(const T* __restrict__ x0, const T* __restrict__ x1,
-                                                       const T* __restrict__ x0_lo, const T* __restrict__ x1_lo, int c0,
+                                                       const lo_t<T>* __restrict__ x0_lo, const lo_t<T>* __restrict__ x1_lo, int c0,
                                                        int c1, int rows, int groups, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float eps, int silu, int bper,
                                                        int pstride, T* __restrict__ out) {
@@ -504,10 +503,10 @@ __global__ void __launch_bounds__(GNF_THREADS) gn_fused_kernel(const T* __restri
             const bool first = c < c0;
             const int64_t off = first ? (row0 + rc) * c0 + c : (row0 + rc) * c1 + (c - c0);
             load_piece<T, P>((first ? x0 : x1) + off, v[u]);
-            const T* lo = first ? x0_lo : x1_lo;
+            const lo_t<T>* lo = first ? x0_lo : x1_lo;
             if (lo) {
                 float w[P];
-                load_piece<T, P>(lo + off, w);
+                load_lo<P>(lo + off, w);
 #pragma unroll
                 for (int k = 0; k < P; ++k) v[u][k] += w[k];
             }
@@ -550,10 +549,10 @@ extern "C" int ur_groupnorm_stats(const void* x0, const void* x1, const void* x0
     dim3 grid(nchunks, B);
     if (dtype == UR_DT_F16)
         hipLaunchKernelGGL((gn_stats_kernel<f16>), grid, dim3(256), 0, s, (const f16*)x0, (const f16*)x1,
-                           (const f16*)x0_lo, (const f16*)x1_lo, c0, c1, rows, groups, nchunks, partial);
+                           (const lo_t<f16>*)x0_lo, (const lo_t<f16>*)x1_lo, c0, c1, rows, groups, nchunks, partial);
     else if (dtype == UR_DT_BF16)
         hipLaunchKernelGGL((gn_stats_kernel<bf16>), grid, dim3(256), 0, s, (const bf16*)x0, (const bf16*)x1,
-                           (const bf16*)x0_lo, (const bf16*)x1_lo, c0, c1, rows, groups, nchunks, partial);
+                           (const lo_t<bf16>*)x0_lo, (const lo_t<bf16>*)x1_lo, c0, c1, rows, groups, nchunks, partial);
     else
         return UR_E_BADARG;
     hipError_t e = hipGetLastError();
@@ -570,11 +569,11 @@ extern "C" int ur_groupnorm_apply(const void* x0, const void* x1, const void* x0
     dim3 grid(nchunks, B);
     if (dtype == UR_DT_F16)
         hipLaunchKernelGGL((gn_apply_kernel<f16>), grid, dim3(256), 0, s, (const f16*)x0, (const f16*)x1,
-                           (const f16*)x0_lo, (const f16*)x1_lo, c0, c1, rows, groups, nstat, nchunks, partial, gamma, beta,
+                           (const lo_t<f16>*)x0_lo, (const lo_t<f16>*)x1_lo, c0, c1, rows, groups, nstat, nchunks, partial, gamma, beta,
                            eps, silu, bper, pstride, (f16*)out);
     else if (dtype == UR_DT_BF16)
         hipLaunchKernelGGL((gn_apply_kernel<bf16>), grid, dim3(256), 0, s, (const bf16*)x0, (const bf16*)x1,
-                           (const bf16*)x0_lo, (const bf16*)x1_lo, c0, c1, rows, groups, nstat, nchunks, partial, gamma,
+                           (const lo_t<bf16>*)x0_lo, (const lo_t<bf16>*)x1_lo, c0, c1, rows, groups, nstat, nchunks, partial, gamma,
                            beta, eps, silu, bper, pstride, (bf16*)out);
     else
         return UR_E_BADARG;
@@ -591,8 +590,8 @@ static int launch_gn_fused(const void* x0, const void* x1, const void* x0_lo, co
     const int cpg = (c0 + c1) / groups;
     dim3 grid(groups, B);
 #define UR_GNF(PP)                                                                                                     \
-    hipLaunchKernelGGL((gn_fused_kernel<T, PP>), grid, dim3(GNF_THREADS), 0, s, (const T*)x0, (const T*)x1, (const T*)x0_lo,   \
-                       (const T*)x1_lo, c0, c1, rows, groups, gamma, beta, eps, silu, bper, pstride, (T*)out)
+    hipLaunchKernelGGL((gn_fused_kernel<T, PP>), grid, dim3(GNF_THREADS), 0, s, (const T*)x0, (const T*)x1, (const lo_t<T>*)x0_lo, \
+                       (const lo_t<T>*)x1_lo, c0, c1, rows, groups, gamma, beta, eps, silu, bper, pstride, (T*)out)
     if (cpg > 128) return UR_E_UNSUPPORTED;  // the group's affine pairs are staged in a 128-entry LDS table
     if (cpg % 8 == 0) UR_GNF(8);
     else if (cpg % 4 == 0) UR_GNF(4);
@@ -622,10 +621,10 @@ static void launch_ln(const void* x, const void* x_lo, const float* gamma, const
     // rows per wave chosen so that a wave keeps >= 4 16-byte loads per lane in flight and the grid still fills the chip
 #define UR_LN(MAXV, R)                                                                                              \
     hipLaunchKernelGGL((layernorm_kernel<T, MAXV, R>), dim3((rows + 4 * R - 1) / (4 * R)), dim3(256), 0, s,          \
-                       (const T*)x, (const T*)x_lo, gamma, beta, eps, rows, C, rows_per_set, pstride, (T*)out)
+                       (const T*)x, (const lo_t<T>*)x_lo, gamma, beta, eps, rows, C, rows_per_set, pstride, (T*)out)
 #define UR_LN5(LL)                                                                                                   \
     hipLaunchKernelGGL((layernorm5_kernel<T, LL>), dim3((rows + 4 * (64 / LL) - 1) / (4 * (64 / LL))), dim3(256), 0, s, \
-                       (const T*)x, (const T*)x_lo, gamma, beta, eps, rows, C, rows_per_set, pstride, (T*)out)
+                       (const T*)x, (const lo_t<T>*)x_lo, gamma, beta, eps, rows, C, rows_per_set, pstride, (T*)out)
     if (C == 320) { UR_LN5(8); return; }
     if (C == 640) { UR_LN5(16); return; }
     if (C == 1280) { UR_LN5(32); return; }

@@ -90,6 +90,60 @@ __device__ __forceinline__ void store8(T* p, const float (&o)[8]) {
     *reinterpret_cast<typename Vec8<T>::type*>(p) = v;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Low parts of the (hi, lo) residual stream (include/ur_kernels.h).  The low part of an fp16 value v is
+// lo = v - float(half(v)), |lo| <= ulp(hi)/2; three significant bits of it already push the pair's rounding error to
+// 2^-14 relative, so fp16 streams store it as ONE byte: e5m2 = the high byte of the fp16 encoding of lo (round to
+// nearest even).  bf16 streams keep a bf16 low part (e5m2 cannot hold bf16's exponent range).
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T> struct LoT { typedef T type; };
+template <> struct LoT<f16> { typedef unsigned char type; };
+template <typename T> using lo_t = typename LoT<T>::type;
+
+__device__ __forceinline__ float lo_to_f(unsigned char b) {
+    const unsigned short bits = (unsigned short)((unsigned)b << 8);
+    return (float)__builtin_bit_cast(f16, bits);
+}
+__device__ __forceinline__ float lo_to_f(bf16 v) { return (float)v; }
+__device__ __forceinline__ float lo_to_f(f16 v) { return (float)v; }
+template <typename L> __device__ __forceinline__ L lo_from_f(float v);
+template <> __device__ __forceinline__ unsigned char lo_from_f<unsigned char>(float v) {
+    const unsigned bits = __builtin_bit_cast(unsigned short, (f16)v);
+    return (unsigned char)((bits + 0x7Fu + ((bits >> 8) & 1u)) >> 8);  // round to nearest even on the dropped byte
+}
+template <> __device__ __forceinline__ bf16 lo_from_f<bf16>(float v) { return (bf16)v; }
+template <> __device__ __forceinline__ f16 lo_from_f<f16>(float v) { return (f16)v; }
+
+// N consecutive low parts (N = 2, 4, 8) -> float, one vector load
+template <int N>
+__device__ __forceinline__ void load_lo(const unsigned char* p, float (&v)[N]) {
+    unsigned char b[N];
+    if constexpr (N == 8) { const uint2 r = *reinterpret_cast<const uint2*>(p); __builtin_memcpy(b, &r, 8); }
+    else if constexpr (N == 4) { const unsigned r = *reinterpret_cast<const unsigned*>(p); __builtin_memcpy(b, &r, 4); }
+    else { const unsigned short r = *reinterpret_cast<const unsigned short*>(p); __builtin_memcpy(b, &r, 2); }
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = lo_to_f(b[i]);
+}
+template <int N>
+__device__ __forceinline__ void load_lo(const bf16* p, float (&v)[N]) {
+    bf16 h[N];
+    if constexpr (N == 8) { const uint4 r = *reinterpret_cast<const uint4*>(p); __builtin_memcpy(h, &r, 16); }
+    else if constexpr (N == 4) { const uint2 r = *reinterpret_cast<const uint2*>(p); __builtin_memcpy(h, &r, 8); }
+    else { const unsigned r = *reinterpret_cast<const unsigned*>(p); __builtin_memcpy(h, &r, 4); }
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = (float)h[i];
+}
+// v[i] - float(T(v[i])) for 8 values -> low parts, one vector store
+template <typename T>
+__device__ __forceinline__ void store_lo8(lo_t<T>* p, const float (&v)[8]) {
+    lo_t<T> b[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) b[i] = lo_from_f<lo_t<T>>(v[i] - to_f(from_f<T>(v[i])));
+    if constexpr (sizeof(lo_t<T>) == 1) { uint2 r; __builtin_memcpy(&r, b, 8); *reinterpret_cast<uint2*>(p) = r; }
+    else { uint4 r; __builtin_memcpy(&r, b, 16); *reinterpret_cast<uint4*>(p) = r; }
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

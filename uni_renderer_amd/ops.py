@@ -213,9 +213,30 @@ def view_hilo(t, *shape):
     return v
 
 
+def lo_dtype(dtype):
+    """Storage type of the low parts: one e5m2 byte (= the high byte of the fp16 encoding of the remainder; three
+    significant bits put the pair at 2^-14 relative) for fp16 streams, bf16 for bf16 streams (csrc/ur_common.h)."""
+    return torch.uint8 if dtype == torch.float16 else dtype
+
+
+def lo_float(lo: torch.Tensor) -> torch.Tensor:
+    """fp32 values of a low-part tensor (tests / diagnostics)."""
+    if lo.dtype == torch.uint8:
+        return (lo.to(torch.int16) << 8).view(torch.float16).float()
+    return lo.float()
+
+
+def lo_encode(v: torch.Tensor, dtype) -> torch.Tensor:
+    """fp32 remainders -> low-part storage of a ``dtype`` stream (round to nearest even; tests / glue)."""
+    if dtype != torch.float16:
+        return v.to(dtype)
+    bits = v.to(torch.float16).view(torch.int16).to(torch.int32) & 0xFFFF
+    return ((bits + 0x7F + ((bits >> 8) & 1)) >> 8).to(torch.uint8)
+
+
 def _with_lo(out, want: bool):
     if want:
-        out.lo = torch.empty_like(out)
+        out.lo = torch.empty(out.shape, dtype=lo_dtype(out.dtype), device=out.device)
     return out
 
 
