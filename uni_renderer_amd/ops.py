@@ -187,8 +187,10 @@ def igemm(*, x0, w, out, M, N, K, c0, c1=0, x1=None, ldx0, ldx1=0, ldw, ldc, tap
         # pixels), weights, output, plus the residual operand and the low parts of the (hi, lo) stream when present
         in_rows = M * (stride * stride if taps == 9 else 1) / (4 ** ups if taps == 9 else 1)
         n_out = N / 2 if act == ACT_GEGLU else N
-        extra = (res is not None) + (res_lo is not None) + (out_lo is not None)
-        _prof_end(e0, key, 2.0 * M * N * K * z, (in_rows * K / taps + N * K + M * n_out * (1 + extra)) * el * z)
+        lo_el = 1 if x0.dtype == torch.float16 else el  # low parts: one e5m2 byte (fp16) / bf16
+        lo_bytes = M * n_out * lo_el * ((res_lo is not None) + (out_lo is not None))
+        _prof_end(e0, key, 2.0 * M * N * K * z,
+                  ((in_rows * K / taps + N * K + M * n_out * (1 + (res is not None))) * el + lo_bytes) * z)
     return out
 
 
