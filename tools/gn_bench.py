@@ -28,6 +28,13 @@ def main():
         usf = time_graph(lambda: ops.groupnorm(x, g, b, 1e-5, x1=x1, silu=True, streams=2, fused=True))
         a = ops.groupnorm(x, g, b, 1e-5, x1=x1, silu=True, streams=2, fused=False).float()
         f = ops.groupnorm(x, g, b, 1e-5, x1=x1, silu=True, streams=2, fused=True).float()
+        if os.environ.get("GN_SWEEP"):
+            ns0, na0 = ops._gn_chunks_bytes(B, hw * hw, C, 2)
+            res = {}
+            for ns in sorted({max(1, ns0 // 2), ns0, min(32, ns0 * 2)}):
+                for na in sorted({max(1, na0 // 4), max(1, na0 // 2), na0, na0 * 2}):
+                    res[f"{ns},{na}"] = round(time_graph(lambda: ops.groupnorm(x, g, b, 1e-5, x1=x1, silu=True, streams=2, nstat=ns, napply=na)), 2)
+            print(json.dumps(dict(hw=hw, c0=c0, c1=c1, default=f"{ns0},{na0}", sweep=dict(sorted(res.items(), key=lambda kv: kv[1])[:5]))), flush=True)
         print(json.dumps(dict(hw=hw, c0=c0, c1=c1, hi_MB=round(B * hw * hw * C * 2 / 1e6, 1), two_launch_us=round(us, 2),
                               fused_us=round(usf, 2), max_abs_diff=float((a - f).abs().max()))), flush=True)
 

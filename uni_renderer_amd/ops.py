@@ -340,12 +340,10 @@ def _gn_chunks_bytes(B: int, rows: int, C: int, esize: int = 2):
     at 32 per sample (every apply workgroup re-reduces them in its prologue)."""
     sample_bytes = rows * C * esize
     nstat = max(1, min(sample_bytes // (64 << 10), rows // 2, 32))
-    napply = max(1, min(sample_bytes // (20 << 10), rows // 2, 512, max(1, 4096 // max(B, 1))))
+    napply = max(1, min(sample_bytes // (20 << 10), rows // 2, 128, max(1, 4096 // max(B, 1))))  # > 128: slower (gn_bench)
     return int(nstat), int(napply)
 
 
-# maps of at most this many pixels per sample (16x16 and 8x8 levels) take the one-launch GroupNorm: measured 6-12 us
-# against 12-21 us for stats + apply; at 32x32 and above the two-launch path wins (tools/gn_bench.py)
 def resize_nearest(x, size):
     """NHWC nearest-neighbour resize to ``size`` = (H, W) with F.interpolate's index rule."""
     _require_gpu(x)
@@ -357,6 +355,8 @@ def resize_nearest(x, size):
     return out
 
 
+# maps of at most this many pixels per sample (16x16 and 8x8 levels) take the one-launch GroupNorm: measured 6-12 us
+# against 12-21 us for stats + apply; at 32x32 and above the two-launch path wins (tools/gn_bench.py)
 GN_FUSED_MAX_ROWS = int(os.environ.get("UR_GN_FUSED_MAX_ROWS", "256"))
 
 
