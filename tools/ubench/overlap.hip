@@ -1,0 +1,73 @@
+// Micro-benchmark: do the matrix pipe and the VALU of ONE SIMD overlap?  512-thread workgroups, one per CU: waves
+// 0-3 (one per SIMD) run back-to-back v_mfma_f32_32x32x16_f16, waves 4-7 (their SIMD partners) run v_exp_f32 + v_fma.
+// Times: MFMA waves alone, VALU waves alone, both, and the same work interleaved inside every wave.
+//   hipcc --offload-arch=gfx950 -O3 -o overlap overlap.hip && ./overlap
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+// mode bit 0: MFMA waves active, bit 1: VALU waves active, mode 4: every wave interleaves both (half the work each)
+template <int MODE, int nm, int nv>
+__global__ void __launch_bounds__(512) k(float* out, int iters) {
+    const int wave = threadIdx.x >> 6;
+    h8 a;
+    for (int i = 0; i < 8; ++i) a[i] = (_Float16)(threadIdx.x * 0.001f + i);
+    f16v d[2] = {};
+    float e[8];
+    for (int i = 0; i < 8; ++i) e[i] = -0.001f * (threadIdx.x + i);
+    if (MODE == 4) {
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int u = 0; u < nm / 2; ++u) {
+                d[u & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, a, d[u & 1], 0, 0, 0);
+#pragma unroll
+                for (int v = 0; v < (nv / 2) / (nm / 2); ++v) e[v & 7] = __builtin_amdgcn_exp2f(e[v & 7]) - 1.0f;
+            }
+        }
+    } else if (wave < 4) {
+        if (MODE & 1)
+            for (int it = 0; it < iters; ++it)
+#pragma unroll
+                for (int u = 0; u < nm; ++u) d[u & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, a, d[u & 1], 0, 0, 0);
+    } else {
+        if (MODE & 2)
+            for (int it = 0; it < iters; ++it)
+#pragma unroll
+                for (int v = 0; v < nv; ++v) e[v & 7] = __builtin_amdgcn_exp2f(e[v & 7]) - 1.0f;
+    }
+    float s = d[0][0] + d[1][5];
+    for (int i = 0; i < 8; ++i) s += e[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+template <int MODE, int nm, int nv>
+float run(float* out, int iters) {
+    k<MODE, nm, nv><<<256, 512>>>(out, 10);
+    hipDeviceSynchronize();
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0);
+    k<MODE, nm, nv><<<256, 512>>>(out, iters);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    return ms;
+}
+
+int main() {
+    float* out;
+    hipMalloc(&out, 256 * 512 * 4);
+    const int iters = 20000;
+#define ROW(NM, NV)                                                                                                   \
+    {                                                                                                                 \
+        const float m = run<1, NM, NV>(out, iters), v = run<2, NM, NV>(out, iters), b = run<3, NM, NV>(out, iters),    \
+                    x = run<4, NM, NV>(out, iters);                                                                    \
+        printf("per iteration: %d MFMA 32x32x16 | %d (v_exp + v_sub): mfma waves alone %.3f ms, valu waves alone %.3f ms, " \
+               "both (partner waves of a SIMD) %.3f ms [sum %.3f, max %.3f], interleaved in every wave (half each) %.3f ms\n", \
+               NM, NV, m, v, b, m + v, m > v ? m : v, x);                                                               \
+    }
+    ROW(8, 16) ROW(8, 32) ROW(8, 64) ROW(8, 128)
+    return 0;
+}
