@@ -28,11 +28,32 @@ def _w2(conv_or_lin, dt):
     return w.reshape(w.shape[0], -1).to(dt)
 
 
-def _resnet(r, x, temb_act, dt, x1=None):
-    """models/unet_2d_blocks.py:1100-1111 (ResnetBlock2D, time_embedding_norm='default')."""
+def _temb_projections(resnets, temb_act, dt):
+    """All ``time_emb_proj`` of a network phase as ONE GEMM (what the inference path does too): the M = batch-size
+    linears, their two backward GEMMs, three transposes and the bias column sum per resnet are launch-bound, ~25
+    launches per resnet.  Returns {id(resnet): [B, C_out] column slice}; autograd splits the gradients back."""
+    w = torch.cat([r.time_emb_proj.weight for r in resnets], 0)
+    b = torch.cat([r.time_emb_proj.bias for r in resnets], 0)
+    t_all = A.linear(temb_act, w.to(dt), b)
+    out, off = {}, 0
+    for r in resnets:
+        n = r.time_emb_proj.weight.shape[0]
+        out[id(r)] = t_all[:, off:off + n]
+        off += n
+    return out
+
+
+def _resnets_of(blocks, mid=None):
+    rs = [r for blk in blocks for r in blk.resnets]
+    return rs + (list(mid.resnets) if mid is not None else [])
+
+
+def _resnet(r, x, temb, dt, x1=None):
+    """models/unet_2d_blocks.py:1100-1111 (ResnetBlock2D, time_embedding_norm='default'); ``temb``: the dict of
+    _temb_projections."""
     xin = torch.cat([x, x1], -1) if x1 is not None else x
     h = A.GroupNorm.apply(xin, r.norm1.weight, r.norm1.bias, r.eps, r.groups, True)
-    t = A.linear(temb_act, _w2(r.time_emb_proj, dt), r.time_emb_proj.bias)
+    t = temb[id(r)]
     h = A.conv3x3(h, A.pack_conv_weight(r.conv1.weight, dt), r.conv1.bias, rowadd=t)
     h = A.GroupNorm.apply(h, r.norm2.weight, r.norm2.bias, r.eps, r.groups, True)
     sc = xin if r.conv_shortcut is None else A.linear(xin, _w2(r.conv_shortcut, dt), r.conv_shortcut.bias)
@@ -82,7 +103,8 @@ def _time(net, timesteps, B, dt, dev):
     return A.SiLU.apply(emb)  # every resnet applies SiLU to the embedding before its projection
 
 
-def _down_mid(net, x, temb, ehs, dt):
+def _down_mid(net, x, temb_act, ehs, dt):
+    temb = _temb_projections(_resnets_of(net.down_blocks, net.mid_block), temb_act, dt)
     skips = [x]
     for blk in net.down_blocks:
         for i, r in enumerate(blk.resnets):
@@ -100,7 +122,8 @@ def _down_mid(net, x, temb, ehs, dt):
     return x, skips
 
 
-def _up_out(net, x, skips: List[torch.Tensor], temb, ehs, dt):
+def _up_out(net, x, skips: List[torch.Tensor], temb_act, ehs, dt):
+    temb = _temb_projections(_resnets_of(net.up_blocks), temb_act, dt)
     skips = list(skips)
     for blk in net.up_blocks:
         for i, r in enumerate(blk.resnets):
