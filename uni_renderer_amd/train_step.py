@@ -62,18 +62,41 @@ def _resnet(r, x, temb, dt, x1=None):
     return A.conv3x3(h, A.pack_conv_weight(r.conv2.weight, dt), r.conv2.bias, res=sc)
 
 
-def _attn(a, xn, ctx_tokens, res, dt):
-    src = xn if ctx_tokens is None else ctx_tokens
-    q = A.linear(xn, _w2(a.to_q, dt))
-    k = A.linear(src, _w2(a.to_k, dt))
-    v = A.linear(src, _w2(a.to_v, dt))
-    o = A.Attention.apply(q, k, v, a.heads)
+def _self_attn(a, xn, res, dt):
+    """q | k | v as ONE projection (one forward and two backward GEMMs instead of three of each)."""
+    Cc = a.to_q.weight.shape[0]
+    qkv = A.linear(xn, torch.cat([a.to_q.weight, a.to_k.weight, a.to_v.weight], 0).to(dt))
+    o = A.Attention.apply(qkv[..., :Cc], qkv[..., Cc:2 * Cc], qkv[..., 2 * Cc:], a.heads)
     return A.linear(o, _w2(a.to_out[0], dt), a.to_out[0].bias, res=res)
 
 
-def _tblock(b, x, ehs, dt):
-    x = _attn(b.attn1, A.LayerNorm.apply(x, b.norm1.weight, b.norm1.bias, b.norm1.eps), None, x, dt)
-    x = _attn(b.attn2, A.LayerNorm.apply(x, b.norm2.weight, b.norm2.bias, b.norm2.eps), ehs, x, dt)
+def _cross_attn(a, xn, kv, res, dt):
+    """``kv`` [B, 77, 2C]: this block's columns of the phase-wide prompt projection (_context_projections)."""
+    Cc = a.to_q.weight.shape[0]
+    q = A.linear(xn, _w2(a.to_q, dt))
+    o = A.Attention.apply(q, kv[..., :Cc], kv[..., Cc:], a.heads)
+    return A.linear(o, _w2(a.to_out[0], dt), a.to_out[0].bias, res=res)
+
+
+def _context_projections(blocks, ehs, dt):
+    """to_k | to_v of every cross-attention of a network phase applied to the prompt embedding as ONE GEMM (M = 77 B
+    rows: per block these projections and their backward are launch-bound).  {id(block): [B, 77, 2C] column slice}."""
+    tbs = [tb for blk in blocks for t in getattr(blk, "attentions", []) for tb in t.transformer_blocks]
+    if not tbs:
+        return {}
+    w = torch.cat([w_ for tb in tbs for w_ in (tb.attn2.to_k.weight, tb.attn2.to_v.weight)], 0)
+    kv_all = A.linear(ehs, w.to(dt))
+    out, off = {}, 0
+    for tb in tbs:
+        n = 2 * tb.attn2.to_k.weight.shape[0]
+        out[id(tb)] = kv_all[..., off:off + n]
+        off += n
+    return out
+
+
+def _tblock(b, x, kvs, dt):
+    x = _self_attn(b.attn1, A.LayerNorm.apply(x, b.norm1.weight, b.norm1.bias, b.norm1.eps), x, dt)
+    x = _cross_attn(b.attn2, A.LayerNorm.apply(x, b.norm2.weight, b.norm2.bias, b.norm2.eps), kvs[id(b)], x, dt)
     proj, out = b.ff.net[0].proj, b.ff.net[2]
     h = A.linear(A.LayerNorm.apply(x, b.norm3.weight, b.norm3.bias, b.norm3.eps), _w2(proj, dt), proj.bias)
     return A.linear(A.GEGLU.apply(h), _w2(out, dt), out.bias, res=x)
@@ -105,6 +128,7 @@ def _time(net, timesteps, B, dt, dev):
 
 def _down_mid(net, x, temb_act, ehs, dt):
     temb = _temb_projections(_resnets_of(net.down_blocks, net.mid_block), temb_act, dt)
+    ehs = _context_projections(list(net.down_blocks) + [net.mid_block], ehs, dt)  # from here on: per-block K | V
     skips = [x]
     for blk in net.down_blocks:
         for i, r in enumerate(blk.resnets):
@@ -124,6 +148,7 @@ def _down_mid(net, x, temb_act, ehs, dt):
 
 def _up_out(net, x, skips: List[torch.Tensor], temb_act, ehs, dt):
     temb = _temb_projections(_resnets_of(net.up_blocks), temb_act, dt)
+    ehs = _context_projections(net.up_blocks, ehs, dt)
     skips = list(skips)
     for blk in net.up_blocks:
         for i, r in enumerate(blk.resnets):
