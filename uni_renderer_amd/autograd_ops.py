@@ -167,7 +167,7 @@ def conv3x3(x, wp, b=None, res=None, rowadd=None, stride=1):
 def pack_conv_weight(weight: torch.Tensor, dtype, cin_pad=None) -> torch.Tensor:
     """differentiable version of layers.pack_conv3x3: [Co, Ci, 3, 3] fp32 master -> [Co][(ky,kx,ci_pad)] compute dtype."""
     co, ci = weight.shape[:2]
-    w = weight.permute(0, 2, 3, 1)
+    w = weight.to(dtype).permute(0, 2, 3, 1)  # cast first: the strided repack then moves 2-byte elements
     if cin_pad is not None and cin_pad != ci:
         w = torch.nn.functional.pad(w, (0, cin_pad - ci))
-    return w.reshape(co, -1).to(dtype).contiguous()
+    return w.reshape(co, -1).contiguous()
