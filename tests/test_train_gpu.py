@@ -188,3 +188,51 @@ def test_reference_losses_match_oracle_autograd(dev, inverse):
     err = (num / den) ** 0.5
     print({"inverse": inverse, "loss": float(loss.detach()), "loss_oracle": float(loss_o.detach()), "grad_rel_l2_all": err})
     assert err < 1.5e-2
+
+
+def test_training_step_captured_into_a_hip_graph(dev):
+    """The whole optimisation step -- forward, losses, backward, clipping, fused AdamW -- captured once into a HIP graph
+    (train_step(as_tensors=True): no host synchronisation inside) and replayed must walk the same parameter trajectory
+    as the eager step."""
+    from uni_renderer_amd.train_step import train_step
+
+    def setup():
+        oracle = O.build_triplet(O.TINY_CONFIG, seed=34)
+        nets = build_product_from_oracle(*oracle, torch.float32, dev)
+        for m in nets:
+            m.train()
+            m.requires_grad_(True)
+        opt = torch.optim.AdamW([p for m in nets for p in m.parameters()], lr=2e-4, fused=True, capturable=True)
+        return nets, opt
+
+    x, c, ehs, ti, ta = [t.to(dev) for t in O.make_inputs(2, 16, 64, seed=20)]
+    g = torch.Generator().manual_seed(21)
+    batch = dict(x_t=x, cond=c, ehs=ehs, t_img=ti, t_attr=ta, target_img=torch.randn(2, 4, 16, 16, generator=g).to(dev),
+                 target_attr=torch.randn(2, 28, 16, 16, generator=g).to(dev))
+    nets_e, opt_e = setup()
+    eager = [train_step(nets_e, batch, optimizer=opt_e, dtype=torch.bfloat16)["loss"] for _ in range(5)]
+
+    nets_g, opt_g = setup()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    losses = []
+    with torch.cuda.stream(side):
+        for _ in range(2):  # the usual warm-up iterations on the capture stream: they are real steps 1 and 2
+            losses.append(train_step(nets_g, batch, optimizer=opt_g, dtype=torch.bfloat16, as_tensors=True)["loss"].clone())
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        st = train_step(nets_g, batch, optimizer=opt_g, dtype=torch.bfloat16, as_tensors=True)
+    # NOTE: capture does not execute; replays are steps 3, 4, 5
+    for _ in range(3):
+        graph.replay()
+        losses.append(st["loss"].clone())
+    torch.cuda.synchronize()
+    losses = [float(l) for l in losses]
+    print({"eager": eager, "graphed": losses})
+    assert all(abs(a - b) <= 2e-3 * abs(a) for a, b in zip(eager, losses)), (eager, losses)
+    num = sum(float(((pe.detach() - pg.detach()) ** 2).sum()) for me, mg in zip(nets_e, nets_g)
+              for pe, pg in zip(me.parameters(), mg.parameters()))
+    den = sum(float((pe.detach() ** 2).sum()) for me in nets_e for pe in me.parameters())
+    assert (num / den) ** 0.5 < 1e-4

@@ -26,6 +26,8 @@ def main():
     ap.add_argument("--latent", type=int, default=64)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--graph", action="store_true", help="capture the whole step (forward, backward, clipping, AdamW) "
+                    "into one HIP graph and time replays (single GPU)")
     args = ap.parse_args()
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
     torch.cuda.set_device(local)
@@ -45,15 +47,36 @@ def main():
                  t_img=torch.randint(0, 1000, (B,), device=dev, generator=g),
                  t_attr=torch.randint(0, 1000, (B,), device=dev, generator=g),
                  target_img=mk(B, 4, L, L), target_attr=mk(B, 28, L, L))
-    opt = torch.optim.AdamW([p for m in nets for p in m.parameters()], lr=1e-5, fused=True)
+    opt = torch.optim.AdamW([p for m in nets for p in m.parameters()], lr=1e-5, fused=True, capturable=args.graph)
     buckets = GradientBuckets(nets, comm_dtype=torch.bfloat16) if world > 1 else None
-    stats = train_step(nets, batch, optimizer=opt, buckets=buckets, dtype=dt)  # warm-up (packs nothing: weights change)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        stats = train_step(nets, batch, optimizer=opt, buckets=buckets, dtype=dt)
-    torch.cuda.synchronize()
-    dtm = (time.perf_counter() - t0) / args.steps
+    if args.graph:
+        assert world == 1, "--graph: single GPU"
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):  # warm-up on the capture stream (allocator pools, lazy optimizer state)
+                train_step(nets, batch, optimizer=opt, dtype=dt, as_tensors=True)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            gstats = train_step(nets, batch, optimizer=opt, dtype=dt, as_tensors=True)
+        g.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            g.replay()
+        torch.cuda.synchronize()
+        dtm = (time.perf_counter() - t0) / args.steps
+        stats = {k: float(v) for k, v in gstats.items()}
+    else:
+        stats = train_step(nets, batch, optimizer=opt, buckets=buckets, dtype=dt)  # warm-up (packs nothing: weights change)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            stats = train_step(nets, batch, optimizer=opt, buckets=buckets, dtype=dt)
+        torch.cuda.synchronize()
+        dtm = (time.perf_counter() - t0) / args.steps
     if world > 1:
         t = torch.tensor([dtm], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -61,7 +84,7 @@ def main():
     if rank == 0:
         print(json.dumps(dict(metric="train-steps/sec (dual-UNet, 512^2, per-GPU batch %d)" % B, value=round(world / dtm, 4),
                               ms_per_step=round(dtm * 1e3, 1), n_gpus=world, dtype=args.dtype, loss=stats["loss"],
-                              grad_norm=stats.get("grad_norm"), peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2**30, 1))))
+                              grad_norm=stats.get("grad_norm"), graph=bool(args.graph), peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2**30, 1))))
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

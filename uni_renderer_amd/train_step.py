@@ -245,13 +245,15 @@ def reference_losses(nets: Sequence[torch.nn.Module], batch: Dict[str, torch.Ten
 
 
 def train_step(nets: Sequence[torch.nn.Module], batch: Dict[str, torch.Tensor], optimizer=None, buckets=None,
-               dtype=torch.bfloat16, max_grad_norm: Optional[float] = 1.0, inverse: Optional[bool] = None
-               ) -> Dict[str, float]:
+               dtype=torch.bfloat16, max_grad_norm: Optional[float] = 1.0, inverse: Optional[bool] = None,
+               as_tensors: bool = False) -> Dict[str, float]:
     """One optimisation step: forward, losses, backward (HIP kernels), gradient all-reduce (``buckets``: a
     parallel.GradientBuckets, no-op on one rank), clipping (train.py:1422-1424), optimizer step.
     ``inverse``: None = the plain two-stream MSE objective (mse_losses); True / False = the reference's inverse-rendering
     (cycle consistency) / rendering (contrastive) objectives (reference_losses).  Ranks may pick different branches
-    (compute_t, train.py:445): parameters without a gradient contribute zeros to the buckets."""
+    (compute_t, train.py:445): parameters without a gradient contribute zeros to the buckets.
+    ``as_tensors``: return the statistics as device tensors (no host synchronisation: the step can then be captured
+    into a HIP graph, tools/train_bench.py --graph)."""
     unet, enc, dec = nets
     if inverse is None:
         out = dual_stream_forward(unet, enc, dec, batch["x_t"], batch["cond"], batch["ehs"], batch["t_img"],
@@ -264,10 +266,10 @@ def train_step(nets: Sequence[torch.nn.Module], batch: Dict[str, torch.Tensor], 
     loss.backward()
     if buckets is not None:
         buckets.all_reduce_mean()
-    stats = {"loss": float(loss.detach())}
+    stats = {"loss": loss.detach()}
     if max_grad_norm is not None:
         params = [p for n in nets for p in n.parameters() if p.grad is not None]
-        stats["grad_norm"] = float(torch.nn.utils.clip_grad_norm_(params, max_grad_norm))
+        stats["grad_norm"] = torch.nn.utils.clip_grad_norm_(params, max_grad_norm)
     if optimizer is not None:
         optimizer.step()
-    return stats
+    return stats if as_tensors else {k: float(v) for k, v in stats.items()}
