@@ -103,6 +103,26 @@ MFMA-busy {100 * att_u[0]['mfma_util'] if att_u else 0:.0f} % (north_star asks >
 Sum over all `ur::` kernels: {tot / 1e6:.1f} ms in the profiled process = {tot / 1e6 / 16:.2f} ms per step execution; all kernels incl.
 the harness's torch fills/copies: {alltot / 1e6:.1f} ms.
 """
+    tk = os.path.join(P, f"{tag}_train_kernel_stats.csv")
+    if os.path.exists(tk):
+        trows = list(csv.DictReader(open(tk)))
+        n = 6  # step executions in that process: 2 warm-up + 1 + 3 graph replays
+        ttot = sum(float(r["TotalDurationNs"]) for r in trows)
+
+        def short(nm):
+            return pretty(nm) if "_ZN2ur" in nm or nm.startswith("ur::") else re.sub(r"\(anonymous namespace\)::|at::native::|void ", "", nm)[:70]
+        tl = "\n".join(f"| {short(r['Name'])} | {int(r['Calls']) // n} | {float(r['TotalDurationNs']) / n / 1e6:.2f} | {float(r['AverageNs']) / 1e3:.1f} |"
+                       for r in trows[:16])
+        out += f"""
+## Training step (`{tag}_train_kernel_stats.csv`: `rocprofv3 --kernel-trace --stats -- python tools/train_bench.py --steps 3 --graph`)
+
+cfg 4's per-GPU shape (B=4, 512x512, bf16 compute, fp32 master parameters, fused AdamW, clipping), the whole step replayed as
+one HIP graph: {ttot / n / 1e6:.0f} ms of kernel time per step under the profiler (144 ms per replay un-profiled).  Top kernels per step:
+
+| kernel | launches / step | ms / step | avg us |
+|---|---|---|---|
+{tl}
+"""
     open(os.path.join(P, "README.md"), "w").write(out)
     print(out[-1500:])
 
