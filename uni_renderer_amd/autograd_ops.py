@@ -116,6 +116,26 @@ class Attention(Function):
         return dq, dk, dv, None
 
 
+class AttentionQKV(Function):
+    """Self-attention over the [B, T, 3C] output of ONE q | k | v projection: the kernels read the three parts at their
+    column offsets (leading dimension 3C) and the backward returns one [B, T, 3C] gradient."""
+
+    @staticmethod
+    def forward(ctx, qkv, heads):
+        qkv = qkv.contiguous()
+        B, T, C3 = qkv.shape
+        Cc = C3 // 3
+        vt = bw._pad_rows64(bw.transpose2d(qkv[..., 2 * Cc:]))  # [B, C, T_pad], read in place (strided)
+        ctx.save_for_backward(qkv)
+        ctx.heads = heads
+        return ops.attention(qkv, qkv, vt, B=B, H=heads, Tq=T, Tk=T, d=Cc // heads, ldq=C3, ldk=C3, q_off=0, k_off=Cc)
+
+    @staticmethod
+    def backward(ctx, do):
+        (qkv,) = ctx.saved_tensors
+        return bw.attention_backward(qkv, qkv, qkv, do.contiguous(), ctx.heads, fused_qkv=True), None
+
+
 class GEGLU(Function):
     """h = [value | gate] -> value * gelu(gate) (diffusers GEGLU)."""
 

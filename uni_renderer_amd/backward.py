@@ -28,12 +28,15 @@ def transpose2d(x: torch.Tensor) -> torch.Tensor:
     dims.  C must be a multiple of 8."""
     _require_gpu(x)
     lib = _lib.load()
-    x = x.contiguous()
     R, Cc = x.shape[-2:]
     Rp = (R + 7) // 8 * 8
-    batch = x.numel() // (R * Cc)
+    if x.dim() == 3 and x.stride(2) == 1 and x.stride(1) % 8 == 0 and x.stride(0) % 8 == 0 and x.storage_offset() % 8 == 0:
+        ld, bs, batch = x.stride(1), x.stride(0), x.shape[0]  # e.g. a column slice of a fused q | k | v projection: no copy
+    else:
+        x = x.contiguous()
+        ld, bs, batch = Cc, R * Cc, x.numel() // (R * Cc)
     out = torch.empty(*x.shape[:-2], Cc, Rp, dtype=x.dtype, device=x.device)
-    check(lib.ur_transpose2d(x.data_ptr(), Cc, R * Cc, out.data_ptr(), Rp, Rp * Cc, R, Cc, batch, DT[x.dtype], _stream()),
+    check(lib.ur_transpose2d(x.data_ptr(), ld, bs, out.data_ptr(), Rp, Rp * Cc, R, Cc, batch, DT[x.dtype], _stream()),
           "ur_transpose2d")
     return out
 
@@ -218,30 +221,37 @@ def _split_heads(x: torch.Tensor, H: int, d: int, Tp: int, dp: int, off: int = 0
     return out
 
 
-def _merge_heads(g: torch.Tensor, B: int, T: int, H: int, d: int) -> torch.Tensor:
+def _merge_heads(g: torch.Tensor, B: int, T: int, H: int, d: int, out: Optional[torch.Tensor] = None, off: int = 0
+                 ) -> torch.Tensor:
+    """[B*H, Tp, dp] -> columns off .. off + H*d of ``out`` [B, T, ld] (a new [B, T, H*d] tensor by default)."""
     lib = _lib.load()
-    out = torch.empty(B, T, H * d, dtype=g.dtype, device=g.device)
-    check(lib.ur_merge_heads(g.data_ptr(), g.shape[1], g.shape[2], B, T, H, d, out.data_ptr(), H * d, 0, DT[g.dtype],
-                             _stream()), "ur_merge_heads")
+    if out is None:
+        out = torch.empty(B, T, H * d, dtype=g.dtype, device=g.device)
+    check(lib.ur_merge_heads(g.data_ptr(), g.shape[1], g.shape[2], B, T, H, d, out.data_ptr(), out.stride(1), off,
+                             DT[g.dtype], _stream()), "ur_merge_heads")
     return out
 
 
 def attention_backward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, do: torch.Tensor, H: int,
-                       scale: Optional[float] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+                       scale: Optional[float] = None, fused_qkv: bool = False):
     """Gradients of o = softmax(q k^T * scale) v per head (q, do [B,Tq,H*d]; k, v [B,Tk,H*d]) -> (dq, dk, dv).
     The forward keeps nothing but q, k, v (flash kernel); here P is recomputed and materialised per (batch, head)
     ([B*H, Tq, Tk] in the compute dtype) and the five GEMMs run z-batched on ``ur_igemm``:
         S = Q K^T,  dV = P^T dO,  dP = dO V^T,  dS = P (dP - rowsum(dP P)) scale,  dQ = dS K,  dK = dS^T Q."""
     lib = _lib.load()
-    B, Tq, Cc = q.shape
+    B, Tq = q.shape[:2]
     Tk = k.shape[1]
+    # fused_qkv: q is k is v = the [B, T, 3C] output of one q | k | v projection; heads are read at column offsets
+    # 0 / C / 2C and the result is ONE [B, T, 3C] gradient (no slice copies, no concatenation)
+    Cc = q.shape[2] // 3 if fused_qkv else q.shape[2]
+    oq, ok, ov = (0, Cc, 2 * Cc) if fused_qkv else (0, 0, 0)
     d = Cc // H
     scale = float(d ** -0.5 if scale is None else scale)
     dp = (d + 63) // 64 * 64
     Tqp, Tkp = (Tq + 63) // 64 * 64, (Tk + 63) // 64 * 64
     S = B * H
-    qp, dop = _split_heads(q, H, d, Tqp, dp), _split_heads(do, H, d, Tqp, dp)       # [S, Tqp, dp]
-    kp, vp = _split_heads(k, H, d, Tkp, dp), _split_heads(v, H, d, Tkp, dp)         # [S, Tkp, dp]
+    qp, dop = _split_heads(q, H, d, Tqp, dp, oq), _split_heads(do, H, d, Tqp, dp)   # [S, Tqp, dp]
+    kp, vp = _split_heads(k, H, d, Tkp, dp, ok), _split_heads(v, H, d, Tkp, dp, ov) # [S, Tkp, dp]
     s_ = _stream()
     # P = softmax(Q K^T * scale): rows = queries (padded rows are all-zero q -> uniform rows, masked out below by dO = 0)
     P = ops.linear(qp, kp, out_scale=scale, streams=S)                              # [S*Tqp, Tkp] viewed [S, Tqp, Tkp]
@@ -257,4 +267,9 @@ def attention_backward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, do: to
     dQ = ops.linear(dS.view(S * Tqp, Tkp), kpt, streams=S).view(S, Tqp, dp)         # dS K
     dSt = transpose2d(dS)                                                           # [S, Tkp, Tqp]
     dK = ops.linear(dSt.view(S * Tkp, Tqp), qpt, streams=S).view(S, Tkp, dp)        # dS^T Q
+    if fused_qkv:
+        g = torch.empty(B, Tq, 3 * Cc, dtype=q.dtype, device=q.device)
+        for part, off in ((dQ, oq), (dK, ok), (dV, ov)):
+            _merge_heads(part, B, Tq, H, d, out=g, off=off)
+        return g
     return _merge_heads(dQ, B, Tq, H, d), _merge_heads(dK, B, Tk, H, d), _merge_heads(dV, B, Tk, H, d)

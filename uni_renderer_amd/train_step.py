@@ -66,7 +66,7 @@ def _self_attn(a, xn, res, dt):
     """q | k | v as ONE projection (one forward and two backward GEMMs instead of three of each)."""
     Cc = a.to_q.weight.shape[0]
     qkv = A.linear(xn, torch.cat([a.to_q.weight, a.to_k.weight, a.to_v.weight], 0).to(dt))
-    o = A.Attention.apply(qkv[..., :Cc], qkv[..., Cc:2 * Cc], qkv[..., 2 * Cc:], a.heads)
+    o = A.AttentionQKV.apply(qkv, a.heads)
     return A.linear(o, _w2(a.to_out[0], dt), a.to_out[0].bias, res=res)
 
 
