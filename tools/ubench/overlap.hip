@@ -35,6 +35,16 @@ __global__ void __launch_bounds__(WPS * 256) k(float* out, int iters) {
             for (int v = 0; v < nv / WPS; ++v) e[v & 7] = __builtin_amdgcn_exp2f(e[v & 7]) - 1.0f;
             __builtin_amdgcn_sched_barrier(0);
         }
+    } else if (MODE == 6) {  // like 5, but the VALU block consumes the MFMA results (softmax after a GEMM)
+        for (int it = 0; it < iters; ++it) {
+            f16v z = {};
+#pragma unroll
+            for (int u = 0; u < nm / WPS; ++u) d[u & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, a, (u < 2) ? z : d[u & 1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int v = 0; v < nv / WPS; ++v) e[v & 7] += __builtin_amdgcn_exp2f(d[v & 1][(v >> 1) & 15] * 1e-6f);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     } else if (wave < 4) {
         if (MODE & 1)
             for (int it = 0; it < iters; ++it)
@@ -74,11 +84,11 @@ int main() {
     {                                                                                                                 \
         const float m = run<1, NM, NV>(out, iters), v = run<2, NM, NV>(out, iters), b = run<3, NM, NV>(out, iters),    \
                     x = run<4, NM, NV>(out, iters), y = run<5, NM, NV>(out, iters), x4 = run<4, NM, NV, 4>(out, iters),  \
-                    y4 = run<5, NM, NV, 4>(out, iters), x1 = run<4, NM, NV, 1>(out, iters), y1 = run<5, NM, NV, 1>(out, iters); \
+                    y4 = run<5, NM, NV, 4>(out, iters), x1 = run<4, NM, NV, 1>(out, iters), y1 = run<5, NM, NV, 1>(out, iters), w4 = run<6, NM, NV, 4>(out, iters), w2 = run<6, NM, NV, 2>(out, iters); \
         printf("per iteration: %d MFMA 32x32x16 | %d (v_exp + v_sub): mfma waves alone %.3f ms, valu waves alone %.3f ms, " \
                "both (partner waves of a SIMD) %.3f ms [sum %.3f, max %.3f]; same total work split over W waves per SIMD, "  \
-               "MFMA/VALU interleaved | blocked inside each wave: W=1 %.3f | %.3f, W=2 %.3f | %.3f, W=4 %.3f | %.3f ms\n", \
-               NM, NV, m, v, b, m + v, m > v ? m : v, x1, y1, x, y, x4, y4);                                                               \
+               "MFMA/VALU interleaved | blocked inside each wave: W=1 %.3f | %.3f, W=2 %.3f | %.3f, W=4 %.3f | %.3f ms; blocked with the VALU consuming the MFMA results: W=2 %.3f, W=4 %.3f ms\n", \
+               NM, NV, m, v, b, m + v, m > v ? m : v, x1, y1, x, y, x4, y4, w2, w4);                                                               \
     }
     ROW(8, 16) ROW(8, 32) ROW(8, 64) ROW(8, 128)
     return 0;
