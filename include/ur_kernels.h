@@ -141,6 +141,15 @@ typedef struct ur_igemm_desc {
      * re-reads an input line after cblock / 64 chunks instead of c0 / 64, which keeps the nine taps of a wide input
      * (c0 = 640 .. 2560) in the XCD's L2.  The weight matrix must be packed in the same order. */
     int32_t cblock;
+    /* 1x1 tail of a 3x3 conv (taps == 9, stride 1, no upsampling): after the 9 * (c0 + c1) tap columns K continues with
+     * ct0 channels of t0 and ct1 channels of t1, both read at the OUTPUT pixel (NHWC, Hout x Wout, leading dimensions
+     * ldt0 / ldt1, per-z strides zt0 / zt1): out += Wtail . [t0 | t1].  This is how a ResnetBlock2D's 1x1 conv_shortcut
+     * over its (possibly concatenated) input rides in the K loop of conv2 instead of being a launch of its own.
+     * K = 9 * (c0 + c1) + ct0 + ct1; ct0, ct1 multiples of 64; ct0 == 0: no tail. */
+    const void* t0;
+    const void* t1;
+    int64_t ldt0, ldt1, zt0, zt1;
+    int32_t ct0, ct1;
 } ur_igemm_desc;
 
 int ur_igemm(const ur_igemm_desc* d, void* stream);

@@ -413,3 +413,32 @@ def test_conv3x3_block_outer_k_order(dev, dtype, cfg):
         xin = F.interpolate(xin, scale_factor=2.0, mode="nearest")
     ref = F.conv2d(xin, w.to(dtype).float().cpu(), b.cpu(), stride=stride, padding=1).permute(0, 2, 3, 1)
     assert rel_l2(y1, ref) < TOL[dtype] and rel_l2(y1, y0.float().cpu()) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", [(320, 320, 640, 320, None, 0), (640, 320, 640, 0, None, 320), (1280, 640, 1280, 640, 4, 320),
+                                 (320, 64, 64, 0, 8, 0)])
+def test_conv3x3_with_1x1_tail(dev, dtype, cfg):
+    """conv3x3(h) + conv1x1(cat(t0, t1)) in ONE launch (ur_igemm_desc.t0/t1): how a resnet's conv_shortcut rides in the
+    K loop of conv2.  Both K orders, split-K slices that start inside the tail, grouped (z = 2) launches."""
+    from uni_renderer_amd import ops
+    from uni_renderer_amd.layers import pack_conv3x3
+    cin, cout, ca, cb, sk, cblock = cfg
+    for S in (1, 2):
+        h = _rand((S * 2, 10, 12, cin), dtype, dev, seed=1)
+        ta = _rand((S * 2, 10, 12, ca), dtype, dev, seed=2)
+        tb = _rand((S * 2, 10, 12, cb), dtype, dev, seed=3) if cb else None
+        w3 = [_rand((cout, cin, 3, 3), torch.float32, dev, seed=4 + s_) * (9 * cin) ** -0.5 for s_ in range(S)]
+        w1 = [_rand((cout, ca + cb), torch.float32, dev, seed=8 + s_) * (ca + cb) ** -0.5 for s_ in range(S)]
+        b = [_rand((cout,), torch.float32, dev, seed=12 + s_) for s_ in range(S)]
+        wp = torch.stack([torch.cat([pack_conv3x3(w3[s_], dtype, cblock=cblock), w1[s_].to(dtype)], 1) for s_ in range(S)])
+        bp = torch.stack(b)
+        if S == 1:
+            wp, bp = wp[0], bp[0]
+        y = ops.conv3x3(h, wp, bp, tail=(ta, tb), cblock=cblock, streams=S, splitk=sk, tile=(None if sk is None else 2))
+        for s_ in range(S):
+            sl = slice(2 * s_, 2 * s_ + 2)
+            tcat = torch.cat([ta[sl], tb[sl]], -1) if cb else ta[sl]
+            ref = F.conv2d(h[sl].float().cpu().permute(0, 3, 1, 2), w3[s_].to(dtype).float().cpu(), b[s_].cpu(), padding=1)
+            ref = ref + F.conv2d(tcat.float().cpu().permute(0, 3, 1, 2), w1[s_].to(dtype).float().cpu()[:, :, None, None])
+            assert rel_l2(y[sl], ref.permute(0, 2, 3, 1)) < TOL[dtype], (cfg, S, s_)

@@ -37,6 +37,7 @@ class IGemmDesc(C.Structure):
         ("zbatch", i32), ("splitk", i32), ("zx_div", i32), ("tile", i32), ("dtype", i32),
         ("res_lo", vp), ("out_lo", vp),
         ("cblock", i32),
+        ("t0", vp), ("t1", vp), ("ldt0", i64), ("ldt1", i64), ("zt0", i64), ("zt1", i64), ("ct0", i32), ("ct1", i32),
     ]
 
 

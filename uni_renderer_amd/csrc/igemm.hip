@@ -210,6 +210,8 @@ __global__ void __launch_bounds__(WM * WN * 64) igemm_kernel(const ur_igemm_desc
     const char* x0 = reinterpret_cast<const char*>(reinterpret_cast<const T*>(p.x0) + (int64_t)(zb / p.zx_div) * p.zx);
     const char* x1 = reinterpret_cast<const char*>(reinterpret_cast<const T*>(p.x1) + (int64_t)zb * p.zx1);
     const char* wp = reinterpret_cast<const char*>(reinterpret_cast<const T*>(p.w) + (int64_t)zb * p.zw);
+    const char* t0 = reinterpret_cast<const char*>(reinterpret_cast<const T*>(p.t0) + (int64_t)zb * p.zt0);  // 1x1 tail sources
+    const char* t1 = reinterpret_cast<const char*>(reinterpret_cast<const T*>(p.t1) + (int64_t)zb * p.zt1);
     const int js = (lane & 7) ^ (lane >> 3);  // swizzled source chunk of this lane's 16 bytes
     const char* zp = reinterpret_cast<const char*>(p.zero_page) + (lane & 7) * 16;
 
@@ -257,14 +259,59 @@ __global__ void __launch_bounds__(WM * WN * 64) igemm_kernel(const ur_igemm_desc
 
     // segment state of the loader (all wave-uniform).  Tap-outer order (cblock == 0): segments (tap, source) of
     // c_src/64 chunks.  Block-outer order (cblock > 0, one source): segments (channel block, tap) of cblock/64 chunks.
-    const int segs_per_tap = (p.c1 > 0) ? 2 : 1;
+    // Then, if ct0 > 0, the 1x1 tail: one segment per tail source (seg_src = 2, 3), read at the centre tap.
+    // (every descriptor field the lambdas below choose between is copied into a scalar first: a runtime select between
+    // p.fieldA and p.fieldB makes the compiler materialise the whole kernel-argument struct in scratch)
+    const int pc0 = p.c0, pc1 = p.c1, pct0 = p.ct0, pct1 = p.ct1;
+    const int64_t pldx0 = p.ldx0, pldx1 = p.ldx1, pldt0 = p.ldt0, pldt1 = p.ldt1;
+    const int pHin = p.Hin << p.ups, pWin = p.Win << p.ups, pups = p.ups, pW = p.Win;
+    const int segs_per_tap = (pc1 > 0) ? 2 : 1;
     const int cblk = p.cblock;
     int seg_tap, seg_src, seg_left, seg_coff = 0;  // seg_coff: first channel of the current block
+    auto uniform_i64 = [](int64_t v) __attribute__((always_inline)) {
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)((uint64_t)v >> 32));
+        return (int64_t)(((uint64_t)hi << 32) | lo);
+    };
+    auto uniform_ptr = [&](const char* q) __attribute__((always_inline)) {
+        return reinterpret_cast<const char*>(uniform_i64(reinterpret_cast<int64_t>(q)));
+    };
+    // base pointer / leading dimension of the current source: loop-carried state assigned where seg_src changes (a
+    // four-way choice by seg_src would be lowered to a lookup table in scratch)
+    const char* seg_base = x0;
+    int64_t seg_ld = pldx0;
+    // pointers of the segment (seg_base, seg_tap, seg_coff), advanced by cc channels
+    auto set_pointers = [&](int cc) __attribute__((always_inline)) {
+        const char* sb = seg_base;
+        const int64_t ld = seg_ld;
+        const int dy = seg_tap / 3, dx = seg_tap - dy * 3;
+#pragma unroll
+        for (int it = 0; it < XI; ++it) {
+            int pix;
+            bool ok;
+            if (CONV) {
+                const int iy = xy[it] + dy, ix = xx[it] + dx;
+                ok = ((unsigned)iy < (unsigned)pHin) && ((unsigned)ix < (unsigned)pWin);
+                pix = xa[it] + (iy >> pups) * pW + (ix >> pups);
+            } else {
+                ok = xa[it] >= 0;
+                pix = xa[it];
+            }
+            const int64_t off = ((int64_t)pix * ld + seg_coff + cc + js * 8) * (int64_t)sizeof(T);
+            xptr[it] = ok ? sb + off : zp;
+            xinc[it] = ok ? 128 : 0;
+        }
+    };
     {
-        const int Cin = p.c0 + p.c1;
+        const int Cin = pc0 + pc1;
         const int kglob = kbeg * BK;
         int cc;
-        if (cblk > 0) {
+        if (CONV && kglob >= 9 * Cin) {  // a split-K slice that starts inside the tail
+            cc = kglob - 9 * Cin;
+            seg_src = 2; seg_base = t0; seg_ld = pldt0;
+            seg_left = (pct0 - cc) / BK;
+            if (cc >= pct0) { seg_src = 3; cc -= pct0; seg_base = t1; seg_ld = pldt1; seg_left = (pct1 - cc) / BK; }
+            seg_tap = 4;
+        } else if (cblk > 0) {
             const int blk = kglob / (9 * cblk);
             const int rem = kglob - blk * 9 * cblk;
             seg_tap = rem / cblk;
@@ -275,62 +322,43 @@ __global__ void __launch_bounds__(WM * WN * 64) igemm_kernel(const ur_igemm_desc
         } else {
             seg_tap = kglob / Cin;
             cc = kglob - seg_tap * Cin;
-            seg_src = (cc >= p.c0) ? 1 : 0;
-            if (seg_src) cc -= p.c0;
-            seg_left = ((seg_src ? p.c1 : p.c0) - cc) / BK;
+            seg_src = (cc >= pc0) ? 1 : 0;
+            if (seg_src) { cc -= pc0; seg_base = x1; seg_ld = pldx1; }
+            seg_left = ((seg_src ? pc1 : pc0) - cc) / BK;
         }
-        // pointers of the first segment, advanced to chunk cc
-        const char* sb = seg_src ? x1 : x0;
-        const int64_t ld = seg_src ? p.ldx1 : p.ldx0;
-        const int dy = seg_tap / 3, dx = seg_tap - dy * 3;
-#pragma unroll
-        for (int it = 0; it < XI; ++it) {
-            int pix;
-            bool ok;
-            if (CONV) {
-                const int iy = xy[it] + dy, ix = xx[it] + dx;
-                ok = ((unsigned)iy < (unsigned)(p.Hin << p.ups)) && ((unsigned)ix < (unsigned)(p.Win << p.ups));
-                pix = xa[it] + (iy >> p.ups) * p.Win + (ix >> p.ups);
-            } else {
-                ok = xa[it] >= 0;
-                pix = xa[it];
-            }
-            const int64_t off = ((int64_t)pix * ld + seg_coff + cc + js * 8) * (int64_t)sizeof(T);
-            xptr[it] = ok ? sb + off : zp;
-            xinc[it] = ok ? 128 : 0;
-        }
+        set_pointers(cc);
     }
 
-    auto next_segment = [&]() {
-        if (cblk > 0) {
+    auto next_segment = [&]() __attribute__((always_inline)) {
+        bool to_tail = false;
+        if (seg_src >= 2) {
+            seg_src = 3;  // tail source 0 -> 1 (or past the end of K: never loaded)
+            seg_base = t1; seg_ld = pldt1; seg_left = pct1 / BK;
+        } else if (cblk > 0) {
             seg_tap += 1;
             if (seg_tap == 9) { seg_tap = 0; seg_coff += cblk; }
             seg_left = cblk / BK;
+            to_tail = CONV && seg_coff >= pc0;
         } else {
             seg_src += 1;
             if (seg_src >= segs_per_tap) { seg_src = 0; seg_tap += 1; }
-            seg_left = (seg_src ? p.c1 : p.c0) / BK;
+            seg_base = seg_src ? x1 : x0;
+            seg_ld = seg_src ? pldx1 : pldx0;
+            seg_left = (seg_src ? pc1 : pc0) / BK;
+            to_tail = CONV && seg_tap == 9;
         }
-        const char* sb = seg_src ? x1 : x0;
-        const int64_t ld = seg_src ? p.ldx1 : p.ldx0;
-        const int dy = seg_tap / 3, dx = seg_tap - dy * 3;
-#pragma unroll
-        for (int it = 0; it < XI; ++it) {
-            int pix;
-            bool ok;
-            if (CONV) {
-                const int iy = xy[it] + dy, ix = xx[it] + dx;
-                ok = ((unsigned)iy < (unsigned)(p.Hin << p.ups)) && ((unsigned)ix < (unsigned)(p.Win << p.ups));
-                pix = xa[it] + (iy >> p.ups) * p.Win + (ix >> p.ups);
-            } else {
-                ok = xa[it] >= 0;
-                pix = xa[it];
-            }
-            const int64_t off = ((int64_t)pix * ld + seg_coff + js * 8) * (int64_t)sizeof(T);
-            const char* cand = sb + off;
-            xptr[it] = ok ? cand : zp;
-            xinc[it] = ok ? 128 : 0;
+        if (to_tail) {  // centre tap of the tail sources (stride 1, no upsampling: output pixel = input pixel)
+            seg_src = 2; seg_base = t0; seg_ld = pldt0; seg_left = pct0 / BK;
+            seg_tap = 4; seg_coff = 0;
         }
+        // the segment state is wave-uniform by construction; say so, or it lives in VGPRs (and spills)
+        seg_tap = __builtin_amdgcn_readfirstlane(seg_tap);
+        seg_src = __builtin_amdgcn_readfirstlane(seg_src);
+        seg_left = __builtin_amdgcn_readfirstlane(seg_left);
+        seg_coff = __builtin_amdgcn_readfirstlane(seg_coff);
+        seg_base = uniform_ptr(seg_base);
+        seg_ld = uniform_i64(seg_ld);
+        set_pointers(0);
     };
 
     // issue the LDS-DMA copies of the loader's current chunk into `buf`, then advance by one chunk
@@ -632,7 +660,11 @@ extern "C" int ur_igemm(const ur_igemm_desc* din, void* stream) {
     if (d.M <= 0 || d.N <= 0 || d.K <= 0) return UR_E_BADARG;
     if (d.taps != 1 && d.taps != 9) return UR_E_BADARG;
     if ((d.c0 % BK) || (d.c1 % BK) || (d.c1 > 0 && !d.x1)) return UR_E_BADARG;
-    if (d.K != d.taps * (d.c0 + d.c1)) return UR_E_BADARG;
+    if (d.ct0 < 0 || d.ct1 < 0 || (d.ct0 == 0 && d.ct1 != 0)) return UR_E_BADARG;
+    if (d.ct0 > 0 && (d.taps != 9 || d.stride != 1 || d.ups || !d.t0 || (d.ct1 > 0 && !d.t1) || (d.ct0 % BK) || (d.ct1 % BK) ||
+                      (d.ldt0 % 8) || (d.ct1 > 0 && (d.ldt1 % 8))))
+        return UR_E_BADARG;
+    if (d.K != d.taps * (d.c0 + d.c1) + d.ct0 + d.ct1) return UR_E_BADARG;
     if ((d.ldx0 % 8) || (d.c1 > 0 && (d.ldx1 % 8)) || (d.ldw % 8)) return UR_E_BADARG;
     if (d.taps == 9) {
         if (d.B <= 0 || d.Hin <= 0 || d.Win <= 0 || d.Hout <= 0 || d.Wout <= 0) return UR_E_BADARG;

@@ -84,6 +84,16 @@ class GroupedDualStreamStep:
         h = ops.groupnorm(x, g1, b1, r0.eps, x1=x1, groups=r0.groups, silu=True, streams=S)
         h = ops.conv3x3(h, w1, c1, rowadd=temb[:, lo:hi], streams=S, cblock=ops.conv_cblock(h.shape[-1]))
         h = ops.groupnorm(h, g2, b2, r0.eps, groups=r0.groups, silu=True, streams=S)
+        if r0.conv_shortcut is not None and ops.FOLD_SHORTCUT:
+            # the 1x1 conv_shortcut over (x | x1) rides in conv2's K loop (ur_igemm_desc.t0 / t1): one launch less and no
+            # round trip of its output through memory
+            w2s = pk.get("r.w2s", rs, [t for r in rs for t in (r.conv2.weight, r.conv_shortcut.weight)], dt,
+                         lambda: _stk(torch.cat([pack_conv3x3(r.conv2.weight, dt, cblock=ops.conv_cblock(r.conv2.weight.shape[1])),
+                                                 pack_matrix(r.conv_shortcut.weight, dt)], 1) for r in rs))
+            c2s = pk.get("r.c2s", rs, [t for r in rs for t in (r.conv2.bias, r.conv_shortcut.bias)], dt,
+                         lambda: _stk(f32(r.conv2.bias) + f32(r.conv_shortcut.bias) for r in rs))
+            return ops.conv3x3(h, w2s, c2s, tail=(x, x1), out_scale=1.0 / r0.output_scale_factor, streams=S, hilo=self.hilo,
+                               cblock=ops.conv_cblock(h.shape[-1]))
         if r0.conv_shortcut is not None:
             ws = pk.get("r.ws", rs, [r.conv_shortcut.weight for r in rs], dt,
                         lambda: _stk(pack_matrix(r.conv_shortcut.weight, dt) for r in rs))

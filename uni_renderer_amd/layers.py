@@ -171,6 +171,15 @@ class ResnetBlock2D(nn.Module):
         h = ops.groupnorm(x, g1, b1, self.eps, x1=x1, groups=self.groups, silu=True)
         h = ops.conv3x3(h, w1, cb1, rowadd=ctx.temb[:, lo:hi], cblock=ops.conv_cblock(h.shape[-1]))
         h = ops.groupnorm(h, g2, b2, self.eps, groups=self.groups, silu=True)
+        if self.conv_shortcut is not None and ops.FOLD_SHORTCUT and extra_res is None:
+            # conv_shortcut rides in conv2's K loop as its 1x1 tail (ops.conv3x3 ``tail``)
+            w2s = pk.get("w2s", [self.conv2.weight, self.conv_shortcut.weight], dt,
+                         lambda: torch.cat([pack_conv3x3(self.conv2.weight, dt, cblock=ops.conv_cblock(self.conv2.weight.shape[1])),
+                                            pack_matrix(self.conv_shortcut.weight, dt)], 1).contiguous())
+            cb2s = pk.get("cb2s", [self.conv2.bias, self.conv_shortcut.bias], dt,
+                          lambda: f32(self.conv2.bias) + f32(self.conv_shortcut.bias))
+            return ops.conv3x3(h, w2s, cb2s, tail=(x, x1), out_scale=1.0 / self.output_scale_factor, hilo=ops.PRECISE_RESIDUAL,
+                               cblock=ops.conv_cblock(h.shape[-1]))
         if self.conv_shortcut is not None:
             ws = pk.get("ws", [self.conv_shortcut.weight], dt, lambda: pack_matrix(self.conv_shortcut.weight, dt))
             bs = pk.get("bs", [self.conv_shortcut.bias], dt, lambda: f32(self.conv_shortcut.bias))

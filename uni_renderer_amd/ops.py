@@ -141,7 +141,7 @@ def plan_igemm(M: int, N: int, K: int, taps: int = 1, zbatch: int = 1) -> Tuple[
 def igemm(*, x0, w, out, M, N, K, c0, c1=0, x1=None, ldx0, ldx1=0, ldw, ldc, taps=1, conv=None, stride=1, ups=0,
           bias=None, rowadd=None, rows_per_b=0, res=None, ldres=0, n_store=0, act=ACT_NONE, out_scale=1.0,
           zbatch=1, zx=0, zw=0, zout=0, zx1=0, zbias=0, zrow=0, zres=0, zx_div=1, tile=None, splitk=None,
-          res_lo=None, out_lo=None, cblock=0):
+          res_lo=None, out_lo=None, cblock=0, t0=None, t1=None, ldt0=0, ldt1=0, zt0=0, zt1=0, ct0=0, ct1=0):
     _require_gpu(x0)
     lib = _lib.load()
     if tile is None or splitk is None:
@@ -153,6 +153,7 @@ def igemm(*, x0, w, out, M, N, K, c0, c1=0, x1=None, ldx0, ldx1=0, ldw, ldc, tap
     d.bias, d.rowadd, d.res, d.out = _ptr(bias), _ptr(rowadd), _ptr(res), _ptr(out)
     d.res_lo, d.out_lo = _ptr(res_lo), _ptr(out_lo)
     d.cblock = cblock
+    d.t0, d.t1, d.ldt0, d.ldt1, d.zt0, d.zt1, d.ct0, d.ct1 = _ptr(t0), _ptr(t1), ldt0, ldt1, zt0, zt1, ct0, ct1
     zp = zero_page(x0.device)
     d.zero_page = zp.data_ptr()
     d.ldx0, d.ldx1, d.ldw, d.ldres, d.ldc = ldx0, ldx1, ldw, ldres, ldc
@@ -190,7 +191,8 @@ def igemm(*, x0, w, out, M, N, K, c0, c1=0, x1=None, ldx0, ldx1=0, ldw, ldc, tap
         lo_el = 1 if x0.dtype == torch.float16 else el  # low parts: one e5m2 byte (fp16) / bf16
         lo_bytes = M * n_out * lo_el * ((res_lo is not None) + (out_lo is not None))
         _prof_end(e0, key, 2.0 * M * N * K * z,
-                  ((in_rows * K / taps + N * K + M * n_out * (1 + (res is not None))) * el + lo_bytes) * z)
+                  ((in_rows * (K - ct0 - ct1) / taps + M * (ct0 + ct1) + N * K + M * n_out * (1 + (res is not None))) * el
+                   + lo_bytes) * z)
     return out
 
 
@@ -275,6 +277,7 @@ def linear(x, w, bias=None, *, x1=None, res=None, act=ACT_NONE, out_scale=1.0, r
 
 
 CONV_CBLOCK = int(os.environ.get("UR_CONV_CBLOCK", "320"))
+FOLD_SHORTCUT = os.environ.get("UR_FOLD_SHORTCUT", "1") != "0"  # resnet conv_shortcut as the 1x1 tail of conv2 (conv3x3 ``tail``)
 
 
 def conv_cblock(cin: int) -> int:
@@ -285,10 +288,12 @@ def conv_cblock(cin: int) -> int:
 
 
 def conv3x3(x, w, bias=None, *, x1=None, stride=1, ups=False, rowadd=None, res=None, out_scale=1.0, n_out=None,
-            tile=None, splitk=None, streams=1, hilo=False, cblock=0):
+            tile=None, splitk=None, streams=1, hilo=False, cblock=0, tail=None):
     """3x3 conv, pad 1, over NHWC ``x`` (optionally cat(x, x1) on channels, optionally after a nearest-2x
     upsample).  ``w`` is [Npad >= n_out, 9*Cin] with k = (ky*3+kx)*Cin + c, or, with ``cblock`` > 0, in the
     block-outer order k = (c // cblock)*9*cblock + (ky*3+kx)*cblock + c % cblock.  Output [B, Ho, Wo, n_out].
+    ``tail=(t0, t1 | None)``: a 1x1 conv over cat(t0, t1) (NHWC, the OUTPUT's spatial size) added in the same K loop;
+    its [N, Ct0 + Ct1] weight matrix is appended to ``w`` along K (stride 1, no upsampling only).
     ``streams=S``: x is [S*B, H, W, C] (stream-major), ``w`` [S, N, 9*Cin], ``bias`` [S, N]: one grouped launch."""
     Bt, H, W, C0 = x.shape
     B = Bt // streams
@@ -305,10 +310,16 @@ def conv3x3(x, w, bias=None, *, x1=None, stride=1, ups=False, rowadd=None, res=N
         z = dict(zbatch=streams, zx=B * H * W * C0, zx1=B * H * W * C1, zw=w.stride(0), zout=M * N,
                  zbias=(bias.stride(0) if bias is not None else 0), zres=(M * N if res is not None else 0),
                  zrow=(rowadd.stride(0) * B) if rowadd is not None else 0)
-    igemm(x0=x, x1=x1, w=w, out=out, M=M, N=N, K=9 * (C0 + C1), c0=C0, c1=C1, ldx0=C0, ldx1=C1,
+    tl = {}
+    if tail is not None:
+        ta, tb = tail
+        ca, cb_ = ta.shape[-1], (tb.shape[-1] if tb is not None else 0)
+        tl = dict(t0=ta, t1=tb, ldt0=ca, ldt1=cb_, ct0=ca, ct1=cb_,
+                  zt0=(M * ca if streams > 1 else 0), zt1=(M * cb_ if streams > 1 else 0))
+    igemm(x0=x, x1=x1, w=w, out=out, M=M, N=N, K=9 * (C0 + C1) + sum(tl.get(k, 0) for k in ("ct0", "ct1")), c0=C0, c1=C1, ldx0=C0, ldx1=C1,
           ldw=w.stride(-2), ldc=N, taps=9, conv=(B, H, W, Ho, Wo), stride=stride, ups=int(ups), bias=bias,
           rowadd=rowadd, rows_per_b=Ho * Wo, res=res, ldres=(N if res is not None else 0), out_scale=out_scale,
-          tile=tile, splitk=splitk, res_lo=lo_of(res), out_lo=lo_of(out), cblock=cblock, **z)
+          tile=tile, splitk=splitk, res_lo=lo_of(res), out_lo=lo_of(out), cblock=cblock, **tl, **z)
     return out
 
 
