@@ -71,7 +71,7 @@ rocprofv3 --kernel-trace --stats -d <out> -o {tag} --output-format csv -- python
 ## Headline (un-profiled, `{tag}_bench_default.json`)
 
 {d['value']:.2f} denoise-steps/s = {d['ms_per_step']:.2f} ms per dual-stream step (enc + unet + dec, SD-1.x size, B=4, 512x512, fp16,
-default (hi, lo) residual stream) on one MI355X (boxes of the pool differ by +-4 %: 12.5 .. 13.3 ms were seen for this
+default (hi, lo) residual stream) on one MI355X (boxes of the pool differ by +-4 %: 12.3 .. 13.1 ms were seen for this
 build, about 0.5 ms less with the plain fp16 residual stream `UR_PRECISE_RESIDUAL=0`); CPU oracle on the same host
 ({cpu['cores']}-core cgroup quota) {cpu['value']:.4f} steps/s.  6.49 TFLOP/step => {6.49 / d['ms_per_step']:.3f} PFLOP/s algorithmic =
 {100 * 6.49 / d['ms_per_step'] / 2.5:.0f} % of the dense fp16 MFMA roofline for the whole step (start of the round: 27.2 ms; first complete
