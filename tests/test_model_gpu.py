@@ -162,3 +162,46 @@ def test_sd_shape_unet_forward_vs_oracle(dev, dtype, tol):
     assert e_img < tol and e_mid < 3 * tol and e_up < 3 * tol
     if y_img is not None:
         assert e_img < 1.25 * y_img and e_mid < 1.25 * y_mid
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 3e-3), (torch.bfloat16, 2.5e-2)])
+def test_upres_decoder_blocks_vs_oracle(dev, dtype, tol):
+    """``UpResBlock2D`` / ``CrossAttnUpResBlock2D`` (unet_2d_blocks.py:2706-2822, 2237-2415) = the Up blocks
+    + ``hidden += up_additional_states_tuple[k]`` after each resnet (2814) / resnet + transformer (2408).  A decoder
+    built with the UpRes block types (AttributeDecoderModel's signature defaults, controlnet.py:1793-1798) is fed the
+    UNet's 13 ``up_block_res_samples`` as ``up_block_additional_residuals``; the oracle consumes them in the order of
+    controlnet.py:3970-3990 (``extra=``).  The extras must matter (a plain-block decoder gives a different answer)."""
+    import uni_renderer_amd as U
+
+    unet_o, enc_o, _ = O.build_triplet(O.TINY_CONFIG, seed=77)
+    kinds = ("UpResBlock2D", "CrossAttnUpResBlock2D", "CrossAttnUpResBlock2D", "CrossAttnUpResBlock2D")
+    torch.manual_seed(78)
+    dec_o = O.AttributeDecoderModel(**dict(O.TINY_CONFIG, up_block_types=kinds, out_channels=28)).eval()
+    O.randomize_exchange(enc_o, dec_o, 0.02)
+    x, c, ehs, ti, ta = O.make_inputs(2, 16, 64, seed=79)
+    with torch.no_grad():
+        res, mid, raw_enc, raw_mid_enc = enc_o(x, ta, ehs, controlnet_cond=c)
+        _, raw_unet, raw_mid_unet, up_res = unet_o(x, ti, ehs, down_block_additional_residuals=res,
+                                                   mid_block_additional_residual=mid)
+        ref = dec_o(raw_mid_enc, raw_enc, ta, ehs, down_block_additional_residuals=raw_unet,
+                    mid_block_additional_residual=raw_mid_unet, up_block_additional_residuals=up_res)
+        ref_plain = dec_o(raw_mid_enc, raw_enc, ta, ehs, down_block_additional_residuals=raw_unet,
+                          mid_block_additional_residual=raw_mid_unet)
+    assert rel_l2(ref, ref_plain) > 0.05  # the in-block adds change the result
+    cfg = {k: v for k, v in O.TINY_CONFIG.items() if k not in ("in_channels", "down_block_types")}
+    dec = U.AttributeDecoderModel(**dict(cfg, up_block_types=kinds, out_channels=28))
+    assert [type(b).__name__ for b in dec.up_blocks] == list(kinds)
+    dec.load_state_dict(dec_o.state_dict())
+    dec = dec.to(dtype).to(dev).eval()
+    g = lambda t: t.to(dev).to(dtype)
+    with torch.no_grad():
+        out = dec(sample=g(raw_mid_enc), down_block_res_samples=[g(t) for t in raw_enc], timestep=ta.to(dev),
+                  encoder_hidden_states=g(ehs), down_block_additional_residuals=[g(t) for t in raw_unet],
+                  mid_block_additional_residual=g(raw_mid_unet), up_block_additional_residuals=[g(t) for t in up_res],
+                  return_dict=False)
+        out_plain = dec(sample=g(raw_mid_enc), down_block_res_samples=[g(t) for t in raw_enc], timestep=ta.to(dev),
+                        encoder_hidden_states=g(ehs), down_block_additional_residuals=[g(t) for t in raw_unet],
+                        mid_block_additional_residual=g(raw_mid_unet), return_dict=False)
+    e, e_plain = rel_l2(out, ref), rel_l2(out_plain, ref_plain)
+    print(json.dumps(dict(upres=str(dtype), with_extras=e, without=e_plain)))
+    assert e < tol and e_plain < tol

@@ -182,3 +182,64 @@ def test_ddim_scheduler_basics():
     for t in s.timesteps:
         xt = s.step(x0, t, xt)[0]
     assert float((xt - x0).abs().max()) < 0.1
+
+
+def test_controlnet_conditioning_scale_reaches_the_encoder(dev):
+    """``controlnet_conditioning_scale`` must scale the encoder's residuals (pipeline.py:2660-2667 passes
+    ``conditioning_scale=cond_scale``) on every executor: step-by-step eager, step graph, fused on-device loop -- and
+    0.0 must switch the control branch off (not mean "unscaled")."""
+    pipe, (unet_o, enc_o, dec_o), img, mask, ehs, noise = _setup(dev, seed=24)
+    g = torch.Generator().manual_seed(12)
+    attr = torch.randn(2, 28, 16, 16, generator=g)
+    kw = dict(prompt_embeds=ehs.to(dev).half(), attr_latents=attr.to(dev), latents=noise, num_inference_steps=1,
+              guidance_scale=0.0, output_type="latent")
+    from uni_renderer_amd.schedulers import DDIMScheduler
+
+    def oracle(scale):
+        s = DDIMScheduler()
+        s.set_timesteps(1)
+        t = s.timesteps[0]
+        e = ehs.repeat(2, 1, 1)
+        with torch.no_grad():
+            res, mid, _, _ = enc_o(noise, torch.zeros(2).long(), e, controlnet_cond=attr, conditioning_scale=scale)
+            pred = unet_o(noise, t.expand(2), e, down_block_additional_residuals=res, mid_block_additional_residual=mid)[0]
+        return s.step(pred, t, noise.clone())[0]
+
+    outs = {}
+    for scale in (1.0, 0.5, 0.0):
+        ref = oracle(scale)
+        for fused, graph in ((True, True), (False, True), (False, False)):
+            pipe.use_fused_sampler, pipe.use_hip_graph = fused, graph
+            o = pipe.mask2image_3mod_albedo(controlnet_conditioning_scale=scale, **kw)
+            assert rel_l2(o, ref) < 5e-3, (scale, fused, graph, rel_l2(o, ref))
+            outs[(scale, fused, graph)] = o
+    assert rel_l2(outs[(0.5, True, True)], outs[(1.0, True, True)]) > 1e-3  # the scale is not ignored
+    assert rel_l2(outs[(0.0, False, False)], outs[(1.0, False, False)]) > 1e-3
+
+
+def test_fused_loop_results_are_not_aliased_and_graphs_follow_weight_updates(dev):
+    """(a) the fused loop hands out a COPY of its static master buffer (fp32 prompt embeddings made
+    ``.to(lat_dtype)`` a no-op and later calls overwrote earlier results); (b) a captured graph bakes in the packed
+    weights: after an in-place weight update (optimizer step, load_state_dict) or ``pipe.to(...)`` the next sampling call
+    must re-capture instead of replaying stale weights."""
+    pipe, _, img, mask, ehs, noise = _setup(dev, seed=25)
+    g = torch.Generator().manual_seed(13)
+    attr = torch.randn(2, 28, 16, 16, generator=g).to(dev)
+    kw = dict(prompt_embeds=ehs.to(dev).float(), attr_latents=attr, num_inference_steps=2, guidance_scale=0.0,
+              output_type="latent")
+    a = pipe.mask2image_3mod_albedo(latents=noise, **kw)
+    a_copy = a.clone()
+    b = pipe.mask2image_3mod_albedo(latents=noise * 0.5, **kw)  # same shapes: same sampling graph, other latents
+    assert torch.equal(a, a_copy) and not torch.equal(a, b)
+    n_graphs = len(pipe._graphs)
+    with torch.no_grad():  # in-place update of every conv / linear weight of the unet, as an optimizer step would do
+        for p_ in pipe.unet.parameters():
+            p_.mul_(0.5)
+    c = pipe.mask2image_3mod_albedo(latents=noise, **kw)
+    assert len(pipe._graphs) == n_graphs and rel_l2(c, a) > 1e-2  # re-captured with the new weights, not replayed
+    pipe.use_fused_sampler = pipe.use_hip_graph = False
+    d = pipe.mask2image_3mod_albedo(latents=noise, **kw)  # eager reference on the updated weights
+    assert rel_l2(c, d) < 3e-3
+    pipe.use_fused_sampler = pipe.use_hip_graph = True
+    pipe.to(dev)
+    assert not pipe._graphs and not pipe._sample_graphs

@@ -236,3 +236,151 @@ def test_training_step_captured_into_a_hip_graph(dev):
               for pe, pg in zip(me.parameters(), mg.parameters()))
     den = sum(float((pe.detach() ** 2).sum()) for me in nets_e for pe in me.parameters())
     assert (num / den) ** 0.5 < 1e-4
+
+
+def _reference_step_losses(controlnet, unet, controldec, b, inverse, F=torch.nn.functional):
+    """The step body of train/train.py:1324-1416 written ONCE over the reference's module call surface (keyword for
+    keyword), so the same function drives the product modules on the GPU and the oracle on the CPU.  ``b``: dict of NCHW
+    tensors.  (The oracle's forwards take the same keywords minus ``return_dict``.)"""
+    kw = {} if b.get("oracle") else {"return_dict": False}
+    down_block_res_samples, mid_block_res_sample, raw_down_ctl, raw_mid_ctl = controlnet(
+        b["noisy_latents_img"], b["timesteps_attribute"], encoder_hidden_states=b["ehs"],
+        controlnet_cond=b["noisy_latents_attr"], **kw)
+    wd = b["weight_dtype"]
+    img_pred, raw_down_unet, raw_mid_unet, _ = unet(
+        b["noisy_latents_img"], b["timesteps_img"], encoder_hidden_states=b["ehs"],
+        down_block_additional_residuals=[s.to(dtype=wd) for s in down_block_res_samples],
+        mid_block_additional_residual=mid_block_res_sample.to(dtype=wd), **kw)
+    mask_pred = controldec(
+        sample=raw_mid_ctl, down_block_res_samples=raw_down_ctl, timestep=b["timesteps_attribute"],
+        encoder_hidden_states=b["ehs"], down_block_additional_residuals=[s.to(dtype=wd) for s in raw_down_unet],
+        mid_block_additional_residual=raw_mid_unet.to(dtype=wd), **kw)
+    mask_pred = mask_pred[:, 4:, :, :]
+    material_pred, albedo_pred, spec_pred = mask_pred[:, :4], mask_pred[:, 8:12], mask_pred[:, 12:16]
+    temperature = 0.1
+    cos = lambda a: F.cosine_similarity(a[0].reshape(-1).float(), a[1].reshape(-1).float(), dim=0) / temperature
+    pos = torch.exp(cos(albedo_pred))
+    neg = pos + torch.exp(cos(material_pred)) + torch.exp(cos(spec_pred))
+    contrastive_loss = -torch.log(pos / neg)
+    loss_img = F.mse_loss(img_pred.float(), b["latents_img"].float(), reduction="mean")
+    loss_mask = F.mse_loss(mask_pred.float(), b["latents_attr"].float(), reduction="mean")
+    loss = loss_img + loss_mask * 10.0 + contrastive_loss * 0.01
+    if inverse:
+        noisy_latents_attr_c = torch.cat((b["latents_mask"].to(mask_pred.dtype), mask_pred), dim=1)
+        res_c, mid_c, _, _ = controlnet(b["noisy_latents_img_c"], b["timesteps_attribute_c"], encoder_hidden_states=b["ehs"],
+                                        controlnet_cond=noisy_latents_attr_c, **kw)
+        img_pred_c = unet(b["noisy_latents_img_c"], b["timesteps_img_c"], encoder_hidden_states=b["ehs"],
+                          down_block_additional_residuals=[s.to(dtype=wd) for s in res_c],
+                          mid_block_additional_residual=mid_c.to(dtype=wd), **kw)[0]
+        loss_c = F.mse_loss(img_pred_c.float(), b["latents_img"].float(), reduction="mean")
+        loss = loss_img + loss_mask + 0.8 * loss_c
+    return loss
+
+
+def _train_batch(B, L, cross, seed):
+    x, c, ehs, ti, ta = O.make_inputs(B, L, cross, seed=seed)
+    g = torch.Generator().manual_seed(seed + 1)
+    return dict(noisy_latents_img=x, noisy_latents_attr=c, ehs=ehs, timesteps_img=ti, timesteps_attribute=ta,
+                latents_img=torch.randn(B, 4, L, L, generator=g), latents_attr=torch.randn(B, 24, L, L, generator=g),
+                latents_mask=c[:, :4].clone(), noisy_latents_img_c=torch.randn(B, 4, L, L, generator=g),
+                timesteps_img_c=torch.randint(0, 1000, (B,), generator=g), timesteps_attribute_c=torch.zeros(B).long())
+
+
+def _grad_error(oracle, nets, sample_every=1):
+    num = den = 0.0
+    for mo, mp in zip(oracle, nets):
+        po = dict(mo.named_parameters())
+        for i, (name, p) in enumerate(mp.named_parameters()):
+            go = po[name].grad
+            if go is None:
+                assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
+                continue
+            assert p.grad is not None, name
+            if i % sample_every:
+                continue
+            d = p.grad.float().cpu() - go
+            num += float((d * d).sum())
+            den += float((go * go).sum())
+    return (num / den) ** 0.5
+
+
+@pytest.mark.parametrize("inverse", [True, False])
+def test_reference_train_step_on_the_module_surface_under_autocast(dev, inverse):
+    """train/train.py:1324-1416 run LITERALLY on the product modules -- the three ``forward``s with the
+    reference's keywords, fp32 master parameters under ``torch.autocast`` (train.py:882-887, 1082-1089), the
+    ``.to(dtype=weight_dtype)`` casts, the losses, then ``loss.backward()`` -- must give the oracle's loss and
+    parameter gradients.  (The module forwards route to the autograd path whenever grad is recording.)"""
+    oracle = O.build_triplet(O.TINY_CONFIG, seed=35)
+    b = _train_batch(2, 16, 64, seed=22)
+    for m in oracle:
+        m.requires_grad_(True)
+    unet_o, enc_o, dec_o = oracle
+    loss_o = _reference_step_losses(enc_o, unet_o, dec_o, dict(b, oracle=True, weight_dtype=torch.float32), inverse)
+    loss_o.backward()
+    nets = build_product_from_oracle(*oracle, torch.float32, dev)
+    for m in nets:
+        m.train()
+        m.requires_grad_(True)
+    unet, enc, dec = nets
+    bg = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in b.items()}
+    with torch.autocast("cuda", dtype=torch.float16):
+        loss = _reference_step_losses(enc, unet, dec, dict(bg, weight_dtype=torch.float16), inverse)
+    assert loss.requires_grad
+    loss.backward()
+    err = _grad_error(oracle, nets)
+    print({"module_surface": True, "inverse": inverse, "loss": float(loss.detach()), "loss_oracle": float(loss_o.detach()),
+           "grad_rel_l2_all": err})
+    assert abs(float(loss.detach()) - float(loss_o.detach())) / abs(float(loss_o.detach())) < 5e-3
+    assert err < 1.5e-2
+    # and with autograd off the same modules take the fused inference path (no graph is recorded)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        r = enc(bg["noisy_latents_img"], bg["timesteps_attribute"], encoder_hidden_states=bg["ehs"],
+                controlnet_cond=bg["noisy_latents_attr"], return_dict=False)
+    assert not r[1].requires_grad and r[1].grad_fn is None
+
+
+def test_cfg4_per_gpu_training_step_vs_oracle(dev):
+    """cfg 4's per-GPU workload: SD-1.x-size networks, batch 4, 512x512 image = 64x64 latent, bf16 autocast over fp32
+    master parameters, the reference's rendering-branch objective (mse + 10 mse + 0.01 contrastive on samples 0 / 1,
+    train.py:1356-1378) through the module call surface.  Loss and parameter gradients (every 7th parameter tensor of
+    each network, ~250 M elements) against the CPU oracle's autograd.  The oracle runs the batch as two half batches
+    (samples are independent except for the contrastive pair, which lives in the first half) to bound host memory:
+    loss = (L_A + L_B) / 2 with the contrastive term only in L_A at weight 2 x 0.01 / 2."""
+    F = torch.nn.functional
+    oracle = O.build_triplet(O.SD15_CONFIG, seed=42)
+    b = _train_batch(4, 64, 768, seed=24)
+    for m in oracle:
+        m.requires_grad_(True)
+    unet_o, enc_o, dec_o = oracle
+    loss_o = 0.0
+    for h in range(2):
+        sl = slice(2 * h, 2 * h + 2)
+        bh = {k: (v[sl] if torch.is_tensor(v) else v) for k, v in b.items()}
+        res, mid, raw_enc, raw_mid_enc = enc_o(bh["noisy_latents_img"], bh["timesteps_attribute"], bh["ehs"],
+                                               controlnet_cond=bh["noisy_latents_attr"])
+        img_pred, raw_unet, raw_mid_unet, _ = unet_o(bh["noisy_latents_img"], bh["timesteps_img"], bh["ehs"],
+                                                     down_block_additional_residuals=res, mid_block_additional_residual=mid)
+        mask_pred = dec_o(raw_mid_enc, raw_enc, bh["timesteps_attribute"], bh["ehs"], down_block_additional_residuals=raw_unet,
+                          mid_block_additional_residual=raw_mid_unet)[:, 4:]
+        lh = 0.5 * (F.mse_loss(img_pred, bh["latents_img"]) + 10.0 * F.mse_loss(mask_pred, bh["latents_attr"]))
+        if h == 0:
+            cos = lambda a: F.cosine_similarity(a[0].reshape(-1), a[1].reshape(-1), dim=0) / 0.1
+            pos = torch.exp(cos(mask_pred[:, 8:12]))
+            lh = lh - 0.01 * torch.log(pos / (pos + torch.exp(cos(mask_pred[:, :4])) + torch.exp(cos(mask_pred[:, 12:16]))))
+        lh.backward()
+        loss_o += float(lh.detach())
+        del res, mid, raw_enc, raw_mid_enc, img_pred, raw_unet, raw_mid_unet, mask_pred, lh
+    nets = build_product_from_oracle(*oracle, torch.float32, dev)
+    for m in nets:
+        m.train()
+        m.requires_grad_(True)
+    unet, enc, dec = nets
+    bg = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in b.items()}
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        loss = _reference_step_losses(enc, unet, dec, dict(bg, weight_dtype=torch.bfloat16), inverse=False)
+    loss.backward()
+    err = _grad_error(oracle, nets, sample_every=7)
+    print({"cfg4_per_gpu_shape": "B=4, 64x64 latent, bf16 autocast, SD size", "loss": float(loss.detach()), "loss_oracle": loss_o,
+           "grad_rel_l2_sampled": err})
+    assert abs(float(loss.detach()) - loss_o) / abs(loss_o) < 2e-2
+    assert err < 8e-2

@@ -106,6 +106,21 @@ class _DenoiserBase(ConfigModelMixin, nn.Module):
         ctx.temb = ops.linear(semb, wcat, bcat)  # [B, sum Cout]
         return ctx
 
+    def _autograd_mode(self, *tensors) -> bool:
+        """True when this call must be differentiable: autograd is recording and a parameter or an input wants a
+        gradient -- the situation of train/train.py:1324-1354 (modules called, then ``accelerator.backward(loss)``).
+        The forwards then run over ``autograd_ops`` (train_step.py: HIP forward AND backward kernels, same return
+        tuples); under ``torch.no_grad()`` / with frozen parameters they take the fused inference path."""
+        if not torch.is_grad_enabled():
+            return False
+        for t in tensors:
+            if torch.is_tensor(t):
+                if t.requires_grad:
+                    return True
+            elif isinstance(t, (list, tuple)) and any(torch.is_tensor(u) and u.requires_grad for u in t):
+                return True
+        return any(p.requires_grad for p in self.parameters())
+
     @staticmethod
     def _tokens(ehs: torch.Tensor, dt) -> torch.Tensor:
         if ehs.dtype != dt or not ehs.is_contiguous():
@@ -285,8 +300,28 @@ class UNet2DConditionModel(_DenoiserBase):
                          cross_attention_kwargs=cross_attention_kwargs, added_cond_kwargs=added_cond_kwargs,
                          down_intrablock_additional_residuals=down_intrablock_additional_residuals,
                          encoder_attention_mask=encoder_attention_mask)
+        if self._autograd_mode(sample, encoder_hidden_states, down_block_additional_residuals, mid_block_additional_residual):
+            return self._forward_autograd(sample, timestep, encoder_hidden_states, down_block_additional_residuals,
+                                          mid_block_additional_residual, return_dict)
         state = self.forward_down_mid(sample, timestep, encoder_hidden_states)
         return self.forward_up(state, down_block_additional_residuals, mid_block_additional_residual, return_dict)
+
+    def _forward_autograd(self, sample, timestep, ehs, down_res, mid_res, return_dict):
+        """The differentiable forward (train_step.unet_forward) behind the reference's signature and return tuple."""
+        from . import train_step as TS
+
+        dt = _compute_dtype(self.dtype, self.compute_dtype)
+        if (down_res is None) != (mid_res is None):
+            raise NotImplementedError("T2I-adapter style down_block_additional_residuals without a mid residual")
+        res = [TS.to_nhwc_grad(r, dt) for r in down_res] if down_res is not None else None
+        mid = TS.to_nhwc_grad(mid_res, dt) if mid_res is not None else None
+        img, raw_down, raw_mid, ups = TS.unet_forward(self, TS.to_nhwc_grad(sample, dt, CIN_PAD),
+                                                      TS._prompt(ehs, sample.shape[0], dt), timestep, dt, res, mid,
+                                                      collect_up=True)
+        v = lambda t: t.permute(0, 3, 1, 2)
+        if not return_dict:
+            return v(img), tuple(v(t) for t in raw_down), v(raw_mid), tuple(v(t) for t in ups)
+        return UNet2DConditionOutput(sample=v(img))
 
     # The forward is split at the point where the other stream's features enter (ref 1078-1087): the down path +
     # mid block do not depend on the encoder, so `graph.GraphedDualStreamStep` runs them concurrently with it.
@@ -457,6 +492,15 @@ class AttributeEncoderModel(_DenoiserBase):
         _reject_inactive(class_labels=class_labels, timestep_cond=timestep_cond, attention_mask=attention_mask,
                          added_cond_kwargs=added_cond_kwargs, cross_attention_kwargs=cross_attention_kwargs)
         B = controlnet_cond.shape[0]
+        if self._autograd_mode(controlnet_cond, encoder_hidden_states):
+            from . import train_step as TS
+
+            dt = _compute_dtype(self.dtype, self.compute_dtype)
+            res, mid, raw_down, raw_mid = TS.encoder_forward(
+                self, TS.to_nhwc_grad(controlnet_cond, dt, CIN_PAD), TS._prompt(encoder_hidden_states, B, dt), timestep, dt,
+                conditioning_scale=float(conditioning_scale))
+            v = lambda t: t.permute(0, 3, 1, 2)
+            return [v(t) for t in res], v(mid), tuple(v(t) for t in raw_down), v(raw_mid)
         ctx = self._begin(B, timestep, controlnet_cond.device, encoder_hidden_states)
         x = self._conv_in(controlnet_cond, ctx)  # `sample` is ignored, as in the reference
         skips = (x,)
@@ -604,6 +648,18 @@ class AttributeDecoderModel(_DenoiserBase):
         if mid_block_additional_residual is None:
             raise ValueError("mid_block_additional_residual is mandatory (the reference crashes on None, ref 2476)")
         B = sample.shape[0]
+        if self._autograd_mode(sample, encoder_hidden_states, down_block_res_samples, down_block_additional_residuals,
+                               up_block_additional_residuals, mid_block_additional_residual):
+            from . import train_step as TS
+
+            dt = _compute_dtype(self.dtype, self.compute_dtype)
+            g = lambda t: TS.to_nhwc_grad(t, dt)
+            extras = [g(u) for u in up_block_additional_residuals[1:]] if up_block_additional_residuals is not None else None
+            out = TS.decoder_forward(
+                self, g(sample), [g(t) for t in down_block_res_samples], TS._prompt(encoder_hidden_states, B, dt), timestep, dt,
+                raw_unet=([g(t) for t in down_block_additional_residuals] if down_block_additional_residuals is not None else None),
+                raw_mid_unet=g(mid_block_additional_residual), extras=extras).permute(0, 3, 1, 2)
+            return out if not return_dict else UNet2DConditionOutput(sample=out)
         H0, W0 = down_block_res_samples[0].shape[-2:]
         f = 2 ** self.num_upsamplers
         forward_upsample_size = (H0 % f != 0) or (W0 % f != 0)

@@ -576,15 +576,9 @@ template <typename T, int D>
 static int launch_attn32(const ur_attn_desc& d, hipStream_t s) {
     constexpr size_t lds = 2 * (64 * 128 + (D + 31) / 32 * 32 * 128);
     constexpr bool HAS_SLOT = ((D + 15) / 16 * 16 > D) && ((D + 31) / 32 * 32 > D);
-    static bool once = false;
-    if (!once) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention32_kernel<T, D, false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (HAS_SLOT)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention32_kernel<T, D, HAS_SLOT>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        once = true;
-    }
+    static std::atomic<uint64_t> done_plain{0}, done_slot{0};  // per (instantiation, device)
+    set_lds_limit_once(done_plain, reinterpret_cast<const void*>(&attention32_kernel<T, D, false>), (int)lds);
+    if (HAS_SLOT) set_lds_limit_once(done_slot, reinterpret_cast<const void*>(&attention32_kernel<T, D, HAS_SLOT>), (int)lds);
     dim3 grid((d.Tq + 127) / 128, d.B * d.H);
     if (HAS_SLOT && d.scale <= 0.f)
         hipLaunchKernelGGL((attention32_kernel<T, D, HAS_SLOT>), grid, dim3(256), lds, s, d);
@@ -598,12 +592,8 @@ template <typename T, int D>
 static int launch_attn(const ur_attn_desc& d, hipStream_t s) {
     constexpr int DK = (D + 31) / 32 * 32, DV = (D + 15) / 16 * 16;
     constexpr size_t lds = 2 * (64 * DK * 2 + DV * 128);
-    static bool once = false;
-    if (!once) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<T, D>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        once = true;
-    }
+    static std::atomic<uint64_t> done{0};  // per (instantiation, device)
+    set_lds_limit_once(done, reinterpret_cast<const void*>(&attention_kernel<T, D>), (int)lds);
     dim3 grid((d.Tq + 127) / 128, d.B * d.H);
     hipLaunchKernelGGL((attention_kernel<T, D>), grid, dim3(256), lds, s, d);
     hipError_t e = hipGetLastError();

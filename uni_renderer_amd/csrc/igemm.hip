@@ -569,6 +569,12 @@ static int pick_tile(const ur_igemm_desc& d) {
     return best;
 }
 
+template <typename T, int BM, int BN, int WM, int WN, int NSTAGE, bool CONV>
+static void ensure_lds_limit(int lds) {
+    static std::atomic<uint64_t> done{0};  // per (instantiation, device), see set_lds_limit_once
+    set_lds_limit_once(done, reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, WM, WN, NSTAGE, CONV>), lds);
+}
+
 template <typename T, int BM, int BN, int WM, int WN, int NSTAGE>
 static int launch_cfg(const ur_igemm_desc& d, hipStream_t s) {
     const int tiles_m = (d.M + BM - 1) / BM, tiles_n = (d.N + BN - 1) / BN;
@@ -576,20 +582,10 @@ static int launch_cfg(const ur_igemm_desc& d, hipStream_t s) {
     const size_t lds = (NSTAGE > 0 ? NSTAGE : 2) * (BM + BN) * 128;
     hipError_t e;
     if (d.taps == 9) {
-        static bool once = false;
-        if (!once) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, WM, WN, NSTAGE, true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            once = true;
-        }
+        ensure_lds_limit<T, BM, BN, WM, WN, NSTAGE, true>((int)lds);
         hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, NSTAGE, true>), grid, dim3(WM * WN * 64), lds, s, d);
     } else {
-        static bool once = false;
-        if (!once) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, WM, WN, NSTAGE, false>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            once = true;
-        }
+        ensure_lds_limit<T, BM, BN, WM, WN, NSTAGE, false>((int)lds);
         hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, NSTAGE, false>), grid, dim3(WM * WN * 64), lds, s, d);
     }
     e = hipGetLastError();
@@ -681,7 +677,6 @@ extern "C" int ur_igemm(const ur_igemm_desc* din, void* stream) {
     if (d.rowadd && d.rows_per_b <= 0) return UR_E_BADARG;
     if (d.act == UR_ACT_GEGLU && (d.N % 16)) return UR_E_BADARG;
     if (d.n_store <= 0) d.n_store = (d.act == UR_ACT_GEGLU) ? d.N / 2 : d.N;
-    if (d.out_scale == 0.0f) d.out_scale = 1.0f;
     if (d.tile == UR_TILE_AUTO) d.tile = pick_tile(d);
     if (d.tile < 1 || d.tile >= UR_TILE_COUNT) return UR_E_BADARG;
     d.ldp = padded_ldp(d, d.tile);

@@ -293,8 +293,15 @@ __global__ void __launch_bounds__(256) ddim_update_kernel(const T* __restrict__ 
 
 // step += 1; t_out[0..B) = tsteps[step] (the timestep the NEXT replay denoises at)
 __global__ void sampler_advance_kernel(int* step, const float* __restrict__ tsteps, int nsteps, float* t_out, int B) {
-    const int st = *step + 1;
-    if (threadIdx.x == 0) *step = st;
+    // ONE thread reads the counter and shares it through LDS: with every thread reading *step, waves 1-3 could see
+    // the value thread 0 had already incremented and write tsteps[st + 1] for the samples beyond the first 64
+    __shared__ int st_sh;
+    if (threadIdx.x == 0) {
+        st_sh = *step + 1;
+        *step = st_sh;
+    }
+    __syncthreads();
+    const int st = st_sh;
     if (t_out && (int)threadIdx.x < B) t_out[threadIdx.x] = tsteps[min(st, nsteps - 1)];
 }
 

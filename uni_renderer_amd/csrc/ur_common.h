@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 namespace ur {
 
 typedef _Float16 f16;
@@ -153,6 +155,19 @@ __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
+}
+
+// Host side: raise the dynamic-LDS limit of kernel `fn` on the CURRENT device once per (call site, device).  `done`
+// is a `static std::atomic<uint64_t>` owned by the calling template instantiation, one bit per device ordinal.
+// Setting the attribute twice is harmless (two host threads racing here set the same value), so there is no lock;
+// it is the only mutable state in the library and it only caches an idempotent driver call.
+inline void set_lds_limit_once(std::atomic<uint64_t>& done, const void* fn, int lds) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint64_t bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return;
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    done.fetch_or(bit, std::memory_order_release);
 }
 
 }  // namespace ur

@@ -26,12 +26,13 @@ from . import ops
 
 
 def dual_stream_step(unet, enc, dec, x_t, cond, ehs, t_img, t_attr, run_decoder: bool = True,
-                     side: Optional[torch.cuda.Stream] = None) -> Dict[str, torch.Tensor]:
-    """One step: the same calls the reference's loops make.  With ``side`` (a second HIP stream) the encoder and
+                     side: Optional[torch.cuda.Stream] = None, conditioning_scale: float = 1.0) -> Dict[str, torch.Tensor]:
+    """One step: the same calls the reference's loops make (``conditioning_scale`` goes to the encoder like
+    pipeline.py:2660-2667 passes ``cond_scale``).  With ``side`` (a second HIP stream) the encoder and
     the decoder run concurrently with the UNet's down and up halves; without it everything is serial."""
     if side is None:
         res, mid, raw_enc, raw_mid_enc = enc(x_t, t_attr, encoder_hidden_states=ehs, controlnet_cond=cond,
-                                             return_dict=False)
+                                             conditioning_scale=conditioning_scale, return_dict=False)
         img_pred, raw_unet, raw_mid_unet, _ = unet(
             x_t, t_img, encoder_hidden_states=ehs, down_block_additional_residuals=res,
             mid_block_additional_residual=mid, return_dict=False)
@@ -46,7 +47,7 @@ def dual_stream_step(unet, enc, dec, x_t, cond, ehs, t_img, t_attr, run_decoder:
     side.wait_stream(main)  # fork: inputs are ready
     with torch.cuda.stream(side):
         res, mid, raw_enc, raw_mid_enc = enc(x_t, t_attr, encoder_hidden_states=ehs, controlnet_cond=cond,
-                                             return_dict=False)
+                                             conditioning_scale=conditioning_scale, return_dict=False)
     state = unet.forward_down_mid(x_t, t_img, ehs)  # main, concurrent with the encoder
     raw_unet = tuple(ops.as_nchw_view(s) for s in state["raw_down"])
     raw_mid_unet = ops.as_nchw_view(state["raw_mid"])
@@ -75,10 +76,13 @@ class GraphedDualStreamStep:
 
     def __init__(self, unet, enc, dec, batch: int, latent_hw, cross_dim: int, dtype=torch.float16,
                  device="cuda", run_decoder: bool = True, cond_channels: int = 28, img_channels: int = 4,
-                 ctx_len: int = 77, concurrent: bool = True, mode: Optional[str] = None):
+                 ctx_len: int = 77, concurrent: bool = True, mode: Optional[str] = None,
+                 conditioning_scale: float = 1.0):
         """mode: "grouped" (default: the two streams as one grouped launch per op, fused.py), "concurrent" (module
-        path, two graph branches on two HIP streams), "serial" (module path, one stream)."""
+        path, two graph branches on two HIP streams), "serial" (module path, one stream).
+        ``conditioning_scale``: the encoder's residual scale (pipeline.py:2660-2667), baked into the captured graph."""
         self.unet, self.enc, self.dec, self.run_decoder = unet, enc, dec, run_decoder
+        self.conditioning_scale = float(conditioning_scale)
         self.mode = mode or ("grouped" if concurrent else "serial")
         if self.mode not in ("grouped", "concurrent", "serial"):
             raise ValueError(self.mode)
@@ -100,9 +104,10 @@ class GraphedDualStreamStep:
                 from .fused import GroupedDualStreamStep
 
                 self._grouped = GroupedDualStreamStep(self.unet, self.enc, self.dec)
-            return self._grouped(self.x_t, self.cond, self.ehs, self.t_img, self.t_attr, self.run_decoder)
+            return self._grouped(self.x_t, self.cond, self.ehs, self.t_img, self.t_attr, self.run_decoder,
+                                 conditioning_scale=self.conditioning_scale)
         return dual_stream_step(self.unet, self.enc, self.dec, self.x_t, self.cond, self.ehs, self.t_img,
-                                self.t_attr, self.run_decoder, side=self.side)
+                                self.t_attr, self.run_decoder, side=self.side, conditioning_scale=self.conditioning_scale)
 
     def load_inputs(self, x_t, cond, ehs, t_img, t_attr):
         self.x_t.copy_(x_t)

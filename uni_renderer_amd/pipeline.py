@@ -69,8 +69,22 @@ class UniRendererPipeline:
             m = getattr(self, n)
             if m is not None and hasattr(m, "to"):
                 setattr(self, n, m.to(*args, **kwargs))
-        self._graphs.clear()
+        self.invalidate_graphs()
         return self
+
+    def invalidate_graphs(self):
+        """Drop every captured step / sampling graph.  A captured graph is bound to the static input buffers of its
+        ``GraphedDualStreamStep`` and to the PACKED copies of the weights it was captured with, so it must not outlive a
+        device move or a weight update.  ``to()`` calls this; weight updates (optimizer steps, ``load_state_dict``) are
+        detected per sampling call through ``_weights_signature``."""
+        self._graphs.clear()
+        self._sample_graphs.clear()
+
+    def _weights_signature(self):
+        """(device, (data_ptr, version) of every parameter) of the three networks: in-place updates bump ``_version``,
+        re-assignments change ``data_ptr``.  ~1.7 k parameters: evaluated once per sampling call, not per step."""
+        nets = [m for m in (self.unet, self.controlnet, self.controldec) if m is not None]
+        return (str(self.device),) + tuple((p_.data_ptr(), p_._version) for m in nets for p_ in m.parameters())
 
     @property
     def device(self):
@@ -194,7 +208,7 @@ class UniRendererPipeline:
 
         if not (self.use_fused_sampler and self.use_hip_graph and torch.device(device).type == "cuda"):
             return False
-        if callback is not None or cond_scale != 1.0:
+        if callback is not None:
             return False
         s0 = scheds[0]
         for s in scheds:
@@ -219,22 +233,31 @@ class UniRendererPipeline:
             rows.append(torch.stack([a_t.sqrt(), (1 - a_t).sqrt(), a_prev.sqrt(), (1 - a_prev).sqrt()]).float())
         return torch.stack(rows), torch.tensor(ts, dtype=torch.float32)
 
-    def _graph_for(self, x_img, cond28, ehs, run_decoder):
+    def _graph_for(self, x_img, cond28, ehs, run_decoder, cond_scale: float = 1.0, sig=None):
+        """The captured step for these shapes / this conditioning scale, re-captured when the weights it baked in have
+        changed since (``sig`` = a ``_weights_signature()`` the caller took once for its whole sampling call)."""
         B, _, h, w = x_img.shape
         dt = self.unet.dtype
-        key = (B, h, w, ehs.shape[1], ehs.shape[2], run_decoder, dt)
+        key = (str(x_img.device), B, h, w, ehs.shape[1], ehs.shape[2], run_decoder, dt, float(cond_scale))
+        sig = sig if sig is not None else self._weights_signature()
         g = self._graphs.get(key)
+        if g is not None and g.weights_sig != sig:  # stale packed weights: drop it and every sampling graph built on it
+            del self._graphs[key]
+            for k in [k for k in self._sample_graphs if k[:len(key)] == key]:
+                del self._sample_graphs[k]
+            g = None
         if g is None:
             g = GraphedDualStreamStep(self.unet, self.controlnet, self.controldec, B, (h, w), ehs.shape[2], dtype=dt,
                                       device=x_img.device, run_decoder=run_decoder, cond_channels=cond28.shape[1],
-                                      img_channels=x_img.shape[1], ctx_len=ehs.shape[1])
+                                      img_channels=x_img.shape[1], ctx_len=ehs.shape[1], conditioning_scale=cond_scale)
             g.load_inputs(x_img, cond28, ehs, 0, 0)
             g.capture()
+            g.weights_sig = sig
             self._graphs[key] = g
         return key, g
 
     def _fused_loop(self, x_img, cond28, ehs, timesteps, sched, run_decoder: bool, lat_dtype=torch.float32,
-                    guidance: Optional[float] = None):
+                    guidance: Optional[float] = None, cond_scale: float = 1.0):
         """All denoise steps as replays of ONE graph = step + ur_ddim_update (prediction -> next input, in the
         graph's static input buffer) + ur_sampler_advance (step counter, next timestep).  Inverse direction: the 24
         attribute channels of ``cond`` evolve at t_attr, the image latent is clean (t_img = 0); rendering direction:
@@ -244,7 +267,7 @@ class UniRendererPipeline:
         n = len(timesteps)
         cfg = guidance is not None
         nb = x_img.shape[0] // 2 if cfg else x_img.shape[0]  # distinct latents
-        key, g = self._graph_for(x_img, cond28, ehs, run_decoder)
+        key, g = self._graph_for(x_img, cond28, ehs, run_decoder, cond_scale)
         t0 = float(timesteps[0])
         g.load_inputs(x_img, cond28, ehs, 0.0 if run_decoder else t0, t0 if run_decoder else 0.0)
         coef, tvals = self._ddim_tables(sched, timesteps)
@@ -279,25 +302,17 @@ class UniRendererPipeline:
         st["master"].copy_((cond28[:nb, 4:] if run_decoder else x_img[:nb]))  # the caller's latents at their own precision
         for _ in range(n):
             st["graph"].replay()
-        return st["master"].to(lat_dtype)
+        # a COPY: ``master`` is this sampling graph's static buffer and the next call with the same shapes overwrites it
+        return st["master"].to(lat_dtype, copy=True)
 
-    def _step(self, x_img, cond28, ehs, t_img, t_attr, run_decoder: bool, cond_scale: float = 1.0):
-        B, _, h, w = x_img.shape
+    def _step(self, x_img, cond28, ehs, t_img, t_attr, run_decoder: bool, cond_scale: float = 1.0, sig=None):
         dt = self.unet.dtype
-        if self.use_hip_graph and x_img.is_cuda and cond_scale == 1.0:
-            key = (B, h, w, ehs.shape[1], ehs.shape[2], run_decoder, dt)
-            g = self._graphs.get(key)
-            if g is None:
-                g = GraphedDualStreamStep(self.unet, self.controlnet, self.controldec, B, (h, w), ehs.shape[2], dtype=dt,
-                                          device=x_img.device, run_decoder=run_decoder, cond_channels=cond28.shape[1],
-                                          img_channels=x_img.shape[1], ctx_len=ehs.shape[1])
-                g.load_inputs(x_img, cond28, ehs, t_img, t_attr)
-                g.capture()
-                self._graphs[key] = g
+        if self.use_hip_graph and x_img.is_cuda:
+            _, g = self._graph_for(x_img, cond28, ehs, run_decoder, cond_scale, sig=sig)
             return g.step(x_img, cond28, ehs, t_img, t_attr)
         tb = lambda t: torch.as_tensor(t, device=x_img.device).float().reshape(-1)
         return dual_stream_step(self.unet, self.controlnet, self.controldec, x_img.to(dt), cond28.to(dt), ehs.to(dt),
-                                tb(t_img), tb(t_attr), run_decoder)
+                                tb(t_img), tb(t_attr), run_decoder, conditioning_scale=cond_scale)
 
     # =====================================================================================================
     @torch.no_grad()
@@ -355,15 +370,17 @@ class UniRendererPipeline:
             cat = torch.cat([dup(lat[n]) for n in ATTR_GROUPS], dim=1)
             cond28 = torch.cat((x_mask.to(cat.dtype), cat), dim=1)
             fin = self._fused_loop(x_img, cond28, prompt_embeds, timesteps_attr, group_scheds[0], run_decoder=True,
-                                   lat_dtype=cat.dtype, guidance=(float(self.guidance_scale) if cfg else None))
+                                   lat_dtype=cat.dtype, guidance=(float(self.guidance_scale) if cfg else None),
+                                   cond_scale=cond_scale)
             lat = {n: fin[:, 4 * k:4 * k + 4].to(lat[n].dtype) for k, n in enumerate(ATTR_GROUPS)}
             timesteps_img = timesteps_attr = []  # loop below is skipped
+        sig = self._weights_signature() if len(timesteps_attr) else None  # once per call, not per step
         with self.progress_bar(total=num_inference_steps) as bar:
             for i, (t_img, t_attr) in enumerate(zip(timesteps_img, timesteps_attr)):
                 cat = torch.cat([dup(lat[n]) for n in ATTR_GROUPS], dim=1)
                 cat = self.scheduler_attr.scale_model_input(cat, t_attr)
                 cond28 = torch.cat((x_mask.to(cat.dtype), cat), dim=1)  # mask latent first: 4 + 6*4 = 28 channels
-                out = self._step(x_img, cond28, prompt_embeds, t_img, t_attr, run_decoder=True, cond_scale=cond_scale)
+                out = self._step(x_img, cond28, prompt_embeds, t_img, t_attr, run_decoder=True, cond_scale=cond_scale, sig=sig)
                 label_pred = out["attr_pred"][:, 4:]  # drop the mask group (ref 2691)
                 for k, n in enumerate(ATTR_GROUPS):
                     pred = label_pred[:, 4 * k:4 * k + 4]
@@ -433,14 +450,16 @@ class UniRendererPipeline:
         if self._fusable([self.scheduler_img], device, float(controlnet_conditioning_scale), None):
             latents_img = self._fused_loop(dup(latents_img), cond28, prompt_embeds, timesteps, self.scheduler_img,
                                            run_decoder=False, lat_dtype=latents_img.dtype,
-                                           guidance=(float(self.guidance_scale) if cfg else None))
+                                           guidance=(float(self.guidance_scale) if cfg else None),
+                                           cond_scale=float(controlnet_conditioning_scale))
             timesteps = timesteps[:0]  # loop below is skipped
+        sig = self._weights_signature() if len(timesteps) else None
         with self.progress_bar(total=num_inference_steps) as bar:
             for i in range(len(timesteps)):
                 t_img, t_attr = timesteps[i], timesteps_attr[i]
                 x = self.scheduler_img.scale_model_input(dup(latents_img), t_img)
                 out = self._step(x, cond28, prompt_embeds, t_img, t_attr, run_decoder=False,
-                                 cond_scale=float(controlnet_conditioning_scale))
+                                 cond_scale=float(controlnet_conditioning_scale), sig=sig)
                 img_pred = out["img_pred"]
                 if cfg:
                     p_cond, p_uncond = img_pred.chunk(2)  # ref 1642-1644

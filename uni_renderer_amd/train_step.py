@@ -146,20 +146,96 @@ def _down_mid(net, x, temb_act, ehs, dt):
     return x, skips
 
 
-def _up_out(net, x, skips: List[torch.Tensor], temb_act, ehs, dt):
+def _up_out(net, x, skips: List[torch.Tensor], temb_act, ehs, dt, extras=None, collect=None):
+    """Up path + conv_out.  ``extras``: per-resnet tensors added after each resnet(/transformer) of an ``UpRes*`` block
+    (unet_2d_blocks.py:2408, 2814); ``collect``: list that receives the per-layer outputs (the reference-modified
+    blocks return them, 2584-2590 / 2697-2704)."""
     temb = _temb_projections(_resnets_of(net.up_blocks), temb_act, dt)
     ehs = _context_projections(net.up_blocks, ehs, dt)
     skips = list(skips)
+    k = 0
     for blk in net.up_blocks:
         for i, r in enumerate(blk.resnets):
             x = _resnet(r, x, temb, dt, x1=skips.pop())
             if getattr(blk, "has_cross_attention", False):
                 x = _transformer(blk.attentions[i], x, ehs, dt)
+            if extras is not None and getattr(blk, "adds_up_states", False):
+                x = A.Add.apply(x, extras[k])
+            k += 1
+            if collect is not None:
+                collect.append(x)
         if blk.upsamplers is not None:
+            tgt = tuple(skips[-1].shape[1:3])  # the reference's upsample_size (controlnet.py:1129-1130)
+            if tgt != (2 * x.shape[1], 2 * x.shape[2]):
+                raise NotImplementedError("training path: latent sides must be multiples of 2**num_upsamplers")
             x = _conv(blk.upsamplers[0].conv, A.Up2x.apply(x), dt)
     n = net.conv_norm_out
     h = A.GroupNorm.apply(x, n.weight, n.bias, n.eps, n.num_groups, True)
     return _conv(net.conv_out, h, dt)
+
+
+def to_nhwc_grad(t: torch.Tensor, dt, cpad: Optional[int] = None) -> torch.Tensor:
+    """NCHW (any strides / dtype, may carry a grad_fn) -> contiguous NHWC in the compute dtype, channels zero padded to
+    ``cpad``; plain differentiable torch glue (a zero-copy view when ``t`` is one of this package's NCHW views)."""
+    v = t.permute(0, 2, 3, 1)
+    if v.dtype != dt:
+        v = v.to(dt)
+    if cpad is not None and v.shape[-1] != cpad:
+        v = torch.nn.functional.pad(v, (0, cpad - v.shape[-1]))
+    return v.contiguous()
+
+
+def _prompt(ehs, B, dt):
+    ehs = ehs.to(dt).contiguous()
+    if ehs.shape[0] == 1 and B > 1:
+        ehs = ehs.expand(B, -1, -1).contiguous()
+    return ehs
+
+
+# The three networks as differentiable functions over NHWC tensors.  ``controlnet.py``'s module ``forward``s route here
+# whenever autograd is recording (train/train.py:1324-1354 calls the modules and then ``accelerator.backward(loss)``),
+# and ``dual_stream_forward`` below composes them without the NCHW views in between.
+def encoder_forward(enc, cond_nhwc, ehs, t_attr, dt, conditioning_scale: float = 1.0):
+    """AttributeEncoderModel (controlnet.py:1657-1778).  ``cond_nhwc`` [B,H,W,CIN_PAD].  Returns
+    (res[12], mid_res, raw_down[12], raw_mid), NHWC."""
+    B, dev = cond_nhwc.shape[0], cond_nhwc.device
+    te = _time(enc, t_attr, B, dt, dev)
+    xe = _conv(enc.conv_in, cond_nhwc, dt, cin_pad=CIN_PAD)
+    raw_mid_enc, raw_enc = _down_mid(enc, xe, te, ehs, dt)
+    res = [A.linear(s, _w2(z, dt), z.bias) for s, z in zip(raw_enc, enc.controlnet_down_blocks)]
+    mid_res = A.linear(raw_mid_enc, _w2(enc.controlnet_mid_block, dt), enc.controlnet_mid_block.bias)
+    if conditioning_scale != 1.0:  # ref 1773-1775
+        res = [r * conditioning_scale for r in res]
+        mid_res = mid_res * conditioning_scale
+    return res, mid_res, raw_enc, raw_mid_enc
+
+
+def unet_forward(unet, x_nhwc, ehs, t_img, dt, res=None, mid_res=None, collect_up: bool = False):
+    """UNet2DConditionModel (controlnet.py:781-1166).  ``x_nhwc`` [B,H,W,CIN_PAD]; ``res`` / ``mid_res``: the encoder's
+    residuals (NHWC) or None.  Returns (img_pred, raw_down[12], raw_mid, up_res[13] | None), NHWC."""
+    B, dev = x_nhwc.shape[0], x_nhwc.device
+    tu = _time(unet, t_img, B, dt, dev)
+    xu = _conv(unet.conv_in, x_nhwc, dt, cin_pad=CIN_PAD)
+    raw_mid_unet, raw_unet = _down_mid(unet, xu, tu, ehs, dt)
+    skips, mid = raw_unet, raw_mid_unet
+    if res is not None:  # ref 1078-1087, 1114-1115
+        skips = [A.Add.apply(s, r) for s, r in zip(raw_unet, res)]
+        mid = A.Add.apply(raw_mid_unet, mid_res)
+    ups = [mid] if collect_up else None
+    img = _up_out(unet, mid, skips, tu, ehs, dt, collect=ups)
+    return img, raw_unet, raw_mid_unet, ups
+
+
+def decoder_forward(dec, raw_mid_enc, raw_enc, ehs, t_attr, dt, raw_unet=None, raw_mid_unet=None, extras=None):
+    """AttributeDecoderModel (controlnet.py:2342-2527): exchange skip_enc + conv1x1(skip_unet) (2446-2461, 2476-2477),
+    up path on its own weights.  All NHWC; returns attr_pred [B,H,W,out_channels]."""
+    B, dev = raw_mid_enc.shape[0], raw_mid_enc.device
+    td = _time(dec, t_attr, B, dt, dev)
+    dskips = list(raw_enc)
+    if raw_unet is not None:
+        dskips = [A.linear(u, _w2(z, dt), z.bias, res=e) for u, e, z in zip(raw_unet, raw_enc, dec.control_down_blocks)]
+    xd = A.linear(raw_mid_unet, _w2(dec.control_mid_block, dt), dec.control_mid_block.bias, res=raw_mid_enc)
+    return _up_out(dec, xd, dskips, td, ehs, dt, extras=extras)
 
 
 def dual_stream_forward(unet, enc, dec, x_t, cond, ehs, t_img, t_attr, dtype=torch.bfloat16, run_decoder: bool = True,
@@ -167,34 +243,18 @@ def dual_stream_forward(unet, enc, dec, x_t, cond, ehs, t_img, t_attr, dtype=tor
     """Differentiable dual-stream step (the call pattern of train.py:1324-1354): NCHW inputs, NHWC predictions
     ``img_pred`` [B,H,W,4] / ``attr_pred`` [B,H,W,28] in the compute dtype.  ``cond_nhwc`` ([B,H,W,28], compute dtype,
     may require grad) replaces ``cond``: the cycle-consistency pass feeds the decoder's own prediction back in."""
-    dev, B = x_t.device, x_t.shape[0]
+    B = x_t.shape[0]
     dt = dtype
-    ehs = ehs.to(dt).contiguous()
-    if ehs.shape[0] == 1 and B > 1:
-        ehs = ehs.expand(B, -1, -1).contiguous()
-    # ---- encoder: conv_in(cond), down, mid, 12 + 1 zero convs (controlnet.py:1657-1778)
-    te = _time(enc, t_attr, B, dt, dev)
+    ehs = _prompt(ehs, B, dt)
     if cond_nhwc is not None:
         cin = torch.nn.functional.pad(cond_nhwc, (0, CIN_PAD - cond_nhwc.shape[-1])).contiguous()
     else:
         cin = ops.to_nhwc(cond, dt, CIN_PAD)
-    xe = _conv(enc.conv_in, cin, dt, cin_pad=CIN_PAD)
-    raw_mid_enc, raw_enc = _down_mid(enc, xe, te, ehs, dt)
-    res = [A.linear(s, _w2(z, dt), z.bias) for s, z in zip(raw_enc, enc.controlnet_down_blocks)]
-    mid_res = A.linear(raw_mid_enc, _w2(enc.controlnet_mid_block, dt), enc.controlnet_mid_block.bias)
-    # ---- unet with the encoder's residuals (controlnet.py:781-1166)
-    tu = _time(unet, t_img, B, dt, dev)
-    xu = _conv(unet.conv_in, ops.to_nhwc(x_t, dt, CIN_PAD), dt, cin_pad=CIN_PAD)
-    raw_mid_unet, raw_unet = _down_mid(unet, xu, tu, ehs, dt)
-    skips = [A.Add.apply(s, r) for s, r in zip(raw_unet, res)]
-    img = _up_out(unet, A.Add.apply(raw_mid_unet, mid_res), skips, tu, ehs, dt)
+    res, mid_res, raw_enc, raw_mid_enc = encoder_forward(enc, cin, ehs, t_attr, dt)
+    img, raw_unet, raw_mid_unet, _ = unet_forward(unet, ops.to_nhwc(x_t, dt, CIN_PAD), ehs, t_img, dt, res, mid_res)
     out = {"img_pred": img}
     if run_decoder:
-        # ---- decoder: exchange skip_enc + conv1x1(skip_unet), up path on its own weights (controlnet.py:2342-2527)
-        td = _time(dec, t_attr, B, dt, dev)
-        dskips = [A.linear(u, _w2(z, dt), z.bias, res=e) for u, e, z in zip(raw_unet, raw_enc, dec.control_down_blocks)]
-        xd = A.linear(raw_mid_unet, _w2(dec.control_mid_block, dt), dec.control_mid_block.bias, res=raw_mid_enc)
-        out["attr_pred"] = _up_out(dec, xd, dskips, td, ehs, dt)
+        out["attr_pred"] = decoder_forward(dec, raw_mid_enc, raw_enc, ehs, t_attr, dt, raw_unet, raw_mid_unet)
     return out
 
 
