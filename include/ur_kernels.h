@@ -30,7 +30,7 @@
  *                   (controlnet.py:1078-1087, 1114-1115).
  *   ur_timestep_embedding   diffusers Timesteps (controlnet.py:285, 909-914).
  *   ur_nchw_to_nhwc / ur_nhwc_to_nchw   layout glue at the module boundary (the reference is NCHW).
- *   ur_ddim_update / ur_sampler_advance   the per-group scheduler `.step()` calls and the timestep bookkeeping between
+ *   ur_ddim_update / ur_unipc_update / ur_sampler_advance   the per-group scheduler `.step()` calls and the timestep bookkeeping between
  *                   two denoise steps of the sampling loops (models/pipeline.py:2691-2730, 1645-1649), on the device.
  */
 #ifndef UR_KERNELS_H
@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define UR_ABI_VERSION 2
+#define UR_ABI_VERSION 3
 
 #define UR_E_BADARG (-1001)   /* inconsistent descriptor (shape / alignment / null pointer)   */
 #define UR_E_UNSUPPORTED (-1002) /* shape outside what the kernels are instantiated for       */
@@ -78,7 +78,18 @@ extern "C" {
 #define UR_TILE_64x64_W1_S3 19
 #define UR_TILE_64x128_W2 20
 #define UR_TILE_64x64_W1_S4 21
-#define UR_TILE_COUNT 22
+/* the same tiles on v_mfma_f32_32x32x16 (csrc/igemm.hip: half the MFMA instructions per chunk; this chip issues the
+ * 16x16x32 shape at ~27 cycles against its nominal 16) */
+#define UR_TILE_128x320_M32 22
+#define UR_TILE_128x128_M32 23
+#define UR_TILE_128x64_M32 24    /* 2-deep */
+#define UR_TILE_128x64_S3_M32 25 /* 3-deep */
+#define UR_TILE_64x64_M32 26     /* 2 x 2 waves of 32 x 32, 2-deep */
+#define UR_TILE_64x64_S3_M32 27
+#define UR_TILE_256x256_M32 28
+#define UR_TILE_256x128_M32 29
+#define UR_TILE_128x256_M32 30
+#define UR_TILE_COUNT 31
 
 /*
  * Implicit GEMM:  out[m][n] = epilogue( sum_k X[m][k] * W[n][k] )
@@ -150,6 +161,10 @@ typedef struct ur_igemm_desc {
     const void* t1;
     int64_t ldt0, ldt1, zt0, zt1;
     int32_t ct0, ct1;
+    /* taps == 9: zero padding on the top / left edge, 1 or 0 (the bottom / right edge is whatever Hout / Wout imply:
+     * taps beyond the image read zeros).  1 = the symmetric `padding=1` of every conv of the UNets; 0 with stride 2 =
+     * the VAE encoder's Downsample2D, F.pad(x, (0, 1, 0, 1)) followed by a stride-2 conv with padding 0. */
+    int32_t pad;
 } ur_igemm_desc;
 
 int ur_igemm(const ur_igemm_desc* d, void* stream);
@@ -256,6 +271,31 @@ int ur_ddim_update(const void* pred, int pred_ld, int pred_c0, void* lat, int64_
                    const float* coef, const int* step, int nsteps, float* master, int round_master, int cfg,
                    float guidance, int cfg_channels, int dtype, void* stream);
 int ur_sampler_advance(int* step, const float* tsteps, int nsteps, float* t_out, int B, void* stream);
+
+/*
+ * ur_unipc_update: the UniPCMultistepScheduler.step() calls of the live sampling loops (eval/test_real.py:485-492
+ * attaches eight UniPC schedulers; models/pipeline.py:2725-2730, 1649) for all latent groups at once.  UniPC with data
+ * (x0) prediction, B(h) = bh2, order <= 2 is a linear recurrence with data-independent scalars (host:
+ * schedulers.UniPCMultistepScheduler.coefficient_table, row i = c0 c1 c2 c3 p0 p1 p2 -):
+ *     L_i = c0 L_{i-1} + c1 m_{i-1} + c2 m_{i-2} + c3 m_i   (corrector; L_0 = the initial sample)
+ *     x_{i+1} = p0 L_i + p1 m_i + p2 m_{i-1}                (predictor = next model input, written to `lat`)
+ * with m_i = pred at step i = *step.  pred / lat / cfg / guidance / round_master as ur_ddim_update; last, xmaster:
+ * fp32 [B][C][HW]; hist: fp32 [2][B][C][HW], zeroed by the caller before step 0.  The caller advances *step with
+ * ur_sampler_advance.
+ */
+int ur_unipc_update(const void* pred, int pred_ld, int pred_c0, void* lat, int64_t lat_bstride, int C, int B, int HW,
+                    const float* coef, const int* step, int nsteps, float* last, float* xmaster, float* hist,
+                    int round_master, int cfg, float guidance, int cfg_channels, int dtype, void* stream);
+
+/*
+ * Weight prefetch into the 256 MB Infinity Cache (MI355X's memory-side last-level cache).  One denoise step reads
+ * 3.5 GB of weights that are all cold (the cache holds < 8 % of them); the deep-level launches are then paced by HBM
+ * latency, while HBM sits idle under the MFMA-bound 64x64-level launches.  This kernel touches `bytes` bytes at `ptr`
+ * (one 4-byte non-temporal load per 128-byte line, results discarded) from `wgs` small workgroups, so that a caller can
+ * run it on a second stream / graph branch one layer AHEAD of the layer that will read those weights.  Speed only:
+ * no effect on results.  No reference counterpart (the reference has no custom kernels).
+ */
+int ur_prefetch(const void* ptr, int64_t bytes, int wgs, void* stream);
 
 /*
  * Backward building blocks (device op 11; csrc/backward.hip).  The GEMM-shaped gradients run on

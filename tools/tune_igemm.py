@@ -169,7 +169,7 @@ def main():
             M, N, K, taps, zb = key
             res = {}
             for tile in tiles:
-                for sk in (1, 2, 4, 8):
+                for sk in (1, 2, 4, 8, 16):
                     if sk > 1 and (zb > 4 or K // 64 < 4 * sk):
                         continue
                     t = time_cfg(kw, tile, sk, graph=not args.eager)

@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must be imported first, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("UR_LIB_PATH", os.path.join(_HERE, "liburhip.so"))  # override = kernel experiments only
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
@@ -38,6 +38,7 @@ class IGemmDesc(C.Structure):
         ("res_lo", vp), ("out_lo", vp),
         ("cblock", i32),
         ("t0", vp), ("t1", vp), ("ldt0", i64), ("ldt1", i64), ("zt0", i64), ("zt1", i64), ("ct0", i32), ("ct1", i32),
+        ("pad", i32),
     ]
 
 
@@ -73,6 +74,9 @@ SYMBOLS = {
     "ur_ddim_update": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int64, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp,
                                  C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, vp]),
     "ur_sampler_advance": (C.c_int, [vp, vp, C.c_int, vp, C.c_int, vp]),
+    "ur_prefetch": (C.c_int, [vp, C.c_int64, C.c_int, vp]),
+    "ur_unipc_update": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int64, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp,
+                                  vp, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, vp]),
     "ur_transpose2d": (C.c_int, [vp, C.c_int64, C.c_int64, vp, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "ur_im2col3x3_t": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int64, C.c_int, vp]),
     "ur_colsum_workspace_floats": (C.c_int64, [C.c_int, C.c_int, C.c_int]),

@@ -166,13 +166,25 @@ __device__ __forceinline__ void epilogue16(const ur_igemm_desc& p, T* __restrict
     }
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int NSTAGE, bool CONV>
+// MF = 16: v_mfma_f32_16x16x32 (the original formulation, described above).
+// MF = 32: v_mfma_f32_32x32x16.  On this chip the 16x16x32 shape issues at ~27 cycles against its nominal 16
+// (tools/ubench/mfma_rate.hip: 1.16 vs 1.91 PFLOP/s), and the big conv tiles run at 85 % of THAT ceiling, so the
+// same wave tiles are also built on the 32x32x16 shape: per 64-deep K chunk a wave issues (BM/WM/32) x (BN/WN/32) x 4
+// MFMAs of 32 nominal cycles instead of twice as many of 16.  Same LDS image except for two details: a fragment
+// read now spans 32 consecutive tile rows per half-wave, so the 16-byte chunk swizzle key is ((row >> 1) & 7) instead
+// of (row & 7) (conflict-free for ds_read_b128's 16-lane service groups, tools/lds_bank_check.py), and the weight
+// rows of a 32-row block are permuted so that the 16 accumulator registers of a lane (MFMA rows 8g + 4h + r) are 16
+// CONSECUTIVE output channels 16h + 4g + r of one pixel -- the epilogue is shared.
+template <typename T, int BM, int BN, int WM, int WN, int NSTAGE, bool CONV, int MF>
 __global__ void __launch_bounds__(WM * WN * 64) igemm_kernel(const ur_igemm_desc p) {
     typedef typename Vec8<T>::type vec8;
     constexpr int NW = WM * WN;  // waves per workgroup
     constexpr int MREP = BM / WM / 16;
     constexpr int NREP = BN / WN / 16;
-    static_assert(NREP == 4, "a wave spans 64 output columns (epilogue layout)");
+    static_assert(MF == 16 || MF == 32, "MFMA shape");
+    static_assert(MF == 32 || NREP == 4, "a wave spans 64 output columns (epilogue layout)");
+    static_assert(MF == 16 || ((BM / WM) % 32 == 0 && (BN / WN) % 32 == 0), "32x32 MFMA: wave tile in multiples of 32");
+    constexpr int MI = BM / WM / 32, NI = BN / WN / 32;  // 32x32 blocks of a wave tile (MF == 32)
     constexpr int XT_BYTES = BM * 128;
     constexpr int WT_BYTES = BN * 128;
     constexpr int STAGE = XT_BYTES + WT_BYTES;
@@ -212,7 +224,11 @@ __global__ void __launch_bounds__(WM * WN * 64) igemm_kernel(const ur_igemm_desc
     const char* wp = reinterpret_cast<const char*>(reinterpret_cast<const T*>(p.w) + (int64_t)zb * p.zw);
     const char* t0 = reinterpret_cast<const char*>(reinterpret_cast<const T*>(p.t0) + (int64_t)zb * p.zt0);  // 1x1 tail sources
     const char* t1 = reinterpret_cast<const char*>(reinterpret_cast<const T*>(p.t1) + (int64_t)zb * p.zt1);
-    const int js = (lane & 7) ^ (lane >> 3);  // swizzled source chunk of this lane's 16 bytes
+    // swizzled source chunk of this lane's 16 bytes in LDS-DMA piece `piece` (8 tile rows, row = 8 * piece + lane / 8):
+    // key = row & 7 (MF 16) or (row >> 1) & 7 (MF 32)
+    auto jsw = [&](int piece) __attribute__((always_inline)) {
+        return MF == 16 ? ((lane & 7) ^ (lane >> 3)) : ((lane & 7) ^ ((4 * piece + (lane >> 4)) & 7));
+    };
     const char* zp = reinterpret_cast<const char*>(p.zero_page) + (lane & 7) * 16;
 
     // ---- per-lane row bookkeeping (fixed over the K loop) ----
@@ -232,8 +248,8 @@ __global__ void __launch_bounds__(WM * WN * 64) igemm_kernel(const ur_igemm_desc
             const int oy = rem / p.Wout;
             const int ox = rem - oy * p.Wout;
             xa[it] = b * p.Hin * p.Win;
-            xy[it] = (m < p.M) ? oy * p.stride - 1 : -(1 << 20);
-            xx[it] = ox * p.stride - 1;
+            xy[it] = (m < p.M) ? oy * p.stride - p.pad : -(1 << 20);
+            xx[it] = ox * p.stride - p.pad;
         } else {
             xa[it] = (m < p.M) ? m : -1;
             xy[it] = 0;
@@ -247,12 +263,19 @@ __global__ void __launch_bounds__(WM * WN * 64) igemm_kernel(const ur_igemm_desc
 #pragma unroll
     for (int it = 0; it < WI; ++it) {
         const int r = (it * NW + wave) * 8 + (lane >> 3);  // LDS row of the tile
-        const int rho = r & 63;
-        // LDS row (f, i) = f*16 + i holds semantic column (i>>2)*16 + f*4 + (i&3) of its 64-group
-        const int sem = (r & ~63) | (((rho >> 2) & 3) << 4) | ((rho >> 4) << 2) | (rho & 3);
+        int sem;
+        if (MF == 16) {
+            const int rho = r & 63;
+            // LDS row (f, i) = f*16 + i holds semantic column (i>>2)*16 + f*4 + (i&3) of its 64-group
+            sem = (r & ~63) | (((rho >> 2) & 3) << 4) | ((rho >> 4) << 2) | (rho & 3);
+        } else {
+            const int rho = r & 31;
+            // LDS row 8g + 4h + rr of a 32-block holds semantic column 16h + 4g + rr
+            sem = (r & ~31) | (((rho >> 2) & 1) << 4) | ((rho >> 3) << 2) | (rho & 3);
+        }
         const int n = n0 + sem;
         const bool ok = n < p.N;
-        const int64_t off = ((int64_t)n * p.ldw + (int64_t)kbeg * BK + js * 8) * (int64_t)sizeof(T);
+        const int64_t off = ((int64_t)n * p.ldw + (int64_t)kbeg * BK + jsw(it * NW + wave) * 8) * (int64_t)sizeof(T);
         wptr[it] = ok ? wp + off : zp;
         winc[it] = ok ? 128 : 0;
     }
@@ -296,7 +319,7 @@ __global__ void __launch_bounds__(WM * WN * 64) igemm_kernel(const ur_igemm_desc
                 ok = xa[it] >= 0;
                 pix = xa[it];
             }
-            const int64_t off = ((int64_t)pix * ld + seg_coff + cc + js * 8) * (int64_t)sizeof(T);
+            const int64_t off = ((int64_t)pix * ld + seg_coff + cc + jsw(it * NW + wave) * 8) * (int64_t)sizeof(T);
             xptr[it] = ok ? sb + off : zp;
             xinc[it] = ok ? 128 : 0;
         }
@@ -414,33 +437,65 @@ __global__ void __launch_bounds__(WM * WN * 64) igemm_kernel(const ur_igemm_desc
             if (it * NW + wave < BN / 8) *reinterpret_cast<u32x4*>(ws + (it * NW + wave) * 1024) = wr[it];
     };
 
-    f32x4 acc[MREP][NREP];
+    f32x4 acc[MF == 16 ? MREP : 1][MF == 16 ? NREP : 1];
+    f32x16 acc32[MF == 32 ? MI : 1][MF == 32 ? NI : 1];
+    if constexpr (MF == 16) {
 #pragma unroll
-    for (int i = 0; i < MREP; ++i)
+        for (int i = 0; i < MREP; ++i)
 #pragma unroll
-        for (int j = 0; j < NREP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < NREP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) acc32[i][j][v] = 0.f;
+    }
 
     const int l15 = lane & 15, q = lane >> 4;
+    const int l31 = lane & 31, hh = lane >> 5;
     auto compute = [&](int buf) {
 #if defined(UR_ABLATE) && UR_ABLATE == 2
         if (buf >= 0) return;
 #endif
         const char* xs = smem + buf * STAGE;
         const char* ws = xs + XT_BYTES;
+        if constexpr (MF == 32) {
+            // four k16 steps per chunk; lane (row l31 of a 32-block, half hh) reads chunk 2 s + hh of its row, swizzled
+            // by ((row >> 1) & 7) = (l31 >> 1) & 7 (block bases are multiples of 32)
+            const int key = (l31 >> 1) & 7;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const int c = ((kk * 4 + q) ^ (l15 & 7)) << 4;  // swizzled 16-B chunk of this lane
-            vec8 wf[NREP], xf[MREP];
+            for (int s = 0; s < 4; ++s) {
+                const int c = ((2 * s + hh) ^ key) << 4;
+                vec8 wf[NI], xf[MI];
 #pragma unroll
-            for (int f = 0; f < NREP; ++f)
-                wf[f] = *reinterpret_cast<const vec8*>(ws + (wn * 64 + f * 16 + l15) * 128 + c);
+                for (int ni = 0; ni < NI; ++ni)
+                    wf[ni] = *reinterpret_cast<const vec8*>(ws + (wn * (32 * NI) + ni * 32 + l31) * 128 + c);
 #pragma unroll
-            for (int mf = 0; mf < MREP; ++mf)
-                xf[mf] = *reinterpret_cast<const vec8*>(xs + (wm * (16 * MREP) + mf * 16 + l15) * 128 + c);
+                for (int mi = 0; mi < MI; ++mi)
+                    xf[mi] = *reinterpret_cast<const vec8*>(xs + (wm * (32 * MI) + mi * 32 + l31) * 128 + c);
 #pragma unroll
-            for (int mf = 0; mf < MREP; ++mf)
+                for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                for (int f = 0; f < NREP; ++f) acc[mf][f] = mfma16(wf[f], xf[mf], acc[mf][f]);
+                    for (int ni = 0; ni < NI; ++ni) acc32[mi][ni] = mfma32(wf[ni], xf[mi], acc32[mi][ni]);
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int c = ((kk * 4 + q) ^ (l15 & 7)) << 4;  // swizzled 16-B chunk of this lane
+                vec8 wf[NREP], xf[MREP];
+#pragma unroll
+                for (int f = 0; f < NREP; ++f)
+                    wf[f] = *reinterpret_cast<const vec8*>(ws + (wn * 64 + f * 16 + l15) * 128 + c);
+#pragma unroll
+                for (int mf = 0; mf < MREP; ++mf)
+                    xf[mf] = *reinterpret_cast<const vec8*>(xs + (wm * (16 * MREP) + mf * 16 + l15) * 128 + c);
+#pragma unroll
+                for (int mf = 0; mf < MREP; ++mf)
+#pragma unroll
+                    for (int f = 0; f < NREP; ++f) acc[mf][f] = mfma16(wf[f], xf[mf], acc[mf][f]);
+            }
         }
     };
 
@@ -482,16 +537,10 @@ __global__ void __launch_bounds__(WM * WN * 64) igemm_kernel(const ur_igemm_desc
         }
     }
 
-    // ---- epilogue: lane (j = lane&15, q = lane>>4) holds pixel row j, channels q*16 .. q*16+15 ----
-    const int nc = n0 + wn * 64 + q * 16;
-#pragma unroll
-    for (int mf = 0; mf < MREP; ++mf) {
-        const int m = m0 + wm * (16 * MREP) + mf * 16 + (lane & 15);
-        float v[16];
-#pragma unroll
-        for (int f = 0; f < NREP; ++f)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[f * 4 + r] = acc[mf][f][r];
+    // ---- epilogue: a lane holds 16 consecutive output channels of one pixel ----
+    //   MF 16: lane (j = lane&15, q = lane>>4): pixel row j of a 16-row block, channels q*16 .. q*16+15 of the wave's 64
+    //   MF 32: lane (j = lane&31, h = lane>>5): pixel row j of a 32-row block, channels h*16 .. h*16+15 of a 32-block
+    auto finish = [&](int m, int nc, float (&v)[16]) __attribute__((always_inline)) {
         if (p.splitk > 1) {
             if (m < p.M) {
                 float4* pp = reinterpret_cast<float4*>(p.partial + ((int64_t)zidx * p.M + m) * p.ldp + nc);
@@ -505,6 +554,31 @@ __global__ void __launch_bounds__(WM * WN * 64) igemm_kernel(const ur_igemm_desc
                           p.res ? reinterpret_cast<const T*>(p.res) + (int64_t)zb * p.zres : nullptr, m, nc, v,
                           HiLo<T>{p.res_lo ? reinterpret_cast<const lo_t<T>*>(p.res_lo) + (int64_t)zb * p.zres : nullptr,
                                   p.out_lo ? reinterpret_cast<lo_t<T>*>(p.out_lo) + (int64_t)zb * p.zout : nullptr});
+        }
+    };
+    if constexpr (MF == 32) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const int m = m0 + wm * (32 * MI) + mi * 32 + l31;
+                const int nc = n0 + wn * (32 * NI) + ni * 32 + hh * 16;
+                float v[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = acc32[mi][ni][r];
+                finish(m, nc, v);
+            }
+    } else {
+        const int nc = n0 + wn * 64 + q * 16;
+#pragma unroll
+        for (int mf = 0; mf < MREP; ++mf) {
+            const int m = m0 + wm * (16 * MREP) + mf * 16 + (lane & 15);
+            float v[16];
+#pragma unroll
+            for (int f = 0; f < NREP; ++f)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[f * 4 + r] = acc[mf][f][r];
+            finish(m, nc, v);
         }
     }
 }
@@ -551,7 +625,10 @@ static const TileCfg kTiles[UR_TILE_COUNT] = {{0, 0, 0},      {128, 128, 2}, {12
                                               {256, 128, 2}, {128, 320, 2}, {128, 256, 2}, {256, 256, 2},
                                               {64, 64, -2},  {128, 64, -2}, {128, 128, -2}, {128, 320, -2},
                                               {256, 128, -2}, {64, 64, 2},   {128, 64, 2},   {64, 64, 3},
-                                              {64, 128, 2},  {64, 64, 4}};
+                                              {64, 128, 2},  {64, 64, 4},
+                                              // 32x32x16-MFMA builds (UR_TILE_*_M32)
+                                              {128, 320, 2}, {128, 128, 2}, {128, 64, 2}, {128, 64, 3}, {64, 64, 2},
+                                              {64, 64, 3},   {256, 256, 2}, {256, 128, 2}, {128, 256, 2}};
 
 static int pick_tile(const ur_igemm_desc& d) {
     // Cost model: the busiest CU runs ceil(workgroups / 256) tiles; bigger tiles have a better
@@ -569,24 +646,24 @@ static int pick_tile(const ur_igemm_desc& d) {
     return best;
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int NSTAGE, bool CONV>
+template <typename T, int BM, int BN, int WM, int WN, int NSTAGE, bool CONV, int MF>
 static void ensure_lds_limit(int lds) {
     static std::atomic<uint64_t> done{0};  // per (instantiation, device), see set_lds_limit_once
-    set_lds_limit_once(done, reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, WM, WN, NSTAGE, CONV>), lds);
+    set_lds_limit_once(done, reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, WM, WN, NSTAGE, CONV, MF>), lds);
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int NSTAGE>
+template <typename T, int BM, int BN, int WM, int WN, int NSTAGE, int MF = 16>
 static int launch_cfg(const ur_igemm_desc& d, hipStream_t s) {
     const int tiles_m = (d.M + BM - 1) / BM, tiles_n = (d.N + BN - 1) / BN;
     dim3 grid(tiles_m * tiles_n, 1, d.zbatch * d.splitk);
     const size_t lds = (NSTAGE > 0 ? NSTAGE : 2) * (BM + BN) * 128;
     hipError_t e;
     if (d.taps == 9) {
-        ensure_lds_limit<T, BM, BN, WM, WN, NSTAGE, true>((int)lds);
-        hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, NSTAGE, true>), grid, dim3(WM * WN * 64), lds, s, d);
+        ensure_lds_limit<T, BM, BN, WM, WN, NSTAGE, true, MF>((int)lds);
+        hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, NSTAGE, true, MF>), grid, dim3(WM * WN * 64), lds, s, d);
     } else {
-        ensure_lds_limit<T, BM, BN, WM, WN, NSTAGE, false>((int)lds);
-        hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, NSTAGE, false>), grid, dim3(WM * WN * 64), lds, s, d);
+        ensure_lds_limit<T, BM, BN, WM, WN, NSTAGE, false, MF>((int)lds);
+        hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, NSTAGE, false, MF>), grid, dim3(WM * WN * 64), lds, s, d);
     }
     e = hipGetLastError();
     if (e != hipSuccess) return -(int)e;
@@ -625,6 +702,15 @@ static int launch_dtype(ur_igemm_desc& d, hipStream_t s) {
         case UR_TILE_64x64_W1_S3: return launch_cfg<T, 64, 64, 1, 1, 3>(d, s);
         case UR_TILE_64x128_W2: return launch_cfg<T, 64, 128, 1, 2, 2>(d, s);
         case UR_TILE_64x64_W1_S4: return launch_cfg<T, 64, 64, 1, 1, 4>(d, s);
+        case UR_TILE_128x320_M32: return launch_cfg<T, 128, 320, 2, 5, 2, 32>(d, s);
+        case UR_TILE_128x128_M32: return launch_cfg<T, 128, 128, 2, 2, 2, 32>(d, s);
+        case UR_TILE_128x64_M32: return launch_cfg<T, 128, 64, 4, 1, 2, 32>(d, s);
+        case UR_TILE_128x64_S3_M32: return launch_cfg<T, 128, 64, 4, 1, 3, 32>(d, s);
+        case UR_TILE_64x64_M32: return launch_cfg<T, 64, 64, 2, 2, 2, 32>(d, s);
+        case UR_TILE_64x64_S3_M32: return launch_cfg<T, 64, 64, 2, 2, 3, 32>(d, s);
+        case UR_TILE_256x256_M32: return launch_cfg<T, 256, 256, 4, 4, 2, 32>(d, s);
+        case UR_TILE_256x128_M32: return launch_cfg<T, 256, 128, 4, 2, 2, 32>(d, s);
+        case UR_TILE_128x256_M32: return launch_cfg<T, 128, 256, 2, 4, 2, 32>(d, s);
     }
     return UR_E_BADARG;
 }
@@ -667,6 +753,7 @@ extern "C" int ur_igemm(const ur_igemm_desc* din, void* stream) {
         if (d.stride != 1 && d.stride != 2) return UR_E_BADARG;
         if (d.M != d.B * d.Hout * d.Wout) return UR_E_BADARG;
         if (d.ups && d.stride != 1) return UR_E_BADARG;
+        if (d.pad != 0 && d.pad != 1) return UR_E_BADARG;
     }
     if (d.cblock < 0 || (d.cblock > 0 && (d.taps != 9 || (d.cblock % BK) || d.c1 != 0 || (d.c0 % d.cblock)))) return UR_E_BADARG;
     if (d.zbatch < 1) d.zbatch = 1;

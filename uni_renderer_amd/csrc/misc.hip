@@ -291,6 +291,52 @@ __global__ void __launch_bounds__(256) ddim_update_kernel(const T* __restrict__ 
     }
 }
 
+// UniPC (order <= 2, x0 / data prediction, B(h) = bh2) predictor-corrector update as ONE pass (schedulers.py
+// UniPCMultistepScheduler.coefficient_table): with m_i the model's x0 prediction at step i,
+//     L_i     = c0 L_{i-1} + c1 m_{i-1} + c2 m_{i-2} + c3 m_i      corrected sample ("last_sample"; step 0: L_0 = x_0)
+//     x_{i+1} = p0 L_i     + p1 m_i     + p2 m_{i-1}               next model input
+// coef row i = (c0, c1, c2, c3, p0, p1, p2, -).  `last` holds L, `xmaster` the evolving x (what the loop returns), `hist`
+// the two previous predictions in a 2-slot ring indexed by the device step counter (m_{i-1} in slot (i+1)&1, m_{i-2}
+// in slot i&1, which m_i then overwrites).  All fp32; with round_master the samples are rounded through the latent dtype
+// where the reference's scheduler casts them (`x_t.to(x.dtype)`).
+template <typename T>
+__global__ void __launch_bounds__(256) unipc_update_kernel(const T* __restrict__ pred, int pred_ld, int pred_c0, T* __restrict__ lat,
+                                                           int64_t lat_bs, int C, int B, int HW, const float* __restrict__ coef,
+                                                           const int* __restrict__ step, int nsteps, float* __restrict__ last,
+                                                           float* __restrict__ xmaster, float* __restrict__ hist, int round_master,
+                                                           int cfg, float guidance, int cfg_channels) {
+    const int st = min(*step, nsteps - 1);
+    const float* cr = coef + (int64_t)st * 8;
+    const float c0 = cr[0], c1 = cr[1], c2 = cr[2], c3 = cr[3], p0 = cr[4], p1 = cr[5], p2 = cr[6];
+    const int64_t total = (int64_t)B * C * HW;
+    float* h1 = hist + (int64_t)((st + 1) & 1) * total;  // m_{i-1}
+    float* h2 = hist + (int64_t)(st & 1) * total;        // m_{i-2}, then m_i
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int p = (int)(i % HW);
+        const int64_t bc = i / HW;
+        const int c = (int)(bc % C), b = (int)(bc / C);
+        T mt = pred[((int64_t)b * HW + p) * pred_ld + pred_c0 + c];
+        if (cfg && c < cfg_channels) {  // as in ddim_update_kernel: the reference's guidance arithmetic in the prediction's dtype
+            const T pu = pred[((int64_t)(b + B) * HW + p) * pred_ld + pred_c0 + c];
+            const T d = (T)((float)mt - (float)pu);
+            const T m = (T)((float)d * guidance);
+            mt = (T)((float)pu + (float)m);
+        }
+        const float m = (float)mt, m1 = h1[i], m2 = h2[i];
+        float L = c0 * last[i] + c1 * m1 + c2 * m2 + c3 * m;
+        if (round_master) L = (float)(T)L;
+        float x = p0 * L + p1 * m + p2 * m1;
+        const T xt = (T)x;
+        if (round_master) x = (float)xt;
+        last[i] = L;
+        xmaster[i] = x;
+        h2[i] = m;
+        T* xp = lat + (int64_t)b * lat_bs + (int64_t)c * HW + p;
+        *xp = xt;
+        if (cfg) xp[(int64_t)B * lat_bs] = xt;
+    }
+}
+
 // step += 1; t_out[0..B) = tsteps[step] (the timestep the NEXT replay denoises at)
 __global__ void sampler_advance_kernel(int* step, const float* __restrict__ tsteps, int nsteps, float* t_out, int B) {
     // ONE thread reads the counter and shares it through LDS: with every thread reading *step, waves 1-3 could see
@@ -328,6 +374,30 @@ extern "C" int ur_ddim_update(const void* pred, int pred_ld, int pred_c0, void* 
     return e == hipSuccess ? 0 : -(int)e;
 }
 
+extern "C" int ur_unipc_update(const void* pred, int pred_ld, int pred_c0, void* lat, int64_t lat_bstride, int C, int B,
+                               int HW, const float* coef, const int* step, int nsteps, float* last, float* xmaster,
+                               float* hist, int round_master, int cfg, float guidance, int cfg_channels, int dtype,
+                               void* stream) {
+    if (!pred || !lat || !coef || !step || !last || !xmaster || !hist || C <= 0 || B <= 0 || HW <= 0 || nsteps <= 0 ||
+        pred_c0 < 0 || pred_c0 + C > pred_ld)
+        return UR_E_BADARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int64_t total = (int64_t)B * C * HW;
+    const int grid = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+    if (dtype == UR_DT_F16)
+        hipLaunchKernelGGL((unipc_update_kernel<f16>), dim3(grid), dim3(256), 0, s, (const f16*)pred, pred_ld, pred_c0,
+                           (f16*)lat, lat_bstride, C, B, HW, coef, step, nsteps, last, xmaster, hist, round_master, cfg,
+                           guidance, cfg_channels);
+    else if (dtype == UR_DT_BF16)
+        hipLaunchKernelGGL((unipc_update_kernel<bf16>), dim3(grid), dim3(256), 0, s, (const bf16*)pred, pred_ld, pred_c0,
+                           (bf16*)lat, lat_bstride, C, B, HW, coef, step, nsteps, last, xmaster, hist, round_master, cfg,
+                           guidance, cfg_channels);
+    else
+        return UR_E_BADARG;
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : -(int)e;
+}
+
 extern "C" int ur_sampler_advance(int* step, const float* tsteps, int nsteps, float* t_out, int B, void* stream) {
     if (!step || !tsteps || nsteps <= 0 || B < 0 || B > 256) return UR_E_BADARG;
     hipLaunchKernelGGL(sampler_advance_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), step, tsteps,
@@ -336,7 +406,25 @@ extern "C" int ur_sampler_advance(int* step, const float* tsteps, int nsteps, fl
     return e == hipSuccess ? 0 : -(int)e;
 }
 
+// One 4-byte load per 128-byte line, grid-strided; the value is consumed by an empty asm so the load is not dropped.
+__global__ void __launch_bounds__(256) prefetch_kernel(const char* __restrict__ p, int64_t lines) {
+    unsigned acc = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < lines; i += (int64_t)gridDim.x * blockDim.x)
+        acc ^= __builtin_nontemporal_load(reinterpret_cast<const unsigned*>(p + i * 128));
+    asm volatile("" ::"v"(acc));
+}
+
+extern "C" int ur_prefetch(const void* ptr, int64_t bytes, int wgs, void* stream) {
+    if (!ptr || bytes < 0 || wgs <= 0) return UR_E_BADARG;
+    const int64_t lines = bytes / 128;
+    if (lines == 0) return 0;
+    hipLaunchKernelGGL(prefetch_kernel, dim3(wgs), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const char*>(ptr), lines);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : -(int)e;
+}
+
 extern "C" int ur_abi_version(void) { return UR_ABI_VERSION; }
-extern "C" const char* ur_build_info(void) { return "liburhip gfx950 (hipcc, MFMA 16x16x32 + 32x32x16, LDS-DMA) abi 2"; }
+extern "C" const char* ur_build_info(void) { return "liburhip gfx950 (hipcc, MFMA 16x16x32 + 32x32x16, LDS-DMA) abi 3"; }
 extern "C" int ur_sizeof_igemm_desc(void) { return (int)sizeof(ur_igemm_desc); }
 extern "C" int ur_sizeof_attn_desc(void) { return (int)sizeof(ur_attn_desc); }

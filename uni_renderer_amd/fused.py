@@ -67,6 +67,62 @@ class GroupedDualStreamStep:
         if precise_residual is None:
             precise_residual = os.environ.get("UR_PRECISE_RESIDUAL", "1") != "0"
         self.hilo = bool(precise_residual)
+        # Independent work on a second HIP stream (= a parallel branch of the captured graph): the 13 exchange GEMMs
+        # (each only needs its own skip pair, which phase 1 produces early), the up phase's time / prompt projections
+        # (inputs only) and every self-attention's V^T projection (beside its q|k projection).  These launches are
+        # small (a few hundred workgroups, 15-25 us each); serialised behind the dependent chain they cost their full
+        # latency, on a sibling branch they fill the chip beside the chain's own launches.  UR_SIDE_STREAM=0: off.
+        # MEASURED (r02, MI355X, cfg 3): 13.06 ms/step without, 13.53 ms with all three kinds of forks -- every
+        # cross-stream edge of a hipGraph costs more in dependency signalling than the overlap returns -- so the default
+        # is OFF; UR_SIDE_STREAM=1 all forks, 2 only the off-critical-path ones (exchange + up-phase context), 3 only V^T.
+        self.side_level = int(os.environ.get("UR_SIDE_STREAM", "0"))
+        self.use_side = self.side_level != 0
+        self._side = None
+
+    # ------------------------------------------------------------------ second stream (graph branch)
+    class _Fork:
+        """``with step._fork(deps) as f:`` runs the body on the side stream after everything enqueued on the current
+        stream so far; ``f.join(*outs)`` makes the current stream wait for it.  Tensors crossing streams are recorded
+        with the caching allocator (``deps`` are read on the side stream, ``outs`` on the main one)."""
+
+        def __init__(self, owner, deps, kind):
+            self.o, self.deps = owner, deps
+            self.main = torch.cuda.current_stream()
+            self.active = owner.side_level == 1 or (owner.side_level == 2 and kind != "vt") or (owner.side_level == 3 and kind == "vt")
+
+        @staticmethod
+        def _rec(t, stream):
+            if torch.is_tensor(t):
+                t.record_stream(stream)
+                lo = ops.lo_of(t)
+                if lo is not None:
+                    lo.record_stream(stream)
+
+        def __enter__(self):
+            if self.active:
+                if self.o._side is None:
+                    self.o._side = torch.cuda.Stream()
+                self.side = self.o._side
+                self.side.wait_stream(self.main)
+                for t in self.deps:
+                    self._rec(t, self.side)
+                self._ctx = torch.cuda.stream(self.side)
+                self._ctx.__enter__()
+            return self
+
+        def __exit__(self, *exc):
+            if self.active:
+                self._ctx.__exit__(*exc)
+            return False
+
+        def join(self, *outs):
+            if self.active:
+                self.main.wait_stream(self.side)
+                for t in outs:
+                    self._rec(t, self.main)
+
+    def _fork(self, *deps, kind="x"):
+        return GroupedDualStreamStep._Fork(self, deps, kind)
 
     # ------------------------------------------------------------------ leaves (S streams in lockstep)
     def _resnet(self, rs: Sequence[ResnetBlock2D], x, temb, slice_, x1=None):
@@ -116,8 +172,10 @@ class GroupedDualStreamStep:
             wqk = pk.get("a.wqk", as_, [p for a in as_ for p in (a.to_q.weight, a.to_k.weight)], dt,
                          lambda: _stk(torch.cat([pack_matrix(a.to_q.weight, dt), pack_matrix(a.to_k.weight, dt)], 0) for a in as_))
             wv = pk.get("a.wv", as_, [a.to_v.weight for a in as_], dt, lambda: _stk(pack_matrix(a.to_v.weight, dt) for a in as_))
+            with self._fork(xn, kind="vt") as f:  # V^T projection on the sibling branch, beside the q|k projection
+                vt = ops.vt_proj(xn, wv, streams=S)
             qk = ops.linear(xn, wqk, streams=S, out_scale=math.sqrt(cs))  # scale folded in, see layers.Attention
-            vt = ops.vt_proj(xn, wv, streams=S)
+            f.join(vt)
             o = ops.attention(qk, qk, vt, B=Bt, H=H, Tq=T, Tk=T, d=d, ldq=2 * C, ldk=2 * C, q_off=0, k_off=C, scale=0.0)
         else:
             wq = pk.get("a.wq", as_, [a.to_q.weight for a in as_], dt, lambda: _stk(pack_matrix(a.to_q.weight, dt) for a in as_))
@@ -252,38 +310,8 @@ class GroupedDualStreamStep:
         b2 = pk.get("te.b2", tes, [t.linear_2.bias for t in tes], dt, lambda: _stk(f32(t.linear_2.bias) for t in tes))
         semb = ops.linear(ops.linear(t_emb, w1, b1, act=ops.ACT_SILU, streams=S3), w2, b2, act=ops.ACT_SILU, streams=S3)
 
-        # ================= phase 1: enc || unet : conv_in, down, mid =================
-        pair = [enc, unet]
-        parts = [[n.down_blocks, n.mid_block] for n in pair]
-        rl = [self._resnets_of(p) for p in parts]
-        cl = [self._cross_of(p) for p in parts]
-        temb, tsl, kc, vtc, ksl = self._phase_ctx(pair, rl, cl, semb[: 2 * B], ehs)
-        x_in = torch.cat([ops.to_nhwc(cond, dt, CIN_PAD), ops.to_nhwc(x_t, dt, CIN_PAD)], 0)
-        cins = [n.conv_in for n in pair]
-        wci = pk.get("cin.w", cins, [m.weight for m in cins], dt, lambda: _stk(pack_conv3x3(m.weight, dt, CIN_PAD) for m in cins))
-        bci = pk.get("cin.b", cins, [m.bias for m in cins], dt, lambda: _stk(f32(m.bias) for m in cins))
-        x = ops.conv3x3(x_in, wci, bci, streams=2, hilo=self.hilo)
-        skips = [x]
-        for bi_ in range(len(enc.down_blocks)):
-            blks = [n.down_blocks[bi_] for n in pair]
-            for li, r0 in enumerate(blks[0].resnets):
-                x = self._resnet([b.resnets[li] for b in blks], x, temb, tsl[id(r0)])
-                if getattr(blks[0], "has_cross_attention", False):
-                    tsf = [b.attentions[li] for b in blks]
-                    x = self._transformer(tsf, x, kc, vtc, self._kvs(tsf[0], ksl))
-                skips.append(x)
-            if blks[0].downsamplers is not None:
-                x = self._conv("ds", [b.downsamplers[0].conv for b in blks], x, stride=2)
-                skips.append(x)
-        mids = [n.mid_block for n in pair]
-        x = self._resnet([m.resnets[0] for m in mids], x, temb, tsl[id(mids[0].resnets[0])])
-        for ai, a0 in enumerate(mids[0].attentions):
-            tsf = [m.attentions[ai] for m in mids]
-            x = self._transformer(tsf, x, kc, vtc, self._kvs(tsf[0], ksl))
-            x = self._resnet([m.resnets[ai + 1] for m in mids], x, temb, tsl[id(mids[0].resnets[ai + 1])])
-        mid = x  # [enc_mid ; unet_mid]
-
-        # ================= phase 2: the exchange, one grouped 1x1 GEMM per skip =================
+        # ---- the exchange (phase 2), defined first: exchange i only needs skip pair i, so it is issued on the sibling
+        # branch as soon as phase 1 has produced that pair
         scale = float(conditioning_scale)
 
         def exchange(name, z_enc, z_dec, t):
@@ -307,16 +335,63 @@ class GroupedDualStreamStep:
             tl = ops.lo_of(t)
             return ops.linear(t[:B], w, b, res=t[B:], hilo=self.hilo, res_lo=(tl[B:] if tl is not None else None))
 
-        up_skips = [exchange(f"ex{i}", enc.controlnet_down_blocks[i], dec.control_down_blocks[i] if run_decoder else None, s)
-                    for i, s in enumerate(skips)]
+        up_skips, forks = [], []
+
+        def exchange_skip(t):
+            i = len(up_skips)
+            with self._fork(t) as f:
+                y = exchange(f"ex{i}", enc.controlnet_down_blocks[i], dec.control_down_blocks[i] if run_decoder else None, t)
+            up_skips.append(y)
+            forks.append((f, y))
+
+        # ---- up-phase context (time projections, prompt K / V^T of the up blocks): depends on the inputs only
+        pair3 = [unet, dec] if run_decoder else [unet]
+        S = len(pair3)
+        rl3 = [self._resnets_of([n.up_blocks]) for n in pair3]
+        cl3 = [self._cross_of([n.up_blocks]) for n in pair3]
+        with self._fork(semb, ehs) as f3:
+            ctx3 = self._phase_ctx(pair3, rl3, cl3, semb[B: B + S * B], ehs)
+
+        # ================= phase 1: enc || unet : conv_in, down, mid =================
+        pair = [enc, unet]
+        parts = [[n.down_blocks, n.mid_block] for n in pair]
+        rl = [self._resnets_of(p) for p in parts]
+        cl = [self._cross_of(p) for p in parts]
+        temb, tsl, kc, vtc, ksl = self._phase_ctx(pair, rl, cl, semb[: 2 * B], ehs)
+        x_in = torch.cat([ops.to_nhwc(cond, dt, CIN_PAD), ops.to_nhwc(x_t, dt, CIN_PAD)], 0)
+        cins = [n.conv_in for n in pair]
+        wci = pk.get("cin.w", cins, [m.weight for m in cins], dt, lambda: _stk(pack_conv3x3(m.weight, dt, CIN_PAD) for m in cins))
+        bci = pk.get("cin.b", cins, [m.bias for m in cins], dt, lambda: _stk(f32(m.bias) for m in cins))
+        x = ops.conv3x3(x_in, wci, bci, streams=2, hilo=self.hilo)
+        exchange_skip(x)
+        for bi_ in range(len(enc.down_blocks)):
+            blks = [n.down_blocks[bi_] for n in pair]
+            for li, r0 in enumerate(blks[0].resnets):
+                x = self._resnet([b.resnets[li] for b in blks], x, temb, tsl[id(r0)])
+                if getattr(blks[0], "has_cross_attention", False):
+                    tsf = [b.attentions[li] for b in blks]
+                    x = self._transformer(tsf, x, kc, vtc, self._kvs(tsf[0], ksl))
+                exchange_skip(x)
+            if blks[0].downsamplers is not None:
+                x = self._conv("ds", [b.downsamplers[0].conv for b in blks], x, stride=2)
+                exchange_skip(x)
+        mids = [n.mid_block for n in pair]
+        x = self._resnet([m.resnets[0] for m in mids], x, temb, tsl[id(mids[0].resnets[0])])
+        for ai, a0 in enumerate(mids[0].attentions):
+            tsf = [m.attentions[ai] for m in mids]
+            x = self._transformer(tsf, x, kc, vtc, self._kvs(tsf[0], ksl))
+            x = self._resnet([m.resnets[ai + 1] for m in mids], x, temb, tsl[id(mids[0].resnets[ai + 1])])
+        mid = x  # [enc_mid ; unet_mid]
+
+        # ================= phase 2: the mid exchange; join the sibling branch =================
         x = exchange("exm", enc.controlnet_mid_block, dec.control_mid_block if run_decoder else None, mid)
+        for f, y in forks:
+            f.join(y)
+        temb, tsl, kc, vtc, ksl = ctx3
+        f3.join(temb, kc, vtc)
 
         # ================= phase 3: unet || dec : up path, conv_out =================
-        pair = [unet, dec] if run_decoder else [unet]
-        S = len(pair)
-        rl = [self._resnets_of([n.up_blocks]) for n in pair]
-        cl = [self._cross_of([n.up_blocks]) for n in pair]
-        temb, tsl, kc, vtc, ksl = self._phase_ctx(pair, rl, cl, semb[B: B + S * B], ehs)
+        pair = pair3
         for bi_ in range(len(unet.up_blocks)):
             blks = [n.up_blocks[bi_] for n in pair]
             for li, r0 in enumerate(blks[0].resnets):

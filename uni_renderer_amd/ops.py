@@ -30,7 +30,11 @@ _TILES = {TILE_128x128: (128, 128, 1.0, 2), TILE_128x64: (128, 64, 0.85, 3), TIL
           16: (256, 128, 1.1, "r"),
           # few-wave workgroups: every wave owns a full 64x64 tile (0.5 KB of LDS reads per MFMA instead of 1.25)
           17: (64, 64, 0.8, "2w1"), 18: (128, 64, 0.9, "2w2"), 19: (64, 64, 0.8, "3w1"), 20: (64, 128, 0.9, "2w2n"),
-          21: (64, 64, 0.8, "4w1")}
+          21: (64, 64, 0.8, "4w1"),
+          # the same tiles on the 32x32x16 MFMA (UR_TILE_*_M32)
+          22: (128, 320, 1.2, "2m32"), 23: (128, 128, 1.1, "2m32"), 24: (128, 64, 0.9, "2m32"), 25: (128, 64, 0.9, "3m32"),
+          26: (64, 64, 0.7, "2m32"), 27: (64, 64, 0.7, "3m32"), 28: (256, 256, 1.3, "2m32"), 29: (256, 128, 1.2, "2m32"),
+          30: (128, 256, 1.2, "2m32")}
 _PLANNER_TILES = (TILE_128x128, TILE_128x64, TILE_64x64)
 
 _zero_pages = {}
@@ -95,8 +99,8 @@ def _require_gpu(t: torch.Tensor):
 def load_tuning_table(path: Optional[str] = None):
     """Optional table {"M,N,K,taps,z": [tile, splitk]} measured on MI355X by tools/tune_igemm.py."""
     global _tune_table
-    if path is None:
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "igemm_tuning.json")
+    if path is None:  # UR_IGEMM_TUNING: an alternative table (A/B runs of tools/tune_igemm.py output)
+        path = os.environ.get("UR_IGEMM_TUNING") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "igemm_tuning.json")
     _tune_table = {}
     if os.path.exists(path):
         with open(path) as f:
@@ -141,7 +145,7 @@ def plan_igemm(M: int, N: int, K: int, taps: int = 1, zbatch: int = 1) -> Tuple[
 def igemm(*, x0, w, out, M, N, K, c0, c1=0, x1=None, ldx0, ldx1=0, ldw, ldc, taps=1, conv=None, stride=1, ups=0,
           bias=None, rowadd=None, rows_per_b=0, res=None, ldres=0, n_store=0, act=ACT_NONE, out_scale=1.0,
           zbatch=1, zx=0, zw=0, zout=0, zx1=0, zbias=0, zrow=0, zres=0, zx_div=1, tile=None, splitk=None,
-          res_lo=None, out_lo=None, cblock=0, t0=None, t1=None, ldt0=0, ldt1=0, zt0=0, zt1=0, ct0=0, ct1=0):
+          res_lo=None, out_lo=None, cblock=0, t0=None, t1=None, ldt0=0, ldt1=0, zt0=0, zt1=0, ct0=0, ct1=0, pad=1):
     _require_gpu(x0)
     lib = _lib.load()
     if tile is None or splitk is None:
@@ -162,7 +166,7 @@ def igemm(*, x0, w, out, M, N, K, c0, c1=0, x1=None, ldx0, ldx1=0, ldw, ldc, tap
     d.c0, d.c1 = c0, c1
     if conv is not None:
         d.B, d.Hin, d.Win, d.Hout, d.Wout = conv
-    d.taps, d.stride, d.ups = taps, stride, ups
+    d.taps, d.stride, d.ups, d.pad = taps, stride, ups, pad
     d.M, d.N, d.K = M, N, K
     d.n_store = n_store
     d.ld_rowadd = rowadd.stride(0) if rowadd is not None else 0
@@ -288,7 +292,7 @@ def conv_cblock(cin: int) -> int:
 
 
 def conv3x3(x, w, bias=None, *, x1=None, stride=1, ups=False, rowadd=None, res=None, out_scale=1.0, n_out=None,
-            tile=None, splitk=None, streams=1, hilo=False, cblock=0, tail=None):
+            tile=None, splitk=None, streams=1, hilo=False, cblock=0, tail=None, pad=1):
     """3x3 conv, pad 1, over NHWC ``x`` (optionally cat(x, x1) on channels, optionally after a nearest-2x
     upsample).  ``w`` is [Npad >= n_out, 9*Cin] with k = (ky*3+kx)*Cin + c, or, with ``cblock`` > 0, in the
     block-outer order k = (c // cblock)*9*cblock + (ky*3+kx)*cblock + c % cblock.  Output [B, Ho, Wo, n_out].
@@ -300,6 +304,10 @@ def conv3x3(x, w, bias=None, *, x1=None, stride=1, ups=False, rowadd=None, res=N
     C1 = x1.shape[-1] if x1 is not None else 0
     if ups:
         Ho, Wo = 2 * H, 2 * W
+    elif pad == 0:  # the VAE encoder's Downsample2D: F.pad(x, (0, 1, 0, 1)) + conv(stride 2, padding 0)
+        if stride != 2:
+            raise RuntimeError("conv3x3: pad=0 is the asymmetric (0, 1, 0, 1) padding of the stride-2 VAE downsample")
+        Ho, Wo = (H + 1 - 3) // 2 + 1, (W + 1 - 3) // 2 + 1
     else:
         Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
     N = n_out if n_out is not None else w.shape[-2]
@@ -319,7 +327,7 @@ def conv3x3(x, w, bias=None, *, x1=None, stride=1, ups=False, rowadd=None, res=N
     igemm(x0=x, x1=x1, w=w, out=out, M=M, N=N, K=9 * (C0 + C1) + sum(tl.get(k, 0) for k in ("ct0", "ct1")), c0=C0, c1=C1, ldx0=C0, ldx1=C1,
           ldw=w.stride(-2), ldc=N, taps=9, conv=(B, H, W, Ho, Wo), stride=stride, ups=int(ups), bias=bias,
           rowadd=rowadd, rows_per_b=Ho * Wo, res=res, ldres=(N if res is not None else 0), out_scale=out_scale,
-          tile=tile, splitk=splitk, res_lo=lo_of(res), out_lo=lo_of(out), cblock=cblock, **tl, **z)
+          tile=tile, splitk=splitk, res_lo=lo_of(res), out_lo=lo_of(out), cblock=cblock, pad=pad, **tl, **z)
     return out
 
 
@@ -478,6 +486,33 @@ def ddim_update(pred_nhwc, c0: int, lat_nchw, coef, step, nsteps: int, master=No
                              B, H * W, coef.data_ptr(), step.data_ptr(), nsteps, _ptr(master), int(round_master),
                              int(cfg), float(guidance or 0.0), int(cfg_channels), DT[lat_nchw.dtype], _stream()),
           "ur_ddim_update")
+
+
+def unipc_update(pred_nhwc, c0: int, lat_nchw, coef, step, nsteps: int, last, xmaster, hist, round_master: bool = False,
+                 guidance: Optional[float] = None, cfg_channels: int = 0):
+    """In-place UniPC (order <= 2, x0 prediction, bh2) predictor-corrector update of the NCHW latent slice ``lat_nchw``
+    from channels c0.. of the NHWC prediction (include/ur_kernels.h ``ur_unipc_update``); ``coef`` [nsteps, 8] from
+    ``schedulers.UniPCMultistepScheduler.coefficient_table``; ``last`` / ``xmaster`` fp32 [B, C, H, W], ``hist`` fp32
+    [2, B, C, H, W] (zero before step 0).  ``guidance``: as in ``ddim_update``."""
+    _require_gpu(pred_nhwc)
+    lib = _lib.load()
+    B, Cc, H, W = lat_nchw.shape
+    cfg = guidance is not None
+    if cfg:
+        if B % 2 or pred_nhwc.shape[0] != B:
+            raise RuntimeError("unipc_update: guidance needs cond + uncond halves")
+        B //= 2
+    if lat_nchw.stride(3) != 1 or lat_nchw.stride(2) != W or lat_nchw.stride(1) != H * W:
+        raise RuntimeError("unipc_update: latent slice must have contiguous channel planes")
+    if pred_nhwc.dtype != lat_nchw.dtype or coef.dtype != torch.float32 or step.dtype != torch.int32 or coef.shape[-1] != 8:
+        raise RuntimeError("unipc_update: dtype / table mismatch")
+    for t, shp in ((last, (B, Cc, H, W)), (xmaster, (B, Cc, H, W)), (hist, (2, B, Cc, H, W))):
+        if t.dtype != torch.float32 or not t.is_contiguous() or tuple(t.shape) != shp:
+            raise RuntimeError("unipc_update: state buffers must be contiguous fp32 [B, C, H, W] / [2, B, C, H, W]")
+    check(lib.ur_unipc_update(pred_nhwc.data_ptr(), pred_nhwc.shape[-1], c0, lat_nchw.data_ptr(), lat_nchw.stride(0), Cc,
+                              B, H * W, coef.data_ptr(), step.data_ptr(), nsteps, last.data_ptr(), xmaster.data_ptr(),
+                              hist.data_ptr(), int(round_master), int(cfg), float(guidance or 0.0), int(cfg_channels),
+                              DT[lat_nchw.dtype], _stream()), "ur_unipc_update")
 
 
 def sampler_advance(step, tsteps, nsteps: int, t_out=None):

@@ -170,13 +170,16 @@ class UniRendererPipeline:
 
     def _batch_prompt(self, prompt_embeds, negative_prompt_embeds, batch_size):
         """Broadcast a single prompt to the image batch (ref 2504-2507), then stack [uncond, cond] for CFG."""
-        if prompt_embeds.shape[0] == 1 and batch_size > 1:
-            prompt_embeds = prompt_embeds.repeat(batch_size, 1, 1)
+        def fit(e):
+            if e.shape[0] != batch_size:
+                if batch_size % e.shape[0]:
+                    raise ValueError(f"{e.shape[0]} prompt embeddings for a batch of {batch_size}")
+                e = e.repeat(batch_size // e.shape[0], 1, 1)
+            return e
+
+        prompt_embeds = fit(prompt_embeds)
         if self.do_classifier_free_guidance:
-            neg = negative_prompt_embeds
-            if neg.shape[0] == 1 and batch_size > 1:
-                neg = neg.repeat(batch_size, 1, 1)
-            prompt_embeds = torch.cat([neg, prompt_embeds])
+            prompt_embeds = torch.cat([fit(negative_prompt_embeds), prompt_embeds])
         return prompt_embeds
 
     def _vae_encode(self, image):
@@ -201,22 +204,29 @@ class UniRendererPipeline:
     # ---- one denoise step of the three networks ----------------------------------------------------------
     # ---- on-device sampling loop -------------------------------------------------------------
     def _fusable(self, scheds, device, cond_scale, callback) -> bool:
-        """The fused loop covers what eval needs: our DDIM (x0 prediction) on every latent group with one common
+        """The fused loop covers what eval needs: this package's DDIM (x0 prediction) or UniPC (order <= 2, x0
+        prediction, bh2 -- the scheduler eval/test_real.py:485-492 attaches) on every latent group with one common
         schedule, with or without classifier-free guidance, no per-step callback, HIP graph on.  Anything else takes
         the step-by-step loop below (identical results: tests/test_pipeline_gpu.py)."""
-        from .schedulers import DDIMScheduler
+        from .schedulers import DDIMScheduler, UniPCMultistepScheduler
 
         if not (self.use_fused_sampler and self.use_hip_graph and torch.device(device).type == "cuda"):
             return False
         if callback is not None:
             return False
         s0 = scheds[0]
+        if type(s0) not in (DDIMScheduler, UniPCMultistepScheduler):
+            return False
         for s in scheds:
-            if type(s) is not DDIMScheduler or s.prediction_type != "sample":
+            if type(s) is not type(s0) or s.prediction_type != "sample":
                 return False
             if s.num_inference_steps != s0.num_inference_steps or not torch.equal(s.timesteps.cpu(), s0.timesteps.cpu()):
                 return False
-            if not torch.equal(s.alphas_cumprod, s0.alphas_cumprod) or float(s.final_alpha_cumprod) != float(s0.final_alpha_cumprod):
+            if not torch.equal(s.alphas_cumprod, s0.alphas_cumprod):
+                return False
+            if type(s0) is DDIMScheduler and float(s.final_alpha_cumprod) != float(s0.final_alpha_cumprod):
+                return False
+            if type(s0) is UniPCMultistepScheduler and s.config != s0.config:
                 return False
         return True
 
@@ -270,27 +280,41 @@ class UniRendererPipeline:
         key, g = self._graph_for(x_img, cond28, ehs, run_decoder, cond_scale)
         t0 = float(timesteps[0])
         g.load_inputs(x_img, cond28, ehs, 0.0 if run_decoder else t0, t0 if run_decoder else 0.0)
-        coef, tvals = self._ddim_tables(sched, timesteps)
-        skey = key + (n, lat_dtype, guidance)
+        from .schedulers import UniPCMultistepScheduler
+
+        unipc = type(sched) is UniPCMultistepScheduler
+        if unipc:
+            coef, tvals = sched.coefficient_table(), timesteps.detach().cpu().to(torch.float32)
+        else:
+            coef, tvals = self._ddim_tables(sched, timesteps)
+        skey = key + (n, lat_dtype, guidance, "unipc" if unipc else "ddim")
         st = self._sample_graphs.get(skey)
         if st is None:
             dev = x_img.device
             evolving = g.cond[:, 4:] if run_decoder else g.x_t
-            st = dict(step=torch.zeros(1, dtype=torch.int32, device=dev), coef=torch.zeros(n, 4, device=dev),
+            mshape = (nb,) + tuple(evolving.shape[1:])
+            st = dict(step=torch.zeros(1, dtype=torch.int32, device=dev), coef=torch.zeros(n, coef.shape[1], device=dev),
                       tvals=torch.zeros(n, device=dev),
-                      master=torch.zeros((nb,) + tuple(evolving.shape[1:]), dtype=torch.float32, device=dev),
+                      master=torch.zeros(mshape, dtype=torch.float32, device=dev),
                       round_master=lat_dtype != torch.float32)
+            if unipc:  # corrected sample L and the two previous predictions (ur_unipc_update)
+                st["last"] = torch.zeros(mshape, dtype=torch.float32, device=dev)
+                st["hist"] = torch.zeros((2,) + mshape, dtype=torch.float32, device=dev)
+
+            def update(pred_nhwc, c0, lat, cfg_channels):
+                if unipc:
+                    ops.unipc_update(pred_nhwc, c0, lat, st["coef"], st["step"], n, st["last"], st["master"], st["hist"],
+                                     round_master=st["round_master"], guidance=guidance, cfg_channels=cfg_channels)
+                else:
+                    ops.ddim_update(pred_nhwc, c0, lat, st["coef"], st["step"], n, master=st["master"],
+                                    round_master=st["round_master"], guidance=guidance, cfg_channels=cfg_channels)
 
             def post(out):
-                if run_decoder:
-                    ops.ddim_update(out["attr_pred"].permute(0, 2, 3, 1), 4, g.cond[:, 4:], st["coef"], st["step"], n,
-                                    master=st["master"], round_master=st["round_master"], guidance=guidance,
-                                    cfg_channels=4)  # the material group is channels 4..7 of the 28
+                if run_decoder:  # the material group is channels 4..7 of the 28
+                    update(out["attr_pred"].permute(0, 2, 3, 1), 4, g.cond[:, 4:], 4)
                     ops.sampler_advance(st["step"], st["tvals"], n, g.t_attr)
                 else:
-                    ops.ddim_update(out["img_pred"].permute(0, 2, 3, 1), 0, g.x_t, st["coef"], st["step"], n,
-                                    master=st["master"], round_master=st["round_master"], guidance=guidance,
-                                    cfg_channels=g.x_t.shape[1])
+                    update(out["img_pred"].permute(0, 2, 3, 1), 0, g.x_t, g.x_t.shape[1])
                     ops.sampler_advance(st["step"], st["tvals"], n, g.t_img)
 
             st["graph"], st["out"] = g.capture_with(post)
@@ -300,6 +324,9 @@ class UniRendererPipeline:
         st["coef"].copy_(coef)
         st["tvals"].copy_(tvals)
         st["master"].copy_((cond28[:nb, 4:] if run_decoder else x_img[:nb]))  # the caller's latents at their own precision
+        if unipc:
+            st["last"].copy_(st["master"])  # L_0 = the initial sample
+            st["hist"].zero_()
         for _ in range(n):
             st["graph"].replay()
         # a COPY: ``master`` is this sampling graph's static buffer and the next call with the same shapes overwrites it
@@ -353,11 +380,21 @@ class UniRendererPipeline:
             image_latents, mask_latents = self._vae_encode(image), self._vae_encode(masks)
         else:
             batch_size = image_latents.shape[0]
-        prompt_embeds = self._batch_prompt(prompt_embeds, negative_prompt_embeds, batch_size)
+        # Repeat folding: eval/test_real.py:547-564 calls this method ``compute_times`` = 5 times on the
+        # same image and averages; ``num_images_per_prompt=5`` is the same protocol as ONE batch of 5 (the reference's
+        # prepare_image repeats the image batch_size * num_images_per_prompt times, ref 2504-2523, and every attribute
+        # group draws batch_size * num_images_per_prompt noise latents, 2540-2609): 5x fewer loop launches.
+        total = batch_size * num_images_per_prompt
+        if image_latents.shape[0] != total:
+            if image_latents.shape[0] * num_images_per_prompt != total:
+                raise ValueError("image batch does not match batch_size * num_images_per_prompt")
+            image_latents = image_latents.repeat_interleave(num_images_per_prompt, dim=0)
+            mask_latents = mask_latents.repeat_interleave(num_images_per_prompt, dim=0)
+        prompt_embeds = self._batch_prompt(prompt_embeds, negative_prompt_embeds, total)
         h8, w8 = image_latents.shape[-2:]
         height, width = height or h8 * self.vae_scale_factor, width or w8 * self.vae_scale_factor
         nlat = self.unet.config.in_channels
-        lat = {n: self.prepare_latents(batch_size * num_images_per_prompt, nlat, height, width, prompt_embeds.dtype,
+        lat = {n: self.prepare_latents(total, nlat, height, width, prompt_embeds.dtype,
                                        device, generator, latents) for n in ATTR_GROUPS}
         cfg = self.do_classifier_free_guidance
         dup = (lambda t: torch.cat([t, t])) if cfg else (lambda t: t)
@@ -394,7 +431,9 @@ class UniRendererPipeline:
                 bar.update()
         if output_type == "latent":
             return tuple(lat[n] for n in ATTR_GROUPS)
-        imgs = [self._postprocess(self._vae_decode(lat[n], generator), output_type) for n in ATTR_GROUPS[1:]]
+        # the five image groups (ref 2755-2769: five vae.decode calls) decoded as ONE batch
+        dec = self._vae_decode(torch.cat([lat[n] for n in ATTR_GROUPS[1:]], dim=0), generator).chunk(len(ATTR_GROUPS) - 1, dim=0)
+        imgs = [self._postprocess(d, output_type) for d in dec]
         return (lat["material"], *imgs)
 
     @torch.no_grad()
