@@ -55,6 +55,84 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _train_worker(rank, world, port, q):
+    """Two train_step-shaped iterations (zero -> forward -> backward with overlapped bucket collectives -> finish ->
+    clip -> optimizer step) on two ranks with DIFFERENT data and DIVERGENT branches (compute_t, train.py:445): in
+    iteration 0 rank 1 skips the "decoder" module entirely, in iteration 1 rank 0 runs the "encoder" twice (the cycle
+    pass).  Every rank must end with bit-identical parameters, equal to a single-process run on the averaged gradients."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from uni_renderer_amd import parallel
+
+    parallel.init_distributed("gloo")
+
+    def build():
+        torch.manual_seed(0)
+        enc = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.Tanh(), torch.nn.Linear(16, 8))
+        unet = torch.nn.Sequential(torch.nn.Linear(8, 32), torch.nn.Tanh(), torch.nn.Linear(32, 8))
+        dec = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Tanh(), torch.nn.Linear(16, 4))
+        return enc, unet, dec
+
+    def loss_fn(nets, x, it, r):
+        enc, unet, dec = nets
+        h = enc(x)
+        if it == 1 and r == 0:
+            h = h + enc(x * 0.5)          # second encoder pass: its parameters are used twice in one backward
+        u = unet(h)
+        loss = (u ** 2).mean()
+        if not (it == 0 and r == 1):
+            loss = loss + (dec(u) ** 2).mean()  # rank 1 takes the branch without the decoder in iteration 0
+        return loss
+
+    data = [[torch.randn(5, 6, generator=torch.Generator().manual_seed(10 * it + r)) for r in range(world)] for it in range(2)]
+    nets = build()
+    opt = torch.optim.SGD([p for m in nets for p in m.parameters()], lr=0.1)
+    gb = parallel.GradientBuckets(nets, bucket_mb=2e-4)  # ~50 floats per bucket: many buckets
+    assert len(gb.buckets) >= 6
+    hooked = 0
+    for it in range(2):
+        gb.zero_grad()
+        loss_fn(nets, data[it][rank], it, rank).backward()
+        hooked += gb.launched_from_hooks
+        gb.finish()
+        gb.clip_grad_norm_(1.0)
+        opt.step()
+    # reference: one process, gradient = mean over the two ranks' losses
+    ref = build()
+    ropt = torch.optim.SGD([p for m in ref for p in m.parameters()], lr=0.1)
+    for it in range(2):
+        ropt.zero_grad(set_to_none=True)
+        sum(loss_fn(ref, data[it][r], it, r) for r in range(world)).div(world).backward()
+        for p in (p for m in ref for p in m.parameters()):
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+        torch.nn.utils.clip_grad_norm_([p for m in ref for p in m.parameters()], 1.0)
+        ropt.step()
+    mine = torch.cat([p.detach().reshape(-1) for m in nets for p in m.parameters()])
+    want = torch.cat([p.detach().reshape(-1) for m in ref for p in m.parameters()])
+    both = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(both, mine)
+    ok = torch.equal(both[0], both[1]) and torch.allclose(mine, want, atol=1e-6) and gb.launched_from_hooks > 0
+    q.put((rank, bool(ok), gb.launched_from_hooks))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_training_iterations_with_divergent_branches():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_train_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert [(r, ok) for r, ok, _ in res] == [(0, True), (1, True)], res
+    assert all(n > 0 for _, _, n in res)  # some buckets were reduced while backward() was still running
+
+
 def test_two_rank_gloo():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

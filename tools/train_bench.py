@@ -26,6 +26,10 @@ def main():
     ap.add_argument("--latent", type=int, default=64)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--algorithm", default="all_reduce", choices=["all_reduce", "rs_ag"],
+                    help="gradient collective per bucket: one all-reduce, or reduce-scatter + all-gather (all 7 xGMI links)")
+    ap.add_argument("--comm-dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-overlap", action="store_true", help="reduce all buckets after the backward instead of during it")
     ap.add_argument("--graph", action="store_true", help="capture the whole step (forward, backward, clipping, AdamW) "
                     "into one HIP graph and time replays (single GPU)")
     args = ap.parse_args()
@@ -48,7 +52,8 @@ def main():
                  t_attr=torch.randint(0, 1000, (B,), device=dev, generator=g),
                  target_img=mk(B, 4, L, L), target_attr=mk(B, 28, L, L))
     opt = torch.optim.AdamW([p for m in nets for p in m.parameters()], lr=1e-5, fused=True, capturable=args.graph)
-    buckets = GradientBuckets(nets, comm_dtype=torch.bfloat16) if world > 1 else None
+    buckets = GradientBuckets(nets, comm_dtype=(torch.bfloat16 if args.comm_dtype == "bf16" else None), algorithm=args.algorithm,
+                              overlap=not args.no_overlap) if world > 1 else None
     if args.graph:
         assert world == 1, "--graph: single GPU"
         side = torch.cuda.Stream()
@@ -84,7 +89,10 @@ def main():
     if rank == 0:
         print(json.dumps(dict(metric="train-steps/sec (dual-UNet, 512^2, per-GPU batch %d)" % B, value=round(world / dtm, 4),
                               ms_per_step=round(dtm * 1e3, 1), n_gpus=world, dtype=args.dtype, loss=stats["loss"],
-                              grad_norm=stats.get("grad_norm"), graph=bool(args.graph), peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2**30, 1))))
+                              grad_norm=stats.get("grad_norm"), graph=bool(args.graph),
+                              grad_sync=(dict(algorithm=args.algorithm, comm_dtype=args.comm_dtype, overlap=not args.no_overlap,
+                                              buckets=len(buckets.buckets), launched_during_backward=buckets.launched_from_hooks)
+                                         if buckets is not None else None), peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2**30, 1))))
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

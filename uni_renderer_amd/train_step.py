@@ -321,15 +321,20 @@ def train_step(nets: Sequence[torch.nn.Module], batch: Dict[str, torch.Tensor], 
         loss = mse_losses(out, batch["target_img"], batch["target_attr"])
     else:
         loss = reference_losses(nets, batch, dtype=dtype, inverse=inverse)["loss"]
-    if optimizer is not None:
-        optimizer.zero_grad(set_to_none=True)
-    loss.backward()
     if buckets is not None:
-        buckets.all_reduce_mean()
+        buckets.zero_grad()  # gradients live in the buckets' flat buffers (views): zero in place, keep the views
+    elif optimizer is not None:
+        optimizer.zero_grad(set_to_none=True)
+    loss.backward()  # with ``buckets``: complete buckets are all-reduced (async) while the backward is still running
+    if buckets is not None:
+        buckets.finish()
     stats = {"loss": loss.detach()}
     if max_grad_norm is not None:
-        params = [p for n in nets for p in n.parameters() if p.grad is not None]
-        stats["grad_norm"] = torch.nn.utils.clip_grad_norm_(params, max_grad_norm)
+        if buckets is not None:
+            stats["grad_norm"] = buckets.clip_grad_norm_(max_grad_norm)
+        else:
+            params = [p for n in nets for p in n.parameters() if p.grad is not None]
+            stats["grad_norm"] = torch.nn.utils.clip_grad_norm_(params, max_grad_norm)
     if optimizer is not None:
         optimizer.step()
     return stats if as_tensors else {k: float(v) for k, v in stats.items()}
