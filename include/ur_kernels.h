@@ -89,7 +89,19 @@ extern "C" {
 #define UR_TILE_256x256_M32 28
 #define UR_TILE_256x128_M32 29
 #define UR_TILE_128x256_M32 30
-#define UR_TILE_COUNT 31
+/* wave-specialised builds: <n> extra waves only issue the global -> LDS copies of the whole tile, the others only
+ * multiply (csrc/igemm.hip NL) */
+#define UR_TILE_128x320_L2 31
+#define UR_TILE_128x320_L4 32
+#define UR_TILE_128x128_L2 33
+#define UR_TILE_128x128_S3_L2 34
+#define UR_TILE_128x64_L1 35
+#define UR_TILE_128x64_S3_L2 36
+#define UR_TILE_64x64_S3_L1 37
+#define UR_TILE_256x128_L2 38
+#define UR_TILE_256x256_L0 39   /* reserved: not instantiated (UR_E_UNSUPPORTED) */
+#define UR_TILE_128x256_L2 40
+#define UR_TILE_COUNT 41
 
 /*
  * Implicit GEMM:  out[m][n] = epilogue( sum_k X[m][k] * W[n][k] )

@@ -42,6 +42,26 @@ def main():
             torch.cuda.synchronize()
             ts.append(time.perf_counter() - t0)
         res[name] = dict(ms_total=round(min(ts) * 1e3, 2), ms_per_step=round(min(ts) * 1e3 / steps, 3))
+    # the reference's live eval protocol (eval/test_real.py:485-492, 547-564): UniPC, 20 steps, guidance 0, the same image
+    # 5 times (compute_times) -- as five calls at batch 1 and folded into ONE batch of 5 (num_images_per_prompt=5)
+    from uni_renderer_amd.pipeline import SCHEDULER_NAMES
+    from uni_renderer_amd.schedulers import UniPCMultistepScheduler
+
+    for n in SCHEDULER_NAMES:
+        setattr(pipe, f"scheduler_{n}", UniPCMultistepScheduler())
+    kw = dict(prompt_embeds=ehs[:1], image_latents=img[:1], mask_latents=msk[:1], num_inference_steps=20, guidance_scale=0.0,
+              output_type="latent")
+    for name, fn in (("unipc20_five_calls_b1", lambda: [pipe.real_image2mask_3mod_albedo(**kw) for _ in range(5)]),
+                     ("unipc20_folded_b5", lambda: pipe.real_image2mask_3mod_albedo(num_images_per_prompt=5, **kw))):
+        fn()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        res[name] = dict(ms_total=round(min(ts) * 1e3, 2))
     print(json.dumps(res))
 
 

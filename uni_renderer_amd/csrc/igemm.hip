@@ -175,10 +175,19 @@ __device__ __forceinline__ void epilogue16(const ur_igemm_desc& p, T* __restrict
 // of (row & 7) (conflict-free for ds_read_b128's 16-lane service groups, tools/lds_bank_check.py), and the weight
 // rows of a 32-row block are permuted so that the 16 accumulator registers of a lane (MFMA rows 8g + 4h + r) are 16
 // CONSECUTIVE output channels 16h + 4g + r of one pixel -- the epilogue is shared.
-template <typename T, int BM, int BN, int WM, int WN, int NSTAGE, bool CONV, int MF>
-__global__ void __launch_bounds__(WM * WN * 64) igemm_kernel(const ur_igemm_desc p) {
+// NL = 0: every wave copies its share of both tiles and multiplies (the original formulation).
+// NL > 0: WAVE SPECIALISATION.  The K loop of the symmetric form costs MFMA time PLUS LDS-DMA issue time (ablation
+// builds): all waves of a workgroup are phase-locked by the chunk barrier, so they all issue their
+// 1-KiB DMA pieces (60-185 cycles of issue each) at the same moment, with every matrix pipe idle, and then all multiply.
+// Here NL extra waves do NOTHING but the loader's bookkeeping and DMA issue for the whole tile, while the WM x WN
+// consumer waves run an uninterrupted MFMA stream; the barrier protocol is unchanged (one s_barrier per chunk: the
+// loader has waited for chunk t, the consumers have left the buffer chunk t+1 goes into).
+template <typename T, int BM, int BN, int WM, int WN, int NSTAGE, bool CONV, int MF, int NL>
+__global__ void __launch_bounds__((WM * WN + NL) * 64) igemm_kernel(const ur_igemm_desc p) {
     typedef typename Vec8<T>::type vec8;
-    constexpr int NW = WM * WN;  // waves per workgroup
+    constexpr int NWC = WM * WN;              // consumer waves (own the output tile)
+    constexpr int NW = NL > 0 ? NL : NWC;     // waves that copy: the NL loader waves, or everybody
+    static_assert(NL == 0 || NSTAGE > 0, "loader waves use the LDS-DMA ring");
     constexpr int MREP = BM / WM / 16;
     constexpr int NREP = BN / WN / 16;
     static_assert(MF == 16 || MF == 32, "MFMA shape");
@@ -197,8 +206,11 @@ __global__ void __launch_bounds__(WM * WN * 64) igemm_kernel(const ur_igemm_desc
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
+    const int wave_id = tid >> 6;
+    const bool is_loader = NL == 0 || wave_id >= NWC;    // wave-uniform roles
+    const bool is_consumer = NL == 0 || wave_id < NWC;
+    const int wave = NL > 0 ? (is_loader ? wave_id - NWC : 0) : wave_id;  // index among the copying waves
+    const int wm = (wave_id % NWC) / WN, wn = (wave_id % NWC) % WN;
 
     const int tiles_n = (p.N + BN - 1) / BN;
     // XCD-aware mapping: logical ids are tile-major within one z slice, n fastest, so an XCD works on a
@@ -519,9 +531,11 @@ __global__ void __launch_bounds__(WM * WN * 64) igemm_kernel(const ur_igemm_desc
         // Raw s_barrier + inline-asm vmcnt(N): __syncthreads() would drain the LDS-DMA queue (vmcnt(0)).
         constexpr int D = (NSTAGE > 0 ? NSTAGE : 2) - 1;
         constexpr int LOADS = XI + WI;  // LDS-DMA instructions per wave per chunk
+        if (is_loader) {
 #pragma unroll
-        for (int s = 0; s < D; ++s)
-            if (s < nk) stage(s);
+            for (int s = 0; s < D; ++s)
+                if (s < nk) stage(s);
+        }
         int buf = 0, nbuf = D % NSTAGE;
         for (int t = 0; t < nk; ++t) {
             const int newer = min(D - 1, nk - 1 - t);  // chunks issued after chunk t that may stay in flight
@@ -530,13 +544,14 @@ __global__ void __launch_bounds__(WM * WN * 64) igemm_kernel(const ur_igemm_desc
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (t + D < nk) stage(nbuf);
-            compute(buf);
+            if (is_loader && t + D < nk) stage(nbuf);
+            if (is_consumer) compute(buf);
             buf = (buf + 1 == NSTAGE) ? 0 : buf + 1;
             nbuf = (nbuf + 1 == NSTAGE) ? 0 : nbuf + 1;
         }
     }
 
+    if (!is_consumer) return;  // loader waves are done (no barrier follows the K loop)
     // ---- epilogue: a lane holds 16 consecutive output channels of one pixel ----
     //   MF 16: lane (j = lane&15, q = lane>>4): pixel row j of a 16-row block, channels q*16 .. q*16+15 of the wave's 64
     //   MF 32: lane (j = lane&31, h = lane>>5): pixel row j of a 32-row block, channels h*16 .. h*16+15 of a 32-block
@@ -628,7 +643,10 @@ static const TileCfg kTiles[UR_TILE_COUNT] = {{0, 0, 0},      {128, 128, 2}, {12
                                               {64, 128, 2},  {64, 64, 4},
                                               // 32x32x16-MFMA builds (UR_TILE_*_M32)
                                               {128, 320, 2}, {128, 128, 2}, {128, 64, 2}, {128, 64, 3}, {64, 64, 2},
-                                              {64, 64, 3},   {256, 256, 2}, {256, 128, 2}, {128, 256, 2}};
+                                              {64, 64, 3},   {256, 256, 2}, {256, 128, 2}, {128, 256, 2},
+                                              // wave-specialised builds: dedicated loader waves (UR_TILE_*_L<n>)
+                                              {128, 320, 2}, {128, 320, 2}, {128, 128, 2}, {128, 128, 3}, {128, 64, 2},
+                                              {128, 64, 3},  {64, 64, 3},   {256, 128, 2}, {256, 256, 2}, {128, 256, 2}};
 
 static int pick_tile(const ur_igemm_desc& d) {
     // Cost model: the busiest CU runs ceil(workgroups / 256) tiles; bigger tiles have a better
@@ -646,24 +664,24 @@ static int pick_tile(const ur_igemm_desc& d) {
     return best;
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int NSTAGE, bool CONV, int MF>
+template <typename T, int BM, int BN, int WM, int WN, int NSTAGE, bool CONV, int MF, int NL>
 static void ensure_lds_limit(int lds) {
     static std::atomic<uint64_t> done{0};  // per (instantiation, device), see set_lds_limit_once
-    set_lds_limit_once(done, reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, WM, WN, NSTAGE, CONV, MF>), lds);
+    set_lds_limit_once(done, reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, WM, WN, NSTAGE, CONV, MF, NL>), lds);
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int NSTAGE, int MF = 16>
+template <typename T, int BM, int BN, int WM, int WN, int NSTAGE, int MF = 16, int NL = 0>
 static int launch_cfg(const ur_igemm_desc& d, hipStream_t s) {
     const int tiles_m = (d.M + BM - 1) / BM, tiles_n = (d.N + BN - 1) / BN;
     dim3 grid(tiles_m * tiles_n, 1, d.zbatch * d.splitk);
     const size_t lds = (NSTAGE > 0 ? NSTAGE : 2) * (BM + BN) * 128;
     hipError_t e;
     if (d.taps == 9) {
-        ensure_lds_limit<T, BM, BN, WM, WN, NSTAGE, true, MF>((int)lds);
-        hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, NSTAGE, true, MF>), grid, dim3(WM * WN * 64), lds, s, d);
+        ensure_lds_limit<T, BM, BN, WM, WN, NSTAGE, true, MF, NL>((int)lds);
+        hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, NSTAGE, true, MF, NL>), grid, dim3((WM * WN + NL) * 64), lds, s, d);
     } else {
-        ensure_lds_limit<T, BM, BN, WM, WN, NSTAGE, false, MF>((int)lds);
-        hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, NSTAGE, false, MF>), grid, dim3(WM * WN * 64), lds, s, d);
+        ensure_lds_limit<T, BM, BN, WM, WN, NSTAGE, false, MF, NL>((int)lds);
+        hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, NSTAGE, false, MF, NL>), grid, dim3((WM * WN + NL) * 64), lds, s, d);
     }
     e = hipGetLastError();
     if (e != hipSuccess) return -(int)e;
@@ -711,6 +729,16 @@ static int launch_dtype(ur_igemm_desc& d, hipStream_t s) {
         case UR_TILE_256x256_M32: return launch_cfg<T, 256, 256, 4, 4, 2, 32>(d, s);
         case UR_TILE_256x128_M32: return launch_cfg<T, 256, 128, 4, 2, 2, 32>(d, s);
         case UR_TILE_128x256_M32: return launch_cfg<T, 128, 256, 2, 4, 2, 32>(d, s);
+        case UR_TILE_128x320_L2: return launch_cfg<T, 128, 320, 2, 5, 2, 16, 2>(d, s);
+        case UR_TILE_128x320_L4: return launch_cfg<T, 128, 320, 2, 5, 2, 16, 4>(d, s);
+        case UR_TILE_128x128_L2: return launch_cfg<T, 128, 128, 2, 2, 2, 16, 2>(d, s);
+        case UR_TILE_128x128_S3_L2: return launch_cfg<T, 128, 128, 2, 2, 3, 16, 2>(d, s);
+        case UR_TILE_128x64_L1: return launch_cfg<T, 128, 64, 4, 1, 2, 16, 1>(d, s);
+        case UR_TILE_128x64_S3_L2: return launch_cfg<T, 128, 64, 4, 1, 3, 16, 2>(d, s);
+        case UR_TILE_64x64_S3_L1: return launch_cfg<T, 64, 64, 4, 1, 3, 16, 1>(d, s);
+        case UR_TILE_256x128_L2: return launch_cfg<T, 256, 128, 4, 2, 2, 16, 2>(d, s);
+        case UR_TILE_256x256_L0: return UR_E_UNSUPPORTED;  /* 16 consumer waves already fill the 1024-thread limit */
+        case UR_TILE_128x256_L2: return launch_cfg<T, 128, 256, 2, 4, 2, 16, 2>(d, s);
     }
     return UR_E_BADARG;
 }

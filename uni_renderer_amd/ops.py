@@ -34,7 +34,11 @@ _TILES = {TILE_128x128: (128, 128, 1.0, 2), TILE_128x64: (128, 64, 0.85, 3), TIL
           # the same tiles on the 32x32x16 MFMA (UR_TILE_*_M32)
           22: (128, 320, 1.2, "2m32"), 23: (128, 128, 1.1, "2m32"), 24: (128, 64, 0.9, "2m32"), 25: (128, 64, 0.9, "3m32"),
           26: (64, 64, 0.7, "2m32"), 27: (64, 64, 0.7, "3m32"), 28: (256, 256, 1.3, "2m32"), 29: (256, 128, 1.2, "2m32"),
-          30: (128, 256, 1.2, "2m32")}
+          30: (128, 256, 1.2, "2m32"),
+          # wave-specialised builds: n dedicated loader waves (UR_TILE_*_L<n>); 39 is reserved / not instantiated
+          31: (128, 320, 1.3, "2L2"), 32: (128, 320, 1.3, "2L4"), 33: (128, 128, 1.2, "2L2"), 34: (128, 128, 1.2, "3L2"),
+          35: (128, 64, 1.0, "2L1"), 36: (128, 64, 1.0, "3L2"), 37: (64, 64, 0.8, "3L1"), 38: (256, 128, 1.3, "2L2"),
+          40: (128, 256, 1.3, "2L2")}
 _PLANNER_TILES = (TILE_128x128, TILE_128x64, TILE_64x64)
 
 _zero_pages = {}
