@@ -21,7 +21,7 @@ def _rand(shape, dtype, dev, scale=1.0, seed=0):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("tile", list(range(1, 31)))
+@pytest.mark.parametrize("tile", [t for t in range(1, 41) if t != 39])
 @pytest.mark.parametrize("shape", [(256, 320, 320), (300, 64, 128), (1000, 448, 640), (4, 1280, 320)])
 def test_linear_bias_res(dev, dtype, tile, shape):
     from uni_renderer_amd import ops
@@ -61,7 +61,7 @@ def test_linear_two_sources(dev, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("tile", list(range(1, 31)))
+@pytest.mark.parametrize("tile", [t for t in range(1, 41) if t != 39])
 def test_geglu(dev, dtype, tile):
     from uni_renderer_amd import ops
     from uni_renderer_amd.layers import geglu_perm
@@ -86,7 +86,7 @@ def _conv_ref(x_nhwc, w_oihw, b, stride=1, ups=False):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("tile", list(range(1, 31)))
+@pytest.mark.parametrize("tile", [t for t in range(1, 41) if t != 39])
 @pytest.mark.parametrize("mode", ["s1", "s2", "ups"])
 def test_conv3x3(dev, dtype, tile, mode):
     from uni_renderer_amd import ops
@@ -436,7 +436,7 @@ def test_conv3x3_with_1x1_tail(dev, dtype, cfg):
         if S == 1:
             wp, bp = wp[0], bp[0]
         # tile None: the planner's choice; 2: 128x64 on the 16x16x32 MFMA; 24 / 22 / 26: 128x64 / 128x320 / 64x64 on 32x32x16
-        for tile in (None, 24, 22, 26):
+        for tile in (None, 24, 22, 26, 31, 35, 36):
             y = ops.conv3x3(h, wp, bp, tail=(ta, tb), cblock=cblock, streams=S, hilo=True,
                             splitk=(sk if sk is not None else (None if tile is None else 1)),
                             tile=(tile if tile is not None else (None if sk is None else 2)))

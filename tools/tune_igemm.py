@@ -85,12 +85,21 @@ def collect_train(B, L, dev, dtype):
 
 
 _side = None
+_scrub = None        # --scrub: buffers streamed between two timed launches (evicts the XCDs' L2s)
+_scrub_ms = None     # time of the scrub pass alone (subtracted)
+
+
+def _scrub_pass():
+    # read + write 2 x 48 MB: more than the 32 MB of L2 on the chip, a fraction of the 256 MB Infinity Cache -- what a
+    # launch finds IN SITU: its activations were written by another kernel (Infinity Cache / a different XCD's L2), its
+    # weights were last read a whole step ago
+    _scrub[0].add_(_scrub[1])
 
 
 def time_cfg(kw, tile, splitk, rounds=3, iters=8, graph=True):
     from uni_renderer_amd import ops
 
-    global _side
+    global _side, _scrub_ms
     kw = dict(kw)
     kw["tile"], kw["splitk"] = tile, splitk
     try:
@@ -102,10 +111,31 @@ def time_cfg(kw, tile, splitk, rounds=3, iters=8, graph=True):
     if graph:
         if _side is None:
             _side = torch.cuda.Stream()
+        if _scrub is not None and _scrub_ms is None:
+            gs = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(_side):
+                with torch.cuda.graph(gs, stream=_side):
+                    for _ in range(iters):
+                        _scrub_pass()
+            torch.cuda.synchronize()
+            gs.replay()
+            torch.cuda.synchronize()
+            tt = []
+            for _ in range(5):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                gs.replay()
+                e1.record()
+                torch.cuda.synchronize()
+                tt.append(e0.elapsed_time(e1) / iters)
+            _scrub_ms = statistics.median(tt)
+            print(f"[tune] scrub pass alone: {_scrub_ms * 1e3:.1f} us", flush=True)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.stream(_side):
             with torch.cuda.graph(g, stream=_side):
                 for _ in range(iters):
+                    if _scrub is not None:
+                        _scrub_pass()
                     ops.igemm(**kw)
         torch.cuda.synchronize()
         g.replay()
@@ -116,7 +146,7 @@ def time_cfg(kw, tile, splitk, rounds=3, iters=8, graph=True):
             g.replay()
             e1.record()
             torch.cuda.synchronize()
-            ts.append(e0.elapsed_time(e1) / iters)
+            ts.append(e0.elapsed_time(e1) / iters - (_scrub_ms or 0.0))
         del g
         return statistics.median(ts)
     for _ in range(rounds):
@@ -140,6 +170,8 @@ def main():
     ap.add_argument("--only-missing", action="store_true", help="tune only problems absent from the existing table")
     ap.add_argument("--train", action="store_true", help="tune the problems of a training step (forward + backward)")
     ap.add_argument("--tiles", default="", help="comma-separated candidate tile ids (default: all)")
+    ap.add_argument("--scrub", action="store_true", help="evict the L2s between timed launches (the in-situ regime: operands "
+                    "come from the Infinity Cache / HBM, not from a previous replay's L2 lines)")
     ap.add_argument("--out", default=os.path.join(ROOT, "uni_renderer_amd", "igemm_tuning.json"))
     ap.add_argument("--report", default=os.path.join(ROOT, "gpurun_out", "tune_report.json"))
     args = ap.parse_args()
@@ -148,6 +180,9 @@ def main():
 
     dev = torch.device("cuda:0")
     dtype = torch.float16 if args.dtype == "fp16" else torch.bfloat16
+    if args.scrub:
+        global _scrub
+        _scrub = (torch.zeros(24 << 20, dtype=torch.float16, device=dev), torch.zeros(24 << 20, dtype=torch.float16, device=dev))
     models = None if args.train else bench.build_models(dev, dtype)
     tiles = [int(t) for t in args.tiles.split(",")] if args.tiles else list(ops._TILES)
     shapes = [(args.batch, args.latent)] + [tuple(int(v) for v in p.split(",")) for p in args.also.split(";") if p]

@@ -531,23 +531,51 @@ __global__ void __launch_bounds__((WM * WN + NL) * 64) igemm_kernel(const ur_ige
         // Raw s_barrier + inline-asm vmcnt(N): __syncthreads() would drain the LDS-DMA queue (vmcnt(0)).
         constexpr int D = (NSTAGE > 0 ? NSTAGE : 2) - 1;
         constexpr int LOADS = XI + WI;  // LDS-DMA instructions per wave per chunk
-        if (is_loader) {
+        if constexpr (NL > 0) {
+            // Two role-specific loops with the SAME barrier sequence (nk s_barriers each): written apart so that the
+            // loader's pointer arrays and the consumers' accumulators are never live at the same program point (one
+            // merged loop made the register allocator hold both: 168+ VGPRs and scratch spills).
+            if (is_loader) {
+#pragma unroll
+                for (int s = 0; s < D; ++s)
+                    if (s < nk) stage(s);
+                int nbuf = D % NSTAGE;
+                for (int t = 0; t < nk; ++t) {
+                    const int newer = min(D - 1, nk - 1 - t);
+                    if (newer >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LOADS) : "memory");
+                    else if (newer == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                    if (t + D < nk) stage(nbuf);
+                    nbuf = (nbuf + 1 == NSTAGE) ? 0 : nbuf + 1;
+                }
+                return;  // loader waves are done (no barrier follows the K loop)
+            }
+            int buf = 0;
+            for (int t = 0; t < nk; ++t) {
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                compute(buf);
+                buf = (buf + 1 == NSTAGE) ? 0 : buf + 1;
+            }
+        } else {
 #pragma unroll
             for (int s = 0; s < D; ++s)
                 if (s < nk) stage(s);
-        }
-        int buf = 0, nbuf = D % NSTAGE;
-        for (int t = 0; t < nk; ++t) {
-            const int newer = min(D - 1, nk - 1 - t);  // chunks issued after chunk t that may stay in flight
-            if (newer >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LOADS) : "memory");
-            else if (newer == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            if (is_loader && t + D < nk) stage(nbuf);
-            if (is_consumer) compute(buf);
-            buf = (buf + 1 == NSTAGE) ? 0 : buf + 1;
-            nbuf = (nbuf + 1 == NSTAGE) ? 0 : nbuf + 1;
+            int buf = 0, nbuf = D % NSTAGE;
+            for (int t = 0; t < nk; ++t) {
+                const int newer = min(D - 1, nk - 1 - t);  // chunks issued after chunk t that may stay in flight
+                if (newer >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LOADS) : "memory");
+                else if (newer == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if (t + D < nk) stage(nbuf);
+                compute(buf);
+                buf = (buf + 1 == NSTAGE) ? 0 : buf + 1;
+                nbuf = (nbuf + 1 == NSTAGE) ? 0 : nbuf + 1;
+            }
         }
     }
 
