@@ -49,11 +49,19 @@ def main():
     dom = [r for n, r in ours if dom_sym in n and ("conv3x3" in n) == ("conv3x3" in roof["kernel"])][0]
     att = [k for k in d["kernel_classes"] if k["kernel"] == "attention_d40"]
     att_u = [v for k, v in mf.items() if "attention32" in k and "Li40" in k and "F16_" in k]
-    out = f"""# profiles/ — rocprofv3 evidence, round 1
+    out = f"""# profiles/ — rocprofv3 evidence
 
 All files were produced on an MI355X `gpurun` box from this repo (`bash tools/collect_profiles.sh {tag}`, which runs the
-commands below and keeps the summaries; this file is `python tools/make_profiles_readme.py {tag}`).  `r01_*` = the first
-complete collection of the round, kept for the history of the numbers; `{tag}_*` = the state at the end of the round.
+commands below and keeps the summaries; this file is `python tools/make_profiles_readme.py {tag}`).  `r01_*` / `r01c_*` =
+round 1 (first complete collection / end of round), kept for the history of the numbers; `{tag}_*` = the state at the
+end of round {tag[1:3].lstrip("0")}.
+
+Other round-2 summaries: `r02_parity_numbers.json` (every rel-L2 the `-m gpu` suite printed: cfg 3 at batch 2 and 4, cfg 5
+vs the oracle, the 16384-token attention, UpRes, the module-surface and cfg-4 training steps, the VAE),
+`r02_bench_cfg2/cfg5/b5/b8/b10/b20.json` (the other configurations and the repeat batches through `bench.py`),
+`r02_loop_bench.json` (50-step DDIM loops; 20-step UniPC x 5 repeats as five calls vs one folded batch),
+`r02_train_graph/eager.json` (`tools/train_bench.py`), `r02_vae_bench.json` (`tools/vae_bench.py`), `r02_insitu_tuning_log.json`
+(whole-step coordinate descent over tile choices, `tools/tune_in_situ.py`).
 
 | file | what |
 |---|---|
@@ -71,11 +79,11 @@ rocprofv3 --kernel-trace --stats -d <out> -o {tag} --output-format csv -- python
 ## Headline (un-profiled, `{tag}_bench_default.json`)
 
 {d['value']:.2f} denoise-steps/s = {d['ms_per_step']:.2f} ms per dual-stream step (enc + unet + dec, SD-1.x size, B=4, 512x512, fp16,
-default (hi, lo) residual stream) on one MI355X (boxes of the pool differ by +-4 %: 12.3 .. 13.1 ms were seen for this
-build, about 0.5 ms less with the plain fp16 residual stream `UR_PRECISE_RESIDUAL=0`); CPU oracle on the same host
-({cpu['cores']}-core cgroup quota) {cpu['value']:.4f} steps/s.  6.49 TFLOP/step => {6.49 / d['ms_per_step']:.3f} PFLOP/s algorithmic =
-{100 * 6.49 / d['ms_per_step'] / 2.5:.0f} % of the dense fp16 MFMA roofline for the whole step (start of the round: 27.2 ms; first complete
-profile `r01_*`: 13.25 ms).
+default (hi, lo) residual stream) on one MI355X (boxes of the pool differ by +-4 %: 12.1 .. 12.9 ms were seen for this
+build in round 2, about 0.5 ms less with the plain fp16 residual stream `UR_PRECISE_RESIDUAL=0`); CPU oracle on the same
+host ({cpu['cores']}-core cgroup quota) {cpu['value']:.4f} steps/s (median of 3 timed steps).  6.49 TFLOP/step => {6.49 / d['ms_per_step']:.3f} PFLOP/s
+algorithmic = {100 * 6.49 / d['ms_per_step'] / 2.5:.0f} % of the dense fp16 MFMA roofline for the whole step (round 1 ended at 12.3 .. 13.1 ms; what was
+tried on the step time in round 2 and why it did not move: DESIGN.md section 4, "Round 2").
 
 Dominant kernel (by symbol; plain + split-K launches {100 * roof.get('share_of_step_incl_splitk_launches', roof['share_of_step']):.0f} % of the step):
 `{roof['kernel']}` at {roof['achieved']:.0f} TFLOP/s = {100 * roof['frac']:.0f} % of peak over its {roof['calls_per_step']} plain launches/step
