@@ -357,13 +357,19 @@ def vt_proj(x, wv, streams=1, shared_x=False):
 # ---------------------------------------------------------------------------------------------
 # norms, attention, glue
 # ---------------------------------------------------------------------------------------------
+_GN_STAT_KB = int(os.environ.get("UR_GN_STAT_KB", "64"))
+_GN_APPLY_KB = int(os.environ.get("UR_GN_APPLY_KB", "20"))
+_GN_APPLY_MAX = int(os.environ.get("UR_GN_APPLY_MAX", "128"))
+
+
 def _gn_chunks_bytes(B: int, rows: int, C: int, esize: int = 2):
     """Chunking by BYTES per workgroup (measured on MI355X with tools/bench_ops.py --what gn): a stats workgroup
     streams ~64 KB, an apply workgroup ~20 KB in + 20 KB out; never fewer than 2 rows per chunk, stats partials capped
-    at 32 per sample (every apply workgroup re-reduces them in its prologue)."""
+    at 32 per sample (every apply workgroup re-reduces them in its prologue).  UR_GN_STAT_KB / UR_GN_APPLY_KB /
+    UR_GN_APPLY_MAX override the three constants (in-situ A/B runs)."""
     sample_bytes = rows * C * esize
-    nstat = max(1, min(sample_bytes // (64 << 10), rows // 2, 32))
-    napply = max(1, min(sample_bytes // (20 << 10), rows // 2, 128, max(1, 4096 // max(B, 1))))  # > 128: slower (gn_bench)
+    nstat = max(1, min(sample_bytes // (_GN_STAT_KB << 10), rows // 2, 32))
+    napply = max(1, min(sample_bytes // (_GN_APPLY_KB << 10), rows // 2, _GN_APPLY_MAX, max(1, 4096 // max(B, 1))))  # > 128: slower (gn_bench)
     return int(nstat), int(napply)
 
 
