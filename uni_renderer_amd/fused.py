@@ -172,9 +172,13 @@ class GroupedDualStreamStep:
             wqk = pk.get("a.wqk", as_, [p for a in as_ for p in (a.to_q.weight, a.to_k.weight)], dt,
                          lambda: _stk(torch.cat([pack_matrix(a.to_q.weight, dt), pack_matrix(a.to_k.weight, dt)], 0) for a in as_))
             wv = pk.get("a.wv", as_, [a.to_v.weight for a in as_], dt, lambda: _stk(pack_matrix(a.to_v.weight, dt) for a in as_))
+            vt_first = os.environ.get("UR_VT_FIRST", "1") != "0"
+            if not vt_first:
+                qk = ops.linear(xn, wqk, streams=S, out_scale=math.sqrt(cs))
             with self._fork(xn, kind="vt") as f:  # V^T projection on the sibling branch, beside the q|k projection
                 vt = ops.vt_proj(xn, wv, streams=S)
-            qk = ops.linear(xn, wqk, streams=S, out_scale=math.sqrt(cs))  # scale folded in, see layers.Attention
+            if vt_first:
+                qk = ops.linear(xn, wqk, streams=S, out_scale=math.sqrt(cs))  # scale folded in, see layers.Attention
             f.join(vt)
             o = ops.attention(qk, qk, vt, B=Bt, H=H, Tq=T, Tk=T, d=d, ldq=2 * C, ldk=2 * C, q_off=0, k_off=C, scale=0.0)
         else:
@@ -337,7 +341,13 @@ class GroupedDualStreamStep:
 
         up_skips, forks = [], []
 
+        late = []  # UR_EXCHANGE_EARLY=0: all exchange GEMMs after the mid block (round-1 order) instead of right behind
+        early = os.environ.get("UR_EXCHANGE_EARLY", "1") != "0"  # the kernel that produced their skip (input still in L2)
+
         def exchange_skip(t):
+            if not early:
+                late.append(t)
+                return
             i = len(up_skips)
             with self._fork(t) as f:
                 y = exchange(f"ex{i}", enc.controlnet_down_blocks[i], dec.control_down_blocks[i] if run_decoder else None, t)
@@ -349,8 +359,9 @@ class GroupedDualStreamStep:
         S = len(pair3)
         rl3 = [self._resnets_of([n.up_blocks]) for n in pair3]
         cl3 = [self._cross_of([n.up_blocks]) for n in pair3]
+        ctx3_early = os.environ.get("UR_CTX3_EARLY", "1") != "0"
         with self._fork(semb, ehs) as f3:
-            ctx3 = self._phase_ctx(pair3, rl3, cl3, semb[B: B + S * B], ehs)
+            ctx3 = self._phase_ctx(pair3, rl3, cl3, semb[B: B + S * B], ehs) if ctx3_early else None
 
         # ================= phase 1: enc || unet : conv_in, down, mid =================
         pair = [enc, unet]
@@ -384,9 +395,13 @@ class GroupedDualStreamStep:
         mid = x  # [enc_mid ; unet_mid]
 
         # ================= phase 2: the mid exchange; join the sibling branch =================
+        for i, t in enumerate(late):
+            up_skips.append(exchange(f"ex{i}", enc.controlnet_down_blocks[i], dec.control_down_blocks[i] if run_decoder else None, t))
         x = exchange("exm", enc.controlnet_mid_block, dec.control_mid_block if run_decoder else None, mid)
         for f, y in forks:
             f.join(y)
+        if ctx3 is None:
+            ctx3 = self._phase_ctx(pair3, rl3, cl3, semb[B: B + S * B], ehs)
         temb, tsl, kc, vtc, ksl = ctx3
         f3.join(temb, kc, vtc)
 
