@@ -119,13 +119,15 @@ the harness's torch fills/copies: {alltot / 1e6:.1f} ms.
 
         def short(nm):
             return pretty(nm) if "_ZN2ur" in nm or nm.startswith("ur::") else re.sub(r"\(anonymous namespace\)::|at::native::|void ", "", nm)[:70]
+        tg = os.path.join(P, f"{tag}_train_graph.json")
+        unprof = json.loads(open(tg).read().strip().split("\n")[-1])["ms_per_step"] if os.path.exists(tg) else 144
         tl = "\n".join(f"| {short(r['Name'])} | {int(r['Calls']) // n} | {float(r['TotalDurationNs']) / n / 1e6:.2f} | {float(r['AverageNs']) / 1e3:.1f} |"
                        for r in trows[:16])
         out += f"""
 ## Training step (`{tag}_train_kernel_stats.csv`: `rocprofv3 --kernel-trace --stats -- python tools/train_bench.py --steps 3 --graph`)
 
 cfg 4's per-GPU shape (B=4, 512x512, bf16 compute, fp32 master parameters, fused AdamW, clipping), the whole step replayed as
-one HIP graph: {ttot / n / 1e6:.0f} ms of kernel time per step under the profiler (144 ms per replay un-profiled).  Top kernels per step:
+one HIP graph: {ttot / n / 1e6:.0f} ms of kernel time per step under the profiler ({unprof:.0f} ms per replay un-profiled).  Top kernels per step:
 
 | kernel | launches / step | ms / step | avg us |
 |---|---|---|---|

@@ -33,7 +33,11 @@ def main():
     ap.add_argument("--latent", type=int, default=64)
     ap.add_argument("--report", default=os.path.join(ROOT, "tools", "data", "tune_report_isolated.json"))
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "igemm_tuning_insitu.json"))
+    ap.add_argument("--train", action="store_true", help="tune the captured TRAINING step (tools/train_bench.py --graph: cfg 4's "
+                    "per-GPU shape, bf16) instead of the inference step; candidates = a fixed tile list at the current split-K")
     args = ap.parse_args()
+    if args.train:
+        return main_train(args)
     import bench
     import tune_igemm
     from uni_renderer_amd import ops
@@ -116,6 +120,97 @@ def main():
         json.dump(log, open(args.out.replace(".json", "_log.json"), "w"))
     final = measure()
     print(f"[in-situ] {min(base, base2):.4f} -> {final:.4f} ms per step (best seen {best:.4f})", flush=True)
+
+
+def main_train(args):
+    import bench
+    from uni_renderer_amd import ops
+    from uni_renderer_amd.train_step import train_step
+
+    dev = torch.device("cuda:0")
+    dt = torch.bfloat16
+    nets = bench.build_models(dev, torch.float32)
+    for m in nets:
+        m.train()
+        m.requires_grad_(True)
+    B, L = args.batch, args.latent
+    g = torch.Generator(device=dev).manual_seed(7)
+    mk = lambda *s_: torch.randn(*s_, device=dev, generator=g)
+    batch = dict(x_t=mk(B, 4, L, L), cond=mk(B, 28, L, L), ehs=mk(B, 77, 768) * 0.5,
+                 t_img=torch.randint(0, 1000, (B,), device=dev, generator=g), t_attr=torch.randint(0, 1000, (B,), device=dev, generator=g),
+                 target_img=mk(B, 4, L, L), target_attr=mk(B, 28, L, L))
+    opt = torch.optim.AdamW([p for m in nets for p in m.parameters()], lr=1e-6, fused=True, capturable=True)
+    ops.load_tuning_table()
+    side = torch.cuda.Stream()
+
+    def measure(replays=6):
+        ops._plan_cache.clear()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            train_step(nets, batch, optimizer=opt, dtype=dt, as_tensors=True)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            train_step(nets, batch, optimizer=opt, dtype=dt, as_tensors=True)
+        gr.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(replays):
+            gr.replay()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) * 1e3 / replays
+        del gr
+        return ms
+
+    calls, flops = {}, {}
+    orig = ops.igemm
+
+    def spy(**kw):
+        key = (kw["M"], kw["N"], kw["K"], kw.get("taps", 1), kw.get("zbatch", 1))
+        calls[key] = calls.get(key, 0) + 1
+        flops[key] = 2.0 * key[0] * key[1] * key[2] * key[4]
+        return orig(**kw)
+
+    ops.igemm = spy
+    try:
+        train_step(nets, batch, optimizer=opt, dtype=dt, as_tensors=True)
+        torch.cuda.synchronize()
+    finally:
+        ops.igemm = orig
+    est = sorted(((n * max(flops[k] / 6e14, 12e-6), k) for k, n in calls.items()), reverse=True)[: args.top]
+    base, base2 = measure(), measure()
+    print(f"[in-situ train] baseline {base:.3f} / {base2:.3f} ms per step; {len(calls)} problems, visiting {len(est)}", flush=True)
+    best = min(base, base2)
+    eps = max(args.eps, 0.04)
+    log = []
+    for _, key in est:
+        skey = "%d,%d,%d,%d,%d" % key
+        cur = tuple(ops._tune_table.get(skey, ops.plan_igemm(*key)))
+        cands = [(t, cur[1]) for t in (9, 10, 1, 5, 7, 2, 3, 11) if t != cur[0]][: args.cands]
+        if cur[1] > 1:
+            cands.append((cur[0], cur[1] // 2))
+        elif key[2] // 64 >= 16 and key[4] <= 4:
+            cands.append((cur[0], 2))
+        for cand in cands:
+            ops._tune_table[skey] = cand
+            try:
+                ms = measure()
+            except RuntimeError:
+                ms = float("inf")
+                torch.cuda.synchronize()
+            ok = ms < best - eps
+            log.append(dict(problem=skey, launches=calls[key], cur=list(cur), cand=list(cand), ms=round(ms, 3), best=round(best, 3), accepted=ok))
+            print(f"  {skey:30s} x{calls[key]:3d} {cur} -> {cand}: {ms:.3f} ms (best {best:.3f}) {'ACCEPT' if ok else ''}", flush=True)
+            if ok:
+                best, cur = ms, cand
+            else:
+                ops._tune_table[skey] = cur
+        ops._tune_table[skey] = cur
+        os.makedirs(os.path.dirname(args.out), exist_ok=True)
+        json.dump({k: list(v) for k, v in ops._tune_table.items()}, open(args.out, "w"), indent=0, sort_keys=True)
+        json.dump(log, open(args.out.replace(".json", "_log.json"), "w"))
+    print(f"[in-situ train] {min(base, base2):.3f} -> {measure():.3f} ms per step (best seen {best:.3f})", flush=True)
 
 
 if __name__ == "__main__":
