@@ -366,6 +366,13 @@ int ur_softmax_backward_rows(const void* p, void* dp, int64_t ld, int64_t rows, 
 int ur_silu_forward(const void* x, void* y, int64_t n, int dtype, void* stream);
 int ur_resample2x(const void* in, void* out, int B, int Hout, int Wout, int C, int mode, int dtype, void* stream);
 
+/* Training: the fp32 master weight of an nn.Conv2d 3x3 ([Co][Ci][3][3]) to the packed compute-dtype matrix
+ * [Co][9 * Cpad] (k = tap * Cpad + c, channels Ci .. Cpad zero) that ur_igemm reads, and the packed weight gradient
+ * (row stride ld >= 9 * Cpad) back to an fp32 [Co][Ci][3][3] gradient: cast + repack in one pass each way, instead of
+ * the cast / permute / contiguous chain of torch kernels the autocast of train/train.py:1324-1354 amounts to. */
+int ur_pack_conv_weight(const float* w, void* out, int Co, int Ci, int Cpad, int dtype, void* stream);
+int ur_unpack_conv_weight_grad(const void* dwp, int64_t ld, float* out, int Co, int Ci, int Cpad, int dtype, void* stream);
+
 /* Library self-description. */
 int ur_abi_version(void);
 const char* ur_build_info(void);

@@ -219,3 +219,30 @@ def test_autograd_functions_chain(dev, dtype):
     assert rel_l2(x.grad, xr.grad) < TOL[dtype] * 4
     for n in par:
         assert rel_l2(par[n].grad, pr[n].grad) < TOL[dtype] * 4, n
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(128, 64, None), (64, 28, 64), (320, 4, 64), (64, 640, None)])
+def test_conv_weight_pack_unpack_and_rotation_kernels(dev, dtype, shape):
+    """ur_pack_conv_weight / ur_unpack_conv_weight_grad (fp32 master <-> packed compute-dtype matrix, one pass each way)
+    against layers.pack_conv3x3 and its autograd; backward._rot_weights as ONE ur_transpose2d launch against the
+    flip / permute expression it replaces."""
+    from uni_renderer_amd import autograd_ops as A
+    from uni_renderer_amd import backward as bw
+    from uni_renderer_amd.layers import pack_conv3x3
+
+    co, ci, cpad = shape
+    g = torch.Generator().manual_seed(co + ci)
+    w = torch.randn(co, ci, 3, 3, generator=g).to(dev).requires_grad_(True)
+    wp = A.pack_conv_weight(w, dtype, cpad)
+    ref = pack_conv3x3(w.detach(), dtype, cpad)
+    assert wp.shape == ref.shape and torch.equal(wp, ref)
+    up = torch.randn(wp.shape, generator=g).to(dev).to(dtype)
+    wp.backward(up)
+    cp = ci if cpad is None else cpad
+    want = up.float().view(co, 3, 3, cp)[..., :ci].permute(0, 3, 1, 2)
+    assert w.grad.shape == w.shape and w.grad.dtype == torch.float32 and torch.equal(w.grad, want.contiguous())
+    if cp % 8 == 0 and co % 8 == 0:
+        rot = bw._rot_weights(ref, cp)
+        w4 = ref.view(co, 3, 3, cp)
+        assert torch.equal(rot, w4.flip(1, 2).permute(3, 1, 2, 0).reshape(cp, 9 * co).contiguous())

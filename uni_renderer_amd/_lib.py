@@ -75,6 +75,8 @@ SYMBOLS = {
                                  C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, vp]),
     "ur_sampler_advance": (C.c_int, [vp, vp, C.c_int, vp, C.c_int, vp]),
     "ur_prefetch": (C.c_int, [vp, C.c_int64, C.c_int, vp]),
+    "ur_pack_conv_weight": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "ur_unpack_conv_weight_grad": (C.c_int, [vp, C.c_int64, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "ur_unipc_update": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int64, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp,
                                   vp, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, vp]),
     "ur_transpose2d": (C.c_int, [vp, C.c_int64, C.c_int64, vp, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, vp]),

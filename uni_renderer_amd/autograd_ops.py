@@ -184,8 +184,37 @@ def conv3x3(x, wp, b=None, res=None, rowadd=None, stride=1):
     return Conv3x3.apply(x, wp, b, res, rowadd, stride)
 
 
+class PackConvWeight(Function):
+    """fp32 master [Co, Ci, 3, 3] -> compute-dtype [Co][(ky, kx, ci_pad)] (ur_pack_conv_weight) and the packed weight
+    gradient back to an fp32 [Co, Ci, 3, 3] gradient (ur_unpack_conv_weight_grad): one kernel each way."""
+
+    @staticmethod
+    def forward(ctx, weight, dtype, cin_pad):
+        lib = _lib.load()
+        co, ci = weight.shape[:2]
+        cp = ci if cin_pad is None else cin_pad
+        ctx.geom = (co, ci, cp)
+        w = weight.detach().contiguous()
+        out = torch.empty(co, 9 * cp, dtype=dtype, device=weight.device)
+        check(lib.ur_pack_conv_weight(w.data_ptr(), out.data_ptr(), co, ci, cp, DT[dtype], _stream()), "ur_pack_conv_weight")
+        return out
+
+    @staticmethod
+    def backward(ctx, dwp):
+        lib = _lib.load()
+        co, ci, cp = ctx.geom
+        if dwp.stride(-1) != 1:
+            dwp = dwp.contiguous()
+        g = torch.empty(co, ci, 3, 3, dtype=torch.float32, device=dwp.device)
+        check(lib.ur_unpack_conv_weight_grad(dwp.data_ptr(), dwp.stride(0), g.data_ptr(), co, ci, cp, DT[dwp.dtype], _stream()),
+              "ur_unpack_conv_weight_grad")
+        return g, None, None
+
+
 def pack_conv_weight(weight: torch.Tensor, dtype, cin_pad=None) -> torch.Tensor:
     """differentiable version of layers.pack_conv3x3: [Co, Ci, 3, 3] fp32 master -> [Co][(ky,kx,ci_pad)] compute dtype."""
+    if weight.is_cuda and weight.dtype == torch.float32 and dtype in DT and weight.dim() == 4 and tuple(weight.shape[2:]) == (3, 3):
+        return PackConvWeight.apply(weight, dtype, cin_pad)
     co, ci = weight.shape[:2]
     w = weight.to(dtype).permute(0, 2, 3, 1)  # cast first: the strided repack then moves 2-byte elements
     if cin_pad is not None and cin_pad != ci:

@@ -83,10 +83,19 @@ def linear_backward(x: torch.Tensor, w: torch.Tensor, dy: torch.Tensor, need_bia
 
 
 def _rot_weights(w_packed: torch.Tensor, cin: int) -> torch.Tensor:
-    """forward conv weights [N][(ky,kx,c)] -> the dgrad conv's [C][(ky',kx',n)] with ky' = 2-ky, kx' = 2-kx."""
+    """forward conv weights [N][(ky,kx,c)] -> the dgrad conv's [C][(ky',kx',n)] with ky' = 2-ky, kx' = 2-kx, i.e.
+    out[c][t' * N + n] = w[n][(8 - t') * C + c]: nine [N][C] -> [C][N] transposes, ONE ``ur_transpose2d`` launch with
+    the tap as batch index (source taps walked backwards: negative batch stride)."""
     N = w_packed.shape[0]
-    w4 = w_packed.view(N, 3, 3, cin)
-    return w4.flip(1, 2).permute(3, 1, 2, 0).reshape(cin, 9 * N).contiguous()
+    if N % 8 or cin % 8 or not w_packed.is_contiguous() or w_packed.shape[1] != 9 * cin:
+        w4 = w_packed.reshape(N, 3, 3, cin)
+        return w4.flip(1, 2).permute(3, 1, 2, 0).reshape(cin, 9 * N).contiguous()
+    lib = _lib.load()
+    out = torch.empty(cin, 9 * N, dtype=w_packed.dtype, device=w_packed.device)
+    esz = w_packed.element_size()
+    check(lib.ur_transpose2d(w_packed.data_ptr() + 8 * cin * esz, 9 * cin, -cin, out.data_ptr(), 9 * N, N, N, cin, 9,
+                             DT[w_packed.dtype], _stream()), "ur_transpose2d")
+    return out
 
 
 def resample2x(x: torch.Tensor, mode: int) -> torch.Tensor:

@@ -642,6 +642,42 @@ static inline int grid_for(int64_t n) {
 
 using namespace ur;
 
+// Conv weight master (fp32 [Co][Ci][3][3], the nn.Conv2d layout) <-> packed compute-dtype matrix [Co][9 * Cpad]
+// (k = tap * Cpad + c, channels Ci .. Cpad zero): cast + repack in ONE pass each way.  A thread owns one (co, c): the
+// nine taps are 36 contiguous bytes of the master and nine coalesced 2-byte accesses of the packed rows.
+template <typename T>
+__global__ void __launch_bounds__(256) pack_conv_weight_kernel(const float* __restrict__ w, T* __restrict__ out, int Co,
+                                                               int Ci, int Cpad) {
+    const int64_t total = (int64_t)Co * Cpad;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % Cpad);
+        const int64_t co = i / Cpad;
+        T* o = out + co * 9 * Cpad + c;
+        if (c < Ci) {
+            const float* src = w + (co * Ci + c) * 9;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) o[(int64_t)t * Cpad] = (T)src[t];
+        } else {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) o[(int64_t)t * Cpad] = (T)0.0f;
+        }
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) unpack_conv_weight_kernel(const T* __restrict__ dwp, int64_t ld, float* __restrict__ out,
+                                                                 int Co, int Ci, int Cpad) {
+    const int64_t total = (int64_t)Co * Ci;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % Ci);
+        const int64_t co = i / Ci;
+        const T* src = dwp + co * ld + c;
+        float* o = out + i * 9;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) o[t] = (float)src[(int64_t)t * Cpad];
+    }
+}
+
 #define UR_DISPATCH(dtype, CALL)                          \
     if ((dtype) == UR_DT_F16) { typedef f16 T; CALL; }    \
     else if ((dtype) == UR_DT_BF16) { typedef bf16 T; CALL; } \
@@ -829,5 +865,25 @@ extern "C" int ur_resample2x(const void* in, void* out, int B, int Hout, int Wou
     const int64_t total = (int64_t)B * Hout * Wout * (C / 8);
     UR_DISPATCH(dtype, hipLaunchKernelGGL((resample2x_kernel<T>), dim3(grid_for(total)), dim3(256), 0, s, (const T*)in, (T*)out, B,
                                           Hout, Wout, C, mode));
+    return last_error();
+}
+
+extern "C" int ur_pack_conv_weight(const float* w, void* out, int Co, int Ci, int Cpad, int dtype, void* stream) {
+    if (!w || !out || Co <= 0 || Ci <= 0 || Cpad < Ci) return UR_E_BADARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int64_t total = (int64_t)Co * Cpad;
+    const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    UR_DISPATCH(dtype, hipLaunchKernelGGL((pack_conv_weight_kernel<T>), dim3(grid), dim3(256), 0, s, w, (T*)out, Co, Ci, Cpad));
+    return last_error();
+}
+
+extern "C" int ur_unpack_conv_weight_grad(const void* dwp, int64_t ld, float* out, int Co, int Ci, int Cpad, int dtype,
+                                          void* stream) {
+    if (!dwp || !out || Co <= 0 || Ci <= 0 || Cpad < Ci || ld < 9 * (int64_t)Cpad) return UR_E_BADARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int64_t total = (int64_t)Co * Ci;
+    const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    UR_DISPATCH(dtype, hipLaunchKernelGGL((unpack_conv_weight_kernel<T>), dim3(grid), dim3(256), 0, s, (const T*)dwp, ld, out,
+                                          Co, Ci, Cpad));
     return last_error();
 }

@@ -329,12 +329,30 @@ def train_step(nets: Sequence[torch.nn.Module], batch: Dict[str, torch.Tensor], 
     if buckets is not None:
         buckets.finish()
     stats = {"loss": loss.detach()}
+    folded = False
     if max_grad_norm is not None:
-        if buckets is not None:
+        # torch's fused Adam / AdamW kernels divide every gradient by ``optimizer.grad_scale`` on the fly (the hook
+        # GradScaler uses): handing them 1 / clip_coefficient applies train.py:1422-1424's clipping inside the optimizer
+        # pass instead of a separate read-modify-write sweep over 7 GB of gradients
+        fold = (optimizer is not None and getattr(optimizer, "_step_supports_amp_scaling", False)
+                and all(g.get("fused") for g in optimizer.param_groups))
+        if fold:
+            if buckets is not None:
+                norm = torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(f) for f in buckets.flat]))
+            else:
+                grads = [p.grad for n in nets for p in n.parameters() if p.grad is not None]
+                norm = torch.linalg.vector_norm(torch.stack(torch._foreach_norm(grads)))
+            stats["grad_norm"] = norm
+            optimizer.grad_scale = torch.clamp((norm + 1e-6) / max_grad_norm, min=1.0).to(torch.float32).reshape(())
+            optimizer.found_inf = torch.zeros((), dtype=torch.float32, device=norm.device)
+            folded = True
+        elif buckets is not None:
             stats["grad_norm"] = buckets.clip_grad_norm_(max_grad_norm)
         else:
             params = [p for n in nets for p in n.parameters() if p.grad is not None]
             stats["grad_norm"] = torch.nn.utils.clip_grad_norm_(params, max_grad_norm)
     if optimizer is not None:
         optimizer.step()
+        if folded:
+            del optimizer.grad_scale, optimizer.found_inf
     return stats if as_tensors else {k: float(v) for k, v in stats.items()}

@@ -263,7 +263,7 @@ class AutoencoderKL(ConfigModelMixin, nn.Module):
             return pack_conv3x3(wc, dt), bc.contiguous()
 
         wc, bc = pk.get("e.out", [e.conv_out.weight, e.conv_out.bias, q.weight, q.bias], dt, compose)
-        moments = ops.to_nchw(ops.conv3x3(h, wc, bc, n_out=q.weight.shape[0]), x.dtype if x.dtype in (torch.float16, torch.bfloat16, torch.float32) else dt)
+        moments = ops.to_nchw(ops.conv3x3(h, wc, bc, n_out=q.weight.shape[0]), x.dtype if x.dtype in (torch.float16, torch.bfloat16, torch.float32) else torch.float32)
         post = DiagonalGaussianDistribution(moments)
         return AutoencoderKLOutput(latent_dist=post) if return_dict else (post,)
 
@@ -289,7 +289,7 @@ class AutoencoderKL(ConfigModelMixin, nn.Module):
         h = ops.groupnorm(h, g, gb, d.conv_norm_out.eps, groups=d.conv_norm_out.num_groups, silu=True)
         wo = pk.get("d.out", [d.conv_out.weight], dt, lambda: pack_conv3x3(d.conv_out.weight, dt))
         bo = pk.get("d.outb", [d.conv_out.bias], dt, lambda: f32(d.conv_out.bias))
-        img = ops.to_nchw(ops.conv3x3(h, wo, bo, n_out=d.conv_out.weight.shape[0]), z.dtype if z.dtype.is_floating_point else dt)
+        img = ops.to_nchw(ops.conv3x3(h, wo, bo, n_out=d.conv_out.weight.shape[0]), z.dtype if z.dtype in (torch.float16, torch.bfloat16, torch.float32) else torch.float32)
         return DecoderOutput(sample=img) if return_dict else (img,)
 
     def forward(self, sample: torch.Tensor, sample_posterior: bool = False, return_dict: bool = True, generator=None):
