@@ -4,6 +4,14 @@
 #include "ur_common.h"
 #include "../../include/ur_kernels.h"
 
+#include <cstdlib>
+
+// UR_NORM_XCD=0 switches the XCD row-ownership remap of the norm kernels off (A/B runs); read once.
+static int norm_xcd() {
+    static const int v = [] { const char* e = std::getenv("UR_NORM_XCD"); return (e && e[0] == '0') ? 0 : 1; }();
+    return v;
+}
+
 namespace ur {
 
 // ------------------------------------------------------------------------------------------
@@ -19,11 +27,15 @@ template <typename T>
 __global__ void __launch_bounds__(256) gn_stats_kernel(const T* __restrict__ x0, const T* __restrict__ x1,
                                                        const lo_t<T>* __restrict__ x0_lo, const lo_t<T>* __restrict__ x1_lo, int c0,
                                                        int c1, int rows, int groups, int nchunks,
-                                                       float* __restrict__ partial) {
+                                                       float* __restrict__ partial, int xcd) {
     __shared__ float4 tpart[256];  // per thread: (sum, sumsq) of its channels in group gA, and in group gA + 1
     __shared__ float2 chs[2048];   // cpg < 8 only (tiny test configurations): per-(row-subset, channel) sums
     const int C = c0 + c1, nvec = C >> 3, cpg = C / groups;
-    const int b = blockIdx.y, chunk = blockIdx.x;
+    // xcd: (sample, chunk) -> XCD so that every XCD owns ONE contiguous range of rows of the (stream-major stacked)
+    // activation tensor, the same partition ur_igemm's tile remap gives its m-tiles: a consumer GEMM then finds the
+    // rows it reads in the L2 of the XCD that wrote them (and this kernel the rows its producer wrote)
+    const int lid_ = xcd ? xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y) : blockIdx.x + gridDim.x * blockIdx.y;
+    const int b = lid_ / gridDim.x, chunk = lid_ - b * gridDim.x;
     const int rpc = (rows + nchunks - 1) / nchunks;
     const int rbeg = chunk * rpc, rend = min(rows, rbeg + rpc);
     const int t = threadIdx.x;
@@ -147,11 +159,15 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const T* __restrict__ x0,
                                                        const float* __restrict__ partial,
                                                        const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float eps, int silu,
-                                                       int bper, int pstride, T* __restrict__ out) {
+                                                       int bper, int pstride, T* __restrict__ out, int xcd) {
     __shared__ float2 stat[64];  // (mean, rstd) per group
     __shared__ float2 red[4][64];
     const int C = c0 + c1, nvec = C >> 3, cpg = C / groups;
-    const int b = blockIdx.y, chunk = blockIdx.x;
+    // xcd: (sample, chunk) -> XCD so that every XCD owns ONE contiguous range of rows of the (stream-major stacked)
+    // activation tensor, the same partition ur_igemm's tile remap gives its m-tiles: a consumer GEMM then finds the
+    // rows it reads in the L2 of the XCD that wrote them (and this kernel the rows its producer wrote)
+    const int lid_ = xcd ? xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y) : blockIdx.x + gridDim.x * blockIdx.y;
+    const int b = lid_ / gridDim.x, chunk = lid_ - b * gridDim.x;
     const int t = threadIdx.x;
     {   // reduce the stats partials of sample b: 4 thread-slices x groups, fixed order (deterministic)
         const int g = t & 63, j = t >> 6;
@@ -245,9 +261,10 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const T* __restrict__ x0,
 template <typename T, int MAXV, int R>
 __global__ void __launch_bounds__(256) layernorm_kernel(const T* __restrict__ x, const lo_t<T>* __restrict__ x_lo, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps, int rows, int C,
-                                                        int rows_per_set, int pstride, T* __restrict__ out) {
+                                                        int rows_per_set, int pstride, T* __restrict__ out, int xcd) {
     const int lane = threadIdx.x & 63;
-    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+    const int bid = xcd ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;  // contiguous row range per XCD (see gn_stats_kernel)
+    const int row0 = (bid * 4 + (threadIdx.x >> 6)) * R;
     if (row0 >= rows) return;
     const int nvec = C >> 3;
     float v[R][MAXV][8];
@@ -326,10 +343,11 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const T* __restrict__ x,
 template <typename T, int L>
 __global__ void __launch_bounds__(256) layernorm5_kernel(const T* __restrict__ x, const lo_t<T>* __restrict__ x_lo, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, float eps, int rows, int C,
-                                                         int rows_per_set, int pstride, T* __restrict__ out) {
+                                                         int rows_per_set, int pstride, T* __restrict__ out, int xcd) {
     constexpr int RPW = 64 / L;  // rows per wave
     const int lane = threadIdx.x & 63, sub = lane % L;
-    const int row = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + lane / L;
+    const int bid = xcd ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+    const int row = (bid * 4 + (threadIdx.x >> 6)) * RPW + lane / L;
     const bool valid = row < rows;
     const T* xr = x + (int64_t)min(row, rows - 1) * C;
     float v[5][8];
@@ -549,10 +567,10 @@ extern "C" int ur_groupnorm_stats(const void* x0, const void* x1, const void* x0
     dim3 grid(nchunks, B);
     if (dtype == UR_DT_F16)
         hipLaunchKernelGGL((gn_stats_kernel<f16>), grid, dim3(256), 0, s, (const f16*)x0, (const f16*)x1,
-                           (const lo_t<f16>*)x0_lo, (const lo_t<f16>*)x1_lo, c0, c1, rows, groups, nchunks, partial);
+                           (const lo_t<f16>*)x0_lo, (const lo_t<f16>*)x1_lo, c0, c1, rows, groups, nchunks, partial, norm_xcd());
     else if (dtype == UR_DT_BF16)
         hipLaunchKernelGGL((gn_stats_kernel<bf16>), grid, dim3(256), 0, s, (const bf16*)x0, (const bf16*)x1,
-                           (const lo_t<bf16>*)x0_lo, (const lo_t<bf16>*)x1_lo, c0, c1, rows, groups, nchunks, partial);
+                           (const lo_t<bf16>*)x0_lo, (const lo_t<bf16>*)x1_lo, c0, c1, rows, groups, nchunks, partial, norm_xcd());
     else
         return UR_E_BADARG;
     hipError_t e = hipGetLastError();
@@ -570,11 +588,11 @@ extern "C" int ur_groupnorm_apply(const void* x0, const void* x1, const void* x0
     if (dtype == UR_DT_F16)
         hipLaunchKernelGGL((gn_apply_kernel<f16>), grid, dim3(256), 0, s, (const f16*)x0, (const f16*)x1,
                            (const lo_t<f16>*)x0_lo, (const lo_t<f16>*)x1_lo, c0, c1, rows, groups, nstat, nchunks, partial, gamma, beta,
-                           eps, silu, bper, pstride, (f16*)out);
+                           eps, silu, bper, pstride, (f16*)out, norm_xcd());
     else if (dtype == UR_DT_BF16)
         hipLaunchKernelGGL((gn_apply_kernel<bf16>), grid, dim3(256), 0, s, (const bf16*)x0, (const bf16*)x1,
                            (const lo_t<bf16>*)x0_lo, (const lo_t<bf16>*)x1_lo, c0, c1, rows, groups, nstat, nchunks, partial, gamma,
-                           beta, eps, silu, bper, pstride, (bf16*)out);
+                           beta, eps, silu, bper, pstride, (bf16*)out, norm_xcd());
     else
         return UR_E_BADARG;
     hipError_t e = hipGetLastError();
@@ -621,10 +639,10 @@ static void launch_ln(const void* x, const void* x_lo, const float* gamma, const
     // rows per wave chosen so that a wave keeps >= 4 16-byte loads per lane in flight and the grid still fills the chip
 #define UR_LN(MAXV, R)                                                                                              \
     hipLaunchKernelGGL((layernorm_kernel<T, MAXV, R>), dim3((rows + 4 * R - 1) / (4 * R)), dim3(256), 0, s,          \
-                       (const T*)x, (const lo_t<T>*)x_lo, gamma, beta, eps, rows, C, rows_per_set, pstride, (T*)out)
+                       (const T*)x, (const lo_t<T>*)x_lo, gamma, beta, eps, rows, C, rows_per_set, pstride, (T*)out, norm_xcd())
 #define UR_LN5(LL)                                                                                                   \
     hipLaunchKernelGGL((layernorm5_kernel<T, LL>), dim3((rows + 4 * (64 / LL) - 1) / (4 * (64 / LL))), dim3(256), 0, s, \
-                       (const T*)x, (const lo_t<T>*)x_lo, gamma, beta, eps, rows, C, rows_per_set, pstride, (T*)out)
+                       (const T*)x, (const lo_t<T>*)x_lo, gamma, beta, eps, rows, C, rows_per_set, pstride, (T*)out, norm_xcd())
     if (C == 320) { UR_LN5(8); return; }
     if (C == 640) { UR_LN5(16); return; }
     if (C == 1280) { UR_LN5(32); return; }
