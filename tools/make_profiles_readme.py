@@ -14,10 +14,14 @@ P = os.path.join(ROOT, "profiles")
 
 
 def pretty(n):
-    m = re.search(r"igemm_kernelID(?:F16_|F16b)Li(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(n?\d+)ELb(\d)", n)
+    m = re.search(r"igemm_kernelID(?:F16_|F16b)Li(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(n?\d+)ELb(\d)(?:ELi(\d+)ELi(\d+))?", n)
     if m:
         bm, bn, wm, wn = (int(m.group(i)) for i in range(1, 5))
-        return f"igemm_kernel<{bm}x{bn}, {wm * wn} waves, stages {m.group(5)}, {'conv3x3' if m.group(6) == '1' else 'gemm'}>"
+        extra = ""
+        if m.group(7):
+            extra += ", 32x32x16 MFMA" if m.group(7) == "32" else ""
+            extra += f", {m.group(8)} loader waves" if m.group(8) != "0" else ""
+        return f"igemm_kernel<{bm}x{bn}, {wm * wn} waves, stages {m.group(5)}, {'conv3x3' if m.group(6) == '1' else 'gemm'}{extra}>"
     m = re.search(r"attention32_kernelID(?:F16_|F16b)Li(\d+)ELb(\d)", n)
     if m:
         return f"attention32_kernel<d={m.group(1)}{', reference slot' if m.group(2) == '1' else ''}>"
