@@ -33,6 +33,11 @@ def main():
     ap.add_argument("--latent", type=int, default=64)
     ap.add_argument("--report", default=os.path.join(ROOT, "tools", "data", "tune_report_isolated.json"))
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "igemm_tuning_insitu.json"))
+    ap.add_argument("--sites", action="store_true", help="tune per call site: the tagged launches of fused.py (q|k, q, attention "
+                    "out, FF in / out, proj_in / out) get their own 'M,N,K,taps,z@site' rows")
+    ap.add_argument("--broad", action="store_true", help="candidates = a fixed broad tile list (x current split-K, x2, /2) instead "
+                    "of the isolated report's best few: the isolated ranking missed in-situ winners (a 128x64 tile for the "
+                    "level-0 feed-forward GEMM whose isolated optimum is 256x256)")
     ap.add_argument("--train", action="store_true", help="tune the captured TRAINING step (tools/train_bench.py --graph: cfg 4's "
                     "per-GPU shape, bf16) instead of the inference step; candidates = a fixed tile list at the current split-K")
     args = ap.parse_args()
@@ -70,7 +75,7 @@ def main():
     orig = ops.igemm
 
     def spy(**kw):
-        key = (kw["M"], kw["N"], kw["K"], kw.get("taps", 1), kw.get("zbatch", 1))
+        key = (kw["M"], kw["N"], kw["K"], kw.get("taps", 1), kw.get("zbatch", 1), ops._site if args.sites else None)
         calls[key] = calls.get(key, 0) + 1
         return orig(**kw)
 
@@ -83,23 +88,33 @@ def main():
     finally:
         ops.igemm = orig
     rep = {(r["M"], r["N"], r["K"], r["taps"], r["z"]): r for r in json.load(open(args.report))}
-    share = sorted(((rep[k]["best_us"] * n, k) for k, n in calls.items() if k in rep), reverse=True)[: args.top]
+    share = sorted(((rep[k[:5]]["best_us"] * n, k) for k, n in calls.items() if k[:5] in rep and (k[5] or not args.sites)),
+                   reverse=True)[: args.top]
     base = measure()
     base2 = measure()
     print(f"[in-situ] baseline {base:.4f} / {base2:.4f} ms per step; {len(share)} problems to visit", flush=True)
     best = min(base, base2)
     log = []
-    for est, key in share:
-        skey = "%d,%d,%d,%d,%d" % key
-        cur = tuple(ops._tune_table.get(skey, ops.plan_igemm(*key)))
+    for est, key6 in share:
+        key, site = key6[:5], key6[5]
+        bkey = "%d,%d,%d,%d,%d" % key
+        skey = bkey + (f"@{site}" if site else "")
+        cur = tuple(ops._tune_table.get(skey) or ops._tune_table.get(bkey) or ops.plan_igemm(*key))
         allc = sorted(rep[key]["all"].items(), key=lambda kv: kv[1])
         cands = []
-        for c, _ in allc:
-            tc = tuple(int(v) for v in c.split(","))
-            if tc != cur and tc not in cands:
-                cands.append(tc)
-            if len(cands) >= args.cands:
-                break
+        if args.broad:
+            sks = [cur[1]] + ([cur[1] * 2] if key[2] // 64 >= 8 * cur[1] and key[4] <= 4 else []) + ([cur[1] // 2] if cur[1] > 1 else [])
+            for sk in sks:
+                for t in (9, 10, 1, 5, 7, 2, 3, 11, 8, 32, 24, 13):
+                    if (t, sk) != cur and (t, sk) not in cands:
+                        cands.append((t, sk))
+        else:
+            for c, _ in allc:
+                tc = tuple(int(v) for v in c.split(","))
+                if tc != cur and tc not in cands:
+                    cands.append(tc)
+                if len(cands) >= args.cands:
+                    break
         for cand in cands:
             ops._tune_table[skey] = cand
             try:
@@ -107,8 +122,8 @@ def main():
             except RuntimeError as e:
                 ms = float("inf")
             ok = ms < best - args.eps
-            log.append(dict(problem=skey, launches=calls[key], cur=list(cur), cand=list(cand), ms=round(ms, 4), best=round(best, 4), accepted=ok))
-            print(f"  {skey:28s} x{calls[key]:2d} {cur} -> {cand}: {ms:.4f} ms (best {best:.4f}) {'ACCEPT' if ok else ''}", flush=True)
+            log.append(dict(problem=skey, launches=calls[key6], cur=list(cur), cand=list(cand), ms=round(ms, 4), best=round(best, 4), accepted=ok))
+            print(f"  {skey:32s} x{calls[key6]:2d} {cur} -> {cand}: {ms:.4f} ms (best {best:.4f}) {'ACCEPT' if ok else ''}", flush=True)
             if ok:
                 best, cur = ms, cand
             else:

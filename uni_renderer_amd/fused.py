@@ -173,21 +173,28 @@ class GroupedDualStreamStep:
                          lambda: _stk(torch.cat([pack_matrix(a.to_q.weight, dt), pack_matrix(a.to_k.weight, dt)], 0) for a in as_))
             wv = pk.get("a.wv", as_, [a.to_v.weight for a in as_], dt, lambda: _stk(pack_matrix(a.to_v.weight, dt) for a in as_))
             vt_first = os.environ.get("UR_VT_FIRST", "1") != "0"
+            ops.set_site("qk")
             if not vt_first:
                 qk = ops.linear(xn, wqk, streams=S, out_scale=math.sqrt(cs))
             with self._fork(xn, kind="vt") as f:  # V^T projection on the sibling branch, beside the q|k projection
+                ops.set_site("vt")
                 vt = ops.vt_proj(xn, wv, streams=S)
+                ops.set_site("qk")
             if vt_first:
                 qk = ops.linear(xn, wqk, streams=S, out_scale=math.sqrt(cs))  # scale folded in, see layers.Attention
             f.join(vt)
             o = ops.attention(qk, qk, vt, B=Bt, H=H, Tq=T, Tk=T, d=d, ldq=2 * C, ldk=2 * C, q_off=0, k_off=C, scale=0.0)
         else:
             wq = pk.get("a.wq", as_, [a.to_q.weight for a in as_], dt, lambda: _stk(pack_matrix(a.to_q.weight, dt) for a in as_))
+            ops.set_site("q")
             q = ops.linear(xn, wq, streams=S, out_scale=cs)
             lo, hi = kv_slice
             o = ops.attention(q, kc[:, :, lo:hi], vtc[:, lo:hi], B=Bt, H=H, Tq=T, Tk=kc.shape[1], d=d, ldq=C,
                               ldk=kc.stride(1), scale=0.0)
-        return ops.linear(o, wo, bo, res=residual, streams=S, hilo=self.hilo)
+        ops.set_site("co" if a0.is_cross else "ao")
+        y = ops.linear(o, wo, bo, res=residual, streams=S, hilo=self.hilo)
+        ops.set_site(None)
+        return y
 
     def _tblock(self, bs: Sequence[BasicTransformerBlock], x, kc, vtc, kv_slice):
         S, pk, dt = len(bs), self.pk, x.dtype
@@ -214,8 +221,12 @@ class GroupedDualStreamStep:
         w_in, b_in = pk.get("t.ffi", bs, [p for pr in projs for p in (pr.weight, pr.bias)], dt, build_in)
         w_out = pk.get("t.ffo", bs, [o.weight for o in outs], dt, lambda: _stk(pack_matrix(o.weight, dt) for o in outs))
         b_out = pk.get("t.ffb", bs, [o.bias for o in outs], dt, lambda: _stk(f32(o.bias) for o in outs))
+        ops.set_site("ffi")
         gg = ops.linear(xn, w_in, b_in, act=ops.ACT_GEGLU, streams=S)
-        return ops.linear(gg, w_out, b_out, res=x, streams=S, hilo=self.hilo)
+        ops.set_site("ffo")
+        y = ops.linear(gg, w_out, b_out, res=x, streams=S, hilo=self.hilo)
+        ops.set_site(None)
+        return y
 
     def _transformer(self, ts: Sequence[Transformer2DModel], x, kc, vtc, kv_slices):
         S, pk, dt = len(ts), self.pk, x.dtype
@@ -227,10 +238,14 @@ class GroupedDualStreamStep:
         wo = pk.get("x.wo", ts, [t.proj_out.weight for t in ts], dt, lambda: _stk(pack_matrix(t.proj_out.weight, dt) for t in ts))
         bo = pk.get("x.bo", ts, [t.proj_out.bias for t in ts], dt, lambda: _stk(f32(t.proj_out.bias) for t in ts))
         h = ops.groupnorm(x, g, b_, ts[0].norm.eps, groups=ts[0].groups, silu=False, streams=S)
+        ops.set_site("pi")
         h = ops.linear(h.view(Bt, H * W, Cc), wi, bi, streams=S, hilo=self.hilo)
+        ops.set_site(None)
         for j in range(len(ts[0].transformer_blocks)):
             h = self._tblock([t.transformer_blocks[j] for t in ts], h, kc, vtc, kv_slices[j])
+        ops.set_site("po")
         y = ops.linear(h, wo, bo, res=ops.view_hilo(x, Bt, H * W, Cc), streams=S, hilo=self.hilo)
+        ops.set_site(None)
         return ops.view_hilo(y, Bt, H, W, Cc)
 
     def _conv(self, name, convs, x, stride=1, ups=False):

@@ -113,16 +113,27 @@ def load_tuning_table(path: Optional[str] = None):
     return _tune_table
 
 
+_site = None  # call-site tag of the launch being planned (fused.py sets it): lets the in-situ tuner give the SAME problem
+              # shape different tiles at different places of the step ("M,N,K,taps,z@site" rows override "M,N,K,taps,z")
+
+
+def set_site(name: Optional[str]):
+    global _site
+    _site = name
+
+
 def plan_igemm(M: int, N: int, K: int, taps: int = 1, zbatch: int = 1) -> Tuple[int, int]:
     """(tile, splitk) for an implicit GEMM.  Measured table first, analytic model otherwise."""
     global _tune_table
-    key = (M, N, K, taps, zbatch)
+    key = (M, N, K, taps, zbatch, _site)
     hit = _plan_cache.get(key)
     if hit is not None:
         return hit
     if _tune_table is None:
         load_tuning_table()
-    t = _tune_table.get(f"{M},{N},{K},{taps},{zbatch}")
+    t = _tune_table.get(f"{M},{N},{K},{taps},{zbatch}@{_site}") if _site else None
+    if t is None:
+        t = _tune_table.get(f"{M},{N},{K},{taps},{zbatch}")
     if t is None:
         per_cu = 2.5e15 / 256 * 0.4
         best, best_t = (TILE_64x64, 1), float("inf")
