@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Copy the summaries of an end-of-round collection (tools/r02_final.sh -> gpurun_out/) into profiles/ under a round tag.
+
+    python tools/install_profiles.py r02
+
+gpurun_out/ is scratch; profiles/ is what is tracked.  Copies prof_<tag>/* (collect_profiles.sh), the final_* bench /
+training / loop / VAE lines, extracts every dict the ``-m gpu`` suite printed (``pytest -rP``) into
+<tag>_parity_numbers.json, and regenerates profiles/README.md.
+"""
+import ast
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT, PROF = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
+
+
+def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+    src = os.path.join(OUT, f"prof_{tag}")
+    for f in sorted(os.listdir(src)):
+        if f.endswith((".json", ".csv")):
+            shutil.copy(os.path.join(src, f), os.path.join(PROF, f"{tag}_{f}"))
+    shutil.copy(os.path.join(src, "pmc_traffic.json"), os.path.join(PROF, "pmc_traffic.json"))  # bench.py reads this one
+    for f in sorted(os.listdir(OUT)):
+        if f.startswith("final_") and f.endswith((".json", ".csv")):
+            shutil.copy(os.path.join(OUT, f), os.path.join(PROF, f"{tag}_{f[len('final_'):]}"))
+    for f in ("ab_final.txt", "ab_knobs.txt"):
+        if os.path.exists(os.path.join(OUT, f)):
+            shutil.copy(os.path.join(OUT, f), os.path.join(PROF, f"{tag}_{f}"))
+    rows, test = [], None
+    log = os.path.join(OUT, "final_pytest.log")
+    if os.path.exists(log):
+        for line in open(log, errors="replace"):
+            s = line.strip()
+            if s.startswith("____") and s.endswith("____"):
+                test = s.strip("_ ").strip()
+            elif s.startswith("{") and s.endswith("}"):
+                try:
+                    d = json.loads(s)
+                except ValueError:
+                    try:
+                        d = ast.literal_eval(s)
+                    except (ValueError, SyntaxError):
+                        continue
+                if isinstance(d, dict):
+                    rows.append({"test": test, **{str(k): v for k, v in d.items()}})
+            elif " passed" in s and s.startswith("="):
+                rows.append({"suite": s.strip("= ")})
+            elif " passed" in s and "deselected" in s:
+                rows.append({"suite": s})
+        with open(os.path.join(PROF, f"{tag}_parity_numbers.json"), "w") as f:
+            json.dump(rows, f, indent=1, default=str)
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_profiles_readme.py"), tag])
+    print(f"installed {tag}: {len(rows)} parity rows")
+
+
+if __name__ == "__main__":
+    main()
