@@ -348,6 +348,20 @@ int ur_groupnorm_backward(const void* x, const void* dy, int C, int B, int rows,
                           float* chan_part, float* chan_sum, int nchunks, void* dx, int dtype, void* stream);
 int ur_layernorm_backward(const void* x, const void* dy, const float* gamma, float eps, int rows, int C,
                           int rows_per_wave, void* dx, float* part, int dtype, void* stream);
+/* Flash backward of o = softmax(q k^T * scale) v for SELF-attention shapes (one token count T for queries and keys,
+ * T % 64 == 0, padded head dim dp in {32, 64, 96, 160}: ur_attention_backward_supported).  Replaces the reference's
+ * autograd through F.scaled_dot_product_attention (diffusers AttnProcessor2_0 under models/attention.py
+ * BasicTransformerBlock) in the training step.  P is never materialised; two launches (row statistics + dq, then
+ * dk / dv), every sum in a fixed order.
+ *   q, k, v, o, dout  [S][T][dp]  per (batch, head) slices, head dim zero-padded to dp (ur_split_heads)
+ *   qt, kt, dot       [S][dp][T]  transposes of q, k, dout (ur_transpose2d)
+ *   stats             [2][S][T]   fp32 workspace (row log-sum-exp in log2 units | rowsum(dout * o)), written here
+ *   dq, dk, dv        [S][T][dp]  outputs (padding columns come out as zeros) */
+int ur_attention_backward(const void* q, const void* k, const void* v, const void* o, const void* dout, const void* qt,
+                          const void* kt, const void* dot, float* stats, void* dq, void* dk, void* dv, int S, int T, int dp,
+                          float scale, int dtype, void* stream);
+int ur_attention_backward_supported(int T, int dp);
+
 /* Attention backward helpers: P = softmax(Q K^T * scale) is recomputed and materialised per (batch, head); the five
  * GEMMs of the gradient (S, dV = P^T dO, dP = dO V^T, dQ = dS K, dK = dS^T Q) run z-batched on ur_igemm.
  * ur_split_heads: x [B][T][ld], head h at columns off + h*d  ->  out [B*H][Tp][dp] (zero padded rows / columns);

@@ -139,6 +139,58 @@ def test_attention_backward(dev, dtype, shape):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(2, 2, 40, 128), (1, 3, 40, 192), (2, 2, 80, 64), (1, 2, 160, 128), (1, 2, 32, 64),
+                                   (1, 8, 40, 1024)])
+@pytest.mark.parametrize("fused", [False, True])
+def test_flash_attention_backward(dev, dtype, shape, fused):
+    """ur_attention_backward (P in registers, two launches) against fp32 autograd through SDPA, with the forward output
+    of the flash kernel as ``o``; head dims of all three levels (40 / 80 / 160 -> padded 64 / 96 / 160), both query
+    widths per wave (T % 128 == 0 or not), separate q / k / v and the fused [B, T, 3C] layout.  Also against the
+    materialised-P path (the two must agree to rounding of P / dS)."""
+    from uni_renderer_amd import backward as bw
+    from uni_renderer_amd import autograd_ops as A
+    B, H, d, T = shape
+    C = H * d
+    q, k, v = (_rand((B, T, C), dtype, dev, i + 1) for i in range(3))
+    do = _rand((B, T, C), dtype, dev, 4)
+    qr, kr, vr = (t.float().cpu().requires_grad_() for t in (q, k, v))
+    o_ref = F.scaled_dot_product_attention(qr.view(B, T, H, d).transpose(1, 2), kr.view(B, T, H, d).transpose(1, 2),
+                                           vr.view(B, T, H, d).transpose(1, 2)).transpose(1, 2).reshape(B, T, C)
+    (o_ref * do.float().cpu()).sum().backward()
+    assert bw.FLASH_BACKWARD and bw._lib.load().ur_attention_backward_supported(T, (d + 31) // 32 * 32)
+    if fused:
+        qkv = torch.cat([q, k, v], dim=-1).requires_grad_()
+        o = A.AttentionQKV.apply(qkv, H)
+        o.backward(do)
+        dq, dk, dv = qkv.grad.split(C, dim=-1)
+        m = bw.attention_backward(qkv.detach(), qkv.detach(), qkv.detach(), do, H, fused_qkv=True).split(C, dim=-1)
+    else:
+        q_, k_, v_ = (t.clone().requires_grad_() for t in (q, k, v))
+        o = A.Attention.apply(q_, k_, v_, H)
+        o.backward(do)
+        dq, dk, dv = q_.grad, k_.grad, v_.grad
+        m = bw.attention_backward(q, k, v, do, H)  # no ``o``: the materialised-P path
+    assert rel_l2(o, o_ref) < TOL[dtype]
+    tol = TOL[dtype] * 2  # P and dS enter the MFMA in the compute dtype
+    errs = [rel_l2(dq, qr.grad), rel_l2(dk, kr.grad), rel_l2(dv, vr.grad)]
+    print({"flash_attention_backward": str(dtype), "shape": shape, "fused": fused, "rel_l2_dq_dk_dv": errs,
+           "vs_materialised": [rel_l2(a, b) for a, b in zip((dq, dk, dv), m)]})
+    assert max(errs) < tol, errs
+    for a, b in zip((dq, dk, dv), m):
+        assert rel_l2(a, b) < tol
+
+
+def test_flash_attention_backward_deterministic(dev):
+    from uni_renderer_amd import backward as bw
+    B, H, d, T = 1, 4, 40, 256
+    q, k, v, do, o = (_rand((B, T, H * d), torch.bfloat16, dev, i + 1) for i in range(5))
+    a = bw.attention_backward(q, k, v, do, H, o=o)
+    b = bw.attention_backward(q, k, v, do, H, o=o)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_autograd_functions_conv_variants(dev, dtype):
     """Conv3x3 Function: stride 2 (zero-insertion dgrad), nearest-2x + conv, fused bias / time-embedding row add /
     residual, and a 28-channel output (conv_out), against nn.functional autograd."""

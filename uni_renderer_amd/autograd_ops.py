@@ -105,14 +105,15 @@ class Attention(Function):
         Tk = k.shape[1]
         d = Cc // heads
         vt = bw._pad_rows64(bw.transpose2d(v.contiguous()))  # [B, C, Tk_pad]
-        ctx.save_for_backward(q, k, v)
+        o = ops.attention(q.contiguous(), k.contiguous(), vt, B=B, H=heads, Tq=Tq, Tk=Tk, d=d, ldq=Cc, ldk=Cc)
+        ctx.save_for_backward(q, k, v, o)  # o: rowsum(do * o) of the flash backward (the out projection keeps it anyway)
         ctx.heads = heads
-        return ops.attention(q.contiguous(), k.contiguous(), vt, B=B, H=heads, Tq=Tq, Tk=Tk, d=d, ldq=Cc, ldk=Cc)
+        return o
 
     @staticmethod
     def backward(ctx, do):
-        q, k, v = ctx.saved_tensors
-        dq, dk, dv = bw.attention_backward(q.contiguous(), k.contiguous(), v.contiguous(), do.contiguous(), ctx.heads)
+        q, k, v, o = ctx.saved_tensors
+        dq, dk, dv = bw.attention_backward(q.contiguous(), k.contiguous(), v.contiguous(), do.contiguous(), ctx.heads, o=o)
         return dq, dk, dv, None
 
 
@@ -126,14 +127,15 @@ class AttentionQKV(Function):
         B, T, C3 = qkv.shape
         Cc = C3 // 3
         vt = bw._pad_rows64(bw.transpose2d(qkv[..., 2 * Cc:]))  # [B, C, T_pad], read in place (strided)
-        ctx.save_for_backward(qkv)
+        o = ops.attention(qkv, qkv, vt, B=B, H=heads, Tq=T, Tk=T, d=Cc // heads, ldq=C3, ldk=C3, q_off=0, k_off=Cc)
+        ctx.save_for_backward(qkv, o)
         ctx.heads = heads
-        return ops.attention(qkv, qkv, vt, B=B, H=heads, Tq=T, Tk=T, d=Cc // heads, ldq=C3, ldk=C3, q_off=0, k_off=Cc)
+        return o
 
     @staticmethod
     def backward(ctx, do):
-        (qkv,) = ctx.saved_tensors
-        return bw.attention_backward(qkv, qkv, qkv, do.contiguous(), ctx.heads, fused_qkv=True), None
+        qkv, o = ctx.saved_tensors
+        return bw.attention_backward(qkv, qkv, qkv, do.contiguous(), ctx.heads, fused_qkv=True, o=o), None
 
 
 class GEGLU(Function):

@@ -14,6 +14,7 @@ Reference semantics: ``nn.Linear`` / ``nn.Conv2d`` / ``nn.GroupNorm`` / ``nn.Lay
 """
 from __future__ import annotations
 
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -241,8 +242,32 @@ def _merge_heads(g: torch.Tensor, B: int, T: int, H: int, d: int, out: Optional[
     return out
 
 
+FLASH_BACKWARD = os.environ.get("UR_FLASH_BACKWARD", "1") != "0"  # 0: always the materialised-P path below
+
+
+def _flash_attention_backward(q, k, v, o, do, H, scale, fused_qkv, oq, ok, ov, Cc, d, dp):
+    """Self-attention shapes: ``ur_attention_backward`` (csrc/attention_bwd.hip) -- P stays in registers, two launches."""
+    lib = _lib.load()
+    B, T = q.shape[:2]
+    S = B * H
+    qp, kp, vp = _split_heads(q, H, d, T, dp, oq), _split_heads(k, H, d, T, dp, ok), _split_heads(v, H, d, T, dp, ov)
+    op, dop = _split_heads(o, H, d, T, dp), _split_heads(do, H, d, T, dp)             # [S, T, dp]
+    qt, kt, dot_ = transpose2d(qp), transpose2d(kp), transpose2d(dop)                 # [S, dp, T]
+    stats = torch.empty(2, S, T, dtype=torch.float32, device=q.device)
+    dQ, dK, dV = torch.empty_like(qp), torch.empty_like(qp), torch.empty_like(qp)
+    check(lib.ur_attention_backward(qp.data_ptr(), kp.data_ptr(), vp.data_ptr(), op.data_ptr(), dop.data_ptr(), qt.data_ptr(),
+                                    kt.data_ptr(), dot_.data_ptr(), stats.data_ptr(), dQ.data_ptr(), dK.data_ptr(),
+                                    dV.data_ptr(), S, T, dp, scale, DT[q.dtype], _stream()), "ur_attention_backward")
+    if fused_qkv:
+        g = torch.empty(B, T, 3 * Cc, dtype=q.dtype, device=q.device)
+        for part, off in ((dQ, oq), (dK, ok), (dV, ov)):
+            _merge_heads(part, B, T, H, d, out=g, off=off)
+        return g
+    return _merge_heads(dQ, B, T, H, d), _merge_heads(dK, B, T, H, d), _merge_heads(dV, B, T, H, d)
+
+
 def attention_backward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, do: torch.Tensor, H: int,
-                       scale: Optional[float] = None, fused_qkv: bool = False):
+                       scale: Optional[float] = None, fused_qkv: bool = False, o: Optional[torch.Tensor] = None):
     """Gradients of o = softmax(q k^T * scale) v per head (q, do [B,Tq,H*d]; k, v [B,Tk,H*d]) -> (dq, dk, dv).
     The forward keeps nothing but q, k, v (flash kernel); here P is recomputed and materialised per (batch, head)
     ([B*H, Tq, Tk] in the compute dtype) and the five GEMMs run z-batched on ``ur_igemm``:
@@ -256,6 +281,9 @@ def attention_backward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, do: to
     oq, ok, ov = (0, Cc, 2 * Cc) if fused_qkv else (0, 0, 0)
     d = Cc // H
     scale = float(d ** -0.5 if scale is None else scale)
+    dp32 = (d + 31) // 32 * 32
+    if (FLASH_BACKWARD and o is not None and Tq == Tk and lib.ur_attention_backward_supported(Tq, dp32)):
+        return _flash_attention_backward(q, k, v, o, do, H, scale, fused_qkv, oq, ok, ov, Cc, d, dp32)
     dp = (d + 63) // 64 * 64
     Tqp, Tkp = (Tq + 63) // 64 * 64, (Tk + 63) // 64 * 64
     S = B * H

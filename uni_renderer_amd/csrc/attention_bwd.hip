@@ -1,0 +1,399 @@
+// Flash backward of o = softmax(q k^T * scale) v for the training path (device op 11; the reference reaches it through
+// torch autograd over F.scaled_dot_product_attention, diffusers AttnProcessor2_0 called from
+// /root/reference models/attention.py BasicTransformerBlock).  P is never materialised: two kernels recompute the
+// score blocks from q, k on the MFMA and keep P / dS in registers.
+//
+//   inputs   q, k, v, o, do   [S][T][DP]   per (batch, head) slices, head dim zero-padded to DP (ur_split_heads)
+//            qt, kt, dot      [S][DP][T]   their transposes (ur_transpose2d)
+//   outputs  dq, dk, dv       [S][T][DP]
+//            stats            [2][S][T]    fp32 workspace: row log-sum-exp (log2 units) | D = rowsum(do * o)
+//
+//   kernel 1 (dq):    a wave owns 16*NB queries (MFMA columns) and streams 64-key tiles: pass A the row log-sum-exp,
+//                     pass B  S^T = K Q^T,  dP^T = V dO^T,  dS^T = P^T o (dP^T - D),  dQ^T += K^T dS^T
+//   kernel 2 (dkdv):  a wave owns 16*NB keys and streams 64-query tiles:
+//                     S = Q K^T,  dP = dO V^T,  P = exp2(S s2 - lse),  dS = P o (dP - D),  dV^T += dO^T P,  dK^T += Q^T dS
+//
+// The score block leaves the 16x16x32 MFMA with lane (j = lane & 15, g = lane >> 4) holding rows 4g .. 4g+3 of column
+// j.  Two such blocks ARE the B operand of the next MFMA when its k index is read as
+//       k = 8g + i  ->  row 4g + i of block 0 (i < 4),  row 4g + i - 4 of block 1 (i >= 4)
+// and the A operand (the transposed tile in LDS) is fetched with the same permutation (two 8-byte reads): no LDS round
+// trip, no shuffles for P / dS.  Every sum is in a fixed order: deterministic, no atomics (dq and dk / dv come from
+// different kernels instead of one kernel with atomic dq).
+#include "ur_common.h"
+#include "../../include/ur_kernels.h"
+
+namespace ur {
+
+struct AttnBwdArgs {
+    const void *q, *k, *v, *o, *dout, *qt, *kt, *dot;
+    float* stats;
+    void *dq, *dk, *dv;
+    int S, T;
+    float scale;
+};
+
+// LDS images: row-major tiles [64][DP] with rows padded by 16 bytes (row stride 2*DP + 16: the 16 rows of an MFMA
+// fragment read start on 16 distinct 4-bank groups for DP = 64 / 96 / 160), transposed tiles [DP][64] with 144-byte rows.
+template <int DP> struct BwdLds {
+    static constexpr int RS = 2 * DP + 16;   // bytes per row of a [64][DP] tile
+    static constexpr int TS = 144;           // bytes per row of a [DP][64] tile
+    static constexpr int ROWS = 64 * RS;
+    static constexpr int TRN = DP * TS;
+};
+
+template <typename T, int DP>
+__device__ __forceinline__ void stage_rows(const T* __restrict__ g, char* lds, int tid) {
+    constexpr int CPR = DP / 8;
+#pragma unroll
+    for (int i = 0; i < (64 * CPR) / 256; ++i) {
+        const int e = tid + i * 256, row = e / CPR, c = e - row * CPR;
+        *reinterpret_cast<uint4*>(lds + row * BwdLds<DP>::RS + c * 16) =
+            *reinterpret_cast<const uint4*>(g + (int64_t)row * DP + c * 8);
+    }
+}
+template <typename T, int DP>
+__device__ __forceinline__ void stage_trn(const T* __restrict__ g, int64_t ld, char* lds, int tid) {
+#pragma unroll
+    for (int i = 0; i < (DP * 8) / 256; ++i) {
+        const int e = tid + i * 256, row = e >> 3, c = e & 7;
+        *reinterpret_cast<uint4*>(lds + row * BwdLds<DP>::TS + c * 16) =
+            *reinterpret_cast<const uint4*>(g + (int64_t)row * ld + c * 8);
+    }
+}
+// A fragment of a row-major tile: row (16 * blk + j), k = 32 * ks + 8 * g .. + 7
+template <typename T, int DP>
+__device__ __forceinline__ typename Vec8<T>::type frag_rows(const char* lds, int blk, int ks, int j, int g) {
+    return *reinterpret_cast<const typename Vec8<T>::type*>(lds + (16 * blk + j) * BwdLds<DP>::RS + (ks * 4 + g) * 16);
+}
+// A fragment of a transposed tile with the permuted k order: row (16 * blk + j), columns 32 * ks + 4g .. +3 and + 16
+template <typename T, int DP>
+__device__ __forceinline__ typename Vec8<T>::type frag_trn(const char* lds, int blk, int ks, int j, int g) {
+    const char* r = lds + (16 * blk + j) * BwdLds<DP>::TS + ks * 64 + g * 8;
+    const uint2 a = *reinterpret_cast<const uint2*>(r), b = *reinterpret_cast<const uint2*>(r + 32);
+    const uint4 u = make_uint4(a.x, a.y, b.x, b.y);
+    return __builtin_bit_cast(typename Vec8<T>::type, u);
+}
+template <typename T>
+__device__ __forceinline__ typename Vec8<T>::type pack2(const f32x4& a, const f32x4& b) {
+    typename Vec8<T>::type v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[i] = (T)a[i]; v[4 + i] = (T)b[i]; }
+    return v;
+}
+template <typename T>
+__device__ __forceinline__ void store4(T* p, const f32x4& a, float scale) {
+    T h[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) h[i] = (T)(a[i] * scale);
+    uint2 u;
+    __builtin_memcpy(&u, h, 8);
+    *reinterpret_cast<uint2*>(p) = u;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// kernel 1: row statistics + dq.  grid (T / (64 * NB), S), 4 waves, wave w owns queries (4 * bx + w) * 16 * NB ...
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T, int DP, int NB>
+__global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const AttnBwdArgs p) {
+    typedef typename Vec8<T>::type vec8;
+    typedef BwdLds<DP> L;
+    constexpr int KS = DP / 32, DB = DP / 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ks = smem;
+    char* Vs = smem + L::ROWS;
+    char* Kts = smem + 2 * L::ROWS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
+    const int s = blockIdx.y, Tn = p.T;
+    const int qbase = (blockIdx.x * 4 + wave) * 16 * NB;
+    const int64_t so = (int64_t)s * Tn * DP;
+    const T* Q = reinterpret_cast<const T*>(p.q) + so;
+    const T* K = reinterpret_cast<const T*>(p.k) + so;
+    const T* V = reinterpret_cast<const T*>(p.v) + so;
+    const T* O = reinterpret_cast<const T*>(p.o) + so;
+    const T* dO = reinterpret_cast<const T*>(p.dout) + so;
+    const T* Kt = reinterpret_cast<const T*>(p.kt) + so;  // [DP][T]
+    const float s2 = p.scale * 1.44269504088896341f;
+
+    // stationary B operands: this lane's query rows, k = 32 ks + 8 g .. + 7; D = rowsum(dO o O) on the way
+    vec8 qf[NB][KS], dof[NB][KS];
+    float dsum[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int64_t ro = (int64_t)(qbase + 16 * nb + j) * DP;
+        float a = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            qf[nb][ks] = *reinterpret_cast<const vec8*>(Q + ro + 32 * ks + 8 * g);
+            dof[nb][ks] = *reinterpret_cast<const vec8*>(dO + ro + 32 * ks + 8 * g);
+            const vec8 of = *reinterpret_cast<const vec8*>(O + ro + 32 * ks + 8 * g);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a = fmaf((float)dof[nb][ks][i], (float)of[i], a);
+        }
+        a += __shfl_xor(a, 16, 64);
+        a += __shfl_xor(a, 32, 64);
+        dsum[nb] = a;
+    }
+
+    // ---- pass A: log-sum-exp of every query row (log2 units) ----
+    float mx[NB], ls[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) { mx[nb] = -1e30f; ls[nb] = 0.f; }
+    for (int kt = 0; kt < Tn; kt += 64) {
+        __syncthreads();
+        stage_rows<T, DP>(K + (int64_t)kt * DP, Ks, tid);
+        __syncthreads();
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            f32x4 sc[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) sc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const vec8 a = frag_rows<T, DP>(Ks, kb, ks, j, g);
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) sc[nb] = mfma16(a, qf[nb][ks], sc[nb]);
+            }
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const float v0 = sc[nb][0] * s2, v1 = sc[nb][1] * s2, v2 = sc[nb][2] * s2, v3 = sc[nb][3] * s2;
+                const float mn = fmaxf(fmaxf(mx[nb], fmaxf(v0, v1)), fmaxf(v2, v3));
+                ls[nb] = ls[nb] * __builtin_amdgcn_exp2f(mx[nb] - mn) + __builtin_amdgcn_exp2f(v0 - mn) +
+                         __builtin_amdgcn_exp2f(v1 - mn) + __builtin_amdgcn_exp2f(v2 - mn) + __builtin_amdgcn_exp2f(v3 - mn);
+                mx[nb] = mn;
+            }
+        }
+    }
+    float lse[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+        for (int o = 16; o <= 32; o <<= 1) {  // the four lanes (g = 0..3) of a query, fixed order
+            const float mo = __shfl_xor(mx[nb], o, 64), lo = __shfl_xor(ls[nb], o, 64);
+            const float mn = fmaxf(mx[nb], mo);
+            ls[nb] = ls[nb] * __builtin_amdgcn_exp2f(mx[nb] - mn) + lo * __builtin_amdgcn_exp2f(mo - mn);
+            mx[nb] = mn;
+        }
+        lse[nb] = mx[nb] + __builtin_amdgcn_logf(ls[nb]);  // v_log_f32 = log2
+        if (g == 0) {
+            p.stats[(int64_t)s * Tn + qbase + 16 * nb + j] = lse[nb];
+            p.stats[(int64_t)(p.S + s) * Tn + qbase + 16 * nb + j] = dsum[nb];
+        }
+    }
+
+    // ---- pass B: dQ^T[d][query] += K^T[d][key] dS^T[key][query] ----
+    f32x4 acc[DB][NB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[db][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < Tn; kt += 64) {
+        __syncthreads();
+        stage_rows<T, DP>(K + (int64_t)kt * DP, Ks, tid);
+        stage_rows<T, DP>(V + (int64_t)kt * DP, Vs, tid);
+        stage_trn<T, DP>(Kt + kt, Tn, Kts, tid);
+        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {  // 32 keys at a time = one k step of the dQ MFMA
+            f32x4 sc[2][NB], dp[2][NB];
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) { sc[b][nb] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[b][nb] = sc[b][nb]; }
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const vec8 ka = frag_rows<T, DP>(Ks, 2 * h + b, ks, j, g);
+                    const vec8 va = frag_rows<T, DP>(Vs, 2 * h + b, ks, j, g);
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        sc[b][nb] = mfma16(ka, qf[nb][ks], sc[b][nb]);
+                        dp[b][nb] = mfma16(va, dof[nb][ks], dp[b][nb]);
+                    }
+                }
+            vec8 dsf[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float pr = __builtin_amdgcn_exp2f(fmaf(sc[b][nb][r], s2, -lse[nb]));
+                        sc[b][nb][r] = pr * (dp[b][nb][r] - dsum[nb]);
+                    }
+                dsf[nb] = pack2<T>(sc[0][nb], sc[1][nb]);
+            }
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+                const vec8 a = frag_trn<T, DP>(Kts, db, h, j, g);
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) acc[db][nb] = mfma16(a, dsf[nb], acc[db][nb]);
+            }
+        }
+    }
+    T* dQ = reinterpret_cast<T*>(p.dq) + so;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+            store4<T>(dQ + (int64_t)(qbase + 16 * nb + j) * DP + 16 * db + 4 * g, acc[db][nb], p.scale);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// kernel 2: dk, dv.  grid (T / (64 * NB), S), wave w owns keys (4 * bx + w) * 16 * NB ...
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T, int DP, int NB>
+__global__ void __launch_bounds__(256) attn_bwd_dkdv_kernel(const AttnBwdArgs p) {
+    typedef typename Vec8<T>::type vec8;
+    typedef BwdLds<DP> L;
+    constexpr int KS = DP / 32, DB = DP / 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Qs = smem;
+    char* dOs = smem + L::ROWS;
+    char* Qts = smem + 2 * L::ROWS;
+    char* dOts = Qts + L::TRN;
+    float* st = reinterpret_cast<float*>(dOts + L::TRN);  // [0..63] lse, [64..127] D of the query tile
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
+    const int s = blockIdx.y, Tn = p.T;
+    const int kbase = (blockIdx.x * 4 + wave) * 16 * NB;
+    const int64_t so = (int64_t)s * Tn * DP;
+    const T* Q = reinterpret_cast<const T*>(p.q) + so;
+    const T* K = reinterpret_cast<const T*>(p.k) + so;
+    const T* V = reinterpret_cast<const T*>(p.v) + so;
+    const T* dO = reinterpret_cast<const T*>(p.dout) + so;
+    const T* Qt = reinterpret_cast<const T*>(p.qt) + so;
+    const T* dOt = reinterpret_cast<const T*>(p.dot) + so;
+    const float* lse_g = p.stats + (int64_t)s * Tn;
+    const float* dsum_g = p.stats + (int64_t)(p.S + s) * Tn;
+    const float s2 = p.scale * 1.44269504088896341f;
+
+    vec8 kf[NB][KS], vf[NB][KS];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int64_t ro = (int64_t)(kbase + 16 * nb + j) * DP;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            kf[nb][ks] = *reinterpret_cast<const vec8*>(K + ro + 32 * ks + 8 * g);
+            vf[nb][ks] = *reinterpret_cast<const vec8*>(V + ro + 32 * ks + 8 * g);
+        }
+    }
+    f32x4 dk[DB][NB], dv[DB][NB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) { dk[db][nb] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[db][nb] = dk[db][nb]; }
+
+    for (int qt = 0; qt < Tn; qt += 64) {
+        __syncthreads();
+        stage_rows<T, DP>(Q + (int64_t)qt * DP, Qs, tid);
+        stage_rows<T, DP>(dO + (int64_t)qt * DP, dOs, tid);
+        stage_trn<T, DP>(Qt + qt, Tn, Qts, tid);
+        stage_trn<T, DP>(dOt + qt, Tn, dOts, tid);
+        if (tid < 64) st[tid] = lse_g[qt + tid];
+        else if (tid < 128) st[tid] = dsum_g[qt + tid - 64];
+        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {  // 32 queries at a time
+            f32x4 sc[2][NB], dp[2][NB];
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) { sc[b][nb] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[b][nb] = sc[b][nb]; }
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const vec8 qa = frag_rows<T, DP>(Qs, 2 * h + b, ks, j, g);
+                    const vec8 da = frag_rows<T, DP>(dOs, 2 * h + b, ks, j, g);
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        sc[b][nb] = mfma16(qa, kf[nb][ks], sc[b][nb]);
+                        dp[b][nb] = mfma16(da, vf[nb][ks], dp[b][nb]);
+                    }
+                }
+            vec8 pf[NB], dsf[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const float4 l4 = *reinterpret_cast<const float4*>(st + 32 * h + 16 * b + 4 * g);
+                    const float4 d4 = *reinterpret_cast<const float4*>(st + 64 + 32 * h + 16 * b + 4 * g);
+                    const float lr[4] = {l4.x, l4.y, l4.z, l4.w}, dr[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float pr = __builtin_amdgcn_exp2f(fmaf(sc[b][nb][r], s2, -lr[r]));
+                        sc[b][nb][r] = pr;
+                        dp[b][nb][r] = pr * (dp[b][nb][r] - dr[r]);
+                    }
+                }
+                pf[nb] = pack2<T>(sc[0][nb], sc[1][nb]);
+                dsf[nb] = pack2<T>(dp[0][nb], dp[1][nb]);
+            }
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+                const vec8 da = frag_trn<T, DP>(dOts, db, h, j, g);
+                const vec8 qa = frag_trn<T, DP>(Qts, db, h, j, g);
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    dv[db][nb] = mfma16(da, pf[nb], dv[db][nb]);
+                    dk[db][nb] = mfma16(qa, dsf[nb], dk[db][nb]);
+                }
+            }
+        }
+    }
+    T* dK = reinterpret_cast<T*>(p.dk) + so;
+    T* dV = reinterpret_cast<T*>(p.dv) + so;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int db = 0; db < DB; ++db) {
+            const int64_t o = (int64_t)(kbase + 16 * nb + j) * DP + 16 * db + 4 * g;
+            store4<T>(dK + o, dk[db][nb], p.scale);
+            store4<T>(dV + o, dv[db][nb], 1.0f);
+        }
+}
+
+template <typename T, int DP, int NB>
+static int launch_bwd(const AttnBwdArgs& a, hipStream_t st) {
+    typedef BwdLds<DP> L;
+    constexpr int lds_dq = 2 * L::ROWS + L::TRN, lds_kv = 2 * L::ROWS + 2 * L::TRN + 512;
+    static std::atomic<uint64_t> done_dq{0}, done_kv{0};
+    set_lds_limit_once(done_dq, reinterpret_cast<const void*>(&attn_bwd_dq_kernel<T, DP, NB>), lds_dq);
+    set_lds_limit_once(done_kv, reinterpret_cast<const void*>(&attn_bwd_dkdv_kernel<T, DP, NB>), lds_kv);
+    const dim3 grid(a.T / (64 * NB), a.S);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<T, DP, NB>), grid, dim3(256), lds_dq, st, a);
+    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, DP, NB>), grid, dim3(256), lds_kv, st, a);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : -(int)e;
+}
+
+template <typename T>
+static int dispatch_bwd(const AttnBwdArgs& a, int dp, hipStream_t st) {
+    const bool wide = (a.T % 128) == 0;
+    switch (dp) {
+        case 32: return launch_bwd<T, 32, 1>(a, st);
+        case 64: return wide ? launch_bwd<T, 64, 2>(a, st) : launch_bwd<T, 64, 1>(a, st);
+        case 96: return launch_bwd<T, 96, 1>(a, st);
+        case 160: return launch_bwd<T, 160, 1>(a, st);
+        default: return UR_E_BADARG;
+    }
+}
+
+}  // namespace ur
+
+extern "C" int ur_attention_backward(const void* q, const void* k, const void* v, const void* o, const void* dout,
+                                     const void* qt, const void* kt, const void* dot, float* stats, void* dq, void* dk,
+                                     void* dv, int S, int T, int dp, float scale, int dtype, void* stream) {
+    if (!q || !k || !v || !o || !dout || !qt || !kt || !dot || !stats || !dq || !dk || !dv || S <= 0 || T <= 0 || (T & 63) ||
+        S > 65535)
+        return UR_E_BADARG;
+    ur::AttnBwdArgs a{q, k, v, o, dout, qt, kt, dot, stats, dq, dk, dv, S, T, scale};
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == UR_DT_F16) return ur::dispatch_bwd<ur::f16>(a, dp, st);
+    if (dtype == UR_DT_BF16) return ur::dispatch_bwd<ur::bf16>(a, dp, st);
+    return UR_E_BADARG;
+}
+
+extern "C" int ur_attention_backward_supported(int T, int dp) {
+    return T > 0 && (T & 63) == 0 && (dp == 32 || dp == 64 || dp == 96 || dp == 160);
+}
