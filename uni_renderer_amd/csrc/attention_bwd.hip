@@ -41,23 +41,42 @@ template <int DP> struct BwdLds {
     static constexpr int TRN = DP * TS;
 };
 
+// Staging of one tile is split into its global loads (into registers) and its LDS stores, so that the loads of tile
+// t + 1 are in flight while tile t is multiplied (PF) or at least while the other waves reach the barrier.
+#define UR_ROWREGS(DP) ((64 * ((DP) / 8)) / 256)
+#define UR_TRNREGS(DP) (((DP) * 8) / 256)
 template <typename T, int DP>
-__device__ __forceinline__ void stage_rows(const T* __restrict__ g, char* lds, int tid) {
+__device__ __forceinline__ void gload_rows(const T* __restrict__ g, u32x4 (&r)[UR_ROWREGS(DP)], int tid) {
     constexpr int CPR = DP / 8;
 #pragma unroll
     for (int i = 0; i < (64 * CPR) / 256; ++i) {
         const int e = tid + i * 256, row = e / CPR, c = e - row * CPR;
-        *reinterpret_cast<uint4*>(lds + row * BwdLds<DP>::RS + c * 16) =
-            *reinterpret_cast<const uint4*>(g + (int64_t)row * DP + c * 8);
+        r[i] = *reinterpret_cast<const u32x4*>(g + (int64_t)row * DP + c * 8);
+    }
+}
+template <int DP>
+__device__ __forceinline__ void lstore_rows(char* lds, const u32x4 (&r)[UR_ROWREGS(DP)], int tid) {
+    constexpr int CPR = DP / 8;
+#pragma unroll
+    for (int i = 0; i < (64 * CPR) / 256; ++i) {
+        const int e = tid + i * 256, row = e / CPR, c = e - row * CPR;
+        *reinterpret_cast<u32x4*>(lds + row * BwdLds<DP>::RS + c * 16) = r[i];
     }
 }
 template <typename T, int DP>
-__device__ __forceinline__ void stage_trn(const T* __restrict__ g, int64_t ld, char* lds, int tid) {
+__device__ __forceinline__ void gload_trn(const T* __restrict__ g, int64_t ld, u32x4 (&r)[UR_TRNREGS(DP)], int tid) {
 #pragma unroll
     for (int i = 0; i < (DP * 8) / 256; ++i) {
         const int e = tid + i * 256, row = e >> 3, c = e & 7;
-        *reinterpret_cast<uint4*>(lds + row * BwdLds<DP>::TS + c * 16) =
-            *reinterpret_cast<const uint4*>(g + (int64_t)row * ld + c * 8);
+        r[i] = *reinterpret_cast<const u32x4*>(g + (int64_t)row * ld + c * 8);
+    }
+}
+template <int DP>
+__device__ __forceinline__ void lstore_trn(char* lds, const u32x4 (&r)[UR_TRNREGS(DP)], int tid) {
+#pragma unroll
+    for (int i = 0; i < (DP * 8) / 256; ++i) {
+        const int e = tid + i * 256, row = e >> 3, c = e & 7;
+        *reinterpret_cast<u32x4*>(lds + row * BwdLds<DP>::TS + c * 16) = r[i];
     }
 }
 // A fragment of a row-major tile: row (16 * blk + j), k = 32 * ks + 8 * g .. + 7
@@ -93,7 +112,7 @@ __device__ __forceinline__ void store4(T* p, const f32x4& a, float scale) {
 // ---------------------------------------------------------------------------------------------------------------
 // kernel 1: row statistics + dq.  grid (T / (64 * NB), S), 4 waves, wave w owns queries (4 * bx + w) * 16 * NB ...
 // ---------------------------------------------------------------------------------------------------------------
-template <typename T, int DP, int NB>
+template <typename T, int DP, int NB, bool PF>
 __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const AttnBwdArgs p) {
     typedef typename Vec8<T>::type vec8;
     typedef BwdLds<DP> L;
@@ -138,10 +157,14 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const AttnBwdArgs p) {
     float mx[NB], ls[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) { mx[nb] = -1e30f; ls[nb] = 0.f; }
+    u32x4 rk[UR_ROWREGS(DP)], rv[UR_ROWREGS(DP)], rkt[UR_TRNREGS(DP)];
+    if (PF) gload_rows<T, DP>(K, rk, tid);
     for (int kt = 0; kt < Tn; kt += 64) {
+        if (!PF) gload_rows<T, DP>(K + (int64_t)kt * DP, rk, tid);
         __syncthreads();
-        stage_rows<T, DP>(K + (int64_t)kt * DP, Ks, tid);
+        lstore_rows<DP>(Ks, rk, tid);
         __syncthreads();
+        if (PF && kt + 64 < Tn) gload_rows<T, DP>(K + (int64_t)(kt + 64) * DP, rk, tid);
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
             f32x4 sc[NB];
@@ -186,12 +209,21 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const AttnBwdArgs p) {
     for (int db = 0; db < DB; ++db)
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) acc[db][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#define UR_GLOAD_KV(kt_)                                          \
+    do {                                                          \
+        gload_rows<T, DP>(K + (int64_t)(kt_) * DP, rk, tid);      \
+        gload_rows<T, DP>(V + (int64_t)(kt_) * DP, rv, tid);      \
+        gload_trn<T, DP>(Kt + (kt_), Tn, rkt, tid);               \
+    } while (0)
+    if (PF) UR_GLOAD_KV(0);
     for (int kt = 0; kt < Tn; kt += 64) {
+        if (!PF) UR_GLOAD_KV(kt);
         __syncthreads();
-        stage_rows<T, DP>(K + (int64_t)kt * DP, Ks, tid);
-        stage_rows<T, DP>(V + (int64_t)kt * DP, Vs, tid);
-        stage_trn<T, DP>(Kt + kt, Tn, Kts, tid);
+        lstore_rows<DP>(Ks, rk, tid);
+        lstore_rows<DP>(Vs, rv, tid);
+        lstore_trn<DP>(Kts, rkt, tid);
         __syncthreads();
+        if (PF && kt + 64 < Tn) UR_GLOAD_KV(kt + 64);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {  // 32 keys at a time = one k step of the dQ MFMA
             f32x4 sc[2][NB], dp[2][NB];
@@ -242,7 +274,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const AttnBwdArgs p) {
 // ---------------------------------------------------------------------------------------------------------------
 // kernel 2: dk, dv.  grid (T / (64 * NB), S), wave w owns keys (4 * bx + w) * 16 * NB ...
 // ---------------------------------------------------------------------------------------------------------------
-template <typename T, int DP, int NB>
+template <typename T, int DP, int NB, bool PF>
 __global__ void __launch_bounds__(256) attn_bwd_dkdv_kernel(const AttnBwdArgs p) {
     typedef typename Vec8<T>::type vec8;
     typedef BwdLds<DP> L;
@@ -283,15 +315,28 @@ __global__ void __launch_bounds__(256) attn_bwd_dkdv_kernel(const AttnBwdArgs p)
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) { dk[db][nb] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[db][nb] = dk[db][nb]; }
 
+    u32x4 rq[UR_ROWREGS(DP)], rdo[UR_ROWREGS(DP)], rqt[UR_TRNREGS(DP)], rdot[UR_TRNREGS(DP)];
+    float rst = 0.f;
+    const float* st_g = tid < 64 ? lse_g + tid : dsum_g + (tid & 63);  // tid < 128 stage the row statistics
+#define UR_GLOAD_Q(qt_)                                           \
+    do {                                                          \
+        gload_rows<T, DP>(Q + (int64_t)(qt_) * DP, rq, tid);      \
+        gload_rows<T, DP>(dO + (int64_t)(qt_) * DP, rdo, tid);    \
+        gload_trn<T, DP>(Qt + (qt_), Tn, rqt, tid);               \
+        gload_trn<T, DP>(dOt + (qt_), Tn, rdot, tid);             \
+        if (tid < 128) rst = st_g[qt_];                           \
+    } while (0)
+    if (PF) UR_GLOAD_Q(0);
     for (int qt = 0; qt < Tn; qt += 64) {
+        if (!PF) UR_GLOAD_Q(qt);
         __syncthreads();
-        stage_rows<T, DP>(Q + (int64_t)qt * DP, Qs, tid);
-        stage_rows<T, DP>(dO + (int64_t)qt * DP, dOs, tid);
-        stage_trn<T, DP>(Qt + qt, Tn, Qts, tid);
-        stage_trn<T, DP>(dOt + qt, Tn, dOts, tid);
-        if (tid < 64) st[tid] = lse_g[qt + tid];
-        else if (tid < 128) st[tid] = dsum_g[qt + tid - 64];
+        lstore_rows<DP>(Qs, rq, tid);
+        lstore_rows<DP>(dOs, rdo, tid);
+        lstore_trn<DP>(Qts, rqt, tid);
+        lstore_trn<DP>(dOts, rdot, tid);
+        if (tid < 128) st[tid] = rst;
         __syncthreads();
+        if (PF && qt + 64 < Tn) UR_GLOAD_Q(qt + 64);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {  // 32 queries at a time
             f32x4 sc[2][NB], dp[2][NB];
@@ -356,13 +401,14 @@ __global__ void __launch_bounds__(256) attn_bwd_dkdv_kernel(const AttnBwdArgs p)
 template <typename T, int DP, int NB>
 static int launch_bwd(const AttnBwdArgs& a, hipStream_t st) {
     typedef BwdLds<DP> L;
+    constexpr bool PF = DP <= 64;  // register prefetch of the next tile: 32 VGPRs at DP = 64, too many above
     constexpr int lds_dq = 2 * L::ROWS + L::TRN, lds_kv = 2 * L::ROWS + 2 * L::TRN + 512;
     static std::atomic<uint64_t> done_dq{0}, done_kv{0};
-    set_lds_limit_once(done_dq, reinterpret_cast<const void*>(&attn_bwd_dq_kernel<T, DP, NB>), lds_dq);
-    set_lds_limit_once(done_kv, reinterpret_cast<const void*>(&attn_bwd_dkdv_kernel<T, DP, NB>), lds_kv);
+    set_lds_limit_once(done_dq, reinterpret_cast<const void*>(&attn_bwd_dq_kernel<T, DP, NB, PF>), lds_dq);
+    set_lds_limit_once(done_kv, reinterpret_cast<const void*>(&attn_bwd_dkdv_kernel<T, DP, NB, PF>), lds_kv);
     const dim3 grid(a.T / (64 * NB), a.S);
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<T, DP, NB>), grid, dim3(256), lds_dq, st, a);
-    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, DP, NB>), grid, dim3(256), lds_kv, st, a);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<T, DP, NB, PF>), grid, dim3(256), lds_dq, st, a);
+    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, DP, NB, PF>), grid, dim3(256), lds_kv, st, a);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : -(int)e;
 }
