@@ -348,6 +348,26 @@ int ur_groupnorm_backward(const void* x, const void* dy, int C, int B, int rows,
                           float* chan_part, float* chan_sum, int nchunks, void* dx, int dtype, void* stream);
 int ur_layernorm_backward(const void* x, const void* dy, const float* gamma, float eps, int rows, int C,
                           int rows_per_wave, void* dx, float* part, int dtype, void* stream);
+/* AdamW over many parameter tensors per launch (the optimizer step of the training loop, train/train.py:1082-1100
+ * torch.optim.AdamW, 1425 optimizer.step()).  Decoupled weight decay, bias correction, no amsgrad, fp32 everywhere; the
+ * arithmetic of torch's fused kernel (param -= lr*wd*param; exp_avg = lerp(exp_avg, g, 1-beta1); exp_avg_sq = beta2*
+ * exp_avg_sq + (1-beta2) g^2; param -= lr/bc1 * exp_avg / (sqrt(exp_avg_sq)/sqrt(bc2) + eps)).  Descriptors travel as
+ * kernel arguments (no device table: pointers may change from step to step, and a captured graph keeps them by value).
+ *   step        device scalar, the step count of THIS update (>= 1)
+ *   grad_scale  device scalar or NULL: every gradient is divided by it (gradient clipping folded into the update)
+ *   found_inf   device scalar or NULL: != 0 skips the update
+ * Tensors whose four pointers are 16-byte aligned take the float4 path. */
+#define UR_ADAMW_MAX_TENSORS 64
+typedef struct ur_adamw_tensor {
+    float* p;
+    const float* g;
+    float* m;
+    float* v;
+    int64_t n;
+} ur_adamw_tensor;
+int ur_adamw_multi(const ur_adamw_tensor* tensors, int n_tensors, float lr, float beta1, float beta2, float eps,
+                   float weight_decay, const float* step, const float* grad_scale, const float* found_inf, void* stream);
+
 /* Flash backward of o = softmax(q k^T * scale) v for SELF-attention shapes (one token count T for queries and keys,
  * T % 64 == 0, padded head dim dp in {32, 64, 96, 160}: ur_attention_backward_supported).  Replaces the reference's
  * autograd through F.scaled_dot_product_attention (diffusers AttnProcessor2_0 under models/attention.py

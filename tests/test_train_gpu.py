@@ -451,3 +451,49 @@ def test_two_rank_training_on_the_real_modules(dev):
         pytest.skip("this torch build's gloo backend does not take device tensors")
     assert [(r[0], r[1]) for r in res] == [(0, True), (1, True)], res
     assert all(r[3] > 4 for r in res)
+
+@pytest.mark.gpu
+def test_fused_adamw_matches_torch(dev):
+    """optim.FusedAdamW (ur_adamw_multi) against torch.optim.AdamW over five steps: > 64 tensors (several launches), odd
+    sizes, a gradient that is an unaligned view of a flat buffer (scalar path), clipping folded through ``grad_scale``;
+    state_dict round trip into torch's optimizer."""
+    from uni_renderer_amd.optim import FusedAdamW
+    g = torch.Generator().manual_seed(3)
+    shapes = [(320, 320), (1280,), (7,), (33, 5), (640, 3, 3, 3), (1,)] * 12  # 72 tensors
+    ref_p = [torch.randn(*s, generator=g).to(dev).requires_grad_() for s in shapes]
+    our_p = [p.detach().clone().requires_grad_() for p in ref_p]
+    kw = dict(lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)
+    ref, our = torch.optim.AdamW(ref_p, **kw), FusedAdamW(our_p, **kw)
+    flat = torch.zeros(sum(p.numel() for p in our_p) + 1, device=dev)
+    for it in range(5):
+        off = 1  # views at odd element offsets: not 16-byte aligned
+        scale = torch.tensor(1.0 + 0.5 * it, device=dev)
+        for a, b in zip(ref_p, our_p):
+            gr = torch.randn(a.shape, generator=g).to(dev)
+            a.grad = gr / scale
+            view = flat[off:off + b.numel()].view_as(b)
+            view.copy_(gr)
+            b.grad = view if it % 2 else gr.clone()
+            off += b.numel()
+        our.grad_scale, our.found_inf = scale, torch.zeros((), device=dev)
+        ref.step()
+        our.step()
+    worst = max(float((a - b).abs().max()) for a, b in zip(ref_p, our_p))  # parameters are O(1), updates O(lr) = 1e-2
+    print({"fused_adamw_vs_torch_abs_max_after_5_steps": worst})
+    assert worst < 5e-6
+    del our.grad_scale, our.found_inf
+    import copy
+    sd = copy.deepcopy(our.state_dict())  # load_state_dict keeps same-dtype tensors uncopied: no sharing between optimizers
+    ref2 = torch.optim.AdamW([p.detach().clone().requires_grad_() for p in our_p], **kw)
+    ref2.load_state_dict(sd)
+    st = ref2.state[ref2.param_groups[0]["params"][0]]
+    assert float(st["step"]) == 5.0 and torch.equal(st["exp_avg"], our.state[our_p[0]]["exp_avg"])
+    our2 = FusedAdamW([p.detach().clone().requires_grad_() for p in our_p], **kw)
+    our2.load_state_dict(copy.deepcopy(ref2.state_dict()))
+    for a, b in zip(our2.param_groups[0]["params"], ref2.param_groups[0]["params"]):
+        a.grad = torch.ones_like(a)
+        b.grad = torch.ones_like(b)
+    our2.step()
+    ref2.step()
+    worst = max(float((a - b).abs().max()) for a, b in zip(our2.param_groups[0]["params"], ref2.param_groups[0]["params"]))
+    assert worst < 1e-5, (worst, float(our2.state[our2.param_groups[0]['params'][0]]['step']), float(ref2.state[ref2.param_groups[0]['params'][0]]['step']))

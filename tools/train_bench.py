@@ -30,6 +30,7 @@ def main():
                     help="gradient collective per bucket: one all-reduce, or reduce-scatter + all-gather (all 7 xGMI links)")
     ap.add_argument("--comm-dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-overlap", action="store_true", help="reduce all buckets after the backward instead of during it")
+    ap.add_argument("--torch-adamw", action="store_true", help="torch.optim.AdamW(fused=True) instead of optim.FusedAdamW")
     ap.add_argument("--graph", action="store_true", help="capture the whole step (forward, backward, clipping, AdamW) "
                     "into one HIP graph and time replays (single GPU)")
     args = ap.parse_args()
@@ -51,7 +52,12 @@ def main():
                  t_img=torch.randint(0, 1000, (B,), device=dev, generator=g),
                  t_attr=torch.randint(0, 1000, (B,), device=dev, generator=g),
                  target_img=mk(B, 4, L, L), target_attr=mk(B, 28, L, L))
-    opt = torch.optim.AdamW([p for m in nets for p in m.parameters()], lr=1e-5, fused=True, capturable=args.graph)
+    params = [p for m in nets for p in m.parameters()]
+    if args.torch_adamw:
+        opt = torch.optim.AdamW(params, lr=1e-5, fused=True, capturable=args.graph)
+    else:
+        from uni_renderer_amd.optim import FusedAdamW
+        opt = FusedAdamW(params, lr=1e-5)
     buckets = GradientBuckets(nets, comm_dtype=(torch.bfloat16 if args.comm_dtype == "bf16" else None), algorithm=args.algorithm,
                               overlap=not args.no_overlap) if world > 1 else None
     if args.graph:

@@ -1,0 +1,115 @@
+"""AdamW for the training loop on one HIP kernel (``ur_adamw_multi``, csrc/backward.hip).
+
+The reference builds ``torch.optim.AdamW`` (or bitsandbytes' 8-bit variant) over the parameters of the three networks in
+ONE parameter group (train/train.py:1082-1100: lr, betas, weight_decay, eps from the command line) and calls
+``optimizer.step()`` once per batch (1425).  This class is that optimizer with the update of up to 64 parameter tensors
+per launch (descriptors as kernel arguments: ~12 launches for the 700 tensors of enc + unet + dec instead of ~95
+multi-tensor launches), fp32 state, the arithmetic of torch's fused AdamW kernel.
+
+Interchangeable with ``torch.optim.AdamW``: same constructor arguments, ``param_groups`` and ``state_dict()`` layout
+(``step`` / ``exp_avg`` / ``exp_avg_sq`` per parameter, so ``optimizer.bin`` of checkpointing.py loads in either), the
+``grad_scale`` / ``found_inf`` attributes of torch's AMP-aware fused optimizers (train_step.py folds gradient clipping
+into the update through ``grad_scale``), and no host synchronisation in ``step()`` (the step counter is a device
+scalar): the whole training step still captures into one HIP graph.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Iterable, Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import check
+from .ops import _stream
+
+MAX_TENSORS = 64
+
+
+class _Tensor(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("n", C.c_int64)]
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    _step_supports_amp_scaling = True
+
+    def __init__(self, params: Iterable, lr: float = 1e-3, betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8,
+                 weight_decay: float = 1e-2, fused: bool = True, capturable: bool = True):
+        if lr < 0 or eps < 0 or weight_decay < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1):
+            raise ValueError("invalid AdamW hyper-parameters")
+        # ``fused`` / ``capturable`` are accepted (and recorded) so that code written for torch.optim.AdamW(fused=True,
+        # capturable=True) constructs this class unchanged; this implementation is always both
+        defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, fused=True, capturable=True,
+                        amsgrad=False, maximize=False, foreach=None, differentiable=False)
+        super().__init__(params, defaults)
+
+    def _init_state(self, p):
+        st = self.state[p]
+        if not st:
+            st["step"] = torch.zeros((), dtype=torch.float32, device=p.device)
+            st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        return st
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        lib = _lib.load()
+        grad_scale = getattr(self, "grad_scale", None)
+        found_inf = getattr(self, "found_inf", None)
+        for group in self.param_groups:
+            if group.get("amsgrad") or group.get("maximize"):
+                raise NotImplementedError("FusedAdamW: amsgrad / maximize are not used by the reference (train.py:1093-1100)")
+            ps = [p for p in group["params"] if p.grad is not None]
+            if not ps:
+                continue
+            for p in ps:
+                if p.dtype != torch.float32 or p.grad.dtype != torch.float32 or not p.is_cuda:
+                    raise RuntimeError("FusedAdamW updates fp32 master parameters on the GPU (train.py:1082-1089)")
+                if not p.is_contiguous() or not p.grad.is_contiguous():
+                    raise RuntimeError("FusedAdamW needs contiguous parameters and gradients")
+            states = [self._init_state(p) for p in ps]
+            # one device step counter per group: the per-parameter ``step`` entries all alias it after the first call
+            step_t = states[0]["step"]
+            for st in states[1:]:
+                if st["step"] is not step_t:
+                    st["step"] = step_t
+            step_t += 1
+            beta1, beta2 = group["betas"]
+            lr = group["lr"]
+            if isinstance(lr, torch.Tensor):
+                raise NotImplementedError("FusedAdamW: tensor learning rates are not supported")
+            s_ = _stream()
+            for i in range(0, len(ps), MAX_TENSORS):
+                chunk = ps[i:i + MAX_TENSORS]
+                arr = (_Tensor * len(chunk))()
+                for k, p in enumerate(chunk):
+                    st = states[i + k]
+                    arr[k].p, arr[k].g = p.data_ptr(), p.grad.data_ptr()
+                    arr[k].m, arr[k].v = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+                    arr[k].n = p.numel()
+                check(lib.ur_adamw_multi(arr, len(chunk), float(lr), float(beta1), float(beta2), float(group["eps"]),
+                                         float(group["weight_decay"]), step_t.data_ptr(),
+                                         grad_scale.data_ptr() if grad_scale is not None else None,
+                                         found_inf.data_ptr() if found_inf is not None else None, s_), "ur_adamw_multi")
+        return loss
+
+    def state_dict(self):
+        """torch.optim.AdamW's layout.  The per-parameter ``step`` entries alias one device scalar inside this object;
+        a state dict hands out independent copies (torch's optimizers increment every entry on their own)."""
+        sd = super().state_dict()
+        for st in sd["state"].values():
+            if "step" in st:
+                st["step"] = st["step"].clone()
+        return sd
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        for group in self.param_groups:  # private fp32 device scalars (torch may hand back the caller's tensors uncopied)
+            for p in group["params"]:
+                st = self.state.get(p)
+                if st and "step" in st:
+                    st["step"] = torch.as_tensor(st["step"], dtype=torch.float32).to(p.device).reshape(()).clone()
