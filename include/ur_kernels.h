@@ -348,6 +348,17 @@ int ur_groupnorm_backward(const void* x, const void* dy, int C, int B, int rows,
                           float* chan_part, float* chan_sum, int nchunks, void* dx, int dtype, void* stream);
 int ur_layernorm_backward(const void* x, const void* dy, const float* gamma, float eps, int rows, int C,
                           int rows_per_wave, void* dx, float* part, int dtype, void* stream);
+/* Up to UR_TRANSPOSE_MAX independent batched transposes (each as ur_transpose2d: dst[b][c][r] = src[b][r][c], rows
+ * R .. ceil8(R) of the source read as zeros) in one launch; same dtype for all. */
+#define UR_TRANSPOSE_MAX 4
+typedef struct ur_transpose_desc {
+    const void* src;
+    void* dst;
+    int64_t ld_src, bs_src, ld_dst, bs_dst;
+    int32_t R, C, batch, pad_;
+} ur_transpose_desc;
+int ur_transpose2d_multi(const ur_transpose_desc* descs, int n, int dtype, void* stream);
+
 /* AdamW over many parameter tensors per launch (the optimizer step of the training loop, train/train.py:1082-1100
  * torch.optim.AdamW, 1425 optimizer.step()).  Decoupled weight decay, bias correction, no amsgrad, fp32 everywhere; the
  * arithmetic of torch's fused kernel (param -= lr*wd*param; exp_avg = lerp(exp_avg, g, 1-beta1); exp_avg_sq = beta2*

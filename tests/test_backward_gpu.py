@@ -298,3 +298,18 @@ def test_conv_weight_pack_unpack_and_rotation_kernels(dev, dtype, shape):
         rot = bw._rot_weights(ref, cp)
         w4 = ref.view(co, 3, 3, cp)
         assert torch.equal(rot, w4.flip(1, 2).permute(3, 1, 2, 0).reshape(cp, 9 * co).contiguous())
+
+def test_transpose2d_many(dev):
+    """ur_transpose2d_multi: several (batched, strided, ragged) transposes in one launch == the single-tensor kernel."""
+    from uni_renderer_amd import backward as bw
+    g = torch.Generator().manual_seed(5)
+    big = torch.randn(3, 100, 3 * 64, generator=g).to(torch.bfloat16).to(dev)
+    xs = [torch.randn(77, 320, generator=g).to(torch.bfloat16).to(dev), torch.randn(4, 130, 64, generator=g).to(torch.bfloat16).to(dev),
+          big[..., 64:128], torch.randn(5, 8, generator=g).to(torch.bfloat16).to(dev),
+          torch.randn(2, 3, 200, 72, generator=g).to(torch.bfloat16).to(dev)]
+    outs = bw.transpose2d_many(xs)
+    for x, o in zip(xs, outs):
+        R = x.shape[-2]
+        assert o.shape[-1] == (R + 7) // 8 * 8
+        assert torch.equal(o[..., :R], x.transpose(-1, -2)) and float(o[..., R:].abs().sum()) == 0.0
+        assert torch.equal(o, bw.transpose2d(x))

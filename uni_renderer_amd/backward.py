@@ -14,6 +14,7 @@ Reference semantics: ``nn.Linear`` / ``nn.Conv2d`` / ``nn.GroupNorm`` / ``nn.Lay
 """
 from __future__ import annotations
 
+import ctypes as C
 import os
 from typing import Optional, Tuple
 
@@ -40,6 +41,49 @@ def transpose2d(x: torch.Tensor) -> torch.Tensor:
     check(lib.ur_transpose2d(x.data_ptr(), ld, bs, out.data_ptr(), Rp, Rp * Cc, R, Cc, batch, DT[x.dtype], _stream()),
           "ur_transpose2d")
     return out
+
+
+class _TransposeDesc(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("ld_src", C.c_int64), ("bs_src", C.c_int64),
+                ("ld_dst", C.c_int64), ("bs_dst", C.c_int64), ("R", C.c_int32), ("C", C.c_int32), ("batch", C.c_int32),
+                ("pad_", C.c_int32)]
+
+
+MULTI_TRANSPOSE = os.environ.get("UR_MULTI_TRANSPOSE", "1") != "0"
+
+
+def transpose2d_many(xs) -> list:
+    """``[transpose2d(x) for x in xs]`` in one launch per four tensors (``ur_transpose2d_multi``): same dtype, each
+    [..., R, C] -> [..., C, ceil8(R)]."""
+    xs = list(xs)
+    if not MULTI_TRANSPOSE or len(xs) == 1:
+        return [transpose2d(x) for x in xs]
+    lib = _lib.load()
+    outs, descs = [], []
+    for x in xs:
+        _require_gpu(x)
+        R, Cc = x.shape[-2:]
+        Rp = (R + 7) // 8 * 8
+        if x.dim() == 3 and x.stride(2) == 1 and x.stride(1) % 8 == 0 and x.stride(0) % 8 == 0 and x.storage_offset() % 8 == 0:
+            ld, bs, batch = x.stride(1), x.stride(0), x.shape[0]
+        else:
+            x = x.contiguous()
+            ld, bs, batch = Cc, R * Cc, x.numel() // (R * Cc)
+        out = torch.empty(*x.shape[:-2], Cc, Rp, dtype=x.dtype, device=x.device)
+        outs.append(out)
+        descs.append((x, out, ld, bs, Rp, Rp * Cc, R, Cc, batch))
+    if len({x.dtype for x in xs}) != 1:
+        raise ValueError("transpose2d_many: one dtype per call")
+    nmax = 4
+    for i in range(0, len(descs), nmax):
+        part = descs[i:i + nmax]
+        arr = (_TransposeDesc * len(part))()
+        for k, (x, out, ld, bs, ldd, bsd, R, Cc, batch) in enumerate(part):
+            arr[k].src, arr[k].dst = x.data_ptr(), out.data_ptr()
+            arr[k].ld_src, arr[k].bs_src, arr[k].ld_dst, arr[k].bs_dst = ld, bs, ldd, bsd
+            arr[k].R, arr[k].C, arr[k].batch = R, Cc, batch
+        check(lib.ur_transpose2d_multi(arr, len(part), DT[xs[0].dtype], _stream()), "ur_transpose2d_multi")
+    return outs
 
 
 def colsum(x: torch.Tensor, rows_per_group: int = 0) -> torch.Tensor:
@@ -75,9 +119,9 @@ def linear_backward(x: torch.Tensor, w: torch.Tensor, dy: torch.Tensor, need_bia
     K, N = x.shape[-1], w.shape[0]
     x2, dy2 = x.reshape(-1, K), dy.reshape(-1, N)
     dy2p = dy2  # transpose2d zero-pads the row count (M = batch rows in the time-embedding GEMMs) to a multiple of 8
-    wt = transpose2d(w)                                   # [K, N]
+    wt, dyt, xt = transpose2d_many([w, dy2p, x2])         # [K, N], [N, M], [K, M]: one launch
     dx = ops.linear(dy2, wt).view(x.shape)                # [M, N] @ [K, N]^T
-    dyt, xt = _pad_rows64(transpose2d(dy2p)), _pad_rows64(transpose2d(x2))  # [N, M], [K, M]
+    dyt, xt = _pad_rows64(dyt), _pad_rows64(xt)
     dw = ops.linear(dyt, xt)                              # [N, M] @ [K, M]^T = [N, K]
     db = colsum(dy2) if need_bias else None
     return dx, dw, db
@@ -252,7 +296,7 @@ def _flash_attention_backward(q, k, v, o, do, H, scale, fused_qkv, oq, ok, ov, C
     S = B * H
     qp, kp, vp = _split_heads(q, H, d, T, dp, oq), _split_heads(k, H, d, T, dp, ok), _split_heads(v, H, d, T, dp, ov)
     op, dop = _split_heads(o, H, d, T, dp), _split_heads(do, H, d, T, dp)             # [S, T, dp]
-    qt, kt, dot_ = transpose2d(qp), transpose2d(kp), transpose2d(dop)                 # [S, dp, T]
+    qt, kt, dot_ = transpose2d_many([qp, kp, dop])                                    # [S, dp, T], one launch
     stats = torch.empty(2, S, T, dtype=torch.float32, device=q.device)
     dQ, dK, dV = torch.empty_like(qp), torch.empty_like(qp), torch.empty_like(qp)
     check(lib.ur_attention_backward(qp.data_ptr(), kp.data_ptr(), vp.data_ptr(), op.data_ptr(), dop.data_ptr(), qt.data_ptr(),

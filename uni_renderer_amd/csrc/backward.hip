@@ -69,6 +69,42 @@ __global__ void __launch_bounds__(256) transpose2d_kernel(const T* __restrict__ 
     transpose_tile_64x64<T>(load_row, tile, dst + (int64_t)c0 * ld_dst + r0, ld_dst, C - c0, ((R + 7) & ~7) - r0, t);
 }
 
+// Up to UR_TRANSPOSE_MAX independent (batched) transposes in ONE launch: the three operand transposes of a linear
+// backward (w, dy, x) or q / k / dO of the flash attention backward are a few microseconds each and were paying one launch
+// apiece.  Descriptors are kernel arguments; blockIdx.x walks the concatenated tile lists.
+struct TransposeMultiArgs {
+    ur_transpose_desc d[UR_TRANSPOSE_MAX];
+    int tile0[UR_TRANSPOSE_MAX + 1];
+    int n;
+};
+template <typename T>
+__global__ void __launch_bounds__(256) transpose2d_multi_kernel(const TransposeMultiArgs a) {
+    __shared__ __attribute__((aligned(16))) uint32_t tile[64 * 32];
+    int k = 0;
+#pragma unroll
+    for (int i = 1; i < UR_TRANSPOSE_MAX; ++i)
+        if (i < a.n && (int)blockIdx.x >= a.tile0[i]) k = i;
+    const ur_transpose_desc d = a.d[k];
+    const int tc = (d.C + 63) / 64, tr = (d.R + 63) / 64;
+    int id = (int)blockIdx.x - a.tile0[k];
+    const int b = id / (tc * tr);
+    id -= b * tc * tr;
+    const int r0 = (id / tc) * 64, c0 = (id % tc) * 64;
+    const T* src = reinterpret_cast<const T*>(d.src) + (int64_t)b * d.bs_src;
+    T* dst = reinterpret_cast<T*>(d.dst) + (int64_t)b * d.bs_dst;
+    const int t = threadIdx.x, R = d.R, C = d.C;
+    const int64_t ld_src = d.ld_src;
+    typedef typename Vec8<T>::type vec8;
+    auto load_row = [&](int r, int cv) {
+        vec8 v;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (T)0.0f;
+        if (r0 + r < R && c0 + cv < C) v = *reinterpret_cast<const vec8*>(src + (int64_t)(r0 + r) * ld_src + c0 + cv);
+        return v;
+    };
+    transpose_tile_64x64<T>(load_row, tile, dst + (int64_t)c0 * d.ld_dst + r0, d.ld_dst, C - c0, ((R + 7) & ~7) - r0, t);
+}
+
 // Transposed im2col of a 3x3 / pad 1 convolution: out[(tap*C + c)][p] = x[pixel(p, tap)][c] (0 outside the image),
 // p = (b, oy, ox) row-major; columns p >= P (padding to ld_out) are written as zeros by the caller's memset.
 template <typename T>
@@ -697,6 +733,27 @@ extern "C" int ur_transpose2d(const void* src, int64_t ld_src, int64_t bs_src, v
     dim3 grid((C + 63) / 64, (R + 63) / 64, batch);
     UR_DISPATCH(dtype, hipLaunchKernelGGL((transpose2d_kernel<T>), grid, dim3(256), 0, s, (const T*)src, ld_src, bs_src,
                                           (T*)dst, ld_dst, bs_dst, R, C));
+    return last_error();
+}
+
+extern "C" int ur_transpose2d_multi(const ur_transpose_desc* descs, int n, int dtype, void* stream) {
+    if (!descs || n <= 0 || n > UR_TRANSPOSE_MAX) return UR_E_BADARG;
+    TransposeMultiArgs a;
+    int64_t tiles = 0;
+    for (int i = 0; i < n; ++i) {
+        const ur_transpose_desc& d = descs[i];
+        if (!d.src || !d.dst || d.R <= 0 || d.C <= 0 || d.batch <= 0 || (d.C & 7) || (d.ld_src & 7) || (d.ld_dst & 7) ||
+            (d.bs_src & 7) || (d.bs_dst & 7) || d.ld_dst < ((d.R + 7) & ~7))
+            return UR_E_BADARG;
+        a.d[i] = d;
+        a.tile0[i] = (int)tiles;
+        tiles += (int64_t)((d.C + 63) / 64) * ((d.R + 63) / 64) * d.batch;
+        if (tiles > 0x7fffffff) return UR_E_BADARG;
+    }
+    a.tile0[n] = (int)tiles;
+    a.n = n;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    UR_DISPATCH(dtype, hipLaunchKernelGGL((transpose2d_multi_kernel<T>), dim3((unsigned)tiles), dim3(256), 0, s, a));
     return last_error();
 }
 
