@@ -12,6 +12,8 @@ python tools/train_bench.py --steps 3 --graph > gpurun_out/final_train_graph.jso
 python tools/train_bench.py --steps 3 > gpurun_out/final_train_eager.json 2>/dev/null
 python tools/loop_bench.py > gpurun_out/final_loop_bench.json 2>/dev/null
 python tools/vae_bench.py > gpurun_out/final_vae_bench.json 2>/dev/null
+python tools/attn_bwd_bench.py > /dev/null 2>&1; cp gpurun_out/attn_bwd_bench.json gpurun_out/final_attn_bwd_bench.json
+python tools/train_bench.py --steps 3 --graph --torch-adamw > gpurun_out/final_train_graph_torch_adamw.json 2>/dev/null
 (cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && rocprofv3 --kernel-trace --stats -d gpurun_out/prof_train -o tr --output-format csv -- python tools/train_bench.py --steps 3 --graph > gpurun_out/final_train_under_rocprof.json 2>/dev/null; cp $(find gpurun_out/prof_train -name "*kernel_stats.csv" | head -1) gpurun_out/final_train_kernel_stats.csv; rm -rf gpurun_out/prof_train)
 tail -1 gpurun_out/prof_r02/bench_default.json | cut -c1-250
 for f in cfg5 cfg2 b5 b8 b10 b20; do python -c "

@@ -137,7 +137,8 @@ class GradientBuckets:
         self.flat: List[torch.Tensor] = []
         self._bucket_of, self._offset = {}, {}
         for bi, bucket in enumerate(self.buckets):
-            n = sum(p.numel() for p in bucket)
+            # every gradient view starts on a 16-byte boundary (optim.FusedAdamW's float4 path; RCCL likes it too)
+            n = sum((p.numel() + 3) // 4 * 4 for p in bucket)
             npad = (n + 63) // 64 * 64
             dev = bucket[0].device
             flat = torch.zeros(npad, dtype=torch.float32, device=dev)
@@ -151,7 +152,7 @@ class GradientBuckets:
                 p.grad = g
                 self._bucket_of[p] = bi
                 self._offset[p] = off
-                off += p.numel()
+                off += (p.numel() + 3) // 4 * 4
             self.flat.append(flat)
         self._comm: List[Optional[torch.Tensor]] = [None] * len(self.buckets)
         self._arrived = [0] * len(self.buckets)
