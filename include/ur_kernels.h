@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define UR_ABI_VERSION 3
+#define UR_ABI_VERSION 4
 
 #define UR_E_BADARG (-1001)   /* inconsistent descriptor (shape / alignment / null pointer)   */
 #define UR_E_UNSUPPORTED (-1002) /* shape outside what the kernels are instantiated for       */
@@ -238,6 +238,8 @@ typedef struct ur_attn_desc {
     int32_t B, H, Tq, Tk, d;
     float scale;  /* see above: <= 0 selects "scores already in log2 units" */
     int32_t dtype;
+    float* lse;   /* NULL, or [B*H][Tq] fp32: the row log-sum-exp of the scaled scores in log2 units (what
+                   * ur_attention_backward takes with has_lse = 1); needs scale > 0 */
 } ur_attn_desc;
 
 int ur_attention(const ur_attn_desc* d, void* stream);
@@ -386,11 +388,13 @@ int ur_adamw_multi(const ur_adamw_tensor* tensors, int n_tensors, float lr, floa
  * dk / dv), every sum in a fixed order.
  *   q, k, v, o, dout  [S][T][dp]  per (batch, head) slices, head dim zero-padded to dp (ur_split_heads)
  *   qt, kt, dot       [S][dp][T]  transposes of q, k, dout (ur_transpose2d)
- *   stats             [2][S][T]   fp32 workspace (row log-sum-exp in log2 units | rowsum(dout * o)), written here
+ *   stats             [2][S][T]   fp32 workspace (row log-sum-exp in log2 units | rowsum(dout * o)), written here;
+ *                                 has_lse = 1: the first half already holds the forward's ur_attn_desc.lse (the
+ *                                 log-sum-exp pass of the dq kernel is skipped)
  *   dq, dk, dv        [S][T][dp]  outputs (padding columns come out as zeros) */
 int ur_attention_backward(const void* q, const void* k, const void* v, const void* o, const void* dout, const void* qt,
-                          const void* kt, const void* dot, float* stats, void* dq, void* dk, void* dv, int S, int T, int dp,
-                          float scale, int dtype, void* stream);
+                          const void* kt, const void* dot, float* stats, int has_lse, void* dq, void* dk, void* dv, int S,
+                          int T, int dp, float scale, int dtype, void* stream);
 int ur_attention_backward_supported(int T, int dp);
 
 /* Attention backward helpers: P = softmax(Q K^T * scale) is recomputed and materialised per (batch, head); the five

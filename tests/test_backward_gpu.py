@@ -313,3 +313,22 @@ def test_transpose2d_many(dev):
         assert o.shape[-1] == (R + 7) // 8 * 8
         assert torch.equal(o[..., :R], x.transpose(-1, -2)) and float(o[..., R:].abs().sum()) == 0.0
         assert torch.equal(o, bw.transpose2d(x))
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(2, 2, 40, 128, 128), (1, 2, 40, 100, 77), (1, 2, 80, 64, 64), (1, 2, 160, 96, 40)])
+def test_attention_forward_lse(dev, dtype, shape):
+    """ur_attn_desc.lse: the forward kernels' row log-sum-exp (log2 units) against fp32 logsumexp of the scaled scores."""
+    from uni_renderer_amd import backward as bw, ops
+    B, H, d, Tq, Tk = shape
+    C = H * d
+    q, k, v = _rand((B, Tq, C), dtype, dev, 1), _rand((B, Tk, C), dtype, dev, 2), _rand((B, Tk, C), dtype, dev, 3)
+    vt = bw._pad_rows64(bw.transpose2d(v))
+    lse = torch.full((B * H, Tq), float("nan"), dtype=torch.float32, device=dev)
+    o = ops.attention(q, k, vt, B=B, H=H, Tq=Tq, Tk=Tk, d=d, ldq=C, ldk=C, lse=lse)
+    o0 = ops.attention(q, k, vt, B=B, H=H, Tq=Tq, Tk=Tk, d=d, ldq=C, ldk=C)
+    assert torch.equal(o, o0)
+    s = torch.einsum("bqhd,bkhd->bhqk", q.float().view(B, Tq, H, d), k.float().view(B, Tk, H, d)) * d ** -0.5
+    ref = torch.logsumexp(s, dim=-1).reshape(B * H, Tq) * 1.4426950408889634
+    err = float((lse - ref).abs().max())
+    print({"attention_forward_lse": str(dtype), "shape": shape, "max_abs_err_log2": err})
+    assert err < (2e-3 if dtype == torch.float16 else 1.5e-2)

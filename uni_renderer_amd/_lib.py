@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must be imported first, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("UR_LIB_PATH", os.path.join(_HERE, "liburhip.so"))  # override = kernel experiments only
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
@@ -51,6 +51,7 @@ class AttnDesc(C.Structure):
         ("q_off", i32), ("k_off", i32),
         ("B", i32), ("H", i32), ("Tq", i32), ("Tk", i32), ("d", i32),
         ("scale", f32), ("dtype", i32),
+        ("lse", vp),
     ]
 
 
@@ -93,7 +94,7 @@ SYMBOLS = {
     "ur_merge_heads": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int64, C.c_int, C.c_int, vp]),
     "ur_softmax_rows": (C.c_int, [vp, C.c_int64, C.c_int64, C.c_int, C.c_int, vp]),
     "ur_softmax_backward_rows": (C.c_int, [vp, vp, C.c_int64, C.c_int64, C.c_int, C.c_float, C.c_int, vp]),
-    "ur_attention_backward": (C.c_int, [vp] * 12 + [C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, vp]),
+    "ur_attention_backward": (C.c_int, [vp] * 9 + [C.c_int] + [vp] * 3 + [C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, vp]),
     "ur_attention_backward_supported": (C.c_int, [C.c_int, C.c_int]),
     "ur_transpose2d_multi": (C.c_int, [vp, C.c_int, C.c_int, vp]),
     "ur_adamw_multi": (C.c_int, [vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, vp, vp, vp, vp]),

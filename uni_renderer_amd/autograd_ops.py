@@ -105,15 +105,18 @@ class Attention(Function):
         Tk = k.shape[1]
         d = Cc // heads
         vt = bw._pad_rows64(bw.transpose2d(v.contiguous()))  # [B, C, Tk_pad]
-        o = ops.attention(q.contiguous(), k.contiguous(), vt, B=B, H=heads, Tq=Tq, Tk=Tk, d=d, ldq=Cc, ldk=Cc)
+        stats = bw.flash_stats(B, heads, Tq, Tk, d, q.device)  # [2, B*H, T] when the flash backward will run, else None
+        o = ops.attention(q.contiguous(), k.contiguous(), vt, B=B, H=heads, Tq=Tq, Tk=Tk, d=d, ldq=Cc, ldk=Cc,
+                          lse=None if stats is None else stats[0])
         ctx.save_for_backward(q, k, v, o)  # o: rowsum(do * o) of the flash backward (the out projection keeps it anyway)
-        ctx.heads = heads
+        ctx.heads, ctx.stats = heads, stats
         return o
 
     @staticmethod
     def backward(ctx, do):
         q, k, v, o = ctx.saved_tensors
-        dq, dk, dv = bw.attention_backward(q.contiguous(), k.contiguous(), v.contiguous(), do.contiguous(), ctx.heads, o=o)
+        dq, dk, dv = bw.attention_backward(q.contiguous(), k.contiguous(), v.contiguous(), do.contiguous(), ctx.heads, o=o,
+                                           stats=ctx.stats)
         return dq, dk, dv, None
 
 
@@ -127,15 +130,17 @@ class AttentionQKV(Function):
         B, T, C3 = qkv.shape
         Cc = C3 // 3
         vt = bw._pad_rows64(bw.transpose2d(qkv[..., 2 * Cc:]))  # [B, C, T_pad], read in place (strided)
-        o = ops.attention(qkv, qkv, vt, B=B, H=heads, Tq=T, Tk=T, d=Cc // heads, ldq=C3, ldk=C3, q_off=0, k_off=Cc)
+        stats = bw.flash_stats(B, heads, T, T, Cc // heads, qkv.device)
+        o = ops.attention(qkv, qkv, vt, B=B, H=heads, Tq=T, Tk=T, d=Cc // heads, ldq=C3, ldk=C3, q_off=0, k_off=Cc,
+                          lse=None if stats is None else stats[0])
         ctx.save_for_backward(qkv, o)
-        ctx.heads = heads
+        ctx.heads, ctx.stats = heads, stats
         return o
 
     @staticmethod
     def backward(ctx, do):
         qkv, o = ctx.saved_tensors
-        return bw.attention_backward(qkv, qkv, qkv, do.contiguous(), ctx.heads, fused_qkv=True, o=o), None
+        return bw.attention_backward(qkv, qkv, qkv, do.contiguous(), ctx.heads, fused_qkv=True, o=o, stats=ctx.stats), None
 
 
 class GEGLU(Function):

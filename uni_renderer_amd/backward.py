@@ -287,9 +287,18 @@ def _merge_heads(g: torch.Tensor, B: int, T: int, H: int, d: int, out: Optional[
 
 
 FLASH_BACKWARD = os.environ.get("UR_FLASH_BACKWARD", "1") != "0"  # 0: always the materialised-P path below
+FORWARD_LSE = os.environ.get("UR_FORWARD_LSE", "1") != "0"        # 0: the dq kernel recomputes the row log-sum-exp
 
 
-def _flash_attention_backward(q, k, v, o, do, H, scale, fused_qkv, oq, ok, ov, Cc, d, dp):
+def flash_stats(B: int, H: int, Tq: int, Tk: int, d: int, device) -> Optional[torch.Tensor]:
+    """The [2, B*H, T] fp32 statistics buffer of the flash backward if it will handle this shape (the forward kernel
+    writes the row log-sum-exp into its first half: ``ops.attention(lse=stats[0])``), else None."""
+    if not (FLASH_BACKWARD and FORWARD_LSE and Tq == Tk and _lib.load().ur_attention_backward_supported(Tq, (d + 31) // 32 * 32)):
+        return None
+    return torch.empty(2, B * H, Tq, dtype=torch.float32, device=device)
+
+
+def _flash_attention_backward(q, k, v, o, do, H, scale, fused_qkv, oq, ok, ov, Cc, d, dp, stats=None):
     """Self-attention shapes: ``ur_attention_backward`` (csrc/attention_bwd.hip) -- P stays in registers, two launches."""
     lib = _lib.load()
     B, T = q.shape[:2]
@@ -297,11 +306,14 @@ def _flash_attention_backward(q, k, v, o, do, H, scale, fused_qkv, oq, ok, ov, C
     qp, kp, vp = _split_heads(q, H, d, T, dp, oq), _split_heads(k, H, d, T, dp, ok), _split_heads(v, H, d, T, dp, ov)
     op, dop = _split_heads(o, H, d, T, dp), _split_heads(do, H, d, T, dp)             # [S, T, dp]
     qt, kt, dot_ = transpose2d_many([qp, kp, dop])                                    # [S, dp, T], one launch
-    stats = torch.empty(2, S, T, dtype=torch.float32, device=q.device)
+    has_lse = stats is not None and tuple(stats.shape) == (2, S, T)
+    if not has_lse:
+        stats = torch.empty(2, S, T, dtype=torch.float32, device=q.device)
     dQ, dK, dV = torch.empty_like(qp), torch.empty_like(qp), torch.empty_like(qp)
     check(lib.ur_attention_backward(qp.data_ptr(), kp.data_ptr(), vp.data_ptr(), op.data_ptr(), dop.data_ptr(), qt.data_ptr(),
-                                    kt.data_ptr(), dot_.data_ptr(), stats.data_ptr(), dQ.data_ptr(), dK.data_ptr(),
-                                    dV.data_ptr(), S, T, dp, scale, DT[q.dtype], _stream()), "ur_attention_backward")
+                                    kt.data_ptr(), dot_.data_ptr(), stats.data_ptr(), int(has_lse), dQ.data_ptr(),
+                                    dK.data_ptr(), dV.data_ptr(), S, T, dp, scale, DT[q.dtype], _stream()),
+          "ur_attention_backward")
     if fused_qkv:
         g = torch.empty(B, T, 3 * Cc, dtype=q.dtype, device=q.device)
         for part, off in ((dQ, oq), (dK, ok), (dV, ov)):
@@ -311,7 +323,8 @@ def _flash_attention_backward(q, k, v, o, do, H, scale, fused_qkv, oq, ok, ov, C
 
 
 def attention_backward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, do: torch.Tensor, H: int,
-                       scale: Optional[float] = None, fused_qkv: bool = False, o: Optional[torch.Tensor] = None):
+                       scale: Optional[float] = None, fused_qkv: bool = False, o: Optional[torch.Tensor] = None,
+                       stats: Optional[torch.Tensor] = None):
     """Gradients of o = softmax(q k^T * scale) v per head (q, do [B,Tq,H*d]; k, v [B,Tk,H*d]) -> (dq, dk, dv).
     The forward keeps nothing but q, k, v (flash kernel); here P is recomputed and materialised per (batch, head)
     ([B*H, Tq, Tk] in the compute dtype) and the five GEMMs run z-batched on ``ur_igemm``:
@@ -327,7 +340,7 @@ def attention_backward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, do: to
     scale = float(d ** -0.5 if scale is None else scale)
     dp32 = (d + 31) // 32 * 32
     if (FLASH_BACKWARD and o is not None and Tq == Tk and lib.ur_attention_backward_supported(Tq, dp32)):
-        return _flash_attention_backward(q, k, v, o, do, H, scale, fused_qkv, oq, ok, ov, Cc, d, dp32)
+        return _flash_attention_backward(q, k, v, o, do, H, scale, fused_qkv, oq, ok, ov, Cc, d, dp32, stats)
     dp = (d + 63) // 64 * 64
     Tqp, Tkp = (Tq + 63) // 64 * 64, (Tk + 63) // 64 * 64
     S = B * H

@@ -291,6 +291,8 @@ __global__ void __launch_bounds__(256) attention_kernel(const ur_attn_desc p) {
         }
         const float inv = 1.0f / l;
         const int qrow = q0 + f * 16 + l15;
+        if (p.lse && qq == 0 && qrow < p.Tq)  // log2-unit log-sum-exp of the row: reference + log2(sum of exp2(s - reference))
+            p.lse[((int64_t)b * p.H + h) * p.Tq + qrow] = __builtin_amdgcn_logf(l) - mc_run[f];
         if (qrow < p.Tq) {
             T* orow = reinterpret_cast<T*>(p.o) + ((int64_t)b * p.Tq + qrow) * p.ldo + h * D;
 #pragma unroll
@@ -554,6 +556,8 @@ __global__ void __launch_bounds__(256) attention32_kernel(const ur_attn_desc p) 
     }
     const float inv = 1.0f / l;
     const int qrow = q0 + l31;
+    if (!SLOT && p.lse && hh == 0 && qrow < p.Tq)
+        p.lse[((int64_t)b * p.H + h) * p.Tq + qrow] = __builtin_amdgcn_logf(l) - mc_run;
     if (qrow < p.Tq) {
         T* orow = reinterpret_cast<T*>(p.o) + ((int64_t)b * p.Tq + qrow) * p.ldo + h * D;
         typedef T vec4 __attribute__((ext_vector_type(4)));
@@ -622,6 +626,7 @@ extern "C" int ur_attention(const ur_attn_desc* d, void* stream) {
     if ((d->ldq & 7) || (d->ldk & 7) || (d->ldvt & 63) || (d->ldo & 3) || (d->q_off & 7) || (d->k_off & 7))
         return UR_E_BADARG;
     if (d->ldvt < (d->Tk + 63) / 64 * 64 || (d->vt_bstride & 7)) return UR_E_BADARG;
+    if (d->lse && !(d->scale > 0.f)) return UR_E_BADARG;  // the pre-scaled (reference slot) mode keeps no row reference
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (d->dtype == UR_DT_F16) return launch_attn_d<f16>(*d, s);
     if (d->dtype == UR_DT_BF16) return launch_attn_d<bf16>(*d, s);

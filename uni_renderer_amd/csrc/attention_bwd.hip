@@ -112,7 +112,7 @@ __device__ __forceinline__ void store4(T* p, const f32x4& a, float scale) {
 // ---------------------------------------------------------------------------------------------------------------
 // kernel 1: row statistics + dq.  grid (T / (64 * NB), S), 4 waves, wave w owns queries (4 * bx + w) * 16 * NB ...
 // ---------------------------------------------------------------------------------------------------------------
-template <typename T, int DP, int NB, bool PF>
+template <typename T, int DP, int NB, bool PF, bool HAS_LSE>
 __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const AttnBwdArgs p) {
     typedef typename Vec8<T>::type vec8;
     typedef BwdLds<DP> L;
@@ -153,53 +153,61 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const AttnBwdArgs p) {
         dsum[nb] = a;
     }
 
-    // ---- pass A: log-sum-exp of every query row (log2 units) ----
-    float mx[NB], ls[NB];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) { mx[nb] = -1e30f; ls[nb] = 0.f; }
+    // ---- pass A: log-sum-exp of every query row (log2 units); skipped when the forward kernel handed it over ----
     u32x4 rk[UR_ROWREGS(DP)], rv[UR_ROWREGS(DP)], rkt[UR_TRNREGS(DP)];
-    if (PF) gload_rows<T, DP>(K, rk, tid);
-    for (int kt = 0; kt < Tn; kt += 64) {
-        if (!PF) gload_rows<T, DP>(K + (int64_t)kt * DP, rk, tid);
-        __syncthreads();
-        lstore_rows<DP>(Ks, rk, tid);
-        __syncthreads();
-        if (PF && kt + 64 < Tn) gload_rows<T, DP>(K + (int64_t)(kt + 64) * DP, rk, tid);
+    float lse[NB];
+    if constexpr (HAS_LSE) {
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) {
-            f32x4 sc[NB];
+        for (int nb = 0; nb < NB; ++nb) {
+            lse[nb] = p.stats[(int64_t)s * Tn + qbase + 16 * nb + j];
+            if (g == 0) p.stats[(int64_t)(p.S + s) * Tn + qbase + 16 * nb + j] = dsum[nb];
+        }
+    } else {
+        float mx[NB], ls[NB];
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) sc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int nb = 0; nb < NB; ++nb) { mx[nb] = -1e30f; ls[nb] = 0.f; }
+        if (PF) gload_rows<T, DP>(K, rk, tid);
+        for (int kt = 0; kt < Tn; kt += 64) {
+            if (!PF) gload_rows<T, DP>(K + (int64_t)kt * DP, rk, tid);
+            __syncthreads();
+            lstore_rows<DP>(Ks, rk, tid);
+            __syncthreads();
+            if (PF && kt + 64 < Tn) gload_rows<T, DP>(K + (int64_t)(kt + 64) * DP, rk, tid);
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const vec8 a = frag_rows<T, DP>(Ks, kb, ks, j, g);
+            for (int kb = 0; kb < 4; ++kb) {
+                f32x4 sc[NB];
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) sc[nb] = mfma16(a, qf[nb][ks], sc[nb]);
+                for (int nb = 0; nb < NB; ++nb) sc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const vec8 a = frag_rows<T, DP>(Ks, kb, ks, j, g);
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) sc[nb] = mfma16(a, qf[nb][ks], sc[nb]);
+                }
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const float v0 = sc[nb][0] * s2, v1 = sc[nb][1] * s2, v2 = sc[nb][2] * s2, v3 = sc[nb][3] * s2;
+                    const float mn = fmaxf(fmaxf(mx[nb], fmaxf(v0, v1)), fmaxf(v2, v3));
+                    ls[nb] = ls[nb] * __builtin_amdgcn_exp2f(mx[nb] - mn) + __builtin_amdgcn_exp2f(v0 - mn) +
+                             __builtin_amdgcn_exp2f(v1 - mn) + __builtin_amdgcn_exp2f(v2 - mn) + __builtin_amdgcn_exp2f(v3 - mn);
+                    mx[nb] = mn;
+                }
             }
+        }
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                const float v0 = sc[nb][0] * s2, v1 = sc[nb][1] * s2, v2 = sc[nb][2] * s2, v3 = sc[nb][3] * s2;
-                const float mn = fmaxf(fmaxf(mx[nb], fmaxf(v0, v1)), fmaxf(v2, v3));
-                ls[nb] = ls[nb] * __builtin_amdgcn_exp2f(mx[nb] - mn) + __builtin_amdgcn_exp2f(v0 - mn) +
-                         __builtin_amdgcn_exp2f(v1 - mn) + __builtin_amdgcn_exp2f(v2 - mn) + __builtin_amdgcn_exp2f(v3 - mn);
+        for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+            for (int o = 16; o <= 32; o <<= 1) {  // the four lanes (g = 0..3) of a query, fixed order
+                const float mo = __shfl_xor(mx[nb], o, 64), lo = __shfl_xor(ls[nb], o, 64);
+                const float mn = fmaxf(mx[nb], mo);
+                ls[nb] = ls[nb] * __builtin_amdgcn_exp2f(mx[nb] - mn) + lo * __builtin_amdgcn_exp2f(mo - mn);
                 mx[nb] = mn;
             }
-        }
-    }
-    float lse[NB];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-#pragma unroll
-        for (int o = 16; o <= 32; o <<= 1) {  // the four lanes (g = 0..3) of a query, fixed order
-            const float mo = __shfl_xor(mx[nb], o, 64), lo = __shfl_xor(ls[nb], o, 64);
-            const float mn = fmaxf(mx[nb], mo);
-            ls[nb] = ls[nb] * __builtin_amdgcn_exp2f(mx[nb] - mn) + lo * __builtin_amdgcn_exp2f(mo - mn);
-            mx[nb] = mn;
-        }
-        lse[nb] = mx[nb] + __builtin_amdgcn_logf(ls[nb]);  // v_log_f32 = log2
-        if (g == 0) {
-            p.stats[(int64_t)s * Tn + qbase + 16 * nb + j] = lse[nb];
-            p.stats[(int64_t)(p.S + s) * Tn + qbase + 16 * nb + j] = dsum[nb];
+            lse[nb] = mx[nb] + __builtin_amdgcn_logf(ls[nb]);  // v_log_f32 = log2
+            if (g == 0) {
+                p.stats[(int64_t)s * Tn + qbase + 16 * nb + j] = lse[nb];
+                p.stats[(int64_t)(p.S + s) * Tn + qbase + 16 * nb + j] = dsum[nb];
+            }
         }
     }
 
@@ -398,29 +406,29 @@ __global__ void __launch_bounds__(256) attn_bwd_dkdv_kernel(const AttnBwdArgs p)
         }
 }
 
-template <typename T, int DP, int NB>
+template <typename T, int DP, int NB, bool HAS_LSE>
 static int launch_bwd(const AttnBwdArgs& a, hipStream_t st) {
     typedef BwdLds<DP> L;
     constexpr bool PF = DP <= 64;  // register prefetch of the next tile: 32 VGPRs at DP = 64, too many above
     constexpr int lds_dq = 2 * L::ROWS + L::TRN, lds_kv = 2 * L::ROWS + 2 * L::TRN + 512;
     static std::atomic<uint64_t> done_dq{0}, done_kv{0};
-    set_lds_limit_once(done_dq, reinterpret_cast<const void*>(&attn_bwd_dq_kernel<T, DP, NB, PF>), lds_dq);
+    set_lds_limit_once(done_dq, reinterpret_cast<const void*>(&attn_bwd_dq_kernel<T, DP, NB, PF, HAS_LSE>), lds_dq);
     set_lds_limit_once(done_kv, reinterpret_cast<const void*>(&attn_bwd_dkdv_kernel<T, DP, NB, PF>), lds_kv);
     const dim3 grid(a.T / (64 * NB), a.S);
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<T, DP, NB, PF>), grid, dim3(256), lds_dq, st, a);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<T, DP, NB, PF, HAS_LSE>), grid, dim3(256), lds_dq, st, a);
     hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, DP, NB, PF>), grid, dim3(256), lds_kv, st, a);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : -(int)e;
 }
 
-template <typename T>
+template <typename T, bool HAS_LSE>
 static int dispatch_bwd(const AttnBwdArgs& a, int dp, hipStream_t st) {
     const bool wide = (a.T % 128) == 0;
     switch (dp) {
-        case 32: return launch_bwd<T, 32, 1>(a, st);
-        case 64: return wide ? launch_bwd<T, 64, 2>(a, st) : launch_bwd<T, 64, 1>(a, st);
-        case 96: return launch_bwd<T, 96, 1>(a, st);
-        case 160: return launch_bwd<T, 160, 1>(a, st);
+        case 32: return launch_bwd<T, 32, 1, HAS_LSE>(a, st);
+        case 64: return wide ? launch_bwd<T, 64, 2, HAS_LSE>(a, st) : launch_bwd<T, 64, 1, HAS_LSE>(a, st);
+        case 96: return launch_bwd<T, 96, 1, HAS_LSE>(a, st);
+        case 160: return launch_bwd<T, 160, 1, HAS_LSE>(a, st);
         default: return UR_E_BADARG;
     }
 }
@@ -428,15 +436,15 @@ static int dispatch_bwd(const AttnBwdArgs& a, int dp, hipStream_t st) {
 }  // namespace ur
 
 extern "C" int ur_attention_backward(const void* q, const void* k, const void* v, const void* o, const void* dout,
-                                     const void* qt, const void* kt, const void* dot, float* stats, void* dq, void* dk,
-                                     void* dv, int S, int T, int dp, float scale, int dtype, void* stream) {
+                                     const void* qt, const void* kt, const void* dot, float* stats, int has_lse, void* dq,
+                                     void* dk, void* dv, int S, int T, int dp, float scale, int dtype, void* stream) {
     if (!q || !k || !v || !o || !dout || !qt || !kt || !dot || !stats || !dq || !dk || !dv || S <= 0 || T <= 0 || (T & 63) ||
         S > 65535)
         return UR_E_BADARG;
     ur::AttnBwdArgs a{q, k, v, o, dout, qt, kt, dot, stats, dq, dk, dv, S, T, scale};
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == UR_DT_F16) return ur::dispatch_bwd<ur::f16>(a, dp, st);
-    if (dtype == UR_DT_BF16) return ur::dispatch_bwd<ur::bf16>(a, dp, st);
+    if (dtype == UR_DT_F16) return has_lse ? ur::dispatch_bwd<ur::f16, true>(a, dp, st) : ur::dispatch_bwd<ur::f16, false>(a, dp, st);
+    if (dtype == UR_DT_BF16) return has_lse ? ur::dispatch_bwd<ur::bf16, true>(a, dp, st) : ur::dispatch_bwd<ur::bf16, false>(a, dp, st);
     return UR_E_BADARG;
 }
 

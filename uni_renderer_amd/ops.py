@@ -457,11 +457,13 @@ def layernorm(x, gamma, beta, eps=1e-5, streams=1):
     return out
 
 
-def attention(q, k, vt, *, B, H, Tq, Tk, d, ldq, ldk, q_off=0, k_off=0, scale=None):
+def attention(q, k, vt, *, B, H, Tq, Tk, d, ldq, ldk, q_off=0, k_off=0, scale=None, lse=None):
     """q/k are token matrices holding head h at columns off + h*d (row strides ldq/ldk, batches contiguous);
     vt is a [B, H*d, Tk_pad] tensor or a row-slice view of a wider batched projection.
     ``scale=None``: d**-0.5.  ``scale=0``: q.k is already in log2 units (the projections folded scale*log2(e) in),
-    which for head dims with a zero-padded k column (d = 40) also selects the kernel without per-score multiply-adds."""
+    which for head dims with a zero-padded k column (d = 40) also selects the kernel without per-score multiply-adds.
+    ``lse``: optional contiguous fp32 [B*H, Tq] output, the row log-sum-exp in log2 units (training: the flash backward
+    starts from it); needs ``scale`` > 0."""
     _require_gpu(q)
     lib = _lib.load()
     o = torch.empty(B, Tq, H * d, dtype=q.dtype, device=q.device)
@@ -474,6 +476,10 @@ def attention(q, k, vt, *, B, H, Tq, Tk, d, ldq, ldk, q_off=0, k_off=0, scale=No
     a.B, a.H, a.Tq, a.Tk, a.d = B, H, Tq, Tk, d
     a.scale = float(scale if scale is not None else d ** -0.5)
     a.dtype = DT[q.dtype]
+    if lse is not None:
+        if lse.dtype != torch.float32 or not lse.is_contiguous() or lse.numel() < B * H * Tq:
+            raise RuntimeError("attention: lse must be a contiguous fp32 [B*H, Tq] tensor")
+        a.lse = lse.data_ptr()
     e0 = _prof_begin()
     check(lib.ur_attention(C.byref(a), _stream()), "ur_attention")
     _prof_end(e0, f"attention_d{d}", 4.0 * B * H * Tq * Tk * d, (2.0 * B * Tq + 2.0 * B * Tk) * H * d * q.element_size())
