@@ -497,3 +497,125 @@ def test_fused_adamw_matches_torch(dev):
     ref2.step()
     worst = max(float((a - b).abs().max()) for a, b in zip(our2.param_groups[0]["params"], ref2.param_groups[0]["params"]))
     assert worst < 1e-5, (worst, float(our2.state[our2.param_groups[0]['params'][0]]['step']), float(ref2.state[ref2.param_groups[0]['params'][0]]['step']))
+
+def _graphed_worker(rank, world, port, q):
+    """one rank of the two-process GraphedTrainStep test (both ranks on cuda:0, gloo collectives between the graphs)"""
+    import os
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import torch.distributed as dist
+
+    from uni_renderer_amd.optim import FusedAdamW
+    from uni_renderer_amd.parallel import GradientBuckets
+    from uni_renderer_amd.train_step import GraphedTrainStep, train_step
+
+    try:
+        import time
+        t0, marks = time.time(), []
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dev = torch.device("cuda:0")
+
+        def setup():
+            oracle = O.build_triplet(O.TINY_CONFIG, seed=36)
+            nets = build_product_from_oracle(*oracle, torch.float32, dev)
+            for m in nets:
+                m.train()
+                m.requires_grad_(True)
+            return nets, FusedAdamW([p for m in nets for p in m.parameters()], lr=2e-4)
+
+        def make_batch(it):
+            x, c, ehs, ti, ta = [t.to(dev) for t in O.make_inputs(2, 16, 64, seed=40 + 2 * it + rank)]
+            g = torch.Generator().manual_seed(50 + 2 * it + rank)
+            return dict(x_t=x, cond=c, ehs=ehs, t_img=ti, t_attr=ta, target_img=torch.randn(2, 4, 16, 16, generator=g).to(dev),
+                        target_attr=torch.randn(2, 28, 16, 16, generator=g).to(dev))
+
+        nets_e, opt_e = setup()
+        b_e = GradientBuckets(nets_e, bucket_mb=32.0, comm_dtype=None, overlap=False)
+        for it in range(3):
+            train_step(nets_e, make_batch(it), optimizer=opt_e, buckets=b_e, dtype=torch.bfloat16)
+        marks.append(round(time.time() - t0, 1))
+        nets_g, opt_g = setup()
+        b_g = GradientBuckets(nets_g, bucket_mb=32.0, comm_dtype=None, overlap=False)
+        step = GraphedTrainStep(nets_g, make_batch(0), opt_g, buckets=b_g, dtype=torch.bfloat16, warmup=0)
+        for it in range(3):
+            st = step.step(make_batch(it))
+        marks.append(round(time.time() - t0, 1))
+        flat_e = torch.cat([p.detach().reshape(-1) for m in nets_e for p in m.parameters()])
+        flat_g = torch.cat([p.detach().reshape(-1) for m in nets_g for p in m.parameters()])
+        same = bool(torch.equal(flat_e, flat_g))
+        worst = float((flat_e - flat_g).abs().max())
+        both = [torch.empty_like(flat_g.cpu()) for _ in range(world)]
+        dist.all_gather(both, flat_g.cpu())
+        marks.append(round(time.time() - t0, 1))
+        q.put((rank, same, worst, bool(torch.equal(both[0], both[1])), float(st["loss"]), float(st["grad_norm"]), marks))
+        dist.barrier()
+        torch.cuda.synchronize()
+        q.close()
+        q.join_thread()
+        os._exit(0)  # tearing down gloo + the interpreter with live HIP graphs was seen to stall for minutes: just leave
+    except Exception as e:  # report instead of hanging the parent
+        import traceback
+        q.put((rank, repr(e) + traceback.format_exc()[-600:], 0.0, False, 0.0, 0.0, []))
+
+
+@pytest.mark.gpu
+def test_graphed_train_step_two_ranks(dev):
+    """train_step.GraphedTrainStep on two ranks: forward + backward as one graph writing into the flat buckets, eager
+    collectives and clipping + FusedAdamW between the replays -- same parameters after three steps as the eager
+    bucketed step, identical on both ranks."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_graphed_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(30)
+        if p.is_alive():
+            p.terminate()
+    print({"graphed_two_rank_training": res})
+    if any(isinstance(r[1], str) and "gloo" in r[1].lower() and "cuda" in r[1].lower() for r in res):
+        pytest.skip("this torch build's gloo backend does not take device tensors")
+    for r in res:
+        assert not isinstance(r[1], str), r
+        assert r[3], res          # both ranks hold the same parameters
+        assert r[2] < 1e-6, res   # and they are the eager trajectory (bit-identical in practice)
+
+
+@pytest.mark.gpu
+def test_graphed_train_step_single_gpu(dev):
+    """GraphedTrainStep without buckets = the whole step as one graph; new batches are copied into the captured inputs."""
+    from uni_renderer_amd.optim import FusedAdamW
+    from uni_renderer_amd.train_step import GraphedTrainStep, train_step
+
+    def setup():
+        oracle = O.build_triplet(O.TINY_CONFIG, seed=34)
+        nets = build_product_from_oracle(*oracle, torch.float32, dev)
+        for m in nets:
+            m.train()
+            m.requires_grad_(True)
+        return nets, FusedAdamW([p for m in nets for p in m.parameters()], lr=2e-4)
+
+    def make_batch(it):
+        x, c, ehs, ti, ta = [t.to(dev) for t in O.make_inputs(2, 16, 64, seed=20 + it)]
+        g = torch.Generator().manual_seed(21 + it)
+        return dict(x_t=x, cond=c, ehs=ehs, t_img=ti, t_attr=ta, target_img=torch.randn(2, 4, 16, 16, generator=g).to(dev),
+                    target_attr=torch.randn(2, 28, 16, 16, generator=g).to(dev))
+
+    nets_e, opt_e = setup()
+    eager = [train_step(nets_e, make_batch(it), optimizer=opt_e, dtype=torch.bfloat16)["loss"] for it in range(4)]
+    nets_g, opt_g = setup()
+    step = GraphedTrainStep(nets_g, make_batch(0), opt_g, dtype=torch.bfloat16, warmup=0)
+    graphed = [float(step.step(make_batch(it))["loss"]) for it in range(4)]
+    print({"eager": eager, "graphed": graphed})
+    assert eager == graphed
+    for a, b in zip((p for m in nets_e for p in m.parameters()), (p for m in nets_g for p in m.parameters())):
+        assert torch.equal(a, b)

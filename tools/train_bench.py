@@ -31,8 +31,8 @@ def main():
     ap.add_argument("--comm-dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-overlap", action="store_true", help="reduce all buckets after the backward instead of during it")
     ap.add_argument("--torch-adamw", action="store_true", help="torch.optim.AdamW(fused=True) instead of optim.FusedAdamW")
-    ap.add_argument("--graph", action="store_true", help="capture the whole step (forward, backward, clipping, AdamW) "
-                    "into one HIP graph and time replays (single GPU)")
+    ap.add_argument("--graph", action="store_true", help="time HIP-graph replays (train_step.GraphedTrainStep): one GPU = the whole step "
+                    "as one graph; several = forward + backward graph, eager bucket collectives and update")
     args = ap.parse_args()
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
     torch.cuda.set_device(local)
@@ -59,24 +59,16 @@ def main():
         from uni_renderer_amd.optim import FusedAdamW
         opt = FusedAdamW(params, lr=1e-5)
     buckets = GradientBuckets(nets, comm_dtype=(torch.bfloat16 if args.comm_dtype == "bf16" else None), algorithm=args.algorithm,
-                              overlap=not args.no_overlap) if world > 1 else None
+                              overlap=not (args.no_overlap or args.graph)) if world > 1 else None
     if args.graph:
-        assert world == 1, "--graph: single GPU"
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(2):  # warm-up on the capture stream (allocator pools, lazy optimizer state)
-                train_step(nets, batch, optimizer=opt, dtype=dt, as_tensors=True)
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            gstats = train_step(nets, batch, optimizer=opt, dtype=dt, as_tensors=True)
-        g.replay()
+        # one GPU: the whole step is one graph; several: forward + backward graph, eager bucket collectives and update
+        from uni_renderer_amd.train_step import GraphedTrainStep
+        gstep = GraphedTrainStep(nets, batch, opt, buckets=buckets, dtype=dt)
+        gstats = gstep.step()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            g.replay()
+            gstats = gstep.step()
         torch.cuda.synchronize()
         dtm = (time.perf_counter() - t0) / args.steps
         stats = {k: float(v) for k, v in gstats.items()}

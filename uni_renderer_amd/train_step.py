@@ -304,16 +304,9 @@ def reference_losses(nets: Sequence[torch.nn.Module], batch: Dict[str, torch.Ten
     return res
 
 
-def train_step(nets: Sequence[torch.nn.Module], batch: Dict[str, torch.Tensor], optimizer=None, buckets=None,
-               dtype=torch.bfloat16, max_grad_norm: Optional[float] = 1.0, inverse: Optional[bool] = None,
-               as_tensors: bool = False) -> Dict[str, float]:
-    """One optimisation step: forward, losses, backward (HIP kernels), gradient all-reduce (``buckets``: a
-    parallel.GradientBuckets, no-op on one rank), clipping (train.py:1422-1424), optimizer step.
-    ``inverse``: None = the plain two-stream MSE objective (mse_losses); True / False = the reference's inverse-rendering
-    (cycle consistency) / rendering (contrastive) objectives (reference_losses).  Ranks may pick different branches
-    (compute_t, train.py:445): parameters without a gradient contribute zeros to the buckets.
-    ``as_tensors``: return the statistics as device tensors (no host synchronisation: the step can then be captured
-    into a HIP graph, tools/train_bench.py --graph)."""
+def _forward_backward(nets, batch, optimizer, buckets, dtype, inverse):
+    """forward, losses, backward; gradients end in ``buckets``' flat buffers (collectives of complete buckets already in
+    flight when the buckets were built with ``overlap=True``) or in fresh ``p.grad`` tensors."""
     unet, enc, dec = nets
     if inverse is None:
         out = dual_stream_forward(unet, enc, dec, batch["x_t"], batch["cond"], batch["ehs"], batch["t_img"],
@@ -326,14 +319,16 @@ def train_step(nets: Sequence[torch.nn.Module], batch: Dict[str, torch.Tensor], 
     elif optimizer is not None:
         optimizer.zero_grad(set_to_none=True)
     loss.backward()  # with ``buckets``: complete buckets are all-reduced (async) while the backward is still running
-    if buckets is not None:
-        buckets.finish()
-    stats = {"loss": loss.detach()}
+    return loss.detach()
+
+
+def _clip_and_update(nets, optimizer, buckets, max_grad_norm, stats):
+    """train.py:1422-1425: clip_grad_norm_ + optimizer.step(), the clipping folded into the optimizer pass when it can."""
     folded = False
     if max_grad_norm is not None:
-        # torch's fused Adam / AdamW kernels divide every gradient by ``optimizer.grad_scale`` on the fly (the hook
-        # GradScaler uses): handing them 1 / clip_coefficient applies train.py:1422-1424's clipping inside the optimizer
-        # pass instead of a separate read-modify-write sweep over 7 GB of gradients
+        # torch's fused Adam / AdamW kernels (and optim.FusedAdamW) divide every gradient by ``optimizer.grad_scale`` on
+        # the fly (the hook GradScaler uses): handing them 1 / clip_coefficient applies train.py:1422-1424's clipping
+        # inside the optimizer pass instead of a separate read-modify-write sweep over 7 GB of gradients
         fold = (optimizer is not None and getattr(optimizer, "_step_supports_amp_scaling", False)
                 and all(g.get("fused") for g in optimizer.param_groups))
         if fold:
@@ -355,4 +350,97 @@ def train_step(nets: Sequence[torch.nn.Module], batch: Dict[str, torch.Tensor], 
         optimizer.step()
         if folded:
             del optimizer.grad_scale, optimizer.found_inf
+
+
+def train_step(nets: Sequence[torch.nn.Module], batch: Dict[str, torch.Tensor], optimizer=None, buckets=None,
+               dtype=torch.bfloat16, max_grad_norm: Optional[float] = 1.0, inverse: Optional[bool] = None,
+               as_tensors: bool = False) -> Dict[str, float]:
+    """One optimisation step: forward, losses, backward (HIP kernels), gradient all-reduce (``buckets``: a
+    parallel.GradientBuckets, no-op on one rank), clipping (train.py:1422-1424), optimizer step.
+    ``inverse``: None = the plain two-stream MSE objective (mse_losses); True / False = the reference's inverse-rendering
+    (cycle consistency) / rendering (contrastive) objectives (reference_losses).  Ranks may pick different branches
+    (compute_t, train.py:445): parameters without a gradient contribute zeros to the buckets.
+    ``as_tensors``: return the statistics as device tensors (no host synchronisation: the step can then be captured
+    into a HIP graph, tools/train_bench.py --graph)."""
+    stats = {"loss": _forward_backward(nets, batch, optimizer, buckets, dtype, inverse)}
+    if buckets is not None:
+        buckets.finish()
+    _clip_and_update(nets, optimizer, buckets, max_grad_norm, stats)
     return stats if as_tensors else {k: float(v) for k, v in stats.items()}
+
+
+class GraphedTrainStep:
+    """The training step as HIP-graph replays, also on several GPUs.
+
+    Eagerly the step is host-bound (~9700 launches issued from Python: 137 ms against 93 ms of GPU work at cfg 4's
+    per-GPU shape), which is also what bounds the data-parallel step when the gradient collectives are launched from
+    autograd hooks.  Here forward + losses + backward are ONE captured graph writing the gradients into the flat bucket
+    buffers of ``buckets`` (built with ``overlap=False``: no hooks, nothing but kernels inside the capture); the
+    collectives run eagerly on those few flat buffers (``buckets.finish()``: one all-reduce or reduce-scatter +
+    all-gather per 256 MB bucket, bf16 on the wire if asked), and so do clipping + the optimizer step (a handful of launches).
+    Without ``buckets`` (one GPU) the whole step is a single graph.  One instance per objective branch (``inverse``):
+    the branch is a host decision (train.py:445), so a training loop keeps one instance per branch over the same
+    networks and optimizer.  ``warmup`` eager steps run first (REAL optimisation steps on ``batch``: allocator pools, lazy
+    optimizer state); 0 is allowed with optimizers whose state can be created up front (optim.FusedAdamW)."""
+
+    def __init__(self, nets, batch: Dict[str, torch.Tensor], optimizer, buckets=None, dtype=torch.bfloat16,
+                 max_grad_norm: Optional[float] = 1.0, inverse: Optional[bool] = None, warmup: int = 2):
+        if buckets is not None and getattr(buckets, "_hooks", None):
+            raise ValueError("GraphedTrainStep needs GradientBuckets(..., overlap=False): hooks cannot run inside a capture")
+        self.nets, self.optimizer, self.buckets = nets, optimizer, buckets
+        # gloo (the CPU-side test transport) stages device tensors through the host; handing it a tensor whose producer
+        # graph is still replaying was measured at 50-140 s per step with two ranks on one GPU (0.03 s after a stream
+        # synchronise).  RCCL collectives are stream-ordered and need no host wait.
+        import torch.distributed as dist
+        self._host_sync_before_collectives = bool(buckets is not None and dist.is_initialized()
+                                                  and dist.get_backend(getattr(buckets, "group", None)) == "gloo")
+        self.batch = {k: v.clone() for k, v in batch.items()}
+        self.stats: Dict[str, torch.Tensor] = {}
+        kw = dict(dtype=dtype, inverse=inverse)
+        if warmup == 0:
+            # nothing may be created lazily inside the capture (a zero-fill captured there would re-run on every replay)
+            init = getattr(optimizer, "_init_state", None)
+            if init is None:
+                raise ValueError("warmup=0 needs an optimizer that can create its state eagerly (optim.FusedAdamW)")
+            for grp in optimizer.param_groups:
+                for p in grp["params"]:
+                    if p.requires_grad:
+                        init(p)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):  # allocator pools, lazy optimizer state, the tuning-table lookups
+                self._eager(kw, max_grad_norm)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.g_fb = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_fb):
+            self.stats["loss"] = _forward_backward(nets, self.batch, optimizer if buckets is None else None, buckets, **kw)
+            if buckets is None:
+                _clip_and_update(nets, optimizer, None, max_grad_norm, self.stats)
+        self.max_grad_norm = max_grad_norm
+        if buckets is not None:
+            buckets._reset()
+
+    def _eager(self, kw, max_grad_norm):
+        st = {"loss": _forward_backward(self.nets, self.batch, self.optimizer, self.buckets, **kw)}
+        if self.buckets is not None:
+            self.buckets.finish()
+        _clip_and_update(self.nets, self.optimizer, self.buckets, max_grad_norm, st)
+
+    def step(self, batch: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
+        """One optimisation step on ``batch`` (copied into the captured input buffers; None: the last one again).
+        Returns device tensors (loss, grad_norm): reading them is the caller's synchronisation."""
+        if batch is not None:
+            for k, v in batch.items():
+                self.batch[k].copy_(v)
+        self.g_fb.replay()
+        if self.buckets is not None:
+            if self._host_sync_before_collectives:
+                torch.cuda.current_stream().synchronize()
+            self.buckets.finish()
+            # clipping + optimizer eagerly (~25 launches with optim.FusedAdamW).  A second captured graph here was measured
+            # to read STALE bucket contents (zeros of the first buckets, as left by zero_grad) after the collective had
+            # rewritten them from another stream -- ordinary launches see the reduced gradients.
+            _clip_and_update(self.nets, self.optimizer, self.buckets, self.max_grad_norm, self.stats)
+        return self.stats
