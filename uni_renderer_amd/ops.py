@@ -74,7 +74,16 @@ def _prof_end(e0, key, flops, nbytes):
     _prof.append((key, float(flops), float(nbytes), e0, e1))
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream() -> int:
+    """The current HIP stream of the current device as an integer handle.  ``torch.cuda.current_stream()`` builds a
+    Stream object through several Python layers (~9 us, once per launch: 8 ms of a host-bound eager training step); the
+    raw accessor is the same value in ~0.3 us."""
+    if _raw_stream is not None and _cur_device is not None:
+        return _raw_stream(_cur_device())
     return torch.cuda.current_stream().cuda_stream
 
 

@@ -66,6 +66,15 @@ class FusedAdamW(torch.optim.Optimizer):
             ps = [p for p in group["params"] if p.grad is not None]
             if not ps:
                 continue
+            gptrs = tuple(p.grad.data_ptr() for p in ps)
+            cached = group.get("_ur_launches")
+            if cached is not None and cached[0] == gptrs and cached[1] == tuple(p.data_ptr() for p in ps):
+                # same tensors as last step (gradient views of flat buckets, or a captured graph's addresses): the
+                # descriptor arrays are reused -- building them is ~6 ms of host time per step for 700 tensors
+                step_t = cached[3]
+                step_t += 1
+                self._launch(lib, group, cached[2], step_t, grad_scale, found_inf)
+                continue
             for p in ps:
                 if p.dtype != torch.float32 or p.grad.dtype != torch.float32 or not p.is_cuda:
                     raise RuntimeError("FusedAdamW updates fp32 master parameters on the GPU (train.py:1082-1089)")
@@ -78,11 +87,7 @@ class FusedAdamW(torch.optim.Optimizer):
                 if st["step"] is not step_t:
                     st["step"] = step_t
             step_t += 1
-            beta1, beta2 = group["betas"]
-            lr = group["lr"]
-            if isinstance(lr, torch.Tensor):
-                raise NotImplementedError("FusedAdamW: tensor learning rates are not supported")
-            s_ = _stream()
+            arrays = []
             for i in range(0, len(ps), MAX_TENSORS):
                 chunk = ps[i:i + MAX_TENSORS]
                 arr = (_Tensor * len(chunk))()
@@ -91,16 +96,31 @@ class FusedAdamW(torch.optim.Optimizer):
                     arr[k].p, arr[k].g = p.data_ptr(), p.grad.data_ptr()
                     arr[k].m, arr[k].v = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
                     arr[k].n = p.numel()
-                check(lib.ur_adamw_multi(arr, len(chunk), float(lr), float(beta1), float(beta2), float(group["eps"]),
-                                         float(group["weight_decay"]), step_t.data_ptr(),
-                                         grad_scale.data_ptr() if grad_scale is not None else None,
-                                         found_inf.data_ptr() if found_inf is not None else None, s_), "ur_adamw_multi")
+                arrays.append(arr)
+            # the cache holds raw addresses: keep what they point into alive next to it (states live in self.state)
+            group["_ur_launches"] = (gptrs, tuple(p.data_ptr() for p in ps), arrays, step_t)
+            self._launch(lib, group, arrays, step_t, grad_scale, found_inf)
         return loss
+
+    @staticmethod
+    def _launch(lib, group, arrays, step_t, grad_scale, found_inf):
+        beta1, beta2 = group["betas"]
+        lr = group["lr"]
+        if isinstance(lr, torch.Tensor):
+            raise NotImplementedError("FusedAdamW: tensor learning rates are not supported")
+        s_ = _stream()
+        for arr in arrays:
+            check(lib.ur_adamw_multi(arr, len(arr), float(lr), float(beta1), float(beta2), float(group["eps"]),
+                                     float(group["weight_decay"]), step_t.data_ptr(),
+                                     grad_scale.data_ptr() if grad_scale is not None else None,
+                                     found_inf.data_ptr() if found_inf is not None else None, s_), "ur_adamw_multi")
 
     def state_dict(self):
         """torch.optim.AdamW's layout.  The per-parameter ``step`` entries alias one device scalar inside this object;
         a state dict hands out independent copies (torch's optimizers increment every entry on their own)."""
         sd = super().state_dict()
+        for grp in sd["param_groups"]:
+            grp.pop("_ur_launches", None)  # host-side launch cache, not optimizer state
         for st in sd["state"].values():
             if "step" in st:
                 st["step"] = st["step"].clone()
@@ -108,6 +128,8 @@ class FusedAdamW(torch.optim.Optimizer):
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
+        for group in self.param_groups:
+            group.pop("_ur_launches", None)  # the state tensors were replaced
         for group in self.param_groups:  # private fp32 device scalars (torch may hand back the caller's tensors uncopied)
             for p in group["params"]:
                 st = self.state.get(p)
