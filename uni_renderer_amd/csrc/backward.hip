@@ -184,13 +184,19 @@ __global__ void __launch_bounds__(256) colsum_kernel(const T* __restrict__ x, in
     }
 }
 
+// 64 columns per workgroup, four 64-lane groups over contiguous quarters of the slices, partial sums added in group order
 __global__ void __launch_bounds__(256) colsum_fold_kernel(const float* __restrict__ ws, int N, int slices,
                                                           float* __restrict__ out) {
-    const int n = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y;
-    if (n >= N) return;
+    __shared__ float red[4][64];
+    const int nl = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + nl, g = blockIdx.y;
+    const int len = (slices + 3) >> 2, k0 = q * len, k1 = min(slices, k0 + len);
     float a = 0.f;
-    for (int k = 0; k < slices; ++k) a += ws[((int64_t)g * slices + k) * N + n];
-    out[(int64_t)g * N + n] = a;
+    if (n < N)
+        for (int k = k0; k < k1; ++k) a += ws[((int64_t)g * slices + k) * N + n];
+    red[q][nl] = a;
+    __syncthreads();
+    if (q == 0 && n < N) out[(int64_t)g * N + n] = ((red[0][nl] + red[1][nl]) + red[2][nl]) + red[3][nl];
 }
 
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
@@ -349,14 +355,27 @@ __global__ void __launch_bounds__(256) gn_bwd_reduce_kernel(const T* __restrict_
 }
 
 // chan_sum[b][c] = sum over the nred chunks of chan_part[b][chunk][c] (fixed order); one thread per (channel, component)
+// A workgroup folds 32 columns: eight 32-lane groups each sum a contiguous eighth of the chunks (up to 512 dependent adds
+// in one thread made this 16 us on a dozen workgroups), then the eight partial sums are added in group order.
 __global__ void __launch_bounds__(256) gn_bwd_fold_kernel(const float* __restrict__ chan_part, int C2, int nred,
                                                           float* __restrict__ chan_sum) {
-    const int e = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
-    if (e >= C2) return;
-    const float* src = chan_part + (int64_t)b * nred * C2 + e;
+    __shared__ float red[8][32];
+    const int el = threadIdx.x & 31, q = threadIdx.x >> 5;
+    const int e = blockIdx.x * 32 + el, b = blockIdx.y;
+    const int len = (nred + 7) >> 3, k0 = q * len, k1 = min(nred, k0 + len);
     float a = 0.f;
-    for (int k = 0; k < nred; ++k) a += src[(int64_t)k * C2];
-    chan_sum[(int64_t)b * C2 + e] = a;
+    if (e < C2) {
+        const float* src = chan_part + (int64_t)b * nred * C2 + e;
+        for (int k = k0; k < k1; ++k) a += src[(int64_t)k * C2];
+    }
+    red[q][el] = a;
+    __syncthreads();
+    if (q == 0 && e < C2) {
+        float t = red[0][el];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) t += red[i][el];
+        chan_sum[(int64_t)b * C2 + e] = t;
+    }
 }
 
 template <typename T>
@@ -802,7 +821,7 @@ extern "C" int ur_colsum(const void* x, int64_t ldx, int M, int N, int rows_per_
     } else {
         UR_DISPATCH(dtype, hipLaunchKernelGGL((colsum_kernel<T>), grid, dim3(256), 0, s, (const T*)x, ldx, M, N, rpg, sl, dst));
     }
-    if (sl > 1) hipLaunchKernelGGL(colsum_fold_kernel, dim3((N + 255) / 256, groups), dim3(256), 0, s, workspace, N, sl, out);
+    if (sl > 1) hipLaunchKernelGGL(colsum_fold_kernel, dim3((N + 63) / 64, groups), dim3(256), 0, s, workspace, N, sl, out);
     return last_error();
 }
 
@@ -842,7 +861,7 @@ extern "C" int ur_groupnorm_backward(const void* x, const void* dy, int C, int B
     UR_DISPATCH(dtype, {
         hipLaunchKernelGGL((gn_bwd_reduce_kernel<T>), dim3(nred, B), dim3(256), 0, s, (const T*)x, (const T*)dy, C, rows,
                            groups, nstat, nred, partial, gamma, beta, eps, silu, chan_part);
-        hipLaunchKernelGGL(gn_bwd_fold_kernel, dim3((2 * C + 255) / 256, B), dim3(256), 0, s, chan_part, 2 * C, nred, chan_sum);
+        hipLaunchKernelGGL(gn_bwd_fold_kernel, dim3((2 * C + 31) / 32, B), dim3(256), 0, s, chan_part, 2 * C, nred, chan_sum);
         hipLaunchKernelGGL((gn_bwd_apply_kernel<T>), dim3(nchunks, B), dim3(256), 0, s, (const T*)x, (const T*)dy, C, rows,
                            groups, nstat, 1, nchunks, partial, chan_sum, gamma, beta, eps, silu, (T*)dx);
     });
