@@ -385,7 +385,7 @@ def train_step(nets: Sequence[torch.nn.Module], batch: Dict[str, torch.Tensor], 
 class GraphedTrainStep:
     """The training step as HIP-graph replays, also on several GPUs.
 
-    Eagerly the step is host-bound (~9700 launches issued from Python: 137 ms against 93 ms of GPU work at cfg 4's
+    Eagerly the step is host-bound (~9700 launches issued from Python: 118 ms against 90 ms of GPU work at cfg 4's
     per-GPU shape), which is also what bounds the data-parallel step when the gradient collectives are launched from
     autograd hooks.  Here forward + losses + backward are ONE captured graph writing the gradients into the flat bucket
     buffers of ``buckets`` (built with ``overlap=False``: no hooks, nothing but kernels inside the capture); the
