@@ -381,21 +381,25 @@ typedef struct ur_adamw_tensor {
 int ur_adamw_multi(const ur_adamw_tensor* tensors, int n_tensors, float lr, float beta1, float beta2, float eps,
                    float weight_decay, const float* step, const float* grad_scale, const float* found_inf, void* stream);
 
-/* Flash backward of o = softmax(q k^T * scale) v for SELF-attention shapes (one token count T for queries and keys,
- * T % 64 == 0, padded head dim dp in {32, 64, 96, 160}: ur_attention_backward_supported).  Replaces the reference's
- * autograd through F.scaled_dot_product_attention (diffusers AttnProcessor2_0 under models/attention.py
- * BasicTransformerBlock) in the training step.  P is never materialised; two launches (row statistics + dq, then
- * dk / dv), every sum in a fixed order.
- *   q, k, v, o, dout  [S][T][dp]  per (batch, head) slices, head dim zero-padded to dp (ur_split_heads)
- *   qt, kt, dot       [S][dp][T]  transposes of q, k, dout (ur_transpose2d)
- *   stats             [2][S][T]   fp32 workspace (row log-sum-exp in log2 units | rowsum(dout * o)), written here;
- *                                 has_lse = 1: the first half already holds the forward's ur_attn_desc.lse (the
- *                                 log-sum-exp pass of the dq kernel is skipped)
- *   dq, dk, dv        [S][T][dp]  outputs (padding columns come out as zeros) */
+/* Flash backward of o = softmax(q k^T * scale) v (ur_attention_backward_supported: Tq % 64 == 0, padded head dim dp in
+ * {32, 64, 96, 160}).  Replaces the reference's autograd through F.scaled_dot_product_attention (diffusers
+ * AttnProcessor2_0 under models/attention.py BasicTransformerBlock) in the training step, for the self-attention and the
+ * 77-key cross-attention.  P is never materialised; two launches (row statistics + dq, then dk / dv; a third that folds
+ * the query splits when there are few keys), every sum in a fixed order.
+ *   q, o, dout        [S][Tq][dp]   per (batch, head) slices, head dim zero-padded to dp (ur_split_heads)
+ *   k, v              [S][Tk][dp]   Tk a multiple of 64 (rows >= Tk_valid are zero padding and masked out of the softmax)
+ *   qt, dot | kt      [S][dp][Tq] | [S][dp][Tk]   transposes of q, dout | k (ur_transpose2d)
+ *   stats             [2][S][Tq]    fp32 workspace (row log-sum-exp in log2 units | rowsum(dout * o)), written here;
+ *                                   has_lse = 1: the first half already holds the forward's ur_attn_desc.lse (the
+ *                                   log-sum-exp pass of the dq kernel is skipped)
+ *   part              fp32 workspace of 2 * G * S * Tk * dp floats, G = ur_attention_backward_splits(S, Tq, Tk, dp);
+ *                     may be NULL when G == 1
+ *   dq | dk, dv       [S][Tq][dp] | [S][Tk][dp]   outputs (padding columns come out as zeros) */
 int ur_attention_backward(const void* q, const void* k, const void* v, const void* o, const void* dout, const void* qt,
-                          const void* kt, const void* dot, float* stats, int has_lse, void* dq, void* dk, void* dv, int S,
-                          int T, int dp, float scale, int dtype, void* stream);
-int ur_attention_backward_supported(int T, int dp);
+                          const void* kt, const void* dot, float* stats, int has_lse, void* dq, void* dk, void* dv,
+                          float* part, int S, int Tq, int Tk, int Tk_valid, int dp, float scale, int dtype, void* stream);
+int ur_attention_backward_supported(int Tq, int Tk, int dp);
+int ur_attention_backward_splits(int S, int Tq, int Tk, int dp);
 
 /* Attention backward helpers: P = softmax(Q K^T * scale) is recomputed and materialised per (batch, head); the five
  * GEMMs of the gradient (S, dV = P^T dO, dP = dO V^T, dQ = dS K, dK = dS^T Q) run z-batched on ur_igemm.

@@ -157,7 +157,7 @@ def test_flash_attention_backward(dev, dtype, shape, fused):
     o_ref = F.scaled_dot_product_attention(qr.view(B, T, H, d).transpose(1, 2), kr.view(B, T, H, d).transpose(1, 2),
                                            vr.view(B, T, H, d).transpose(1, 2)).transpose(1, 2).reshape(B, T, C)
     (o_ref * do.float().cpu()).sum().backward()
-    assert bw.FLASH_BACKWARD and bw._lib.load().ur_attention_backward_supported(T, (d + 31) // 32 * 32)
+    assert bw.FLASH_BACKWARD and bw._lib.load().ur_attention_backward_supported(T, T, (d + 31) // 32 * 32)
     if fused:
         qkv = torch.cat([q, k, v], dim=-1).requires_grad_()
         o = A.AttentionQKV.apply(qkv, H)
@@ -332,3 +332,34 @@ def test_attention_forward_lse(dev, dtype, shape):
     err = float((lse - ref).abs().max())
     print({"attention_forward_lse": str(dtype), "shape": shape, "max_abs_err_log2": err})
     assert err < (2e-3 if dtype == torch.float16 else 1.5e-2)
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(2, 2, 40, 128, 77), (1, 8, 40, 1024, 77), (4, 8, 40, 4096, 77), (1, 2, 80, 64, 77),
+                                   (1, 2, 160, 64, 40), (1, 2, 40, 128, 200), (1, 4, 40, 256, 128)])
+def test_flash_attention_backward_cross(dev, dtype, shape):
+    """The flash backward with fewer (padded, masked) keys than queries -- the 77-key cross-attention -- incl. shapes whose
+    dk / dv kernel splits the queries and folds fp32 partial sums; through autograd_ops.Attention (forward log-sum-exp
+    handed over) and directly (log-sum-exp pass in the dq kernel), against fp32 SDPA autograd."""
+    from uni_renderer_amd import backward as bw
+    from uni_renderer_amd import autograd_ops as A
+    B, H, d, Tq, Tk = shape
+    C = H * d
+    q, do = _rand((B, Tq, C), dtype, dev, 1), _rand((B, Tq, C), dtype, dev, 4)
+    k, v = _rand((B, Tk, C), dtype, dev, 2), _rand((B, Tk, C), dtype, dev, 3)
+    qr, kr, vr = (t.float().cpu().requires_grad_() for t in (q, k, v))
+    o_ref = F.scaled_dot_product_attention(qr.view(B, Tq, H, d).transpose(1, 2), kr.view(B, Tk, H, d).transpose(1, 2),
+                                           vr.view(B, Tk, H, d).transpose(1, 2)).transpose(1, 2).reshape(B, Tq, C)
+    (o_ref * do.float().cpu()).sum().backward()
+    lib = bw._lib.load()
+    assert lib.ur_attention_backward_supported(Tq, Tk, (d + 31) // 32 * 32)
+    q_, k_, v_ = (t.clone().requires_grad_() for t in (q, k, v))
+    o = A.Attention.apply(q_, k_, v_, H)
+    o.backward(do)
+    direct = bw.attention_backward(q, k, v, do, H, o=o.detach())  # no stats: the dq kernel computes the log-sum-exp
+    tol = TOL[dtype] * 2
+    errs = [rel_l2(q_.grad, qr.grad), rel_l2(k_.grad, kr.grad), rel_l2(v_.grad, vr.grad)]
+    errs2 = [rel_l2(a, b.grad) for a, b in zip(direct, (qr, kr, vr))]
+    G = lib.ur_attention_backward_splits(B * H, Tq, (Tk + 63) // 64 * 64, (d + 31) // 32 * 32)
+    print({"flash_attention_backward_cross": str(dtype), "shape": shape, "query_splits": G, "rel_l2_dq_dk_dv": errs,
+           "own_lse": errs2})
+    assert rel_l2(o, o_ref) < TOL[dtype] and max(errs) < tol and max(errs2) < tol, (errs, errs2)

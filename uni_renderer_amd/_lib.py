@@ -94,8 +94,9 @@ SYMBOLS = {
     "ur_merge_heads": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int64, C.c_int, C.c_int, vp]),
     "ur_softmax_rows": (C.c_int, [vp, C.c_int64, C.c_int64, C.c_int, C.c_int, vp]),
     "ur_softmax_backward_rows": (C.c_int, [vp, vp, C.c_int64, C.c_int64, C.c_int, C.c_float, C.c_int, vp]),
-    "ur_attention_backward": (C.c_int, [vp] * 9 + [C.c_int] + [vp] * 3 + [C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, vp]),
-    "ur_attention_backward_supported": (C.c_int, [C.c_int, C.c_int]),
+    "ur_attention_backward": (C.c_int, [vp] * 9 + [C.c_int] + [vp] * 4 + [C.c_int] * 5 + [C.c_float, C.c_int, vp]),
+    "ur_attention_backward_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "ur_attention_backward_splits": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "ur_transpose2d_multi": (C.c_int, [vp, C.c_int, C.c_int, vp]),
     "ur_adamw_multi": (C.c_int, [vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, vp, vp, vp, vp]),
     "ur_silu_forward": (C.c_int, [vp, vp, C.c_int64, C.c_int, vp]),

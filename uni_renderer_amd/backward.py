@@ -291,35 +291,40 @@ FORWARD_LSE = os.environ.get("UR_FORWARD_LSE", "1") != "0"        # 0: the dq ke
 
 
 def flash_stats(B: int, H: int, Tq: int, Tk: int, d: int, device) -> Optional[torch.Tensor]:
-    """The [2, B*H, T] fp32 statistics buffer of the flash backward if it will handle this shape (the forward kernel
+    """The [2, B*H, Tq] fp32 statistics buffer of the flash backward if it will handle this shape (the forward kernel
     writes the row log-sum-exp into its first half: ``ops.attention(lse=stats[0])``), else None."""
-    if not (FLASH_BACKWARD and FORWARD_LSE and Tq == Tk and _lib.load().ur_attention_backward_supported(Tq, (d + 31) // 32 * 32)):
+    if not (FLASH_BACKWARD and FORWARD_LSE and _lib.load().ur_attention_backward_supported(Tq, Tk, (d + 31) // 32 * 32)):
         return None
     return torch.empty(2, B * H, Tq, dtype=torch.float32, device=device)
 
 
 def _flash_attention_backward(q, k, v, o, do, H, scale, fused_qkv, oq, ok, ov, Cc, d, dp, stats=None):
-    """Self-attention shapes: ``ur_attention_backward`` (csrc/attention_bwd.hip) -- P stays in registers, two launches."""
+    """``ur_attention_backward`` (csrc/attention_bwd.hip) -- P stays in registers; self-attention and the 77-key
+    cross-attention (keys padded to a multiple of 64 and masked; its dk / dv kernel splits the queries)."""
     lib = _lib.load()
-    B, T = q.shape[:2]
+    B, Tq = q.shape[:2]
+    Tk = k.shape[1]
+    Tkp = (Tk + 63) // 64 * 64
     S = B * H
-    qp, kp, vp = _split_heads(q, H, d, T, dp, oq), _split_heads(k, H, d, T, dp, ok), _split_heads(v, H, d, T, dp, ov)
-    op, dop = _split_heads(o, H, d, T, dp), _split_heads(do, H, d, T, dp)             # [S, T, dp]
+    qp, kp, vp = _split_heads(q, H, d, Tq, dp, oq), _split_heads(k, H, d, Tkp, dp, ok), _split_heads(v, H, d, Tkp, dp, ov)
+    op, dop = _split_heads(o, H, d, Tq, dp), _split_heads(do, H, d, Tq, dp)           # [S, T, dp]
     qt, kt, dot_ = transpose2d_many([qp, kp, dop])                                    # [S, dp, T], one launch
-    has_lse = stats is not None and tuple(stats.shape) == (2, S, T)
+    has_lse = stats is not None and tuple(stats.shape) == (2, S, Tq)
     if not has_lse:
-        stats = torch.empty(2, S, T, dtype=torch.float32, device=q.device)
-    dQ, dK, dV = torch.empty_like(qp), torch.empty_like(qp), torch.empty_like(qp)
+        stats = torch.empty(2, S, Tq, dtype=torch.float32, device=q.device)
+    G = lib.ur_attention_backward_splits(S, Tq, Tkp, dp)
+    part = torch.empty(2 * G * S * Tkp * dp, dtype=torch.float32, device=q.device) if G > 1 else None
+    dQ, dK, dV = torch.empty_like(qp), torch.empty_like(kp), torch.empty_like(kp)
     check(lib.ur_attention_backward(qp.data_ptr(), kp.data_ptr(), vp.data_ptr(), op.data_ptr(), dop.data_ptr(), qt.data_ptr(),
                                     kt.data_ptr(), dot_.data_ptr(), stats.data_ptr(), int(has_lse), dQ.data_ptr(),
-                                    dK.data_ptr(), dV.data_ptr(), S, T, dp, scale, DT[q.dtype], _stream()),
-          "ur_attention_backward")
+                                    dK.data_ptr(), dV.data_ptr(), part.data_ptr() if part is not None else None, S, Tq, Tkp,
+                                    Tk, dp, scale, DT[q.dtype], _stream()), "ur_attention_backward")
     if fused_qkv:
-        g = torch.empty(B, T, 3 * Cc, dtype=q.dtype, device=q.device)
-        for part, off in ((dQ, oq), (dK, ok), (dV, ov)):
-            _merge_heads(part, B, T, H, d, out=g, off=off)
+        g = torch.empty(B, Tq, 3 * Cc, dtype=q.dtype, device=q.device)
+        for part_, off in ((dQ, oq), (dK, ok), (dV, ov)):
+            _merge_heads(part_, B, Tq, H, d, out=g, off=off)
         return g
-    return _merge_heads(dQ, B, T, H, d), _merge_heads(dK, B, T, H, d), _merge_heads(dV, B, T, H, d)
+    return _merge_heads(dQ, B, Tq, H, d), _merge_heads(dK, B, Tk, H, d), _merge_heads(dV, B, Tk, H, d)
 
 
 def attention_backward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, do: torch.Tensor, H: int,
@@ -339,7 +344,7 @@ def attention_backward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, do: to
     d = Cc // H
     scale = float(d ** -0.5 if scale is None else scale)
     dp32 = (d + 31) // 32 * 32
-    if (FLASH_BACKWARD and o is not None and Tq == Tk and lib.ur_attention_backward_supported(Tq, dp32)):
+    if FLASH_BACKWARD and o is not None and lib.ur_attention_backward_supported(Tq, Tk, dp32):
         return _flash_attention_backward(q, k, v, o, do, H, scale, fused_qkv, oq, ok, ov, Cc, d, dp32, stats)
     dp = (d + 63) // 64 * 64
     Tqp, Tkp = (Tq + 63) // 64 * 64, (Tk + 63) // 64 * 64

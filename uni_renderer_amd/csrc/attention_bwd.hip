@@ -28,7 +28,10 @@ struct AttnBwdArgs {
     const void *q, *k, *v, *o, *dout, *qt, *kt, *dot;
     float* stats;
     void *dq, *dk, *dv;
-    int S, T;
+    float* part;       // [2][G][S][Tk][DP] fp32 partial dk | dv of the query splits (G > 1), else unused
+    int S, Tq, Tk;     // padded token counts (multiples of 64)
+    int Tk_valid;      // keys >= Tk_valid are padding: P = 0 there (cross-attention: 77 of 128)
+    int G;             // query splits of the dk / dv kernel (blockIdx.z)
     float scale;
 };
 
@@ -112,7 +115,7 @@ __device__ __forceinline__ void store4(T* p, const f32x4& a, float scale) {
 // ---------------------------------------------------------------------------------------------------------------
 // kernel 1: row statistics + dq.  grid (T / (64 * NB), S), 4 waves, wave w owns queries (4 * bx + w) * 16 * NB ...
 // ---------------------------------------------------------------------------------------------------------------
-template <typename T, int DP, int NB, bool PF, bool HAS_LSE>
+template <typename T, int DP, int NB, bool PF, bool HAS_LSE, bool MASK>
 __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const AttnBwdArgs p) {
     typedef typename Vec8<T>::type vec8;
     typedef BwdLds<DP> L;
@@ -122,15 +125,15 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const AttnBwdArgs p) {
     char* Vs = smem + L::ROWS;
     char* Kts = smem + 2 * L::ROWS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
-    const int s = blockIdx.y, Tn = p.T;
+    const int s = blockIdx.y, Tn = p.Tk, Tq = p.Tq;  // Tn: the streamed (key) side
     const int qbase = (blockIdx.x * 4 + wave) * 16 * NB;
-    const int64_t so = (int64_t)s * Tn * DP;
+    const int64_t so = (int64_t)s * Tq * DP, sk = (int64_t)s * Tn * DP;
     const T* Q = reinterpret_cast<const T*>(p.q) + so;
-    const T* K = reinterpret_cast<const T*>(p.k) + so;
-    const T* V = reinterpret_cast<const T*>(p.v) + so;
+    const T* K = reinterpret_cast<const T*>(p.k) + sk;
+    const T* V = reinterpret_cast<const T*>(p.v) + sk;
     const T* O = reinterpret_cast<const T*>(p.o) + so;
     const T* dO = reinterpret_cast<const T*>(p.dout) + so;
-    const T* Kt = reinterpret_cast<const T*>(p.kt) + so;  // [DP][T]
+    const T* Kt = reinterpret_cast<const T*>(p.kt) + sk;  // [DP][Tk]
     const float s2 = p.scale * 1.44269504088896341f;
 
     // stationary B operands: this lane's query rows, k = 32 ks + 8 g .. + 7; D = rowsum(dO o O) on the way
@@ -159,8 +162,8 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const AttnBwdArgs p) {
     if constexpr (HAS_LSE) {
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
-            lse[nb] = p.stats[(int64_t)s * Tn + qbase + 16 * nb + j];
-            if (g == 0) p.stats[(int64_t)(p.S + s) * Tn + qbase + 16 * nb + j] = dsum[nb];
+            lse[nb] = p.stats[(int64_t)s * Tq + qbase + 16 * nb + j];
+            if (g == 0) p.stats[(int64_t)(p.S + s) * Tq + qbase + 16 * nb + j] = dsum[nb];
         }
     } else {
         float mx[NB], ls[NB];
@@ -186,7 +189,14 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const AttnBwdArgs p) {
                 }
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
-                    const float v0 = sc[nb][0] * s2, v1 = sc[nb][1] * s2, v2 = sc[nb][2] * s2, v3 = sc[nb][3] * s2;
+                    float v0 = sc[nb][0] * s2, v1 = sc[nb][1] * s2, v2 = sc[nb][2] * s2, v3 = sc[nb][3] * s2;
+                    if (MASK) {  // padded keys leave the softmax
+                        const int key = kt + 16 * kb + 4 * g;
+                        if (key + 0 >= p.Tk_valid) v0 = -1e30f;
+                        if (key + 1 >= p.Tk_valid) v1 = -1e30f;
+                        if (key + 2 >= p.Tk_valid) v2 = -1e30f;
+                        if (key + 3 >= p.Tk_valid) v3 = -1e30f;
+                    }
                     const float mn = fmaxf(fmaxf(mx[nb], fmaxf(v0, v1)), fmaxf(v2, v3));
                     ls[nb] = ls[nb] * __builtin_amdgcn_exp2f(mx[nb] - mn) + __builtin_amdgcn_exp2f(v0 - mn) +
                              __builtin_amdgcn_exp2f(v1 - mn) + __builtin_amdgcn_exp2f(v2 - mn) + __builtin_amdgcn_exp2f(v3 - mn);
@@ -205,8 +215,8 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const AttnBwdArgs p) {
             }
             lse[nb] = mx[nb] + __builtin_amdgcn_logf(ls[nb]);  // v_log_f32 = log2
             if (g == 0) {
-                p.stats[(int64_t)s * Tn + qbase + 16 * nb + j] = lse[nb];
-                p.stats[(int64_t)(p.S + s) * Tn + qbase + 16 * nb + j] = dsum[nb];
+                p.stats[(int64_t)s * Tq + qbase + 16 * nb + j] = lse[nb];
+                p.stats[(int64_t)(p.S + s) * Tq + qbase + 16 * nb + j] = dsum[nb];
             }
         }
     }
@@ -258,7 +268,8 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const AttnBwdArgs p) {
                 for (int b = 0; b < 2; ++b)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float pr = __builtin_amdgcn_exp2f(fmaf(sc[b][nb][r], s2, -lse[nb]));
+                        float pr = __builtin_amdgcn_exp2f(fmaf(sc[b][nb][r], s2, -lse[nb]));
+                        if (MASK && kt + 16 * (2 * h + b) + 4 * g + r >= p.Tk_valid) pr = 0.f;
                         sc[b][nb][r] = pr * (dp[b][nb][r] - dsum[nb]);
                     }
                 dsf[nb] = pack2<T>(sc[0][nb], sc[1][nb]);
@@ -282,7 +293,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const AttnBwdArgs p) {
 // ---------------------------------------------------------------------------------------------------------------
 // kernel 2: dk, dv.  grid (T / (64 * NB), S), wave w owns keys (4 * bx + w) * 16 * NB ...
 // ---------------------------------------------------------------------------------------------------------------
-template <typename T, int DP, int NB, bool PF>
+template <typename T, int DP, int NB, bool PF, bool SPLIT>
 __global__ void __launch_bounds__(256) attn_bwd_dkdv_kernel(const AttnBwdArgs p) {
     typedef typename Vec8<T>::type vec8;
     typedef BwdLds<DP> L;
@@ -294,17 +305,21 @@ __global__ void __launch_bounds__(256) attn_bwd_dkdv_kernel(const AttnBwdArgs p)
     char* dOts = Qts + L::TRN;
     float* st = reinterpret_cast<float*>(dOts + L::TRN);  // [0..63] lse, [64..127] D of the query tile
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
-    const int s = blockIdx.y, Tn = p.T;
+    const int s = blockIdx.y, Tn = p.Tq, Tk = p.Tk;  // Tn: the streamed (query) side
     const int kbase = (blockIdx.x * 4 + wave) * 16 * NB;
-    const int64_t so = (int64_t)s * Tn * DP;
+    const int64_t so = (int64_t)s * Tn * DP, sk = (int64_t)s * Tk * DP;
     const T* Q = reinterpret_cast<const T*>(p.q) + so;
-    const T* K = reinterpret_cast<const T*>(p.k) + so;
-    const T* V = reinterpret_cast<const T*>(p.v) + so;
+    const T* K = reinterpret_cast<const T*>(p.k) + sk;
+    const T* V = reinterpret_cast<const T*>(p.v) + sk;
     const T* dO = reinterpret_cast<const T*>(p.dout) + so;
     const T* Qt = reinterpret_cast<const T*>(p.qt) + so;
     const T* dOt = reinterpret_cast<const T*>(p.dot) + so;
     const float* lse_g = p.stats + (int64_t)s * Tn;
     const float* dsum_g = p.stats + (int64_t)(p.S + s) * Tn;
+    // SPLIT: blockIdx.z owns one of G contiguous query ranges and leaves fp32 partial sums (few keys, many queries: the
+    // 77-key cross-attention would otherwise run on S workgroups)
+    const int qlen = SPLIT ? (Tn / 64 + p.G - 1) / p.G * 64 : Tn;
+    const int q_beg = SPLIT ? (int)blockIdx.z * qlen : 0, q_end = SPLIT ? min(Tn, q_beg + qlen) : Tn;
     const float s2 = p.scale * 1.44269504088896341f;
 
     vec8 kf[NB][KS], vf[NB][KS];
@@ -334,8 +349,8 @@ __global__ void __launch_bounds__(256) attn_bwd_dkdv_kernel(const AttnBwdArgs p)
         gload_trn<T, DP>(dOt + (qt_), Tn, rdot, tid);             \
         if (tid < 128) rst = st_g[qt_];                           \
     } while (0)
-    if (PF) UR_GLOAD_Q(0);
-    for (int qt = 0; qt < Tn; qt += 64) {
+    if (PF && q_beg < q_end) UR_GLOAD_Q(q_beg);
+    for (int qt = q_beg; qt < q_end; qt += 64) {
         if (!PF) UR_GLOAD_Q(qt);
         __syncthreads();
         lstore_rows<DP>(Qs, rq, tid);
@@ -344,7 +359,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dkdv_kernel(const AttnBwdArgs p)
         lstore_trn<DP>(dOts, rdot, tid);
         if (tid < 128) st[tid] = rst;
         __syncthreads();
-        if (PF && qt + 64 < Tn) UR_GLOAD_Q(qt + 64);
+        if (PF && qt + 64 < q_end) UR_GLOAD_Q(qt + 64);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {  // 32 queries at a time
             f32x4 sc[2][NB], dp[2][NB];
@@ -394,60 +409,122 @@ __global__ void __launch_bounds__(256) attn_bwd_dkdv_kernel(const AttnBwdArgs p)
             }
         }
     }
-    T* dK = reinterpret_cast<T*>(p.dk) + so;
-    T* dV = reinterpret_cast<T*>(p.dv) + so;
+    if constexpr (SPLIT) {
+        float* pk = p.part + (((int64_t)blockIdx.z * p.S + s) * Tk) * DP;
+        float* pv = pk + (int64_t)p.G * p.S * Tk * DP;
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
+        for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-        for (int db = 0; db < DB; ++db) {
-            const int64_t o = (int64_t)(kbase + 16 * nb + j) * DP + 16 * db + 4 * g;
-            store4<T>(dK + o, dk[db][nb], p.scale);
-            store4<T>(dV + o, dv[db][nb], 1.0f);
-        }
+            for (int db = 0; db < DB; ++db) {
+                const int64_t o = (int64_t)(kbase + 16 * nb + j) * DP + 16 * db + 4 * g;
+                *reinterpret_cast<f32x4*>(pk + o) = dk[db][nb];
+                *reinterpret_cast<f32x4*>(pv + o) = dv[db][nb];
+            }
+    } else {
+        T* dK = reinterpret_cast<T*>(p.dk) + sk;
+        T* dV = reinterpret_cast<T*>(p.dv) + sk;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+                const int64_t o = (int64_t)(kbase + 16 * nb + j) * DP + 16 * db + 4 * g;
+                store4<T>(dK + o, dk[db][nb], p.scale);
+                store4<T>(dV + o, dv[db][nb], 1.0f);
+            }
+    }
 }
 
-template <typename T, int DP, int NB, bool HAS_LSE>
-static int launch_bwd(const AttnBwdArgs& a, hipStream_t st) {
+// dk | dv = sum over the G query splits, in split order (fixed order); one thread per 4 elements
+template <typename T>
+__global__ void __launch_bounds__(256) attn_bwd_fold_kernel(const float* __restrict__ part, int G, int64_t n4, float scale,
+                                                            T* __restrict__ dk, T* __restrict__ dv) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const bool is_v = blockIdx.y == 1;
+    const float* src = part + (is_v ? (int64_t)G * n4 * 4 : 0) + i * 4;
+    f32x4 a = *reinterpret_cast<const f32x4*>(src);
+    for (int z = 1; z < G; ++z) a += *reinterpret_cast<const f32x4*>(src + (int64_t)z * n4 * 4);
+    store4<T>((is_v ? dv : dk) + i * 4, a, is_v ? 1.0f : scale);
+}
+
+template <typename T, int DP, int NB, bool HAS_LSE, bool MASK>
+static void launch_dq(const AttnBwdArgs& a, hipStream_t st) {
     typedef BwdLds<DP> L;
     constexpr bool PF = DP <= 64;  // register prefetch of the next tile: 32 VGPRs at DP = 64, too many above
-    constexpr int lds_dq = 2 * L::ROWS + L::TRN, lds_kv = 2 * L::ROWS + 2 * L::TRN + 512;
-    static std::atomic<uint64_t> done_dq{0}, done_kv{0};
-    set_lds_limit_once(done_dq, reinterpret_cast<const void*>(&attn_bwd_dq_kernel<T, DP, NB, PF, HAS_LSE>), lds_dq);
-    set_lds_limit_once(done_kv, reinterpret_cast<const void*>(&attn_bwd_dkdv_kernel<T, DP, NB, PF>), lds_kv);
-    const dim3 grid(a.T / (64 * NB), a.S);
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<T, DP, NB, PF, HAS_LSE>), grid, dim3(256), lds_dq, st, a);
-    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, DP, NB, PF>), grid, dim3(256), lds_kv, st, a);
+    constexpr int lds_dq = 2 * L::ROWS + L::TRN;
+    static std::atomic<uint64_t> done{0};
+    set_lds_limit_once(done, reinterpret_cast<const void*>(&attn_bwd_dq_kernel<T, DP, NB, PF, HAS_LSE, MASK>), lds_dq);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<T, DP, NB, PF, HAS_LSE, MASK>), dim3(a.Tq / (64 * NB), a.S), dim3(256), lds_dq, st, a);
+}
+template <typename T, int DP, int NB, bool SPLIT>
+static void launch_dkdv(const AttnBwdArgs& a, hipStream_t st) {
+    typedef BwdLds<DP> L;
+    constexpr bool PF = DP <= 64;
+    constexpr int lds_kv = 2 * L::ROWS + 2 * L::TRN + 512;
+    static std::atomic<uint64_t> done{0};
+    set_lds_limit_once(done, reinterpret_cast<const void*>(&attn_bwd_dkdv_kernel<T, DP, NB, PF, SPLIT>), lds_kv);
+    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, DP, NB, PF, SPLIT>), dim3(a.Tk / (64 * NB), a.S, SPLIT ? a.G : 1), dim3(256),
+                       lds_kv, st, a);
+    if (SPLIT) {
+        const int64_t n4 = (int64_t)a.S * a.Tk * DP / 4;
+        hipLaunchKernelGGL((attn_bwd_fold_kernel<T>), dim3((unsigned)((n4 + 255) / 256), 2), dim3(256), 0, st, a.part, a.G, n4,
+                           a.scale, reinterpret_cast<T*>(a.dk), reinterpret_cast<T*>(a.dv));
+    }
+}
+
+template <typename T, int DP, int NBQ, int NBK, bool HAS_LSE>
+static int launch_bwd(const AttnBwdArgs& a, hipStream_t st) {
+    if (a.Tk_valid < a.Tk) launch_dq<T, DP, NBQ, HAS_LSE, true>(a, st);
+    else launch_dq<T, DP, NBQ, HAS_LSE, false>(a, st);
+    if (a.G > 1) launch_dkdv<T, DP, NBK, true>(a, st);
+    else launch_dkdv<T, DP, NBK, false>(a, st);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : -(int)e;
 }
 
 template <typename T, bool HAS_LSE>
 static int dispatch_bwd(const AttnBwdArgs& a, int dp, hipStream_t st) {
-    const bool wide = (a.T % 128) == 0;
+    const bool wq = (a.Tq % 128) == 0, wk = (a.Tk % 128) == 0;
     switch (dp) {
-        case 32: return launch_bwd<T, 32, 1, HAS_LSE>(a, st);
-        case 64: return wide ? launch_bwd<T, 64, 2, HAS_LSE>(a, st) : launch_bwd<T, 64, 1, HAS_LSE>(a, st);
-        case 96: return launch_bwd<T, 96, 1, HAS_LSE>(a, st);
-        case 160: return launch_bwd<T, 160, 1, HAS_LSE>(a, st);
+        case 32: return launch_bwd<T, 32, 1, 1, HAS_LSE>(a, st);
+        case 64:
+            if (wq && wk) return launch_bwd<T, 64, 2, 2, HAS_LSE>(a, st);
+            if (wq) return launch_bwd<T, 64, 2, 1, HAS_LSE>(a, st);
+            if (wk) return launch_bwd<T, 64, 1, 2, HAS_LSE>(a, st);
+            return launch_bwd<T, 64, 1, 1, HAS_LSE>(a, st);
+        case 96: return launch_bwd<T, 96, 1, 1, HAS_LSE>(a, st);
+        case 160: return launch_bwd<T, 160, 1, 1, HAS_LSE>(a, st);
         default: return UR_E_BADARG;
     }
 }
 
 }  // namespace ur
 
+extern "C" int ur_attention_backward_splits(int S, int Tq, int Tk, int dp) {
+    // query splits of the dk / dv kernel: enough workgroups to fill the chip when there are few keys
+    const int nbk = (dp == 64 && (Tk % 128) == 0) ? 2 : 1;
+    const int64_t wgs = (int64_t)(Tk / (64 * nbk)) * S;
+    int G = 1;
+    while (wgs * G < 256 && G < 16 && (Tq / 64) >= 4 * G) G *= 2;
+    return G;
+}
+
 extern "C" int ur_attention_backward(const void* q, const void* k, const void* v, const void* o, const void* dout,
                                      const void* qt, const void* kt, const void* dot, float* stats, int has_lse, void* dq,
-                                     void* dk, void* dv, int S, int T, int dp, float scale, int dtype, void* stream) {
-    if (!q || !k || !v || !o || !dout || !qt || !kt || !dot || !stats || !dq || !dk || !dv || S <= 0 || T <= 0 || (T & 63) ||
-        S > 65535)
+                                     void* dk, void* dv, float* part, int S, int Tq, int Tk, int Tk_valid, int dp,
+                                     float scale, int dtype, void* stream) {
+    if (!q || !k || !v || !o || !dout || !qt || !kt || !dot || !stats || !dq || !dk || !dv || S <= 0 || Tq <= 0 || Tk <= 0 ||
+        (Tq & 63) || (Tk & 63) || Tk_valid <= 0 || Tk_valid > Tk || S > 65535)
         return UR_E_BADARG;
-    ur::AttnBwdArgs a{q, k, v, o, dout, qt, kt, dot, stats, dq, dk, dv, S, T, scale};
+    const int G = ur_attention_backward_splits(S, Tq, Tk, dp);
+    if (G > 1 && !part) return UR_E_BADARG;
+    ur::AttnBwdArgs a{q, k, v, o, dout, qt, kt, dot, stats, dq, dk, dv, part, S, Tq, Tk, Tk_valid, G, scale};
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == UR_DT_F16) return has_lse ? ur::dispatch_bwd<ur::f16, true>(a, dp, st) : ur::dispatch_bwd<ur::f16, false>(a, dp, st);
     if (dtype == UR_DT_BF16) return has_lse ? ur::dispatch_bwd<ur::bf16, true>(a, dp, st) : ur::dispatch_bwd<ur::bf16, false>(a, dp, st);
     return UR_E_BADARG;
 }
 
-extern "C" int ur_attention_backward_supported(int T, int dp) {
-    return T > 0 && (T & 63) == 0 && (dp == 32 || dp == 64 || dp == 96 || dp == 160);
+extern "C" int ur_attention_backward_supported(int Tq, int Tk, int dp) {
+    return Tq > 0 && Tk > 0 && (Tq & 63) == 0 && (dp == 32 || dp == 64 || dp == 96 || dp == 160);
 }
