@@ -381,25 +381,37 @@ typedef struct ur_adamw_tensor {
 int ur_adamw_multi(const ur_adamw_tensor* tensors, int n_tensors, float lr, float beta1, float beta2, float eps,
                    float weight_decay, const float* step, const float* grad_scale, const float* found_inf, void* stream);
 
-/* Flash backward of o = softmax(q k^T * scale) v (ur_attention_backward_supported: Tq % 64 == 0, padded head dim dp in
- * {32, 64, 96, 160}).  Replaces the reference's autograd through F.scaled_dot_product_attention (diffusers
- * AttnProcessor2_0 under models/attention.py BasicTransformerBlock) in the training step, for the self-attention and the
- * 77-key cross-attention.  P is never materialised; two launches (row statistics + dq, then dk / dv; a third that folds
- * the query splits when there are few keys), every sum in a fixed order.
- *   q, o, dout        [S][Tq][dp]   per (batch, head) slices, head dim zero-padded to dp (ur_split_heads)
- *   k, v              [S][Tk][dp]   Tk a multiple of 64 (rows >= Tk_valid are zero padding and masked out of the softmax)
- *   qt, dot | kt      [S][dp][Tq] | [S][dp][Tk]   transposes of q, dout | k (ur_transpose2d)
- *   stats             [2][S][Tq]    fp32 workspace (row log-sum-exp in log2 units | rowsum(dout * o)), written here;
- *                                   has_lse = 1: the first half already holds the forward's ur_attn_desc.lse (the
- *                                   log-sum-exp pass of the dq kernel is skipped)
- *   part              fp32 workspace of 2 * G * S * Tk * dp floats, G = ur_attention_backward_splits(S, Tq, Tk, dp);
- *                     may be NULL when G == 1
- *   dq | dk, dv       [S][Tq][dp] | [S][Tk][dp]   outputs (padding columns come out as zeros) */
-int ur_attention_backward(const void* q, const void* k, const void* v, const void* o, const void* dout, const void* qt,
-                          const void* kt, const void* dot, float* stats, int has_lse, void* dq, void* dk, void* dv,
-                          float* part, int S, int Tq, int Tk, int Tk_valid, int dp, float scale, int dtype, void* stream);
-int ur_attention_backward_supported(int Tq, int Tk, int dp);
-int ur_attention_backward_splits(int S, int Tq, int Tk, int dp);
+/* Flash backward of o = softmax(q k^T * scale) v (ur_attention_backward_supported: Tq % 64 == 0, d % 8 == 0, d <= 160).
+ * Replaces the reference's autograd through F.scaled_dot_product_attention (diffusers AttnProcessor2_0 under
+ * models/attention.py BasicTransformerBlock) in the training step, for the self-attention and the 77-key
+ * cross-attention.  P is never materialised; two launches (dq, then dk / dv; a third that folds the query splits when
+ * there are few keys), every sum in a fixed order.  All matrices are the reference's token matrices [B][T][ld] with head
+ * h at columns h*d .. h*d+d-1 of the pointer handed in (q | k | v parts of a fused projection = column offsets):
+ *   q, o, dout  [B][Tq][ld*]     k, v  [B][Tk][ld*]          dq | dk, dv: same layouts as q | k, v
+ *   qt, dot     [B][H*d][ldqt | lddot]  transposes of q, dout (ur_transpose2d), row stride >= Tq
+ *   kt          [B][H*d][ldkt]          transpose of k, row stride >= Tk rounded up to 64, columns >= Tk ZERO
+ *   stats       [2][B*H][Tq] fp32 workspace (row log-sum-exp in log2 units | rowsum(dout * o)), written here;
+ *               has_lse = 1: the first half already holds the forward's ur_attn_desc.lse
+ * Per-head copies are the same interface with B = batch * heads, H = 1, d = the padded head dim (what the host side
+ * does for d = 40: 80-byte rows inside 640-byte token rows stream 40 % slower than a [slices][T][64] copy).
+ *   part        fp32 workspace of 2 * G * B*H * Tk64 * dp floats, G = ur_attention_backward_splits(B*H, Tq, Tk64, dp),
+ *               Tk64 = Tk rounded up to 64, dp = d rounded up to 32; may be NULL when G == 1 */
+typedef struct ur_attn_bwd_desc {
+    const void *q, *k, *v, *o, *dout, *qt, *kt, *dot;
+    int64_t ldq, ldk, ldv, ldo, lddo, ldqt, ldkt, lddot;
+    float* stats;
+    void *dq, *dk, *dv;
+    int64_t lddq, lddk, lddv;
+    float* part;
+    int32_t B, H, d, Tq, Tk;
+    int32_t Tk_rows;  /* rows per batch of k / v / dk / dv (0: Tk); > Tk when the caller padded the key rows */
+    int32_t has_lse;
+    float scale;
+    int32_t dtype;
+} ur_attn_bwd_desc;
+int ur_attention_backward(const ur_attn_bwd_desc* d, void* stream);
+int ur_attention_backward_supported(int Tq, int Tk, int d);
+int ur_attention_backward_splits(int S, int Tq, int Tk64, int dp);
 
 /* Attention backward helpers: P = softmax(Q K^T * scale) is recomputed and materialised per (batch, head); the five
  * GEMMs of the gradient (S, dV = P^T dO, dP = dO V^T, dQ = dS K, dK = dS^T Q) run z-batched on ur_igemm.

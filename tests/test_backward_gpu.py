@@ -142,13 +142,16 @@ def test_attention_backward(dev, dtype, shape):
 @pytest.mark.parametrize("shape", [(2, 2, 40, 128), (1, 3, 40, 192), (2, 2, 80, 64), (1, 2, 160, 128), (1, 2, 32, 64),
                                    (1, 8, 40, 1024)])
 @pytest.mark.parametrize("fused", [False, True])
-def test_flash_attention_backward(dev, dtype, shape, fused):
+@pytest.mark.parametrize("direct", [None, 0, 1000])
+def test_flash_attention_backward(dev, dtype, shape, fused, direct, monkeypatch):
     """ur_attention_backward (P in registers, two launches) against fp32 autograd through SDPA, with the forward output
     of the flash kernel as ``o``; head dims of all three levels (40 / 80 / 160 -> padded 64 / 96 / 160), both query
     widths per wave (T % 128 == 0 or not), separate q / k / v and the fused [B, T, 3C] layout.  Also against the
     materialised-P path (the two must agree to rounding of P / dS)."""
     from uni_renderer_amd import backward as bw
     from uni_renderer_amd import autograd_ops as A
+    if direct is not None:  # 0: every head dim reads the [B, T, H*d] layout in place; 1000: every head dim through copies
+        monkeypatch.setattr(bw, "FLASH_DIRECT_MIN_D", direct)
     B, H, d, T = shape
     C = H * d
     q, k, v = (_rand((B, T, C), dtype, dev, i + 1) for i in range(3))
@@ -157,7 +160,7 @@ def test_flash_attention_backward(dev, dtype, shape, fused):
     o_ref = F.scaled_dot_product_attention(qr.view(B, T, H, d).transpose(1, 2), kr.view(B, T, H, d).transpose(1, 2),
                                            vr.view(B, T, H, d).transpose(1, 2)).transpose(1, 2).reshape(B, T, C)
     (o_ref * do.float().cpu()).sum().backward()
-    assert bw.FLASH_BACKWARD and bw._lib.load().ur_attention_backward_supported(T, T, (d + 31) // 32 * 32)
+    assert bw.FLASH_BACKWARD and bw._lib.load().ur_attention_backward_supported(T, T, d)
     if fused:
         qkv = torch.cat([q, k, v], dim=-1).requires_grad_()
         o = A.AttentionQKV.apply(qkv, H)
@@ -336,12 +339,15 @@ def test_attention_forward_lse(dev, dtype, shape):
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("shape", [(2, 2, 40, 128, 77), (1, 8, 40, 1024, 77), (4, 8, 40, 4096, 77), (1, 2, 80, 64, 77),
                                    (1, 2, 160, 64, 40), (1, 2, 40, 128, 200), (1, 4, 40, 256, 128)])
-def test_flash_attention_backward_cross(dev, dtype, shape):
+@pytest.mark.parametrize("direct", [None, 0, 1000])
+def test_flash_attention_backward_cross(dev, dtype, shape, direct, monkeypatch):
     """The flash backward with fewer (padded, masked) keys than queries -- the 77-key cross-attention -- incl. shapes whose
     dk / dv kernel splits the queries and folds fp32 partial sums; through autograd_ops.Attention (forward log-sum-exp
     handed over) and directly (log-sum-exp pass in the dq kernel), against fp32 SDPA autograd."""
     from uni_renderer_amd import backward as bw
     from uni_renderer_amd import autograd_ops as A
+    if direct is not None:
+        monkeypatch.setattr(bw, "FLASH_DIRECT_MIN_D", direct)
     B, H, d, Tq, Tk = shape
     C = H * d
     q, do = _rand((B, Tq, C), dtype, dev, 1), _rand((B, Tq, C), dtype, dev, 4)
@@ -351,7 +357,7 @@ def test_flash_attention_backward_cross(dev, dtype, shape):
                                            vr.view(B, Tk, H, d).transpose(1, 2)).transpose(1, 2).reshape(B, Tq, C)
     (o_ref * do.float().cpu()).sum().backward()
     lib = bw._lib.load()
-    assert lib.ur_attention_backward_supported(Tq, Tk, (d + 31) // 32 * 32)
+    assert lib.ur_attention_backward_supported(Tq, Tk, d)
     q_, k_, v_ = (t.clone().requires_grad_() for t in (q, k, v))
     o = A.Attention.apply(q_, k_, v_, H)
     o.backward(do)

@@ -55,6 +55,20 @@ class AttnDesc(C.Structure):
     ]
 
 
+class AttnBwdDesc(C.Structure):
+    """Mirror of ``ur_attn_bwd_desc``."""
+
+    _fields_ = [
+        ("q", vp), ("k", vp), ("v", vp), ("o", vp), ("dout", vp), ("qt", vp), ("kt", vp), ("dot", vp),
+        ("ldq", i64), ("ldk", i64), ("ldv", i64), ("ldo", i64), ("lddo", i64), ("ldqt", i64), ("ldkt", i64), ("lddot", i64),
+        ("stats", vp), ("dq", vp), ("dk", vp), ("dv", vp),
+        ("lddq", i64), ("lddk", i64), ("lddv", i64),
+        ("part", vp),
+        ("B", i32), ("H", i32), ("d", i32), ("Tq", i32), ("Tk", i32), ("Tk_rows", i32), ("has_lse", i32),
+        ("scale", f32), ("dtype", i32),
+    ]
+
+
 # name -> (restype, argtypes): every symbol include/ur_kernels.h declares
 SYMBOLS = {
     "ur_igemm": (C.c_int, [C.POINTER(IGemmDesc), vp]),
@@ -94,7 +108,7 @@ SYMBOLS = {
     "ur_merge_heads": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int64, C.c_int, C.c_int, vp]),
     "ur_softmax_rows": (C.c_int, [vp, C.c_int64, C.c_int64, C.c_int, C.c_int, vp]),
     "ur_softmax_backward_rows": (C.c_int, [vp, vp, C.c_int64, C.c_int64, C.c_int, C.c_float, C.c_int, vp]),
-    "ur_attention_backward": (C.c_int, [vp] * 9 + [C.c_int] + [vp] * 4 + [C.c_int] * 5 + [C.c_float, C.c_int, vp]),
+    "ur_attention_backward": (C.c_int, [C.POINTER(AttnBwdDesc), vp]),
     "ur_attention_backward_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "ur_attention_backward_splits": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "ur_transpose2d_multi": (C.c_int, [vp, C.c_int, C.c_int, vp]),

@@ -115,8 +115,10 @@ class Attention(Function):
     @staticmethod
     def backward(ctx, do):
         q, k, v, o = ctx.saved_tensors
-        dq, dk, dv = bw.attention_backward(q.contiguous(), k.contiguous(), v.contiguous(), do.contiguous(), ctx.heads, o=o,
-                                           stats=ctx.stats)
+        # column slices of a wider projection (the [B, 77, 2C] k | v of a cross-attention) are read in place
+        q, k, v = (t if t.stride(-1) == 1 and t.stride(0) == t.shape[1] * t.stride(1) and t.stride(1) % 8 == 0 else t.contiguous()
+                   for t in (q, k, v))
+        dq, dk, dv = bw.attention_backward(q, k, v, do.contiguous(), ctx.heads, o=o, stats=ctx.stats)
         return dq, dk, dv, None
 
 

@@ -293,32 +293,72 @@ FORWARD_LSE = os.environ.get("UR_FORWARD_LSE", "1") != "0"        # 0: the dq ke
 def flash_stats(B: int, H: int, Tq: int, Tk: int, d: int, device) -> Optional[torch.Tensor]:
     """The [2, B*H, Tq] fp32 statistics buffer of the flash backward if it will handle this shape (the forward kernel
     writes the row log-sum-exp into its first half: ``ops.attention(lse=stats[0])``), else None."""
-    if not (FLASH_BACKWARD and FORWARD_LSE and _lib.load().ur_attention_backward_supported(Tq, Tk, (d + 31) // 32 * 32)):
+    if not (FLASH_BACKWARD and FORWARD_LSE and _lib.load().ur_attention_backward_supported(Tq, Tk, d)):
         return None
     return torch.empty(2, B * H, Tq, dtype=torch.float32, device=device)
 
 
-def _flash_attention_backward(q, k, v, o, do, H, scale, fused_qkv, oq, ok, ov, Cc, d, dp, stats=None):
+FLASH_DIRECT_MIN_D = int(os.environ.get("UR_FLASH_DIRECT_MIN_D", "64"))
+
+
+def _flash_attention_backward(q, k, v, o, do, H, scale, fused_qkv, oq, ok, ov, Cc, d, stats=None):
     """``ur_attention_backward`` (csrc/attention_bwd.hip) -- P stays in registers; self-attention and the 77-key
-    cross-attention (keys padded to a multiple of 64 and masked; its dk / dv kernel splits the queries)."""
+    cross-attention.  Head dims >= 64 (d = 80 / 160): the kernels read q / k / v / o / dO and write dq / dk / dv in the
+    [B, T, H*d] layouts (column offsets for the parts of a fused projection); the only prepared operands are the
+    transposes of q, k and dO.  d = 40: per-head copies [B*H, T, 64] first (``ur_split_heads`` / ``ur_merge_heads``) --
+    the same kernels with H = 1 -- because 80-byte head rows inside 640-byte token rows stream 40 % slower (dq 545 vs
+    383 us, dk / dv 520 vs 337 us at the 4096-token level)."""
     lib = _lib.load()
     B, Tq = q.shape[:2]
     Tk = k.shape[1]
     Tkp = (Tk + 63) // 64 * 64
-    S = B * H
-    qp, kp, vp = _split_heads(q, H, d, Tq, dp, oq), _split_heads(k, H, d, Tkp, dp, ok), _split_heads(v, H, d, Tkp, dp, ov)
-    op, dop = _split_heads(o, H, d, Tq, dp), _split_heads(do, H, d, Tq, dp)           # [S, T, dp]
-    qt, kt, dot_ = transpose2d_many([qp, kp, dop])                                    # [S, dp, T], one launch
+    S, dp = B * H, (d + 31) // 32 * 32
+    esz = q.element_size()
+    direct = d >= FLASH_DIRECT_MIN_D
     has_lse = stats is not None and tuple(stats.shape) == (2, S, Tq)
     if not has_lse:
         stats = torch.empty(2, S, Tq, dtype=torch.float32, device=q.device)
     G = lib.ur_attention_backward_splits(S, Tq, Tkp, dp)
     part = torch.empty(2 * G * S * Tkp * dp, dtype=torch.float32, device=q.device) if G > 1 else None
-    dQ, dK, dV = torch.empty_like(qp), torch.empty_like(kp), torch.empty_like(kp)
-    check(lib.ur_attention_backward(qp.data_ptr(), kp.data_ptr(), vp.data_ptr(), op.data_ptr(), dop.data_ptr(), qt.data_ptr(),
-                                    kt.data_ptr(), dot_.data_ptr(), stats.data_ptr(), int(has_lse), dQ.data_ptr(),
-                                    dK.data_ptr(), dV.data_ptr(), part.data_ptr() if part is not None else None, S, Tq, Tkp,
-                                    Tk, dp, scale, DT[q.dtype], _stream()), "ur_attention_backward")
+    a = _lib.AttnBwdDesc()
+    if direct:
+        for t in (q, k, v, o, do):
+            if t.stride(2) != 1 or t.stride(0) != t.shape[1] * t.stride(1):
+                raise RuntimeError("flash attention backward: [B, T, ld] operands with contiguous batches")
+        qt, kt, dot_ = transpose2d_many([q[..., oq:oq + Cc], k[..., ok:ok + Cc], do])  # [B, C, T], one launch
+        if kt.shape[-1] != Tkp:
+            kt = _pad_rows64(kt)                                                      # zero columns for the padded keys
+        if fused_qkv:
+            g = torch.empty(B, Tq, 3 * Cc, dtype=q.dtype, device=q.device)
+            outs, ldg, offs = (g, g, g), 3 * Cc, (oq, ok, ov)
+        else:
+            outs = (torch.empty(B, Tq, Cc, dtype=q.dtype, device=q.device), torch.empty(B, Tk, Cc, dtype=q.dtype, device=q.device),
+                    torch.empty(B, Tk, Cc, dtype=q.dtype, device=q.device))
+            ldg, offs = Cc, (0, 0, 0)
+        a.q, a.k, a.v = q.data_ptr() + oq * esz, k.data_ptr() + ok * esz, v.data_ptr() + ov * esz
+        a.o, a.dout = o.data_ptr(), do.data_ptr()
+        a.ldq, a.ldk, a.ldv, a.ldo, a.lddo = q.stride(1), k.stride(1), v.stride(1), o.stride(1), do.stride(1)
+        a.dq, a.dk, a.dv = (t.data_ptr() + off * esz for t, off in zip(outs, offs))
+        a.lddq = a.lddk = a.lddv = ldg
+        a.B, a.H, a.d, a.Tk_rows = B, H, d, Tk
+    else:
+        qp, kp, vp = _split_heads(q, H, d, Tq, dp, oq), _split_heads(k, H, d, Tkp, dp, ok), _split_heads(v, H, d, Tkp, dp, ov)
+        op, dop = _split_heads(o, H, d, Tq, dp), _split_heads(do, H, d, Tq, dp)       # [S, T, dp]
+        qt, kt, dot_ = transpose2d_many([qp, kp, dop])                                # [S, dp, T], one launch
+        dQ, dK, dV = torch.empty_like(qp), torch.empty_like(kp), torch.empty_like(kp)
+        a.q, a.k, a.v, a.o, a.dout = qp.data_ptr(), kp.data_ptr(), vp.data_ptr(), op.data_ptr(), dop.data_ptr()
+        a.ldq = a.ldk = a.ldv = a.ldo = a.lddo = a.lddq = a.lddk = a.lddv = dp
+        a.dq, a.dk, a.dv = dQ.data_ptr(), dK.data_ptr(), dV.data_ptr()
+        a.B, a.H, a.d, a.Tk_rows = S, 1, dp, Tkp
+    a.qt, a.kt, a.dot = qt.data_ptr(), kt.data_ptr(), dot_.data_ptr()
+    a.ldqt, a.ldkt, a.lddot = qt.shape[-1], kt.shape[-1], dot_.shape[-1]
+    a.stats = stats.data_ptr()
+    a.part = part.data_ptr() if part is not None else None
+    a.Tq, a.Tk, a.has_lse = Tq, Tk, int(has_lse)
+    a.scale, a.dtype = scale, DT[q.dtype]
+    check(lib.ur_attention_backward(C.byref(a), _stream()), "ur_attention_backward")
+    if direct:
+        return outs[0] if fused_qkv else outs
     if fused_qkv:
         g = torch.empty(B, Tq, 3 * Cc, dtype=q.dtype, device=q.device)
         for part_, off in ((dQ, oq), (dK, ok), (dV, ov)):
@@ -343,9 +383,8 @@ def attention_backward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, do: to
     oq, ok, ov = (0, Cc, 2 * Cc) if fused_qkv else (0, 0, 0)
     d = Cc // H
     scale = float(d ** -0.5 if scale is None else scale)
-    dp32 = (d + 31) // 32 * 32
-    if FLASH_BACKWARD and o is not None and lib.ur_attention_backward_supported(Tq, Tk, dp32):
-        return _flash_attention_backward(q, k, v, o, do, H, scale, fused_qkv, oq, ok, ov, Cc, d, dp32, stats)
+    if FLASH_BACKWARD and o is not None and lib.ur_attention_backward_supported(Tq, Tk, d):
+        return _flash_attention_backward(q, k, v, o, do, H, scale, fused_qkv, oq, ok, ov, Cc, d, stats)
     dp = (d + 63) // 64 * 64
     Tqp, Tkp = (Tq + 63) // 64 * 64, (Tk + 63) // 64 * 64
     S = B * H

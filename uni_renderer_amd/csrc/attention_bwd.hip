@@ -3,10 +3,13 @@
 // /root/reference models/attention.py BasicTransformerBlock).  P is never materialised: two kernels recompute the
 // score blocks from q, k on the MFMA and keep P / dS in registers.
 //
-//   inputs   q, k, v, o, do   [S][T][DP]   per (batch, head) slices, head dim zero-padded to DP (ur_split_heads)
-//            qt, kt, dot      [S][DP][T]   their transposes (ur_transpose2d)
-//   outputs  dq, dk, dv       [S][T][DP]
-//            stats            [2][S][T]    fp32 workspace: row log-sum-exp (log2 units) | D = rowsum(do * o)
+//   inputs   q, o, do | k, v   [B][Tq][ld] | [B][Tk][ld] token matrices, head h at columns h*d .. h*d+d-1 (the reference's
+//                               layout: no per-head copies; the q | k | v parts of a fused projection are column offsets)
+//            qt, dot | kt       [B][H*d][ldt] transposes of those matrices (ur_transpose2d), ldt >= the padded token count
+//   outputs  dq | dk, dv        same layouts as q | k, v
+//            stats              [2][S][Tq]  fp32 workspace: row log-sum-exp (log2 units) | D = rowsum(do * o), S = B*H
+//   Head dims are zero-extended to DP (64 / 96 / 160 for d = 40 / 80 / 160) and key rows to a multiple of 64 by the
+//   loaders (bounds-checked 16-byte chunks), not in memory.
 //
 //   kernel 1 (dq):    a wave owns 16*NB queries (MFMA columns) and streams 64-key tiles: pass A the row log-sum-exp,
 //                     pass B  S^T = K Q^T,  dP^T = V dO^T,  dS^T = P^T o (dP^T - D),  dQ^T += K^T dS^T
@@ -25,12 +28,17 @@
 namespace ur {
 
 struct AttnBwdArgs {
-    const void *q, *k, *v, *o, *dout, *qt, *kt, *dot;
+    const void *q, *k, *v, *o, *dout, *qt, *kt, *dot;  // pre-offset to the first column (row) of head 0 of their part
+    int64_t ldq, ldk, ldv, ldo, lddo;                  // row strides (elements)
+    int64_t ldqt, ldkt, lddot;                         // row strides of the transposed matrices
     float* stats;
     void *dq, *dk, *dv;
+    int64_t lddq, lddk, lddv;
     float* part;       // [2][G][S][Tk][DP] fp32 partial dk | dv of the query splits (G > 1), else unused
-    int S, Tq, Tk;     // padded token counts (multiples of 64)
-    int Tk_valid;      // keys >= Tk_valid are padding: P = 0 there (cross-attention: 77 of 128)
+    int S, H, d;       // S = B * H slices, head dim d (multiple of 8)
+    int Tq, Tk;        // query rows (multiple of 64), key rows rounded up to a multiple of 64
+    int Tk_valid;      // real key rows: rows >= Tk_valid read as zeros and P = 0 there (cross-attention: 77 of 128)
+    int Tk_rows;       // rows per batch of the k / v / dk / dv matrices (>= Tk_valid)
     int G;             // query splits of the dk / dv kernel (blockIdx.z)
     float scale;
 };
@@ -49,12 +57,14 @@ template <int DP> struct BwdLds {
 #define UR_ROWREGS(DP) ((64 * ((DP) / 8)) / 256)
 #define UR_TRNREGS(DP) (((DP) * 8) / 256)
 template <typename T, int DP>
-__device__ __forceinline__ void gload_rows(const T* __restrict__ g, u32x4 (&r)[UR_ROWREGS(DP)], int tid) {
+__device__ __forceinline__ void gload_rows(const T* __restrict__ g, int64_t ld, int rows_valid, int d,
+                                           u32x4 (&r)[UR_ROWREGS(DP)], int tid) {
     constexpr int CPR = DP / 8;
 #pragma unroll
     for (int i = 0; i < (64 * CPR) / 256; ++i) {
         const int e = tid + i * 256, row = e / CPR, c = e - row * CPR;
-        r[i] = *reinterpret_cast<const u32x4*>(g + (int64_t)row * DP + c * 8);
+        r[i] = u32x4{0u, 0u, 0u, 0u};
+        if (row < rows_valid && c * 8 < d) r[i] = *reinterpret_cast<const u32x4*>(g + (int64_t)row * ld + c * 8);
     }
 }
 template <int DP>
@@ -67,11 +77,12 @@ __device__ __forceinline__ void lstore_rows(char* lds, const u32x4 (&r)[UR_ROWRE
     }
 }
 template <typename T, int DP>
-__device__ __forceinline__ void gload_trn(const T* __restrict__ g, int64_t ld, u32x4 (&r)[UR_TRNREGS(DP)], int tid) {
+__device__ __forceinline__ void gload_trn(const T* __restrict__ g, int64_t ld, int d, u32x4 (&r)[UR_TRNREGS(DP)], int tid) {
 #pragma unroll
     for (int i = 0; i < (DP * 8) / 256; ++i) {
         const int e = tid + i * 256, row = e >> 3, c = e & 7;
-        r[i] = *reinterpret_cast<const u32x4*>(g + (int64_t)row * ld + c * 8);
+        r[i] = u32x4{0u, 0u, 0u, 0u};
+        if (row < d) r[i] = *reinterpret_cast<const u32x4*>(g + (int64_t)row * ld + c * 8);
     }
 }
 template <int DP>
@@ -102,6 +113,14 @@ __device__ __forceinline__ typename Vec8<T>::type pack2(const f32x4& a, const f3
     for (int i = 0; i < 4; ++i) { v[i] = (T)a[i]; v[4 + i] = (T)b[i]; }
     return v;
 }
+template <typename T, typename V>
+__device__ __forceinline__ V load_or_zero(const T* p, bool ok) {
+    V v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (T)0.0f;
+    if (ok) v = *reinterpret_cast<const V*>(p);
+    return v;
+}
 template <typename T>
 __device__ __forceinline__ void store4(T* p, const f32x4& a, float scale) {
     T h[4];
@@ -126,14 +145,14 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const AttnBwdArgs p) {
     char* Kts = smem + 2 * L::ROWS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
     const int s = blockIdx.y, Tn = p.Tk, Tq = p.Tq;  // Tn: the streamed (key) side
+    const int b = s / p.H, hd = (s - b * p.H) * p.d, d = p.d, C = p.H * p.d;
     const int qbase = (blockIdx.x * 4 + wave) * 16 * NB;
-    const int64_t so = (int64_t)s * Tq * DP, sk = (int64_t)s * Tn * DP;
-    const T* Q = reinterpret_cast<const T*>(p.q) + so;
-    const T* K = reinterpret_cast<const T*>(p.k) + sk;
-    const T* V = reinterpret_cast<const T*>(p.v) + sk;
-    const T* O = reinterpret_cast<const T*>(p.o) + so;
-    const T* dO = reinterpret_cast<const T*>(p.dout) + so;
-    const T* Kt = reinterpret_cast<const T*>(p.kt) + sk;  // [DP][Tk]
+    const T* Q = reinterpret_cast<const T*>(p.q) + (int64_t)b * Tq * p.ldq + hd;
+    const T* O = reinterpret_cast<const T*>(p.o) + (int64_t)b * Tq * p.ldo + hd;
+    const T* dO = reinterpret_cast<const T*>(p.dout) + (int64_t)b * Tq * p.lddo + hd;
+    const T* K = reinterpret_cast<const T*>(p.k) + (int64_t)b * p.Tk_rows * p.ldk + hd;
+    const T* V = reinterpret_cast<const T*>(p.v) + (int64_t)b * p.Tk_rows * p.ldv + hd;
+    const T* Kt = reinterpret_cast<const T*>(p.kt) + ((int64_t)b * C + hd) * p.ldkt;  // rows = head dims, columns = keys
     const float s2 = p.scale * 1.44269504088896341f;
 
     // stationary B operands: this lane's query rows, k = 32 ks + 8 g .. + 7; D = rowsum(dO o O) on the way
@@ -141,13 +160,14 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const AttnBwdArgs p) {
     float dsum[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-        const int64_t ro = (int64_t)(qbase + 16 * nb + j) * DP;
+        const int64_t row = qbase + 16 * nb + j;
         float a = 0.f;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            qf[nb][ks] = *reinterpret_cast<const vec8*>(Q + ro + 32 * ks + 8 * g);
-            dof[nb][ks] = *reinterpret_cast<const vec8*>(dO + ro + 32 * ks + 8 * g);
-            const vec8 of = *reinterpret_cast<const vec8*>(O + ro + 32 * ks + 8 * g);
+            const int col = 32 * ks + 8 * g;
+            qf[nb][ks] = load_or_zero<T, vec8>(Q + row * p.ldq + col, col < d);
+            dof[nb][ks] = load_or_zero<T, vec8>(dO + row * p.lddo + col, col < d);
+            const vec8 of = load_or_zero<T, vec8>(O + row * p.ldo + col, col < d);
 #pragma unroll
             for (int i = 0; i < 8; ++i) a = fmaf((float)dof[nb][ks][i], (float)of[i], a);
         }
@@ -169,13 +189,13 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const AttnBwdArgs p) {
         float mx[NB], ls[NB];
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) { mx[nb] = -1e30f; ls[nb] = 0.f; }
-        if (PF) gload_rows<T, DP>(K, rk, tid);
+        if (PF) gload_rows<T, DP>(K, p.ldk, p.Tk_valid, d, rk, tid);
         for (int kt = 0; kt < Tn; kt += 64) {
-            if (!PF) gload_rows<T, DP>(K + (int64_t)kt * DP, rk, tid);
+            if (!PF) gload_rows<T, DP>(K + (int64_t)kt * p.ldk, p.ldk, p.Tk_valid - kt, d, rk, tid);
             __syncthreads();
             lstore_rows<DP>(Ks, rk, tid);
             __syncthreads();
-            if (PF && kt + 64 < Tn) gload_rows<T, DP>(K + (int64_t)(kt + 64) * DP, rk, tid);
+            if (PF && kt + 64 < Tn) gload_rows<T, DP>(K + (int64_t)(kt + 64) * p.ldk, p.ldk, p.Tk_valid - kt - 64, d, rk, tid);
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb) {
                 f32x4 sc[NB];
@@ -229,9 +249,9 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const AttnBwdArgs p) {
         for (int nb = 0; nb < NB; ++nb) acc[db][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #define UR_GLOAD_KV(kt_)                                          \
     do {                                                          \
-        gload_rows<T, DP>(K + (int64_t)(kt_) * DP, rk, tid);      \
-        gload_rows<T, DP>(V + (int64_t)(kt_) * DP, rv, tid);      \
-        gload_trn<T, DP>(Kt + (kt_), Tn, rkt, tid);               \
+        gload_rows<T, DP>(K + (int64_t)(kt_) * p.ldk, p.ldk, p.Tk_valid - (kt_), d, rk, tid); \
+        gload_rows<T, DP>(V + (int64_t)(kt_) * p.ldv, p.ldv, p.Tk_valid - (kt_), d, rv, tid); \
+        gload_trn<T, DP>(Kt + (kt_), p.ldkt, d, rkt, tid);        \
     } while (0)
     if (PF) UR_GLOAD_KV(0);
     for (int kt = 0; kt < Tn; kt += 64) {
@@ -282,12 +302,13 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const AttnBwdArgs p) {
             }
         }
     }
-    T* dQ = reinterpret_cast<T*>(p.dq) + so;
+    T* dQ = reinterpret_cast<T*>(p.dq) + (int64_t)b * Tq * p.lddq + hd;
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
         for (int db = 0; db < DB; ++db)
-            store4<T>(dQ + (int64_t)(qbase + 16 * nb + j) * DP + 16 * db + 4 * g, acc[db][nb], p.scale);
+            if (16 * db + 4 * g + 4 <= d)
+                store4<T>(dQ + (int64_t)(qbase + 16 * nb + j) * p.lddq + 16 * db + 4 * g, acc[db][nb], p.scale);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -306,14 +327,14 @@ __global__ void __launch_bounds__(256) attn_bwd_dkdv_kernel(const AttnBwdArgs p)
     float* st = reinterpret_cast<float*>(dOts + L::TRN);  // [0..63] lse, [64..127] D of the query tile
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
     const int s = blockIdx.y, Tn = p.Tq, Tk = p.Tk;  // Tn: the streamed (query) side
+    const int b = s / p.H, hd = (s - b * p.H) * p.d, d = p.d, C = p.H * p.d;
     const int kbase = (blockIdx.x * 4 + wave) * 16 * NB;
-    const int64_t so = (int64_t)s * Tn * DP, sk = (int64_t)s * Tk * DP;
-    const T* Q = reinterpret_cast<const T*>(p.q) + so;
-    const T* K = reinterpret_cast<const T*>(p.k) + sk;
-    const T* V = reinterpret_cast<const T*>(p.v) + sk;
-    const T* dO = reinterpret_cast<const T*>(p.dout) + so;
-    const T* Qt = reinterpret_cast<const T*>(p.qt) + so;
-    const T* dOt = reinterpret_cast<const T*>(p.dot) + so;
+    const T* Q = reinterpret_cast<const T*>(p.q) + (int64_t)b * Tn * p.ldq + hd;
+    const T* dO = reinterpret_cast<const T*>(p.dout) + (int64_t)b * Tn * p.lddo + hd;
+    const T* K = reinterpret_cast<const T*>(p.k) + (int64_t)b * p.Tk_rows * p.ldk + hd;
+    const T* V = reinterpret_cast<const T*>(p.v) + (int64_t)b * p.Tk_rows * p.ldv + hd;
+    const T* Qt = reinterpret_cast<const T*>(p.qt) + ((int64_t)b * C + hd) * p.ldqt;
+    const T* dOt = reinterpret_cast<const T*>(p.dot) + ((int64_t)b * C + hd) * p.lddot;
     const float* lse_g = p.stats + (int64_t)s * Tn;
     const float* dsum_g = p.stats + (int64_t)(p.S + s) * Tn;
     // SPLIT: blockIdx.z owns one of G contiguous query ranges and leaves fp32 partial sums (few keys, many queries: the
@@ -325,11 +346,13 @@ __global__ void __launch_bounds__(256) attn_bwd_dkdv_kernel(const AttnBwdArgs p)
     vec8 kf[NB][KS], vf[NB][KS];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-        const int64_t ro = (int64_t)(kbase + 16 * nb + j) * DP;
+        const int64_t row = kbase + 16 * nb + j;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            kf[nb][ks] = *reinterpret_cast<const vec8*>(K + ro + 32 * ks + 8 * g);
-            vf[nb][ks] = *reinterpret_cast<const vec8*>(V + ro + 32 * ks + 8 * g);
+            const int col = 32 * ks + 8 * g;
+            const bool ok = row < p.Tk_valid && col < d;
+            kf[nb][ks] = load_or_zero<T, vec8>(K + row * p.ldk + col, ok);
+            vf[nb][ks] = load_or_zero<T, vec8>(V + row * p.ldv + col, ok);
         }
     }
     f32x4 dk[DB][NB], dv[DB][NB];
@@ -343,10 +366,10 @@ __global__ void __launch_bounds__(256) attn_bwd_dkdv_kernel(const AttnBwdArgs p)
     const float* st_g = tid < 64 ? lse_g + tid : dsum_g + (tid & 63);  // tid < 128 stage the row statistics
 #define UR_GLOAD_Q(qt_)                                           \
     do {                                                          \
-        gload_rows<T, DP>(Q + (int64_t)(qt_) * DP, rq, tid);      \
-        gload_rows<T, DP>(dO + (int64_t)(qt_) * DP, rdo, tid);    \
-        gload_trn<T, DP>(Qt + (qt_), Tn, rqt, tid);               \
-        gload_trn<T, DP>(dOt + (qt_), Tn, rdot, tid);             \
+        gload_rows<T, DP>(Q + (int64_t)(qt_) * p.ldq, p.ldq, 64, d, rq, tid);     \
+        gload_rows<T, DP>(dO + (int64_t)(qt_) * p.lddo, p.lddo, 64, d, rdo, tid); \
+        gload_trn<T, DP>(Qt + (qt_), p.ldqt, d, rqt, tid);        \
+        gload_trn<T, DP>(dOt + (qt_), p.lddot, d, rdot, tid);     \
         if (tid < 128) rst = st_g[qt_];                           \
     } while (0)
     if (PF && q_beg < q_end) UR_GLOAD_Q(q_beg);
@@ -421,30 +444,39 @@ __global__ void __launch_bounds__(256) attn_bwd_dkdv_kernel(const AttnBwdArgs p)
                 *reinterpret_cast<f32x4*>(pv + o) = dv[db][nb];
             }
     } else {
-        T* dK = reinterpret_cast<T*>(p.dk) + sk;
-        T* dV = reinterpret_cast<T*>(p.dv) + sk;
+        T* dK = reinterpret_cast<T*>(p.dk) + (int64_t)b * p.Tk_rows * p.lddk + hd;
+        T* dV = reinterpret_cast<T*>(p.dv) + (int64_t)b * p.Tk_rows * p.lddv + hd;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
             for (int db = 0; db < DB; ++db) {
-                const int64_t o = (int64_t)(kbase + 16 * nb + j) * DP + 16 * db + 4 * g;
-                store4<T>(dK + o, dk[db][nb], p.scale);
-                store4<T>(dV + o, dv[db][nb], 1.0f);
+                const int64_t row = kbase + 16 * nb + j;
+                const int col = 16 * db + 4 * g;
+                if (row < p.Tk_valid && col + 4 <= d) {
+                    store4<T>(dK + row * p.lddk + col, dk[db][nb], p.scale);
+                    store4<T>(dV + row * p.lddv + col, dv[db][nb], 1.0f);
+                }
             }
     }
 }
 
-// dk | dv = sum over the G query splits, in split order (fixed order); one thread per 4 elements
+// dk | dv = sum over the G query splits, in split order (fixed order); one thread per 4 elements of [S][Tk][DP]
 template <typename T>
-__global__ void __launch_bounds__(256) attn_bwd_fold_kernel(const float* __restrict__ part, int G, int64_t n4, float scale,
-                                                            T* __restrict__ dk, T* __restrict__ dv) {
+__global__ void __launch_bounds__(256) attn_bwd_fold_kernel(const AttnBwdArgs p, int DP, int64_t n4) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n4) return;
     const bool is_v = blockIdx.y == 1;
-    const float* src = part + (is_v ? (int64_t)G * n4 * 4 : 0) + i * 4;
+    const int col = (int)((i * 4) % DP);
+    const int64_t sr = (i * 4) / DP;
+    const int row = (int)(sr % p.Tk), s = (int)(sr / p.Tk);
+    if (row >= p.Tk_valid || col + 4 > p.d) return;
+    const float* src = p.part + (is_v ? (int64_t)p.G * n4 * 4 : 0) + i * 4;
     f32x4 a = *reinterpret_cast<const f32x4*>(src);
-    for (int z = 1; z < G; ++z) a += *reinterpret_cast<const f32x4*>(src + (int64_t)z * n4 * 4);
-    store4<T>((is_v ? dv : dk) + i * 4, a, is_v ? 1.0f : scale);
+    for (int z = 1; z < p.G; ++z) a += *reinterpret_cast<const f32x4*>(src + (int64_t)z * n4 * 4);
+    const int b = s / p.H, hd = (s - b * p.H) * p.d;
+    T* dst = reinterpret_cast<T*>(is_v ? p.dv : p.dk);
+    const int64_t ld = is_v ? p.lddv : p.lddk;
+    store4<T>(dst + ((int64_t)b * p.Tk_rows + row) * ld + hd + col, a, is_v ? 1.0f : p.scale);
 }
 
 template <typename T, int DP, int NB, bool HAS_LSE, bool MASK>
@@ -467,8 +499,7 @@ static void launch_dkdv(const AttnBwdArgs& a, hipStream_t st) {
                        lds_kv, st, a);
     if (SPLIT) {
         const int64_t n4 = (int64_t)a.S * a.Tk * DP / 4;
-        hipLaunchKernelGGL((attn_bwd_fold_kernel<T>), dim3((unsigned)((n4 + 255) / 256), 2), dim3(256), 0, st, a.part, a.G, n4,
-                           a.scale, reinterpret_cast<T*>(a.dk), reinterpret_cast<T*>(a.dv));
+        hipLaunchKernelGGL((attn_bwd_fold_kernel<T>), dim3((unsigned)((n4 + 255) / 256), 2), dim3(256), 0, st, a, DP, n4);
     }
 }
 
@@ -509,22 +540,30 @@ extern "C" int ur_attention_backward_splits(int S, int Tq, int Tk, int dp) {
     return G;
 }
 
-extern "C" int ur_attention_backward(const void* q, const void* k, const void* v, const void* o, const void* dout,
-                                     const void* qt, const void* kt, const void* dot, float* stats, int has_lse, void* dq,
-                                     void* dk, void* dv, float* part, int S, int Tq, int Tk, int Tk_valid, int dp,
-                                     float scale, int dtype, void* stream) {
-    if (!q || !k || !v || !o || !dout || !qt || !kt || !dot || !stats || !dq || !dk || !dv || S <= 0 || Tq <= 0 || Tk <= 0 ||
-        (Tq & 63) || (Tk & 63) || Tk_valid <= 0 || Tk_valid > Tk || S > 65535)
+extern "C" int ur_attention_backward(const ur_attn_bwd_desc* dsc, void* stream) {
+    if (!dsc) return UR_E_BADARG;
+    const ur_attn_bwd_desc& x = *dsc;
+    if (!x.q || !x.k || !x.v || !x.o || !x.dout || !x.qt || !x.kt || !x.dot || !x.stats || !x.dq || !x.dk || !x.dv || x.B <= 0 ||
+        x.H <= 0 || x.d <= 0 || (x.d & 7) || x.Tq <= 0 || (x.Tq & 63) || x.Tk <= 0 || (x.Tk_rows != 0 && x.Tk_rows < x.Tk))
         return UR_E_BADARG;
-    const int G = ur_attention_backward_splits(S, Tq, Tk, dp);
-    if (G > 1 && !part) return UR_E_BADARG;
-    ur::AttnBwdArgs a{q, k, v, o, dout, qt, kt, dot, stats, dq, dk, dv, part, S, Tq, Tk, Tk_valid, G, scale};
+    const int64_t lds[] = {x.ldq, x.ldk, x.ldv, x.ldo, x.lddo, x.ldqt, x.ldkt, x.lddot, x.lddq, x.lddk, x.lddv};
+    for (int64_t ld : lds)
+        if (ld <= 0 || (ld & 7)) return UR_E_BADARG;
+    const int S = x.B * x.H, Tkp = (x.Tk + 63) / 64 * 64, dp = (x.d + 31) / 32 * 32;
+    if (S > 65535 || x.ldqt < x.Tq || x.lddot < x.Tq || x.ldkt < Tkp) return UR_E_BADARG;
+    const int G = ur_attention_backward_splits(S, x.Tq, Tkp, dp);
+    if (G > 1 && !x.part) return UR_E_BADARG;
+    ur::AttnBwdArgs a{x.q, x.k, x.v, x.o, x.dout, x.qt, x.kt, x.dot, x.ldq, x.ldk, x.ldv, x.ldo, x.lddo, x.ldqt, x.ldkt, x.lddot,
+                      x.stats, x.dq, x.dk, x.dv, x.lddq, x.lddk, x.lddv, x.part, S, x.H, x.d, x.Tq, Tkp, x.Tk,
+                      x.Tk_rows > 0 ? x.Tk_rows : x.Tk, G, x.scale};
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == UR_DT_F16) return has_lse ? ur::dispatch_bwd<ur::f16, true>(a, dp, st) : ur::dispatch_bwd<ur::f16, false>(a, dp, st);
-    if (dtype == UR_DT_BF16) return has_lse ? ur::dispatch_bwd<ur::bf16, true>(a, dp, st) : ur::dispatch_bwd<ur::bf16, false>(a, dp, st);
+    const bool has_lse = x.has_lse != 0;
+    if (x.dtype == UR_DT_F16) return has_lse ? ur::dispatch_bwd<ur::f16, true>(a, dp, st) : ur::dispatch_bwd<ur::f16, false>(a, dp, st);
+    if (x.dtype == UR_DT_BF16) return has_lse ? ur::dispatch_bwd<ur::bf16, true>(a, dp, st) : ur::dispatch_bwd<ur::bf16, false>(a, dp, st);
     return UR_E_BADARG;
 }
 
-extern "C" int ur_attention_backward_supported(int Tq, int Tk, int dp) {
-    return Tq > 0 && Tk > 0 && (Tq & 63) == 0 && (dp == 32 || dp == 64 || dp == 96 || dp == 160);
+extern "C" int ur_attention_backward_supported(int Tq, int Tk, int d) {
+    const int dp = (d + 31) / 32 * 32;
+    return Tq > 0 && Tk > 0 && (Tq & 63) == 0 && d > 0 && (d & 7) == 0 && (dp == 32 || dp == 64 || dp == 96 || dp == 160);
 }
