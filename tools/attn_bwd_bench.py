@@ -19,9 +19,14 @@ def main():
         for (B, H, d, T) in ((4, 8, 40, 4096), (4, 8, 80, 1024), (4, 8, 160, 256), (4, 8, 160, 64)):
             g = torch.Generator(device="cpu").manual_seed(1)
             mk = lambda: (torch.randn(B, T, H * d, generator=g) * 0.5).to(dtype).to(dev)
-            q, k, v, do, o = mk(), mk(), mk(), mk(), mk()
+            q, k, v, do = mk(), mk(), mk(), mk()
+            # the forward kernel's output and row log-sum-exp, as autograd_ops.Attention hands them to the backward
+            from uni_renderer_amd import ops
+            stats = bw.flash_stats(B, H, T, T, d, dev)
+            vt = bw._pad_rows64(bw.transpose2d(v))
+            o = ops.attention(q, k, vt, B=B, H=H, Tq=T, Tk=T, d=d, ldq=H * d, ldk=H * d, lse=stats[0])
             res = {}
-            for name, kw in (("flash", dict(o=o)), ("materialised", dict())):
+            for name, kw in (("flash", dict(o=o, stats=stats)), ("materialised", dict())):
                 for _ in range(2):
                     bw.attention_backward(q, k, v, do, H, **kw)
                 torch.cuda.synchronize()

@@ -22,6 +22,8 @@
 // and the A operand (the transposed tile in LDS) is fetched with the same permutation (two 8-byte reads): no LDS round
 // trip, no shuffles for P / dS.  Every sum is in a fixed order: deterministic, no atomics (dq and dk / dv come from
 // different kernels instead of one kernel with atomic dq).
+#include <cstdlib>
+
 #include "ur_common.h"
 #include "../../include/ur_kernels.h"
 
@@ -479,6 +481,249 @@ __global__ void __launch_bounds__(256) attn_bwd_fold_kernel(const AttnBwdArgs p,
     store4<T>(dst + ((int64_t)b * p.Tk_rows + row) * ld + hd + col, a, is_v ? 1.0f : p.scale);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same two kernels on the 32x32x16 MFMA for the 64-wide padded head dim (d = 40, the 4096-token level where the
+// time is).  The 16x16x32 shape issues at ~27 cycles per instruction on this chip (tools/ubench/mfma_rate.hip), the
+// 32x32x16 shape does twice the work in its nominal 32; LDS bytes per FLOP are the same as the NB = 2 kernels above.
+// A wave owns 32 columns (queries / keys); lane (j = lane & 31, hh = lane >> 5) receives, in register v, row
+// 8 (v >> 2) + 4 hh + (v & 3) of column j: registers 8t .. 8t+7 ARE the B operand of k step t of the next MFMA when its k
+// index is read as k = 8 hh + i -> row 16 t + 4 hh + i (i < 4), 16 t + 8 + 4 hh + i - 4 (i >= 4); the transposed tile is
+// read with that permutation (two 8-byte reads).  The dq kernel needs the forward's log-sum-exp (has_lse).
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ typename Vec8<T>::type frag_rows32(const char* lds, int blk, int ks, int j, int hh) {
+    return *reinterpret_cast<const typename Vec8<T>::type*>(lds + (32 * blk + j) * BwdLds<64>::RS + (ks * 2 + hh) * 16);
+}
+template <typename T>
+__device__ __forceinline__ typename Vec8<T>::type frag_trn32(const char* lds, int blk, int col0, int j, int hh) {
+    const char* r = lds + (32 * blk + j) * BwdLds<64>::TS + (col0 + 4 * hh) * 2;
+    const uint2 a = *reinterpret_cast<const uint2*>(r), b = *reinterpret_cast<const uint2*>(r + 16);
+    const uint4 u = make_uint4(a.x, a.y, b.x, b.y);
+    return __builtin_bit_cast(typename Vec8<T>::type, u);
+}
+template <typename T>
+__device__ __forceinline__ typename Vec8<T>::type pack8(const f32x16& a, int t) {
+    typename Vec8<T>::type v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (T)a[8 * t + i];
+    return v;
+}
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = 0.f;
+    return z;
+}
+template <typename T>
+__device__ __forceinline__ void store4v(T* p, const f32x16& a, int g4, float scale) {
+    T h[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) h[i] = (T)(a[4 * g4 + i] * scale);
+    uint2 u;
+    __builtin_memcpy(&u, h, 8);
+    *reinterpret_cast<uint2*>(p) = u;
+}
+
+template <typename T, bool MASK>
+__global__ void __launch_bounds__(256) attn_bwd_dq32_kernel(const AttnBwdArgs p) {
+    typedef typename Vec8<T>::type vec8;
+    constexpr int DP = 64;
+    typedef BwdLds<DP> L;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ks = smem;
+    char* Vs = smem + L::ROWS;
+    char* Kts = smem + 2 * L::ROWS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, hh = lane >> 5;
+    const int s = blockIdx.y, Tn = p.Tk, Tq = p.Tq;
+    const int b = s / p.H, hd = (s - b * p.H) * p.d, d = p.d, C = p.H * p.d;
+    const int64_t row = (blockIdx.x * 4 + wave) * 32 + j;  // this lane's query
+    const T* Q = reinterpret_cast<const T*>(p.q) + (int64_t)b * Tq * p.ldq + hd;
+    const T* O = reinterpret_cast<const T*>(p.o) + (int64_t)b * Tq * p.ldo + hd;
+    const T* dO = reinterpret_cast<const T*>(p.dout) + (int64_t)b * Tq * p.lddo + hd;
+    const T* K = reinterpret_cast<const T*>(p.k) + (int64_t)b * p.Tk_rows * p.ldk + hd;
+    const T* V = reinterpret_cast<const T*>(p.v) + (int64_t)b * p.Tk_rows * p.ldv + hd;
+    const T* Kt = reinterpret_cast<const T*>(p.kt) + ((int64_t)b * C + hd) * p.ldkt;
+    const float s2 = p.scale * 1.44269504088896341f;
+
+    vec8 qf[4], dof[4];
+    float dsum = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const int col = 16 * ks + 8 * hh;
+        qf[ks] = load_or_zero<T, vec8>(Q + row * p.ldq + col, col < d);
+        dof[ks] = load_or_zero<T, vec8>(dO + row * p.lddo + col, col < d);
+        const vec8 of = load_or_zero<T, vec8>(O + row * p.ldo + col, col < d);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dsum = fmaf((float)dof[ks][i], (float)of[i], dsum);
+    }
+    dsum += __shfl_xor(dsum, 32, 64);
+    const float lse = p.stats[(int64_t)s * Tq + row];
+    if (hh == 0) p.stats[(int64_t)(p.S + s) * Tq + row] = dsum;
+
+    f32x16 acc[2] = {zero16(), zero16()};
+    u32x4 rk[UR_ROWREGS(DP)], rv[UR_ROWREGS(DP)], rkt[UR_TRNREGS(DP)];
+#define UR_GLOAD_KV32(kt_)                                        \
+    do {                                                          \
+        gload_rows<T, DP>(K + (int64_t)(kt_) * p.ldk, p.ldk, p.Tk_valid - (kt_), d, rk, tid); \
+        gload_rows<T, DP>(V + (int64_t)(kt_) * p.ldv, p.ldv, p.Tk_valid - (kt_), d, rv, tid); \
+        gload_trn<T, DP>(Kt + (kt_), p.ldkt, d, rkt, tid);        \
+    } while (0)
+    UR_GLOAD_KV32(0);
+    for (int kt = 0; kt < Tn; kt += 64) {
+        __syncthreads();
+        lstore_rows<DP>(Ks, rk, tid);
+        lstore_rows<DP>(Vs, rv, tid);
+        lstore_trn<DP>(Kts, rkt, tid);
+        __syncthreads();
+        if (kt + 64 < Tn) UR_GLOAD_KV32(kt + 64);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {  // 32 keys at a time
+            f32x16 sc = zero16(), dp = zero16();
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                sc = mfma32(frag_rows32<T>(Ks, kb, ks, j, hh), qf[ks], sc);
+                dp = mfma32(frag_rows32<T>(Vs, kb, ks, j, hh), dof[ks], dp);
+            }
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                float pr = __builtin_amdgcn_exp2f(fmaf(sc[v], s2, -lse));
+                if (MASK && kt + 32 * kb + 8 * (v >> 2) + 4 * hh + (v & 3) >= p.Tk_valid) pr = 0.f;
+                sc[v] = pr * (dp[v] - dsum);
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const vec8 dsf = pack8<T>(sc, t);
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+                    acc[db] = mfma32(frag_trn32<T>(Kts, db, 32 * kb + 16 * t, j, hh), dsf, acc[db]);
+            }
+        }
+    }
+    T* dQ = reinterpret_cast<T*>(p.dq) + (int64_t)b * Tq * p.lddq + hd;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const int col = 32 * db + 8 * g4 + 4 * hh;
+            if (col + 4 <= d) store4v<T>(dQ + row * p.lddq + col, acc[db], g4, p.scale);
+        }
+}
+
+template <typename T, bool SPLIT>
+__global__ void __launch_bounds__(256) attn_bwd_dkdv32_kernel(const AttnBwdArgs p) {
+    typedef typename Vec8<T>::type vec8;
+    constexpr int DP = 64;
+    typedef BwdLds<DP> L;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Qs = smem;
+    char* dOs = smem + L::ROWS;
+    char* Qts = smem + 2 * L::ROWS;
+    char* dOts = Qts + L::TRN;
+    float* st = reinterpret_cast<float*>(dOts + L::TRN);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, hh = lane >> 5;
+    const int s = blockIdx.y, Tn = p.Tq, Tk = p.Tk;
+    const int b = s / p.H, hd = (s - b * p.H) * p.d, d = p.d, C = p.H * p.d;
+    const int64_t row = (blockIdx.x * 4 + wave) * 32 + j;  // this lane's key
+    const T* Q = reinterpret_cast<const T*>(p.q) + (int64_t)b * Tn * p.ldq + hd;
+    const T* dO = reinterpret_cast<const T*>(p.dout) + (int64_t)b * Tn * p.lddo + hd;
+    const T* K = reinterpret_cast<const T*>(p.k) + (int64_t)b * p.Tk_rows * p.ldk + hd;
+    const T* V = reinterpret_cast<const T*>(p.v) + (int64_t)b * p.Tk_rows * p.ldv + hd;
+    const T* Qt = reinterpret_cast<const T*>(p.qt) + ((int64_t)b * C + hd) * p.ldqt;
+    const T* dOt = reinterpret_cast<const T*>(p.dot) + ((int64_t)b * C + hd) * p.lddot;
+    const float* lse_g = p.stats + (int64_t)s * Tn;
+    const float* dsum_g = p.stats + (int64_t)(p.S + s) * Tn;
+    const float s2 = p.scale * 1.44269504088896341f;
+    const int qlen = SPLIT ? (Tn / 64 + p.G - 1) / p.G * 64 : Tn;
+    const int q_beg = SPLIT ? (int)blockIdx.z * qlen : 0, q_end = SPLIT ? min(Tn, q_beg + qlen) : Tn;
+
+    vec8 kf[4], vf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const int col = 16 * ks + 8 * hh;
+        const bool ok = row < p.Tk_valid && col < d;
+        kf[ks] = load_or_zero<T, vec8>(K + row * p.ldk + col, ok);
+        vf[ks] = load_or_zero<T, vec8>(V + row * p.ldv + col, ok);
+    }
+    f32x16 dk[2] = {zero16(), zero16()}, dv[2] = {zero16(), zero16()};
+    u32x4 rq[UR_ROWREGS(DP)], rdo[UR_ROWREGS(DP)], rqt[UR_TRNREGS(DP)], rdot[UR_TRNREGS(DP)];
+    float rst = 0.f;
+    const float* st_g = tid < 64 ? lse_g + tid : dsum_g + (tid & 63);
+#define UR_GLOAD_Q32(qt_)                                         \
+    do {                                                          \
+        gload_rows<T, DP>(Q + (int64_t)(qt_) * p.ldq, p.ldq, 64, d, rq, tid);     \
+        gload_rows<T, DP>(dO + (int64_t)(qt_) * p.lddo, p.lddo, 64, d, rdo, tid); \
+        gload_trn<T, DP>(Qt + (qt_), p.ldqt, d, rqt, tid);        \
+        gload_trn<T, DP>(dOt + (qt_), p.lddot, d, rdot, tid);     \
+        if (tid < 128) rst = st_g[qt_];                           \
+    } while (0)
+    if (q_beg < q_end) UR_GLOAD_Q32(q_beg);
+    for (int qt = q_beg; qt < q_end; qt += 64) {
+        __syncthreads();
+        lstore_rows<DP>(Qs, rq, tid);
+        lstore_rows<DP>(dOs, rdo, tid);
+        lstore_trn<DP>(Qts, rqt, tid);
+        lstore_trn<DP>(dOts, rdot, tid);
+        if (tid < 128) st[tid] = rst;
+        __syncthreads();
+        if (qt + 64 < q_end) UR_GLOAD_Q32(qt + 64);
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {  // 32 queries at a time
+            f32x16 sc = zero16(), dp = zero16();
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                sc = mfma32(frag_rows32<T>(Qs, qb, ks, j, hh), kf[ks], sc);
+                dp = mfma32(frag_rows32<T>(dOs, qb, ks, j, hh), vf[ks], dp);
+            }
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const float4 l4 = *reinterpret_cast<const float4*>(st + 32 * qb + 8 * g4 + 4 * hh);
+                const float4 d4 = *reinterpret_cast<const float4*>(st + 64 + 32 * qb + 8 * g4 + 4 * hh);
+                const float lr[4] = {l4.x, l4.y, l4.z, l4.w}, dr[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pr = __builtin_amdgcn_exp2f(fmaf(sc[4 * g4 + r], s2, -lr[r]));
+                    sc[4 * g4 + r] = pr;
+                    dp[4 * g4 + r] = pr * (dp[4 * g4 + r] - dr[r]);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const vec8 pf = pack8<T>(sc, t), dsf = pack8<T>(dp, t);
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    dv[db] = mfma32(frag_trn32<T>(dOts, db, 32 * qb + 16 * t, j, hh), pf, dv[db]);
+                    dk[db] = mfma32(frag_trn32<T>(Qts, db, 32 * qb + 16 * t, j, hh), dsf, dk[db]);
+                }
+            }
+        }
+    }
+    if constexpr (SPLIT) {
+        float* pk = p.part + (((int64_t)blockIdx.z * p.S + s) * Tk) * DP;
+        float* pv = pk + (int64_t)p.G * p.S * Tk * DP;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int64_t o = row * DP + 32 * db + 8 * g4 + 4 * hh;
+                *reinterpret_cast<f32x4*>(pk + o) = f32x4{dk[db][4 * g4], dk[db][4 * g4 + 1], dk[db][4 * g4 + 2], dk[db][4 * g4 + 3]};
+                *reinterpret_cast<f32x4*>(pv + o) = f32x4{dv[db][4 * g4], dv[db][4 * g4 + 1], dv[db][4 * g4 + 2], dv[db][4 * g4 + 3]};
+            }
+    } else {
+        T* dK = reinterpret_cast<T*>(p.dk) + (int64_t)b * p.Tk_rows * p.lddk + hd;
+        T* dV = reinterpret_cast<T*>(p.dv) + (int64_t)b * p.Tk_rows * p.lddv + hd;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int col = 32 * db + 8 * g4 + 4 * hh;
+                if (row < p.Tk_valid && col + 4 <= d) {
+                    store4v<T>(dK + row * p.lddk + col, dk[db], g4, p.scale);
+                    store4v<T>(dV + row * p.lddv + col, dv[db], g4, 1.0f);
+                }
+            }
+    }
+}
+
 template <typename T, int DP, int NB, bool HAS_LSE, bool MASK>
 static void launch_dq(const AttnBwdArgs& a, hipStream_t st) {
     typedef BwdLds<DP> L;
@@ -503,6 +748,28 @@ static void launch_dkdv(const AttnBwdArgs& a, hipStream_t st) {
     }
 }
 
+static bool flash_m32() {
+    static const int v = [] { const char* e = std::getenv("UR_FLASH_M32"); return (e && e[0] == '0') ? 0 : 1; }();
+    return v != 0;
+}
+template <typename T>
+static int launch_bwd32(const AttnBwdArgs& a, hipStream_t st) {
+    typedef BwdLds<64> L;
+    constexpr int lds_dq = 2 * L::ROWS + L::TRN, lds_kv = 2 * L::ROWS + 2 * L::TRN + 512;
+    const dim3 gq(a.Tq / 128, a.S), gk(a.Tk / 128, a.S, a.G);
+    if (a.Tk_valid < a.Tk) hipLaunchKernelGGL((attn_bwd_dq32_kernel<T, true>), gq, dim3(256), lds_dq, st, a);
+    else hipLaunchKernelGGL((attn_bwd_dq32_kernel<T, false>), gq, dim3(256), lds_dq, st, a);
+    if (a.G > 1) {
+        hipLaunchKernelGGL((attn_bwd_dkdv32_kernel<T, true>), gk, dim3(256), lds_kv, st, a);
+        const int64_t n4 = (int64_t)a.S * a.Tk * 64 / 4;
+        hipLaunchKernelGGL((attn_bwd_fold_kernel<T>), dim3((unsigned)((n4 + 255) / 256), 2), dim3(256), 0, st, a, 64, n4);
+    } else {
+        hipLaunchKernelGGL((attn_bwd_dkdv32_kernel<T, false>), gk, dim3(256), lds_kv, st, a);
+    }
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : -(int)e;
+}
+
 template <typename T, int DP, int NBQ, int NBK, bool HAS_LSE>
 static int launch_bwd(const AttnBwdArgs& a, hipStream_t st) {
     if (a.Tk_valid < a.Tk) launch_dq<T, DP, NBQ, HAS_LSE, true>(a, st);
@@ -519,6 +786,7 @@ static int dispatch_bwd(const AttnBwdArgs& a, int dp, hipStream_t st) {
     switch (dp) {
         case 32: return launch_bwd<T, 32, 1, 1, HAS_LSE>(a, st);
         case 64:
+            if (wq && wk && HAS_LSE && flash_m32()) return launch_bwd32<T>(a, st);
             if (wq && wk) return launch_bwd<T, 64, 2, 2, HAS_LSE>(a, st);
             if (wq) return launch_bwd<T, 64, 2, 1, HAS_LSE>(a, st);
             if (wk) return launch_bwd<T, 64, 1, 2, HAS_LSE>(a, st);
