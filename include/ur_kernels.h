@@ -361,6 +361,16 @@ typedef struct ur_transpose_desc {
 } ur_transpose_desc;
 int ur_transpose2d_multi(const ur_transpose_desc* descs, int n, int dtype, void* stream);
 
+/* dst[i] = (dst type) src[i] for up to UR_CAST_MAX_TENSORS contiguous tensors in one launch: fp32 -> dtype (to_f32 = 0: the
+ * master parameters into the compute dtype) or dtype -> fp32 (to_f32 = 1: their gradients back).  dtype: UR_DT_F16 / BF16. */
+#define UR_CAST_MAX_TENSORS 128
+typedef struct ur_cast_tensor {
+    const void* src;
+    void* dst;
+    int64_t n;
+} ur_cast_tensor;
+int ur_cast_multi(const ur_cast_tensor* tensors, int n_tensors, int to_f32, int dtype, void* stream);
+
 /* AdamW over many parameter tensors per launch (the optimizer step of the training loop, train/train.py:1082-1100
  * torch.optim.AdamW, 1425 optimizer.step()).  Decoupled weight decay, bias correction, no amsgrad, fp32 everywhere; the
  * arithmetic of torch's fused kernel (param -= lr*wd*param; exp_avg = lerp(exp_avg, g, 1-beta1); exp_avg_sq = beta2*

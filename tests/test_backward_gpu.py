@@ -369,3 +369,17 @@ def test_flash_attention_backward_cross(dev, dtype, shape, direct, monkeypatch):
     print({"flash_attention_backward_cross": str(dtype), "shape": shape, "query_splits": G, "rel_l2_dq_dk_dv": errs,
            "own_lse": errs2})
     assert rel_l2(o, o_ref) < TOL[dtype] and max(errs) < tol and max(errs2) < tol, (errs, errs2)
+
+def test_cast_many(dev):
+    """ur_cast_multi: > 128 tensors, odd sizes and unaligned views, both directions, against Tensor.to."""
+    from uni_renderer_amd import backward as bw
+    g = torch.Generator().manual_seed(9)
+    base = torch.randn(100000, generator=g).to(dev)
+    srcs = [torch.randn(n, generator=g).to(dev) for n in (1, 7, 8, 4096, 8192, 8193, 100003)] * 20 + [base[1:50002], base[3:11]]
+    for dt in (torch.bfloat16, torch.float16):
+        outs = bw.cast_many(srcs, dt)
+        for a, b in zip(srcs, outs):
+            assert b.dtype == dt and torch.equal(b, a.to(dt))
+        back = bw.cast_many(outs, torch.float32)
+        for a, b in zip(outs, back):
+            assert b.dtype == torch.float32 and torch.equal(b, a.float())

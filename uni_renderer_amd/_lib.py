@@ -112,6 +112,7 @@ SYMBOLS = {
     "ur_attention_backward_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "ur_attention_backward_splits": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "ur_transpose2d_multi": (C.c_int, [vp, C.c_int, C.c_int, vp]),
+    "ur_cast_multi": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp]),
     "ur_adamw_multi": (C.c_int, [vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, vp, vp, vp, vp]),
     "ur_silu_forward": (C.c_int, [vp, vp, C.c_int64, C.c_int, vp]),
     "ur_resample2x": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),

@@ -86,6 +86,37 @@ def transpose2d_many(xs) -> list:
     return outs
 
 
+class _CastDesc(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("n", C.c_int64)]
+
+
+def cast_many(srcs, dtype) -> list:
+    """``[s.to(dtype) for s in srcs]`` for fp32 -> fp16 / bf16 or fp16 / bf16 -> fp32, 128 tensors per launch
+    (``ur_cast_multi``)."""
+    lib = _lib.load()
+    srcs = [s_.contiguous() for s_ in srcs]
+    outs = [torch.empty_like(s_, dtype=dtype) for s_ in srcs]
+    if not srcs:
+        return outs
+    to_f32 = dtype == torch.float32
+    low = srcs[0].dtype if to_f32 else dtype
+    for s_ in srcs:
+        _require_gpu(s_)
+        if s_.dtype != (low if to_f32 else torch.float32):
+            raise ValueError("cast_many: one source dtype per call (fp32 -> half or half -> fp32)")
+    st = _stream()
+    for i in range(0, len(srcs), 128):
+        part = list(zip(srcs[i:i + 128], outs[i:i + 128]))
+        part = [(a, b) for a, b in part if a.numel()]
+        if not part:
+            continue
+        arr = (_CastDesc * len(part))()
+        for k, (a, b) in enumerate(part):
+            arr[k].src, arr[k].dst, arr[k].n = a.data_ptr(), b.data_ptr(), a.numel()
+        check(lib.ur_cast_multi(arr, len(part), int(to_f32), DT[low], st), "ur_cast_multi")
+    return outs
+
+
 def colsum(x: torch.Tensor, rows_per_group: int = 0) -> torch.Tensor:
     """fp32 column sums of the 2-D view [M, N] of ``x``; with ``rows_per_group`` one sum per group of rows."""
     _require_gpu(x)

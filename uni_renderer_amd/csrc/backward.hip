@@ -1048,3 +1048,69 @@ extern "C" int ur_adamw_multi(const ur_adamw_tensor* tensors, int n_tensors, flo
     hipLaunchKernelGGL(adamw_multi_kernel, dim3((unsigned)chunks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
     return last_error();
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// fp32 <-> compute dtype casts of up to UR_CAST_MAX_TENSORS tensors per launch (chunk table in the kernel arguments)
+// ---------------------------------------------------------------------------------------------------------------
+struct CastArgs {
+    ur_cast_tensor t[UR_CAST_MAX_TENSORS];
+    int chunk0[UR_CAST_MAX_TENSORS + 1];
+    int n;
+};
+constexpr int CAST_CHUNK = 8192;
+
+template <typename T, bool TO_F32>
+__global__ void __launch_bounds__(256) cast_multi_kernel(const CastArgs a) {
+    int lo = 0, hi = a.n;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (a.chunk0[mid] <= (int)blockIdx.x) lo = mid; else hi = mid;
+    }
+    const ur_cast_tensor t = a.t[lo];
+    const int64_t beg = (int64_t)((int)blockIdx.x - a.chunk0[lo]) * CAST_CHUNK;
+    const int64_t end = beg + CAST_CHUNK < t.n ? beg + CAST_CHUNK : t.n;
+    const bool vec = ((((uintptr_t)t.src) | ((uintptr_t)t.dst)) & 15) == 0;
+    const int64_t end8 = vec ? beg + ((end - beg) & ~(int64_t)7) : beg;
+    if constexpr (TO_F32) {
+        const T* src = reinterpret_cast<const T*>(t.src);
+        float* dst = reinterpret_cast<float*>(t.dst);
+        for (int64_t i = beg + 8 * threadIdx.x; i < end8; i += 2048) {
+            float v[8];
+            load8(src + i, v);
+            *reinterpret_cast<float4*>(dst + i) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(dst + i + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        }
+        for (int64_t i = end8 + threadIdx.x; i < end; i += 256) dst[i] = (float)src[i];
+    } else {
+        const float* src = reinterpret_cast<const float*>(t.src);
+        T* dst = reinterpret_cast<T*>(t.dst);
+        for (int64_t i = beg + 8 * threadIdx.x; i < end8; i += 2048) {
+            const float4 x = *reinterpret_cast<const float4*>(src + i), y = *reinterpret_cast<const float4*>(src + i + 4);
+            const float v[8] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w};
+            store8(dst + i, v);
+        }
+        for (int64_t i = end8 + threadIdx.x; i < end; i += 256) dst[i] = (T)src[i];
+    }
+}
+
+extern "C" int ur_cast_multi(const ur_cast_tensor* tensors, int n_tensors, int to_f32, int dtype, void* stream) {
+    if (!tensors || n_tensors <= 0 || n_tensors > UR_CAST_MAX_TENSORS) return UR_E_BADARG;
+    CastArgs a;
+    int64_t chunks = 0;
+    for (int i = 0; i < n_tensors; ++i) {
+        if (!tensors[i].src || !tensors[i].dst || tensors[i].n <= 0) return UR_E_BADARG;
+        a.t[i] = tensors[i];
+        a.chunk0[i] = (int)chunks;
+        chunks += (tensors[i].n + CAST_CHUNK - 1) / CAST_CHUNK;
+        if (chunks > 0x7fffffff) return UR_E_BADARG;
+    }
+    a.chunk0[n_tensors] = (int)chunks;
+    a.n = n_tensors;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (to_f32) {
+        UR_DISPATCH(dtype, hipLaunchKernelGGL((cast_multi_kernel<T, true>), dim3((unsigned)chunks), dim3(256), 0, s, a));
+    } else {
+        UR_DISPATCH(dtype, hipLaunchKernelGGL((cast_multi_kernel<T, false>), dim3((unsigned)chunks), dim3(256), 0, s, a));
+    }
+    return last_error();
+}

@@ -13,6 +13,8 @@ loss and gradients against the CPU restatement of the reference under autograd i
 """
 from __future__ import annotations
 
+import os
+
 from typing import Dict, List, Optional, Sequence
 
 import torch
@@ -22,19 +24,59 @@ from . import ops
 from .controlnet import CIN_PAD
 
 
+BATCH_CASTS = os.environ.get("UR_BATCH_CASTS", "1") != "0"
+_cast: Dict[int, torch.Tensor] = {}          # id(fp32 weight) -> its compute-dtype copy, valid inside one network forward
+_castable: Dict[int, tuple] = {}             # id(network) -> (network, its Linear / 1x1-conv weights)
+
+
+class _batched_casts:
+    """All Linear / 1x1-conv weights of ``net`` cast to ``dt`` by ONE multi-tensor launch (autograd_ops.CastParams) for
+    the duration of a network forward; ``_wc`` / ``_w2`` pick the copies up.  Their gradients return to fp32 in one
+    launch when the network's backward has produced the last of them."""
+
+    def __init__(self, net, dt):
+        self.net, self.dt = net, dt
+
+    def __enter__(self):
+        if not (BATCH_CASTS and torch.is_grad_enabled()):
+            return self
+        hit = _castable.get(id(self.net))
+        if hit is None or hit[0] is not self.net:
+            ws = [m.weight for m in self.net.modules()
+                  if isinstance(m, torch.nn.Linear) or (isinstance(m, torch.nn.Conv2d) and m.kernel_size == (1, 1))]
+            hit = _castable[id(self.net)] = (self.net, [w for w in ws if w.dtype == torch.float32])
+        ws = [w for w in hit[1] if w.requires_grad]
+        if ws:
+            for w, c in zip(ws, A.CastParams.apply(self.dt, *ws)):
+                _cast[id(w)] = c
+        self.keys = [id(w) for w in ws]
+        return self
+
+    def __exit__(self, *exc):
+        for k in getattr(self, "keys", ()):
+            _cast.pop(k, None)
+        return False
+
+
+def _wc(w, dt):
+    """compute-dtype copy of the weight ``w`` (from the network's batched cast when there is one)."""
+    c = _cast.get(id(w))
+    return c if c is not None and c.dtype == dt else w.to(dt)
+
+
 def _w2(conv_or_lin, dt):
     """[N, K] compute-dtype view of a Linear / 1x1-conv weight (differentiable)."""
-    w = conv_or_lin.weight
-    return w.reshape(w.shape[0], -1).to(dt)
+    w = _wc(conv_or_lin.weight, dt)
+    return w.reshape(w.shape[0], -1)
 
 
 def _temb_projections(resnets, temb_act, dt):
     """All ``time_emb_proj`` of a network phase as ONE GEMM (what the inference path does too): the M = batch-size
     linears, their two backward GEMMs, three transposes and the bias column sum per resnet are launch-bound, ~25
     launches per resnet.  Returns {id(resnet): [B, C_out] column slice}; autograd splits the gradients back."""
-    w = torch.cat([r.time_emb_proj.weight for r in resnets], 0)
+    w = torch.cat([_wc(r.time_emb_proj.weight, dt) for r in resnets], 0)
     b = torch.cat([r.time_emb_proj.bias for r in resnets], 0)
-    t_all = A.linear(temb_act, w.to(dt), b)
+    t_all = A.linear(temb_act, w, b)
     out, off = {}, 0
     for r in resnets:
         n = r.time_emb_proj.weight.shape[0]
@@ -65,7 +107,7 @@ def _resnet(r, x, temb, dt, x1=None):
 def _self_attn(a, xn, res, dt):
     """q | k | v as ONE projection (one forward and two backward GEMMs instead of three of each)."""
     Cc = a.to_q.weight.shape[0]
-    qkv = A.linear(xn, torch.cat([a.to_q.weight, a.to_k.weight, a.to_v.weight], 0).to(dt))
+    qkv = A.linear(xn, torch.cat([_wc(a.to_q.weight, dt), _wc(a.to_k.weight, dt), _wc(a.to_v.weight, dt)], 0))
     o = A.AttentionQKV.apply(qkv, a.heads)
     return A.linear(o, _w2(a.to_out[0], dt), a.to_out[0].bias, res=res)
 
@@ -84,8 +126,8 @@ def _context_projections(blocks, ehs, dt):
     tbs = [tb for blk in blocks for t in getattr(blk, "attentions", []) for tb in t.transformer_blocks]
     if not tbs:
         return {}
-    w = torch.cat([w_ for tb in tbs for w_ in (tb.attn2.to_k.weight, tb.attn2.to_v.weight)], 0)
-    kv_all = A.linear(ehs, w.to(dt))
+    w = torch.cat([_wc(w_, dt) for tb in tbs for w_ in (tb.attn2.to_k.weight, tb.attn2.to_v.weight)], 0)
+    kv_all = A.linear(ehs, w)
     out, off = {}, 0
     for tb in tbs:
         n = 2 * tb.attn2.to_k.weight.shape[0]
@@ -199,11 +241,12 @@ def encoder_forward(enc, cond_nhwc, ehs, t_attr, dt, conditioning_scale: float =
     """AttributeEncoderModel (controlnet.py:1657-1778).  ``cond_nhwc`` [B,H,W,CIN_PAD].  Returns
     (res[12], mid_res, raw_down[12], raw_mid), NHWC."""
     B, dev = cond_nhwc.shape[0], cond_nhwc.device
-    te = _time(enc, t_attr, B, dt, dev)
-    xe = _conv(enc.conv_in, cond_nhwc, dt, cin_pad=CIN_PAD)
-    raw_mid_enc, raw_enc = _down_mid(enc, xe, te, ehs, dt)
-    res = [A.linear(s, _w2(z, dt), z.bias) for s, z in zip(raw_enc, enc.controlnet_down_blocks)]
-    mid_res = A.linear(raw_mid_enc, _w2(enc.controlnet_mid_block, dt), enc.controlnet_mid_block.bias)
+    with _batched_casts(enc, dt):
+        te = _time(enc, t_attr, B, dt, dev)
+        xe = _conv(enc.conv_in, cond_nhwc, dt, cin_pad=CIN_PAD)
+        raw_mid_enc, raw_enc = _down_mid(enc, xe, te, ehs, dt)
+        res = [A.linear(s, _w2(z, dt), z.bias) for s, z in zip(raw_enc, enc.controlnet_down_blocks)]
+        mid_res = A.linear(raw_mid_enc, _w2(enc.controlnet_mid_block, dt), enc.controlnet_mid_block.bias)
     if conditioning_scale != 1.0:  # ref 1773-1775
         res = [r * conditioning_scale for r in res]
         mid_res = mid_res * conditioning_scale
@@ -214,15 +257,16 @@ def unet_forward(unet, x_nhwc, ehs, t_img, dt, res=None, mid_res=None, collect_u
     """UNet2DConditionModel (controlnet.py:781-1166).  ``x_nhwc`` [B,H,W,CIN_PAD]; ``res`` / ``mid_res``: the encoder's
     residuals (NHWC) or None.  Returns (img_pred, raw_down[12], raw_mid, up_res[13] | None), NHWC."""
     B, dev = x_nhwc.shape[0], x_nhwc.device
-    tu = _time(unet, t_img, B, dt, dev)
-    xu = _conv(unet.conv_in, x_nhwc, dt, cin_pad=CIN_PAD)
-    raw_mid_unet, raw_unet = _down_mid(unet, xu, tu, ehs, dt)
-    skips, mid = raw_unet, raw_mid_unet
-    if res is not None:  # ref 1078-1087, 1114-1115
-        skips = [A.Add.apply(s, r) for s, r in zip(raw_unet, res)]
-        mid = A.Add.apply(raw_mid_unet, mid_res)
-    ups = [mid] if collect_up else None
-    img = _up_out(unet, mid, skips, tu, ehs, dt, collect=ups)
+    with _batched_casts(unet, dt):
+        tu = _time(unet, t_img, B, dt, dev)
+        xu = _conv(unet.conv_in, x_nhwc, dt, cin_pad=CIN_PAD)
+        raw_mid_unet, raw_unet = _down_mid(unet, xu, tu, ehs, dt)
+        skips, mid = raw_unet, raw_mid_unet
+        if res is not None:  # ref 1078-1087, 1114-1115
+            skips = [A.Add.apply(s, r) for s, r in zip(raw_unet, res)]
+            mid = A.Add.apply(raw_mid_unet, mid_res)
+        ups = [mid] if collect_up else None
+        img = _up_out(unet, mid, skips, tu, ehs, dt, collect=ups)
     return img, raw_unet, raw_mid_unet, ups
 
 
@@ -230,12 +274,13 @@ def decoder_forward(dec, raw_mid_enc, raw_enc, ehs, t_attr, dt, raw_unet=None, r
     """AttributeDecoderModel (controlnet.py:2342-2527): exchange skip_enc + conv1x1(skip_unet) (2446-2461, 2476-2477),
     up path on its own weights.  All NHWC; returns attr_pred [B,H,W,out_channels]."""
     B, dev = raw_mid_enc.shape[0], raw_mid_enc.device
-    td = _time(dec, t_attr, B, dt, dev)
-    dskips = list(raw_enc)
-    if raw_unet is not None:
-        dskips = [A.linear(u, _w2(z, dt), z.bias, res=e) for u, e, z in zip(raw_unet, raw_enc, dec.control_down_blocks)]
-    xd = A.linear(raw_mid_unet, _w2(dec.control_mid_block, dt), dec.control_mid_block.bias, res=raw_mid_enc)
-    return _up_out(dec, xd, dskips, td, ehs, dt, extras=extras)
+    with _batched_casts(dec, dt):
+        td = _time(dec, t_attr, B, dt, dev)
+        dskips = list(raw_enc)
+        if raw_unet is not None:
+            dskips = [A.linear(u, _w2(z, dt), z.bias, res=e) for u, e, z in zip(raw_unet, raw_enc, dec.control_down_blocks)]
+        xd = A.linear(raw_mid_unet, _w2(dec.control_mid_block, dt), dec.control_mid_block.bias, res=raw_mid_enc)
+        return _up_out(dec, xd, dskips, td, ehs, dt, extras=extras)
 
 
 def dual_stream_forward(unet, enc, dec, x_t, cond, ehs, t_img, t_attr, dtype=torch.bfloat16, run_decoder: bool = True,
