@@ -58,15 +58,24 @@ template <int DP> struct BwdLds {
 // t + 1 are in flight while tile t is multiplied (PF) or at least while the other waves reach the barrier.
 #define UR_ROWREGS(DP) ((64 * ((DP) / 8)) / 256)
 #define UR_TRNREGS(DP) (((DP) * 8) / 256)
-template <typename T, int DP>
+template <typename T, int DP, bool GEN>
 __device__ __forceinline__ void gload_rows(const T* __restrict__ g, int64_t ld, int rows_valid, int d,
                                            u32x4 (&r)[UR_ROWREGS(DP)], int tid) {
     constexpr int CPR = DP / 8;
+    if (!GEN || (rows_valid >= 64 && d == DP)) {  // whole tile in bounds: plain loads (GEN = false: known at compile time)
 #pragma unroll
-    for (int i = 0; i < (64 * CPR) / 256; ++i) {
-        const int e = tid + i * 256, row = e / CPR, c = e - row * CPR;
-        r[i] = u32x4{0u, 0u, 0u, 0u};
-        if (row < rows_valid && c * 8 < d) r[i] = *reinterpret_cast<const u32x4*>(g + (int64_t)row * ld + c * 8);
+        for (int i = 0; i < (64 * CPR) / 256; ++i) {
+            const int e = tid + i * 256, row = e / CPR, c = e - row * CPR;
+            r[i] = *reinterpret_cast<const u32x4*>(g + (int64_t)row * ld + c * 8);
+        }
+    } else {  // out-of-range chunks read chunk 0 of the tile (always valid) and are zeroed: no divergent loads
+#pragma unroll
+        for (int i = 0; i < (64 * CPR) / 256; ++i) {
+            const int e = tid + i * 256, row = e / CPR, c = e - row * CPR;
+            const bool ok = row < rows_valid && c * 8 < d;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(g + (ok ? (int64_t)row * ld + c * 8 : 0));
+            r[i] = ok ? v : u32x4{0u, 0u, 0u, 0u};
+        }
     }
 }
 template <int DP>
@@ -78,13 +87,22 @@ __device__ __forceinline__ void lstore_rows(char* lds, const u32x4 (&r)[UR_ROWRE
         *reinterpret_cast<u32x4*>(lds + row * BwdLds<DP>::RS + c * 16) = r[i];
     }
 }
-template <typename T, int DP>
+template <typename T, int DP, bool GEN>
 __device__ __forceinline__ void gload_trn(const T* __restrict__ g, int64_t ld, int d, u32x4 (&r)[UR_TRNREGS(DP)], int tid) {
+    if (!GEN || d == DP) {
 #pragma unroll
-    for (int i = 0; i < (DP * 8) / 256; ++i) {
-        const int e = tid + i * 256, row = e >> 3, c = e & 7;
-        r[i] = u32x4{0u, 0u, 0u, 0u};
-        if (row < d) r[i] = *reinterpret_cast<const u32x4*>(g + (int64_t)row * ld + c * 8);
+        for (int i = 0; i < (DP * 8) / 256; ++i) {
+            const int e = tid + i * 256, row = e >> 3, c = e & 7;
+            r[i] = *reinterpret_cast<const u32x4*>(g + (int64_t)row * ld + c * 8);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < (DP * 8) / 256; ++i) {
+            const int e = tid + i * 256, row = e >> 3, c = e & 7;
+            const bool ok = row < d;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(g + (ok ? (int64_t)row * ld : 0) + c * 8);
+            r[i] = ok ? v : u32x4{0u, 0u, 0u, 0u};
+        }
     }
 }
 template <int DP>
@@ -115,8 +133,9 @@ __device__ __forceinline__ typename Vec8<T>::type pack2(const f32x4& a, const f3
     for (int i = 0; i < 4; ++i) { v[i] = (T)a[i]; v[4 + i] = (T)b[i]; }
     return v;
 }
-template <typename T, typename V>
+template <typename T, typename V, bool GEN>
 __device__ __forceinline__ V load_or_zero(const T* p, bool ok) {
+    if (!GEN) return *reinterpret_cast<const V*>(p);
     V v;
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = (T)0.0f;
@@ -136,7 +155,7 @@ __device__ __forceinline__ void store4(T* p, const f32x4& a, float scale) {
 // ---------------------------------------------------------------------------------------------------------------
 // kernel 1: row statistics + dq.  grid (T / (64 * NB), S), 4 waves, wave w owns queries (4 * bx + w) * 16 * NB ...
 // ---------------------------------------------------------------------------------------------------------------
-template <typename T, int DP, int NB, bool PF, bool HAS_LSE, bool MASK>
+template <typename T, int DP, int NB, bool PF, bool HAS_LSE, bool MASK, bool GEN>
 __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const AttnBwdArgs p) {
     typedef typename Vec8<T>::type vec8;
     typedef BwdLds<DP> L;
@@ -167,9 +186,9 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const AttnBwdArgs p) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const int col = 32 * ks + 8 * g;
-            qf[nb][ks] = load_or_zero<T, vec8>(Q + row * p.ldq + col, col < d);
-            dof[nb][ks] = load_or_zero<T, vec8>(dO + row * p.lddo + col, col < d);
-            const vec8 of = load_or_zero<T, vec8>(O + row * p.ldo + col, col < d);
+            qf[nb][ks] = load_or_zero<T, vec8, GEN>(Q + row * p.ldq + col, col < d);
+            dof[nb][ks] = load_or_zero<T, vec8, GEN>(dO + row * p.lddo + col, col < d);
+            const vec8 of = load_or_zero<T, vec8, GEN>(O + row * p.ldo + col, col < d);
 #pragma unroll
             for (int i = 0; i < 8; ++i) a = fmaf((float)dof[nb][ks][i], (float)of[i], a);
         }
@@ -191,13 +210,13 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const AttnBwdArgs p) {
         float mx[NB], ls[NB];
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) { mx[nb] = -1e30f; ls[nb] = 0.f; }
-        if (PF) gload_rows<T, DP>(K, p.ldk, p.Tk_valid, d, rk, tid);
+        if (PF) gload_rows<T, DP, GEN>(K, p.ldk, p.Tk_valid, d, rk, tid);
         for (int kt = 0; kt < Tn; kt += 64) {
-            if (!PF) gload_rows<T, DP>(K + (int64_t)kt * p.ldk, p.ldk, p.Tk_valid - kt, d, rk, tid);
+            if (!PF) gload_rows<T, DP, GEN>(K + (int64_t)kt * p.ldk, p.ldk, p.Tk_valid - kt, d, rk, tid);
             __syncthreads();
             lstore_rows<DP>(Ks, rk, tid);
             __syncthreads();
-            if (PF && kt + 64 < Tn) gload_rows<T, DP>(K + (int64_t)(kt + 64) * p.ldk, p.ldk, p.Tk_valid - kt - 64, d, rk, tid);
+            if (PF && kt + 64 < Tn) gload_rows<T, DP, GEN>(K + (int64_t)(kt + 64) * p.ldk, p.ldk, p.Tk_valid - kt - 64, d, rk, tid);
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb) {
                 f32x4 sc[NB];
@@ -251,9 +270,9 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const AttnBwdArgs p) {
         for (int nb = 0; nb < NB; ++nb) acc[db][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #define UR_GLOAD_KV(kt_)                                          \
     do {                                                          \
-        gload_rows<T, DP>(K + (int64_t)(kt_) * p.ldk, p.ldk, p.Tk_valid - (kt_), d, rk, tid); \
-        gload_rows<T, DP>(V + (int64_t)(kt_) * p.ldv, p.ldv, p.Tk_valid - (kt_), d, rv, tid); \
-        gload_trn<T, DP>(Kt + (kt_), p.ldkt, d, rkt, tid);        \
+        gload_rows<T, DP, GEN>(K + (int64_t)(kt_) * p.ldk, p.ldk, p.Tk_valid - (kt_), d, rk, tid); \
+        gload_rows<T, DP, GEN>(V + (int64_t)(kt_) * p.ldv, p.ldv, p.Tk_valid - (kt_), d, rv, tid); \
+        gload_trn<T, DP, GEN>(Kt + (kt_), p.ldkt, d, rkt, tid);        \
     } while (0)
     if (PF) UR_GLOAD_KV(0);
     for (int kt = 0; kt < Tn; kt += 64) {
@@ -309,14 +328,14 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const AttnBwdArgs p) {
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
         for (int db = 0; db < DB; ++db)
-            if (16 * db + 4 * g + 4 <= d)
+            if (!GEN || 16 * db + 4 * g + 4 <= d)
                 store4<T>(dQ + (int64_t)(qbase + 16 * nb + j) * p.lddq + 16 * db + 4 * g, acc[db][nb], p.scale);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // kernel 2: dk, dv.  grid (T / (64 * NB), S), wave w owns keys (4 * bx + w) * 16 * NB ...
 // ---------------------------------------------------------------------------------------------------------------
-template <typename T, int DP, int NB, bool PF, bool SPLIT>
+template <typename T, int DP, int NB, bool PF, bool SPLIT, bool GEN>
 __global__ void __launch_bounds__(256) attn_bwd_dkdv_kernel(const AttnBwdArgs p) {
     typedef typename Vec8<T>::type vec8;
     typedef BwdLds<DP> L;
@@ -352,9 +371,9 @@ __global__ void __launch_bounds__(256) attn_bwd_dkdv_kernel(const AttnBwdArgs p)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const int col = 32 * ks + 8 * g;
-            const bool ok = row < p.Tk_valid && col < d;
-            kf[nb][ks] = load_or_zero<T, vec8>(K + row * p.ldk + col, ok);
-            vf[nb][ks] = load_or_zero<T, vec8>(V + row * p.ldv + col, ok);
+            const bool ok = row < p.Tk_valid && col < d;  // GEN = false: the rows exist (zero padded) and d == DP
+            kf[nb][ks] = load_or_zero<T, vec8, GEN>(K + row * p.ldk + col, ok);
+            vf[nb][ks] = load_or_zero<T, vec8, GEN>(V + row * p.ldv + col, ok);
         }
     }
     f32x4 dk[DB][NB], dv[DB][NB];
@@ -368,10 +387,10 @@ __global__ void __launch_bounds__(256) attn_bwd_dkdv_kernel(const AttnBwdArgs p)
     const float* st_g = tid < 64 ? lse_g + tid : dsum_g + (tid & 63);  // tid < 128 stage the row statistics
 #define UR_GLOAD_Q(qt_)                                           \
     do {                                                          \
-        gload_rows<T, DP>(Q + (int64_t)(qt_) * p.ldq, p.ldq, 64, d, rq, tid);     \
-        gload_rows<T, DP>(dO + (int64_t)(qt_) * p.lddo, p.lddo, 64, d, rdo, tid); \
-        gload_trn<T, DP>(Qt + (qt_), p.ldqt, d, rqt, tid);        \
-        gload_trn<T, DP>(dOt + (qt_), p.lddot, d, rdot, tid);     \
+        gload_rows<T, DP, GEN>(Q + (int64_t)(qt_) * p.ldq, p.ldq, 64, d, rq, tid);     \
+        gload_rows<T, DP, GEN>(dO + (int64_t)(qt_) * p.lddo, p.lddo, 64, d, rdo, tid); \
+        gload_trn<T, DP, GEN>(Qt + (qt_), p.ldqt, d, rqt, tid);        \
+        gload_trn<T, DP, GEN>(dOt + (qt_), p.lddot, d, rdot, tid);     \
         if (tid < 128) rst = st_g[qt_];                           \
     } while (0)
     if (PF && q_beg < q_end) UR_GLOAD_Q(q_beg);
@@ -454,7 +473,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dkdv_kernel(const AttnBwdArgs p)
             for (int db = 0; db < DB; ++db) {
                 const int64_t row = kbase + 16 * nb + j;
                 const int col = 16 * db + 4 * g;
-                if (row < p.Tk_valid && col + 4 <= d) {
+                if (!GEN || (row < p.Tk_valid && col + 4 <= d)) {
                     store4<T>(dK + row * p.lddk + col, dk[db][nb], p.scale);
                     store4<T>(dV + row * p.lddv + col, dv[db][nb], 1.0f);
                 }
@@ -524,7 +543,7 @@ __device__ __forceinline__ void store4v(T* p, const f32x16& a, int g4, float sca
     *reinterpret_cast<uint2*>(p) = u;
 }
 
-template <typename T, bool MASK>
+template <typename T, bool MASK, bool GEN>
 __global__ void __launch_bounds__(256) attn_bwd_dq32_kernel(const AttnBwdArgs p) {
     typedef typename Vec8<T>::type vec8;
     constexpr int DP = 64;
@@ -550,9 +569,9 @@ __global__ void __launch_bounds__(256) attn_bwd_dq32_kernel(const AttnBwdArgs p)
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
         const int col = 16 * ks + 8 * hh;
-        qf[ks] = load_or_zero<T, vec8>(Q + row * p.ldq + col, col < d);
-        dof[ks] = load_or_zero<T, vec8>(dO + row * p.lddo + col, col < d);
-        const vec8 of = load_or_zero<T, vec8>(O + row * p.ldo + col, col < d);
+        qf[ks] = load_or_zero<T, vec8, GEN>(Q + row * p.ldq + col, col < d);
+        dof[ks] = load_or_zero<T, vec8, GEN>(dO + row * p.lddo + col, col < d);
+        const vec8 of = load_or_zero<T, vec8, GEN>(O + row * p.ldo + col, col < d);
 #pragma unroll
         for (int i = 0; i < 8; ++i) dsum = fmaf((float)dof[ks][i], (float)of[i], dsum);
     }
@@ -564,9 +583,9 @@ __global__ void __launch_bounds__(256) attn_bwd_dq32_kernel(const AttnBwdArgs p)
     u32x4 rk[UR_ROWREGS(DP)], rv[UR_ROWREGS(DP)], rkt[UR_TRNREGS(DP)];
 #define UR_GLOAD_KV32(kt_)                                        \
     do {                                                          \
-        gload_rows<T, DP>(K + (int64_t)(kt_) * p.ldk, p.ldk, p.Tk_valid - (kt_), d, rk, tid); \
-        gload_rows<T, DP>(V + (int64_t)(kt_) * p.ldv, p.ldv, p.Tk_valid - (kt_), d, rv, tid); \
-        gload_trn<T, DP>(Kt + (kt_), p.ldkt, d, rkt, tid);        \
+        gload_rows<T, DP, GEN>(K + (int64_t)(kt_) * p.ldk, p.ldk, p.Tk_valid - (kt_), d, rk, tid); \
+        gload_rows<T, DP, GEN>(V + (int64_t)(kt_) * p.ldv, p.ldv, p.Tk_valid - (kt_), d, rv, tid); \
+        gload_trn<T, DP, GEN>(Kt + (kt_), p.ldkt, d, rkt, tid);        \
     } while (0)
     UR_GLOAD_KV32(0);
     for (int kt = 0; kt < Tn; kt += 64) {
@@ -605,11 +624,11 @@ __global__ void __launch_bounds__(256) attn_bwd_dq32_kernel(const AttnBwdArgs p)
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
             const int col = 32 * db + 8 * g4 + 4 * hh;
-            if (col + 4 <= d) store4v<T>(dQ + row * p.lddq + col, acc[db], g4, p.scale);
+            if (!GEN || col + 4 <= d) store4v<T>(dQ + row * p.lddq + col, acc[db], g4, p.scale);
         }
 }
 
-template <typename T, bool SPLIT>
+template <typename T, bool SPLIT, bool GEN>
 __global__ void __launch_bounds__(256) attn_bwd_dkdv32_kernel(const AttnBwdArgs p) {
     typedef typename Vec8<T>::type vec8;
     constexpr int DP = 64;
@@ -641,8 +660,8 @@ __global__ void __launch_bounds__(256) attn_bwd_dkdv32_kernel(const AttnBwdArgs 
     for (int ks = 0; ks < 4; ++ks) {
         const int col = 16 * ks + 8 * hh;
         const bool ok = row < p.Tk_valid && col < d;
-        kf[ks] = load_or_zero<T, vec8>(K + row * p.ldk + col, ok);
-        vf[ks] = load_or_zero<T, vec8>(V + row * p.ldv + col, ok);
+        kf[ks] = load_or_zero<T, vec8, GEN>(K + row * p.ldk + col, ok);
+        vf[ks] = load_or_zero<T, vec8, GEN>(V + row * p.ldv + col, ok);
     }
     f32x16 dk[2] = {zero16(), zero16()}, dv[2] = {zero16(), zero16()};
     u32x4 rq[UR_ROWREGS(DP)], rdo[UR_ROWREGS(DP)], rqt[UR_TRNREGS(DP)], rdot[UR_TRNREGS(DP)];
@@ -650,10 +669,10 @@ __global__ void __launch_bounds__(256) attn_bwd_dkdv32_kernel(const AttnBwdArgs 
     const float* st_g = tid < 64 ? lse_g + tid : dsum_g + (tid & 63);
 #define UR_GLOAD_Q32(qt_)                                         \
     do {                                                          \
-        gload_rows<T, DP>(Q + (int64_t)(qt_) * p.ldq, p.ldq, 64, d, rq, tid);     \
-        gload_rows<T, DP>(dO + (int64_t)(qt_) * p.lddo, p.lddo, 64, d, rdo, tid); \
-        gload_trn<T, DP>(Qt + (qt_), p.ldqt, d, rqt, tid);        \
-        gload_trn<T, DP>(dOt + (qt_), p.lddot, d, rdot, tid);     \
+        gload_rows<T, DP, GEN>(Q + (int64_t)(qt_) * p.ldq, p.ldq, 64, d, rq, tid);     \
+        gload_rows<T, DP, GEN>(dO + (int64_t)(qt_) * p.lddo, p.lddo, 64, d, rdo, tid); \
+        gload_trn<T, DP, GEN>(Qt + (qt_), p.ldqt, d, rqt, tid);        \
+        gload_trn<T, DP, GEN>(dOt + (qt_), p.lddot, d, rdot, tid);     \
         if (tid < 128) rst = st_g[qt_];                           \
     } while (0)
     if (q_beg < q_end) UR_GLOAD_Q32(q_beg);
@@ -716,7 +735,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dkdv32_kernel(const AttnBwdArgs 
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 const int col = 32 * db + 8 * g4 + 4 * hh;
-                if (row < p.Tk_valid && col + 4 <= d) {
+                if (!GEN || (row < p.Tk_valid && col + 4 <= d)) {
                     store4v<T>(dK + row * p.lddk + col, dk[db], g4, p.scale);
                     store4v<T>(dV + row * p.lddv + col, dv[db], g4, 1.0f);
                 }
@@ -724,23 +743,23 @@ __global__ void __launch_bounds__(256) attn_bwd_dkdv32_kernel(const AttnBwdArgs 
     }
 }
 
-template <typename T, int DP, int NB, bool HAS_LSE, bool MASK>
+template <typename T, int DP, int NB, bool HAS_LSE, bool MASK, bool GEN>
 static void launch_dq(const AttnBwdArgs& a, hipStream_t st) {
     typedef BwdLds<DP> L;
     constexpr bool PF = DP <= 64;  // register prefetch of the next tile: 32 VGPRs at DP = 64, too many above
     constexpr int lds_dq = 2 * L::ROWS + L::TRN;
     static std::atomic<uint64_t> done{0};
-    set_lds_limit_once(done, reinterpret_cast<const void*>(&attn_bwd_dq_kernel<T, DP, NB, PF, HAS_LSE, MASK>), lds_dq);
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<T, DP, NB, PF, HAS_LSE, MASK>), dim3(a.Tq / (64 * NB), a.S), dim3(256), lds_dq, st, a);
+    set_lds_limit_once(done, reinterpret_cast<const void*>(&attn_bwd_dq_kernel<T, DP, NB, PF, HAS_LSE, MASK, GEN>), lds_dq);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<T, DP, NB, PF, HAS_LSE, MASK, GEN>), dim3(a.Tq / (64 * NB), a.S), dim3(256), lds_dq, st, a);
 }
-template <typename T, int DP, int NB, bool SPLIT>
+template <typename T, int DP, int NB, bool SPLIT, bool GEN>
 static void launch_dkdv(const AttnBwdArgs& a, hipStream_t st) {
     typedef BwdLds<DP> L;
     constexpr bool PF = DP <= 64;
     constexpr int lds_kv = 2 * L::ROWS + 2 * L::TRN + 512;
     static std::atomic<uint64_t> done{0};
-    set_lds_limit_once(done, reinterpret_cast<const void*>(&attn_bwd_dkdv_kernel<T, DP, NB, PF, SPLIT>), lds_kv);
-    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, DP, NB, PF, SPLIT>), dim3(a.Tk / (64 * NB), a.S, SPLIT ? a.G : 1), dim3(256),
+    set_lds_limit_once(done, reinterpret_cast<const void*>(&attn_bwd_dkdv_kernel<T, DP, NB, PF, SPLIT, GEN>), lds_kv);
+    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, DP, NB, PF, SPLIT, GEN>), dim3(a.Tk / (64 * NB), a.S, SPLIT ? a.G : 1), dim3(256),
                        lds_kv, st, a);
     if (SPLIT) {
         const int64_t n4 = (int64_t)a.S * a.Tk * DP / 4;
@@ -752,32 +771,41 @@ static bool flash_m32() {
     static const int v = [] { const char* e = std::getenv("UR_FLASH_M32"); return (e && e[0] == '0') ? 0 : 1; }();
     return v != 0;
 }
-template <typename T>
+// GEN = false: every tile is fully in bounds (d == DP, key rows allocated up to the padded count): the loaders, operand
+// loads and stores carry no predicates -- the per-head-copy mode of the host side
+static bool full_tiles(const AttnBwdArgs& a, int dp) { return a.d == dp && a.Tk_rows >= a.Tk; }
+
+template <typename T, bool GEN>
 static int launch_bwd32(const AttnBwdArgs& a, hipStream_t st) {
     typedef BwdLds<64> L;
     constexpr int lds_dq = 2 * L::ROWS + L::TRN, lds_kv = 2 * L::ROWS + 2 * L::TRN + 512;
     const dim3 gq(a.Tq / 128, a.S), gk(a.Tk / 128, a.S, a.G);
-    if (a.Tk_valid < a.Tk) hipLaunchKernelGGL((attn_bwd_dq32_kernel<T, true>), gq, dim3(256), lds_dq, st, a);
-    else hipLaunchKernelGGL((attn_bwd_dq32_kernel<T, false>), gq, dim3(256), lds_dq, st, a);
+    if (a.Tk_valid < a.Tk) hipLaunchKernelGGL((attn_bwd_dq32_kernel<T, true, GEN>), gq, dim3(256), lds_dq, st, a);
+    else hipLaunchKernelGGL((attn_bwd_dq32_kernel<T, false, GEN>), gq, dim3(256), lds_dq, st, a);
     if (a.G > 1) {
-        hipLaunchKernelGGL((attn_bwd_dkdv32_kernel<T, true>), gk, dim3(256), lds_kv, st, a);
+        hipLaunchKernelGGL((attn_bwd_dkdv32_kernel<T, true, GEN>), gk, dim3(256), lds_kv, st, a);
         const int64_t n4 = (int64_t)a.S * a.Tk * 64 / 4;
         hipLaunchKernelGGL((attn_bwd_fold_kernel<T>), dim3((unsigned)((n4 + 255) / 256), 2), dim3(256), 0, st, a, 64, n4);
     } else {
-        hipLaunchKernelGGL((attn_bwd_dkdv32_kernel<T, false>), gk, dim3(256), lds_kv, st, a);
+        hipLaunchKernelGGL((attn_bwd_dkdv32_kernel<T, false, GEN>), gk, dim3(256), lds_kv, st, a);
     }
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : -(int)e;
 }
 
-template <typename T, int DP, int NBQ, int NBK, bool HAS_LSE>
-static int launch_bwd(const AttnBwdArgs& a, hipStream_t st) {
-    if (a.Tk_valid < a.Tk) launch_dq<T, DP, NBQ, HAS_LSE, true>(a, st);
-    else launch_dq<T, DP, NBQ, HAS_LSE, false>(a, st);
-    if (a.G > 1) launch_dkdv<T, DP, NBK, true>(a, st);
-    else launch_dkdv<T, DP, NBK, false>(a, st);
+template <typename T, int DP, int NBQ, int NBK, bool HAS_LSE, bool GEN>
+static int launch_bwd_g(const AttnBwdArgs& a, hipStream_t st) {
+    if (a.Tk_valid < a.Tk) launch_dq<T, DP, NBQ, HAS_LSE, true, GEN>(a, st);
+    else launch_dq<T, DP, NBQ, HAS_LSE, false, GEN>(a, st);
+    if (a.G > 1) launch_dkdv<T, DP, NBK, true, GEN>(a, st);
+    else launch_dkdv<T, DP, NBK, false, GEN>(a, st);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : -(int)e;
+}
+template <typename T, int DP, int NBQ, int NBK, bool HAS_LSE>
+static int launch_bwd(const AttnBwdArgs& a, hipStream_t st) {
+    return full_tiles(a, DP) ? launch_bwd_g<T, DP, NBQ, NBK, HAS_LSE, false>(a, st)
+                             : launch_bwd_g<T, DP, NBQ, NBK, HAS_LSE, true>(a, st);
 }
 
 template <typename T, bool HAS_LSE>
@@ -786,7 +814,8 @@ static int dispatch_bwd(const AttnBwdArgs& a, int dp, hipStream_t st) {
     switch (dp) {
         case 32: return launch_bwd<T, 32, 1, 1, HAS_LSE>(a, st);
         case 64:
-            if (wq && wk && HAS_LSE && flash_m32()) return launch_bwd32<T>(a, st);
+            if (wq && wk && HAS_LSE && flash_m32())
+                return full_tiles(a, 64) ? launch_bwd32<T, false>(a, st) : launch_bwd32<T, true>(a, st);
             if (wq && wk) return launch_bwd<T, 64, 2, 2, HAS_LSE>(a, st);
             if (wq) return launch_bwd<T, 64, 2, 1, HAS_LSE>(a, st);
             if (wk) return launch_bwd<T, 64, 1, 2, HAS_LSE>(a, st);
