@@ -403,7 +403,7 @@ int ur_adamw_multi(const ur_adamw_tensor* tensors, int n_tensors, float lr, floa
  *   stats       [2][B*H][Tq] fp32 workspace (row log-sum-exp in log2 units | rowsum(dout * o)), written here;
  *               has_lse = 1: the first half already holds the forward's ur_attn_desc.lse
  * Per-head copies are the same interface with B = batch * heads, H = 1, d = the padded head dim (what the host side
- * does for d = 40: 80-byte rows inside 640-byte token rows stream 40 % slower than a [slices][T][64] copy).
+ * does for d = 40: no bounds predicates in the kernels, slightly faster than reading 80-byte head rows in place).
  *   part        fp32 workspace of 2 * G * B*H * Tk64 * dp floats, G = ur_attention_backward_splits(B*H, Tq, Tk64, dp),
  *               Tk64 = Tk rounded up to 64, dp = d rounded up to 32; may be NULL when G == 1 */
 typedef struct ur_attn_bwd_desc {

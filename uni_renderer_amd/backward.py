@@ -337,8 +337,8 @@ def _flash_attention_backward(q, k, v, o, do, H, scale, fused_qkv, oq, ok, ov, C
     cross-attention.  Head dims >= 64 (d = 80 / 160): the kernels read q / k / v / o / dO and write dq / dk / dv in the
     [B, T, H*d] layouts (column offsets for the parts of a fused projection); the only prepared operands are the
     transposes of q, k and dO.  d = 40: per-head copies [B*H, T, 64] first (``ur_split_heads`` / ``ur_merge_heads``) --
-    the same kernels with H = 1 -- because 80-byte head rows inside 640-byte token rows stream 40 % slower (dq 545 vs
-    383 us, dk / dv 520 vs 337 us at the 4096-token level)."""
+    the same kernels with H = 1 and no bounds predicates -- which measured 0.4-0.5 ms per training step faster than
+    reading the 80-byte head rows in place."""
     lib = _lib.load()
     B, Tq = q.shape[:2]
     Tk = k.shape[1]
