@@ -64,8 +64,11 @@ Other round-2 summaries: `r02_parity_numbers.json` (every rel-L2 the `-m gpu` su
 vs the oracle, the 16384-token attention, UpRes, the module-surface and cfg-4 training steps, the VAE),
 `r02_bench_cfg2/cfg5/b5/b8/b10/b20.json` (the other configurations and the repeat batches through `bench.py`),
 `r02_loop_bench.json` (50-step DDIM loops; 20-step UniPC x 5 repeats as five calls vs one folded batch),
-`r02_train_graph/eager.json` (`tools/train_bench.py`), `r02_vae_bench.json` (`tools/vae_bench.py`), `r02_insitu_tuning_log.json`
-(whole-step coordinate descent over tile choices, `tools/tune_in_situ.py`).
+`r02_train_graph/eager.json` (`tools/train_bench.py`; `r02_train_graph_torch_adamw.json`: the same with torch's fused AdamW instead
+of `optim.FusedAdamW`), `r02_attn_bwd_bench.json` (flash vs materialised-P attention backward per transformer level,
+`tools/attn_bwd_bench.py`), `r02_ab_final.txt` / `r02_ab_knobs.txt` (same-box alternations of the tile table before / after the
+in-situ passes), `r02_vae_bench.json` (`tools/vae_bench.py`), `r02_insitu_tuning_log.json` (whole-step coordinate descent over
+tile choices, `tools/tune_in_situ.py`).
 
 | file | what |
 |---|---|
