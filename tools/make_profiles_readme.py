@@ -67,7 +67,7 @@ vs the oracle, the 16384-token attention, UpRes, the module-surface and cfg-4 tr
 `r02_train_graph/eager.json` (`tools/train_bench.py`; `r02_train_graph_torch_adamw.json`: the same with torch's fused AdamW instead
 of `optim.FusedAdamW`), `r02_attn_bwd_bench.json` (flash vs materialised-P attention backward per transformer level,
 `tools/attn_bwd_bench.py`), `r02_ab_final.txt` / `r02_ab_knobs.txt` (same-box alternations of the tile table before / after the
-in-situ passes), `r02_vae_bench.json` (`tools/vae_bench.py`), `r02_insitu_tuning_log.json` (whole-step coordinate descent over
+in-situ passes), `r02_train_ab.txt` (same-box alternation of the training-path switches), `r02_vae_bench.json` (`tools/vae_bench.py`), `r02_insitu_tuning_log.json` (whole-step coordinate descent over
 tile choices, `tools/tune_in_situ.py`).
 
 | file | what |
