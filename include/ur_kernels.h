@@ -454,6 +454,7 @@ const char* ur_build_info(void);
 /* sizeof() of the descriptor structs as compiled, so a binding can verify its mirror of the layout. */
 int ur_sizeof_igemm_desc(void);
 int ur_sizeof_attn_desc(void);
+int ur_sizeof_attn_bwd_desc(void);
 
 #ifdef __cplusplus
 }

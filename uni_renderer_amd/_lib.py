@@ -120,6 +120,7 @@ SYMBOLS = {
     "ur_build_info": (C.c_char_p, []),
     "ur_sizeof_igemm_desc": (C.c_int, []),
     "ur_sizeof_attn_desc": (C.c_int, []),
+    "ur_sizeof_attn_bwd_desc": (C.c_int, []),
 }
 
 _lib = None
@@ -152,7 +153,8 @@ def load() -> C.CDLL:
         fn.argtypes = args
     if lib.ur_abi_version() != ABI_VERSION:
         raise UrLibraryError(f"ABI version mismatch: library {lib.ur_abi_version()} vs binding {ABI_VERSION}")
-    if lib.ur_sizeof_igemm_desc() != C.sizeof(IGemmDesc) or lib.ur_sizeof_attn_desc() != C.sizeof(AttnDesc):
+    if (lib.ur_sizeof_igemm_desc() != C.sizeof(IGemmDesc) or lib.ur_sizeof_attn_desc() != C.sizeof(AttnDesc)
+            or lib.ur_sizeof_attn_bwd_desc() != C.sizeof(AttnBwdDesc)):
         raise UrLibraryError("descriptor layout mismatch between include/ur_kernels.h and _lib.py")
     _lib = lib
     return lib
