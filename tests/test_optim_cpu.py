@@ -1,0 +1,55 @@
+"""Host logic of optim.FusedAdamW that needs no GPU: torch-compatible construction / state_dict layout, loud failure on
+CPU parameters (no CPU fallback), launch-cache hygiene."""
+import pytest
+import torch
+
+from uni_renderer_amd.optim import FusedAdamW
+
+
+def _params():
+    g = torch.Generator().manual_seed(0)
+    return [torch.randn(4, 3, generator=g).requires_grad_(), torch.randn(5, generator=g).requires_grad_()]
+
+
+def test_constructor_matches_torch_adamw_groups():
+    ps = _params()
+    ours = FusedAdamW(ps, lr=2e-4, betas=(0.8, 0.95), eps=1e-6, weight_decay=0.1)
+    ref = torch.optim.AdamW(ps, lr=2e-4, betas=(0.8, 0.95), eps=1e-6, weight_decay=0.1)
+    for k in ("lr", "betas", "eps", "weight_decay", "amsgrad", "maximize"):
+        assert ours.param_groups[0][k] == ref.param_groups[0][k]
+    assert ours.param_groups[0]["fused"] and ours._step_supports_amp_scaling  # train_step folds clipping through grad_scale
+    with pytest.raises(ValueError):
+        FusedAdamW(ps, lr=-1.0)
+    with pytest.raises(ValueError):
+        FusedAdamW(ps, betas=(1.0, 0.9))
+
+
+def test_state_dict_layout_is_torch_adamw():
+    ps = _params()
+    ours = FusedAdamW(ps, lr=1e-3)
+    for p in ps:
+        ours._init_state(p)
+    sd = ours.state_dict()
+    assert sorted(sd["state"]) == [0, 1]
+    assert sorted(sd["state"][0]) == ["exp_avg", "exp_avg_sq", "step"]
+    assert "_ur_launches" not in sd["param_groups"][0]
+    ref = torch.optim.AdamW([p.detach().clone().requires_grad_() for p in ps], lr=1e-3)
+    ref.load_state_dict(sd)  # torch accepts it
+    assert float(ref.state[ref.param_groups[0]["params"][0]]["step"]) == 0.0
+    ours2 = FusedAdamW([p.detach().clone().requires_grad_() for p in ps], lr=1e-3)
+    ours2.load_state_dict(ref.state_dict())
+    st = ours2.state[ours2.param_groups[0]["params"][1]]
+    assert st["step"].dtype == torch.float32 and st["step"].shape == ()
+    # the step entries handed out are independent tensors (torch's optimizers increment each one)
+    assert sd["state"][0]["step"] is not sd["state"][1]["step"]
+
+
+def test_step_fails_loudly_without_a_gpu():
+    ps = _params()
+    for p in ps:
+        p.grad = torch.ones_like(p)
+    ours = FusedAdamW(ps, lr=1e-3)
+    with pytest.raises(Exception) as e:  # no CPU fallback: either the library refuses to load or the dtype / device check fires
+        ours.step()
+    assert "GPU" in str(e.value) or "HIP" in str(e.value) or "liburhip" in str(e.value) or "hip" in str(e.value).lower()
+    assert all(torch.equal(p, q) for p, q in zip(ps, _params()))  # nothing was updated
