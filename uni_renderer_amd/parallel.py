@@ -261,7 +261,7 @@ class GradientBuckets:
     @torch.no_grad()
     def clip_grad_norm_(self, max_norm: float) -> torch.Tensor:
         """train.py:1422-1424 over the flat buffers: one norm per bucket instead of one per parameter."""
-        total = torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(f) for f in self.flat]))
+        total = torch.linalg.vector_norm(torch.stack(torch._foreach_norm(list(self.flat))))
         coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
         for f in self.flat:
             f.mul_(coef)

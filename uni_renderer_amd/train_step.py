@@ -391,7 +391,9 @@ def _clip_and_update(nets, optimizer, buckets, max_grad_norm, stats):
                 and all(g.get("fused") for g in optimizer.param_groups))
         if fold:
             if buckets is not None:
-                norm = torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(f) for f in buckets.flat]))
+                # _foreach_norm, not vector_norm per bucket: a CAPTURED vector_norm over a 32 MB tensor returns wrong
+                # values on replay in this torch / ROCm build (tools/graph_norm_repro.py)
+                norm = torch.linalg.vector_norm(torch.stack(torch._foreach_norm(list(buckets.flat))))
             else:
                 grads = [p.grad for p in _parameters(nets) if p.grad is not None]
                 norm = torch.linalg.vector_norm(torch.stack(torch._foreach_norm(grads)))
@@ -435,7 +437,7 @@ class GraphedTrainStep:
     autograd hooks.  Here forward + losses + backward are ONE captured graph writing the gradients into the flat bucket
     buffers of ``buckets`` (built with ``overlap=False``: no hooks, nothing but kernels inside the capture); the
     collectives run eagerly on those few flat buffers (``buckets.finish()``: one all-reduce or reduce-scatter +
-    all-gather per 256 MB bucket, bf16 on the wire if asked), and so do clipping + the optimizer step (a handful of launches).
+    all-gather per 256 MB bucket, bf16 on the wire if asked), and clipping + the optimizer step are a second graph.
     Without ``buckets`` (one GPU) the whole step is a single graph.  One instance per objective branch (``inverse``):
     the branch is a host decision (train.py:445), so a training loop keeps one instance per branch over the same
     networks and optimizer.  ``warmup`` eager steps run first (REAL optimisation steps on ``batch``: allocator pools, lazy
@@ -477,8 +479,12 @@ class GraphedTrainStep:
             if buckets is None:
                 _clip_and_update(nets, optimizer, None, max_grad_norm, self.stats)
         self.max_grad_norm = max_grad_norm
+        self.g_up = None
         if buckets is not None:
             buckets._reset()
+            self.g_up = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_up):
+                _clip_and_update(nets, optimizer, buckets, max_grad_norm, self.stats)
 
     def _eager(self, kw, max_grad_norm):
         st = {"loss": _forward_backward(self.nets, self.batch, self.optimizer, self.buckets, **kw)}
@@ -497,8 +503,5 @@ class GraphedTrainStep:
             if self._host_sync_before_collectives:
                 torch.cuda.current_stream().synchronize()
             self.buckets.finish()
-            # clipping + optimizer eagerly (~25 launches with optim.FusedAdamW).  A second captured graph here was measured
-            # to read STALE bucket contents (zeros of the first buckets, as left by zero_grad) after the collective had
-            # rewritten them from another stream -- ordinary launches see the reduced gradients.
-            _clip_and_update(self.nets, self.optimizer, self.buckets, self.max_grad_norm, self.stats)
+            self.g_up.replay()  # clipping (torch._foreach_norm over the buckets) + optimizer step
         return self.stats
