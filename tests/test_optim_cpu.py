@@ -53,3 +53,12 @@ def test_step_fails_loudly_without_a_gpu():
         ours.step()
     assert "GPU" in str(e.value) or "HIP" in str(e.value) or "liburhip" in str(e.value) or "hip" in str(e.value).lower()
     assert all(torch.equal(p, q) for p, q in zip(ps, _params()))  # nothing was updated
+
+
+def test_pickle_drops_the_launch_cache():
+    import pickle
+    ps = _params()
+    ours = FusedAdamW(ps, lr=1e-3)
+    ours.param_groups[0]["_ur_launches"] = ("not", "picklable", (lambda: None), None)
+    clone = pickle.loads(pickle.dumps(ours))
+    assert "_ur_launches" not in clone.param_groups[0] and clone.param_groups[0]["lr"] == 1e-3

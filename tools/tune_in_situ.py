@@ -205,6 +205,8 @@ def main_train(args):
         cands = [(t, cur[1]) for t in (9, 10, 1, 5, 7, 2, 3, 11) if t != cur[0]][: args.cands]
         if cur[1] > 1:
             cands.append((cur[0], cur[1] // 2))
+            if cur[1] * 2 <= 16 and key[2] // 64 >= 8 * cur[1] and key[4] <= 4:
+                cands.append((cur[0], cur[1] * 2))
         elif key[2] // 64 >= 16 and key[4] <= 4:
             cands.append((cur[0], 2))
         for cand in cands:

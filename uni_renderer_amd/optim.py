@@ -115,6 +115,11 @@ class FusedAdamW(torch.optim.Optimizer):
                                      grad_scale.data_ptr() if grad_scale is not None else None,
                                      found_inf.data_ptr() if found_inf is not None else None, s_), "ur_adamw_multi")
 
+    def __getstate__(self):
+        state = super().__getstate__()
+        state["param_groups"] = [{k: v for k, v in g.items() if k != "_ur_launches"} for g in state["param_groups"]]
+        return state  # the launch cache holds raw device addresses in ctypes arrays: never pickled, rebuilt on the next step
+
     def state_dict(self):
         """torch.optim.AdamW's layout.  The per-parameter ``step`` entries alias one device scalar inside this object;
         a state dict hands out independent copies (torch's optimizers increment every entry on their own)."""
