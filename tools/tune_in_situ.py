@@ -27,6 +27,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--top", type=int, default=40)
     ap.add_argument("--cands", type=int, default=5)
+    ap.add_argument("--skip", type=int, default=0, help="--train: leave out the heaviest N problems (a previous pass visited them)")
     ap.add_argument("--replays", type=int, default=100)
     ap.add_argument("--eps", type=float, default=0.008)
     ap.add_argument("--batch", type=int, default=4)
@@ -193,7 +194,7 @@ def main_train(args):
         torch.cuda.synchronize()
     finally:
         ops.igemm = orig
-    est = sorted(((n * max(flops[k] / 6e14, 12e-6), k) for k, n in calls.items()), reverse=True)[: args.top]
+    est = sorted(((n * max(flops[k] / 6e14, 12e-6), k) for k, n in calls.items()), reverse=True)[args.skip: args.top]
     base, base2 = measure(), measure()
     print(f"[in-situ train] baseline {base:.3f} / {base2:.3f} ms per step; {len(calls)} problems, visiting {len(est)}", flush=True)
     best = min(base, base2)
