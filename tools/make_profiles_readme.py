@@ -134,7 +134,9 @@ the harness's torch fills/copies: {alltot / 1e6:.1f} ms.
 ## Training step (`{tag}_train_kernel_stats.csv`: `rocprofv3 --kernel-trace --stats -- python tools/train_bench.py --steps 3 --graph`)
 
 cfg 4's per-GPU shape (B=4, 512x512, bf16 compute, fp32 master parameters, fused AdamW, clipping), the whole step replayed as
-one HIP graph: {ttot / n / 1e6:.0f} ms of kernel time per step under the profiler ({unprof:.0f} ms per replay un-profiled).  Top kernels per step:
+one HIP graph: {ttot / n / 1e6:.0f} ms of kernel time per step under the profiler ({unprof:.0f} ms per replay un-profiled).  The profiled
+process also builds and initialises the three networks: the `FillFunctor<float>` / `distribution_elementwise` rows are that, not
+the step.  Top kernels per step:
 
 | kernel | launches / step | ms / step | avg us |
 |---|---|---|---|
