@@ -32,6 +32,78 @@ PEAK_MFMA_TFLOPS = 2500.0  # dense fp16/bf16, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
 
 
+def algorithmic_flops(L, B=1, direction="inverse", cross_tokens=77, cross_dim=768):
+    """Algorithmic FLOPs (2 x MAC) of one dual-stream step at latent side L, per-class formulae of SURVEY.md section 8d:
+    conv `2 B Cin Cout k^2 Ho Wo`, linear `2 B T Cin Cout`, self-attention `4 B heads T^2 d` (quadratic in the token
+    count: cfg 5 is NOT cfg 3 x 4), cross-attention `4 B heads T 77 d`.  SD-1.x layout:
+    cfg 3 = 6.49, cfg 5 = 9.41, cfg 2 = 0.479 TFLOP (tests/test_host_cpu.py pins the three)."""
+    ch = [320, 640, 1280, 1280]
+
+    def conv(ci, co, H): return 2 * ci * co * 9 * H * H
+    def lin(T, ci, co): return 2 * T * ci * co
+
+    def resnet(ci, co, H):
+        return conv(ci, co, H) + conv(co, co, H) + 2 * 1280 * co + (lin(H * H, ci, co) if ci != co else 0)
+
+    def transformer(C, H):
+        T = H * H
+        f = 2 * lin(T, C, C)                                   # proj_in / proj_out
+        f += 4 * lin(T, C, C) + 4 * T * T * C                  # self: q, k, v, out + QK^T / PV
+        f += 2 * lin(T, C, C) + 2 * lin(cross_tokens, cross_dim, C) + 4 * T * cross_tokens * C  # cross
+        return f + lin(T, C, 8 * C) + lin(T, 4 * C, C)         # GEGLU feed-forward
+
+    def net(part, cin=4, cout=4):
+        f, H, prev = 0, L, 320
+        if part in ("unet", "enc"):
+            f += conv(cin, 320, L) + 2 * 320 * 1280 + 2 * 1280 * 1280
+            for i, c in enumerate(ch):
+                for _ in range(2):
+                    f += resnet(prev, c, H) + (transformer(c, H) if i < 3 else 0)
+                    prev = c
+                if i < 3:
+                    H //= 2
+                    f += conv(c, c, H)
+            f += 2 * resnet(1280, 1280, H) + transformer(1280, H)
+        if part in ("unet", "dec"):
+            H, prev = L // 8, 1280
+            skips = [320, 320, 320, 320, 640, 640, 640, 1280, 1280, 1280, 1280, 1280]
+            for i, c in enumerate([1280, 1280, 640, 320]):
+                for _ in range(3):
+                    f += resnet(prev + skips.pop(), c, H) + (transformer(c, H) if i > 0 else 0)
+                    prev = c
+                if i < 3:
+                    H *= 2
+                    f += conv(c, c, H)
+            f += conv(320, cout, L) + (2 * 320 * 1280 + 2 * 1280 * 1280 if part == "dec" else 0)
+        if part in ("enc", "dec"):  # the 12 + 1 exchange 1x1 convs
+            for h, c in zip([L] * 3 + [L // 2] * 3 + [L // 4] * 3 + [L // 8] * 4, [320] * 4 + [640] * 3 + [1280] * 6):
+                f += lin(h * h, c, c)
+        return f
+
+    total = net("unet") + net("enc", cin=28) + (net("dec", cout=28) if direction == "inverse" else 0)
+    return float(B) * total
+
+
+def _spawn_ranks(n, script=None):
+    """`python bench.py --gpus N` with no launcher: start the N ranks ourselves, exactly the way the driver's own
+    command does (one process per GPU through torch.distributed.run, rendezvous on 127.0.0.1), and hand its exit code
+    back.  Rank 0 of the children prints the JSON line."""
+    import socket
+    import subprocess
+
+    ngpu = torch.cuda.device_count()
+    if ngpu < n:
+        raise SystemExit(f"bench.py --gpus {n}: only {ngpu} GPU(s) visible")
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(script or __file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
 def build_models(dev, dtype, seed=1234):
     import uni_renderer_amd as U
 
@@ -217,8 +289,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
+            _spawn_ranks(args.gpus)  # no launcher around us: become one (does not return)
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
@@ -293,8 +366,7 @@ def main():
                 "launch": "eager" if args.eager else {"grouped": "hipGraph replay; enc||unet.down and unet.up||dec issued as grouped (zbatch=2) launches",
                                                       "concurrent": "hipGraph replay, 2 concurrent branches (enc || unet.down, dec || unet.up)",
                                                       "serial": "hipGraph replay, serial"}[runner.mode],
-                "algorithmic_tflop_per_step": round((1.623 if args.direction == "inverse" else 1.074) * args.batch
-                                                    * (args.latent / 64) ** 2, 3),  # unet .804 + enc .27 + dec .55
+                "algorithmic_tflop_per_step": round(algorithmic_flops(args.latent, args.batch, args.direction) / 1e12, 3),
                 "residual_stream": ("(hi, lo) pairs (parity <= 1e-3, DESIGN.md section 5)"
                                     if os.environ.get("UR_PRECISE_RESIDUAL", "1") != "0" else "plain (UR_PRECISE_RESIDUAL=0)"),
             },

@@ -184,3 +184,46 @@ def test_attention_key_permutation_gives_consecutive_keys():
                     i = 4 * q + r
                     keys.append(kb * 32 + (i >> 2) * 8 + sub * 4 + (i & 3))
             assert keys == list(range(kb * 32 + 8 * q, kb * 32 + 8 * q + 8))
+
+
+def test_algorithmic_flop_model_matches_the_survey():
+    """bench.py's per-class FLOP formulae (attention quadratic in tokens) reproduce SURVEY 8d: 6.49 / 9.41 / 0.479."""
+    import bench
+
+    assert abs(bench.algorithmic_flops(64, 4, "inverse") / 1e12 - 6.49) < 0.01    # cfg 3
+    assert abs(bench.algorithmic_flops(128, 1, "inverse") / 1e12 - 9.41) < 0.01   # cfg 5 (was printed as 6.49)
+    assert abs(bench.algorithmic_flops(32, 2, "render") / 1e12 - 0.479) < 0.001   # cfg 2 (was printed as 0.537)
+    # per sample at 512^2: unet 0.804 + enc 0.27 + dec 0.55
+    assert abs(bench.algorithmic_flops(64, 1, "inverse") / 1e12 - 1.622) < 0.005
+
+
+def test_eval_modules_keep_the_inference_path_and_train_selects_autograd():
+    """after from_pretrained() (eval mode, parameters still requires_grad) a plain call outside no_grad must
+    not silently take the activation-saving autograd path; train() -- what train.py:1050-1052 calls -- selects it."""
+    import uni_renderer_amd as U
+
+    unet = U.UNet2DConditionModel(**{k: v for k, v in O.TINY_CONFIG.items()})
+    x = torch.zeros(1, 4, 8, 8)
+    unet.eval()
+    assert any(p.requires_grad for p in unet.parameters())
+    assert unet._autograd_mode(x) is False
+    assert unet._autograd_mode(x.clone().requires_grad_()) is True   # an input that wants a gradient still does
+    unet.train()
+    assert unet._autograd_mode(x) is True
+    with torch.no_grad():
+        assert unet._autograd_mode(x) is False
+
+
+def test_enable_gradient_checkpointing_tells_the_caller():
+    import warnings
+
+    import uni_renderer_amd as U
+    from uni_renderer_amd.modeling_utils import ConfigModelMixin
+
+    ConfigModelMixin._warned_gc = False
+    unet = U.UNet2DConditionModel(**{k: v for k, v in O.TINY_CONFIG.items()})
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        unet.enable_gradient_checkpointing()
+        unet.enable_gradient_checkpointing()
+    assert len(w) == 1 and "no recompute" in str(w[0].message)

@@ -62,3 +62,21 @@ def test_pickle_drops_the_launch_cache():
     ours.param_groups[0]["_ur_launches"] = ("not", "picklable", (lambda: None), None)
     clone = pickle.loads(pickle.dumps(ours))
     assert "_ur_launches" not in clone.param_groups[0] and clone.param_groups[0]["lr"] == 1e-3
+
+
+def test_state_dict_does_not_cut_the_shared_step_counter():
+    """state_dict() used to replace the LIVE ``step`` entries with clones, so the device counter the cached
+    launches increment and ``state[p]["step"]`` drifted apart (every later checkpoint froze at the first save)."""
+    ps = _params()
+    ours = FusedAdamW(ps, lr=1e-3)
+    states = [ours._init_state(p) for p in ps]
+    counter = states[0]["step"]
+    states[1]["step"] = counter  # what step() does on its first call: one counter per group
+    counter += 1
+    sd1 = ours.state_dict()
+    assert all(ours.state[p]["step"] is counter for p in ps)  # live entries untouched
+    counter += 1  # the next (cached) step
+    sd2 = ours.state_dict()
+    assert float(sd1["state"][0]["step"]) == 1.0 and float(sd1["state"][1]["step"]) == 1.0  # snapshots stay snapshots
+    assert float(sd2["state"][0]["step"]) == 2.0 and float(sd2["state"][1]["step"]) == 2.0
+    assert sd2["state"][0]["exp_avg"] is ours.state[ps[0]]["exp_avg"]  # like torch: moments are handed out uncopied

@@ -59,3 +59,36 @@ def test_shapes_and_posterior():
     s1 = p.sample(g)
     g = torch.Generator().manual_seed(1)
     assert torch.equal(s1, p.mean + p.std * torch.randn(mean.shape, generator=g)) and torch.equal(p.mode(), mean)
+
+
+def test_from_pretrained_accepts_the_deprecated_attention_key_names(tmp_path):
+    """SD 1.4 / 1.5 / 2.x ``vae/`` folders name the mid-block attention query / key / value / proj_attn (diffusers renames
+    them on load); ADVICE r2: strict loading rejected them."""
+    import json
+    import os
+
+    from safetensors.torch import save_file
+
+    from uni_renderer_amd.vae import AutoencoderKL
+
+    torch.manual_seed(0)
+    small = dict(block_out_channels=(64, 64), down_block_types=("DownEncoderBlock2D",) * 2, up_block_types=("UpDecoderBlock2D",) * 2,
+                 layers_per_block=1, norm_num_groups=8)
+    m = AutoencoderKL(**small)
+    new2old = {"to_q": "query", "to_k": "key", "to_v": "value", "to_out.0": "proj_attn"}
+    sd = {}
+    for k, v in m.state_dict().items():
+        for new, old in new2old.items():
+            if f".attentions.0.{new}." in k:
+                k = k.replace(f".attentions.0.{new}.", f".attentions.0.{old}.")
+                if k.endswith("weight") and "decoder" in k:
+                    v = v[:, :, None, None]  # the still older 1x1-conv shape, on one of the two blocks
+        sd[k] = v.detach().clone().contiguous()
+    assert any(".query." in k for k in sd) and not any(".to_q." in k for k in sd)
+    d = tmp_path / "vae"
+    os.makedirs(d)
+    json.dump({k: (list(v) if isinstance(v, tuple) else v) for k, v in m.config.items()}, open(d / "config.json", "w"))
+    save_file(sd, str(d / "diffusion_pytorch_model.safetensors"))
+    m2 = AutoencoderKL.from_pretrained(str(tmp_path), subfolder="vae")
+    for (k, a), (_, b) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a, b), k

@@ -31,10 +31,13 @@ def main():
     ap.add_argument("--comm-dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-overlap", action="store_true", help="reduce all buckets after the backward instead of during it")
     ap.add_argument("--torch-adamw", action="store_true", help="torch.optim.AdamW(fused=True) instead of optim.FusedAdamW")
+    ap.add_argument("--gpus", type=int, default=0, help="without a launcher: start this many ranks (one per GPU) ourselves")
     ap.add_argument("--graph", action="store_true", help="time HIP-graph replays (train_step.GraphedTrainStep): one GPU = the whole step "
                     "as one graph; several = forward + backward graph, eager bucket collectives and update")
     args = ap.parse_args()
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
+    if args.gpus > 1 and world == 1 and "RANK" not in os.environ:
+        bench._spawn_ranks(args.gpus, script=__file__)  # does not return
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:

@@ -110,7 +110,8 @@ class _DenoiserBase(ConfigModelMixin, nn.Module):
         """True when this call must be differentiable: autograd is recording and a parameter or an input wants a
         gradient -- the situation of train/train.py:1324-1354 (modules called, then ``accelerator.backward(loss)``).
         The forwards then run over ``autograd_ops`` (train_step.py: HIP forward AND backward kernels, same return
-        tuples); under ``torch.no_grad()`` / with frozen parameters they take the fused inference path."""
+        tuples); under ``torch.no_grad()``, with frozen parameters, or in ``eval()`` mode with no input that requires a
+        gradient, they take the fused inference path."""
         if not torch.is_grad_enabled():
             return False
         for t in tensors:
@@ -119,7 +120,10 @@ class _DenoiserBase(ConfigModelMixin, nn.Module):
                     return True
             elif isinstance(t, (list, tuple)) and any(torch.is_tensor(u) and u.requires_grad for u in t):
                 return True
-        return any(p.requires_grad for p in self.parameters())
+        # parameters alone select the training path only in train() mode (the reference calls controlnet.train() /
+        # unet.train(), train.py:1233-1235): an eval() module called outside torch.no_grad() -- the default state after
+        # from_pretrained() -- keeps the fused inference path instead of silently saving activations
+        return self.training and any(p.requires_grad for p in self.parameters())
 
     @staticmethod
     def _tokens(ehs: torch.Tensor, dt) -> torch.Tensor:

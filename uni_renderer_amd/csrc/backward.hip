@@ -1029,8 +1029,8 @@ __global__ void __launch_bounds__(256) adamw_multi_kernel(const AdamwArgs a) {
 extern "C" int ur_adamw_multi(const ur_adamw_tensor* tensors, int n_tensors, float lr, float beta1, float beta2, float eps,
                               float weight_decay, const float* step, const float* grad_scale, const float* found_inf,
                               void* stream) {
-    if (!tensors || n_tensors <= 0 || n_tensors > UR_ADAMW_MAX_TENSORS || !step || !(beta1 > 0.f && beta1 < 1.f) ||
-        !(beta2 > 0.f && beta2 < 1.f))
+    if (!tensors || n_tensors <= 0 || n_tensors > UR_ADAMW_MAX_TENSORS || !step || !(beta1 >= 0.f && beta1 < 1.f) ||
+        !(beta2 >= 0.f && beta2 < 1.f))  // the same range torch.optim.AdamW (and optim.FusedAdamW) accept
         return UR_E_BADARG;
     AdamwArgs a;
     int64_t chunks = 0;

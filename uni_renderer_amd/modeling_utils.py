@@ -122,7 +122,7 @@ class ConfigModelMixin:
         p = os.path.join(pretrained_model_name_or_path, subfolder) if subfolder else pretrained_model_name_or_path
         model = cls.from_config(cls.load_config(p))
         name = WEIGHTS_NAME if variant is None else WEIGHTS_NAME.replace(".safetensors", f".{variant}.safetensors")
-        sd = load_file(os.path.join(p, name))
+        sd = cls._convert_state_dict(load_file(os.path.join(p, name)))
         # channel surgery (train.py:976,988-989) changes conv_in/conv_out shapes: honour the file
         own = model.state_dict()
         for k, v in sd.items():
@@ -134,11 +134,26 @@ class ConfigModelMixin:
             model = model.to(torch_dtype)
         return model.eval()
 
+    @classmethod
+    def _convert_state_dict(cls, sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        """Hook for on-disk key layouts older than the module tree (AutoencoderKL overrides it)."""
+        return sd
+
     # -- no-ops kept for caller compatibility (train.py:1066-1074) --------------------------------
     def enable_xformers_memory_efficient_attention(self, *_, **__):
         return None
 
     def enable_gradient_checkpointing(self):
+        """The reference recomputes the down blocks' resnets in the backward (unet_2d_blocks.py:1172-1197, caller
+        train.py:1073-1074) to fit its GPUs.  Not needed here -- cfg 4's per-GPU step peaks at 35 GB of the 288 GB --
+        so nothing is recomputed; the caller is told once instead of being silently ignored."""
+        import warnings
+
+        if not getattr(ConfigModelMixin, "_warned_gc", False):
+            ConfigModelMixin._warned_gc = True
+            warnings.warn("uni_renderer_amd: enable_gradient_checkpointing() keeps all activations (no recompute): the "
+                          "training step of cfg 4 peaks at ~35 GB of the MI355X's 288 GB", stacklevel=2)
+        self.gradient_checkpointing = False
         return None
 
     def set_attention_slice(self, *_):

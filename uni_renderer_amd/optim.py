@@ -114,6 +114,10 @@ class FusedAdamW(torch.optim.Optimizer):
                                      float(group["weight_decay"]), step_t.data_ptr(),
                                      grad_scale.data_ptr() if grad_scale is not None else None,
                                      found_inf.data_ptr() if found_inf is not None else None, s_), "ur_adamw_multi")
+        if found_inf is not None:
+            # the kernel leaves parameters and moments alone when found_inf != 0; like torch's fused AdamW, a skipped
+            # step must not advance the bias correction either (a device op: no host synchronisation, capturable)
+            step_t -= found_inf.to(step_t.dtype).reshape(())
 
     def __getstate__(self):
         state = super().__getstate__()
@@ -126,9 +130,9 @@ class FusedAdamW(torch.optim.Optimizer):
         sd = super().state_dict()
         for grp in sd["param_groups"]:
             grp.pop("_ur_launches", None)  # host-side launch cache, not optimizer state
-        for st in sd["state"].values():
-            if "step" in st:
-                st["step"] = st["step"].clone()
+        # torch hands out the LIVE per-parameter dicts: build copies, never assign into them (replacing the live
+        # ``step`` entry would cut its alias to the device counter the cached launches keep incrementing)
+        sd["state"] = {k: ({**st, "step": st["step"].clone()} if "step" in st else dict(st)) for k, st in sd["state"].items()}
         return sd
 
     def load_state_dict(self, state_dict):

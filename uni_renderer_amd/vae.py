@@ -232,6 +232,24 @@ class AutoencoderKL(ConfigModelMixin, nn.Module):
         self.compute_dtype: Optional[torch.dtype] = None
         self._pk = PackCache()
 
+    _DEPRECATED_ATTN = {"query": "to_q", "key": "to_k", "value": "to_v", "proj_attn": "to_out.0"}
+
+    @classmethod
+    def _convert_state_dict(cls, sd):
+        """The ``vae/`` folders of SD 1.4 (the base the reference trains from), 1.5 and 2.x store the mid-block
+        attention under the deprecated names ``query / key / value / proj_attn``; diffusers renames them while loading
+        (``ModelMixin._convert_deprecated_attention_blocks``).  Same conversion here, plus the 1x1-conv weight shape
+        ``[C, C, 1, 1]`` of still older exports."""
+        out = {}
+        for k, v in sd.items():
+            parts = k.split(".")
+            if len(parts) >= 4 and parts[-2] in cls._DEPRECATED_ATTN and "attentions" in parts:
+                k = ".".join(parts[:-2] + [cls._DEPRECATED_ATTN[parts[-2]], parts[-1]])
+                if parts[-1] == "weight" and v.dim() == 4 and v.shape[2:] == (1, 1):
+                    v = v[:, :, 0, 0].contiguous()
+            out[k] = v
+        return out
+
     def _dt(self):
         dt = self.compute_dtype or self.dtype
         if dt not in (torch.float16, torch.bfloat16):
