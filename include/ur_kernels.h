@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define UR_ABI_VERSION 4
+#define UR_ABI_VERSION 5
 
 #define UR_E_BADARG (-1001)   /* inconsistent descriptor (shape / alignment / null pointer)   */
 #define UR_E_UNSUPPORTED (-1002) /* shape outside what the kernels are instantiated for       */
@@ -448,6 +448,50 @@ int ur_resample2x(const void* in, void* out, int B, int Hout, int Wout, int C, i
 int ur_pack_conv_weight(const float* w, void* out, int Co, int Ci, int Cpad, int dtype, void* stream);
 int ur_unpack_conv_weight_grad(const void* dwp, int64_t ld, float* out, int Co, int Ci, int Cpad, int dtype, void* stream);
 
+/*
+ * Row-local transformer chains at C = 320 (csrc/tchain.hip): the GEMMs, LayerNorm, GEGLU and residual adds that follow an
+ * attention inside one BasicTransformerBlock (diffusers 0.24, instantiated by models/unet_2d_blocks.py:1115-1126 of the
+ * reference) as ONE launch, with the activations of a 128-row tile resident in registers and
+ * only the weights streamed through LDS.
+ *
+ *   UR_TCHAIN_Q   y = a0 W0^T + b0 + res              (attention out-projection + residual; y leaves as (hi, lo))
+ *                 out = LayerNorm(y) Wq^T             (the query projection of the next attention; no bias)
+ *   UR_TCHAIN_FF  y = a0 W0^T + b0 + res              (never stored)
+ *                 y3 = y + b2 + GEGLU(LayerNorm(y) W1^T + b1) W2^T
+ *                 out = y3 Wpo^T + bpo + blk          (Transformer2DModel.proj_out + the block input; (hi, lo))
+ *
+ * Operands: a0 / res / blk / y_out / out are [zbatch][M][320] row-major token matrices (row stride 320, z stride
+ * M * 320); *_lo are the low parts of (hi, lo) residual-stream tensors (NULL: plain tensors / no low part written).
+ * `wstream` = per z a sequence of 40960-byte LDS stage images in the order the kernel consumes them, `consts` = per z
+ * the fp32 vectors [b0 | gamma | beta] (Q) or [b0 | gamma | beta | b1 value | b1 gate | b2 | bpo] (FF); both are built by
+ * the host once per parameter version (uni_renderer_amd/tchain.py documents the image layout: rows x 64 k, 16-byte
+ * chunks XOR-swizzled by (row >> 1) & 7, the k columns of every matrix whose operand comes out of an accumulator in the
+ * order [0 1 2 3 8 9 10 11 4 5 6 7 12 13 14 15] per 16).  ur_tchain_stream_bytes / ur_tchain_const_floats give the
+ * per-z sizes.  Rows >= M of the last tile are computed and not stored.
+ */
+#define UR_TCHAIN_Q 0
+#define UR_TCHAIN_FF 1
+typedef struct ur_tchain_desc {
+    const void* a0;
+    const void* res;
+    const void* res_lo;
+    const void* blk;
+    const void* blk_lo;
+    void* y_out;
+    void* y_out_lo;
+    void* out;
+    void* out_lo;
+    const void* wstream;
+    const float* consts;
+    int64_t z_wstream;   /* bytes between the weight streams of two z (multiple of 16) */
+    int64_t z_consts;    /* floats between the constant blocks of two z */
+    int M, zbatch, mode, dtype, channels;
+    float eps;           /* LayerNorm epsilon */
+} ur_tchain_desc;
+int ur_tchain(const ur_tchain_desc* d, void* stream);
+int64_t ur_tchain_stream_bytes(int mode);
+int ur_tchain_const_floats(int mode);
+
 /* Library self-description. */
 int ur_abi_version(void);
 const char* ur_build_info(void);
@@ -455,6 +499,7 @@ const char* ur_build_info(void);
 int ur_sizeof_igemm_desc(void);
 int ur_sizeof_attn_desc(void);
 int ur_sizeof_attn_bwd_desc(void);
+int ur_sizeof_tchain_desc(void);
 
 #ifdef __cplusplus
 }

@@ -227,3 +227,61 @@ def test_enable_gradient_checkpointing_tells_the_caller():
         unet.enable_gradient_checkpointing()
         unet.enable_gradient_checkpointing()
     assert len(w) == 1 and "no recompute" in str(w[0].message)
+
+
+def test_tchain_stage_images_are_the_lds_layout_the_kernel_reads():
+    """tchain.py lays weights out byte for byte as the LDS ring slot: emulate the kernel's fragment reads (row l31 of a
+    32-row block, 16-byte chunk (2 s + h) ^ ((row >> 1) & 7)) and the accumulator -> operand hand-off (KPERM) with plain
+    indexing and check that the products equal x @ W^T."""
+    from uni_renderer_amd import tchain
+
+    torch.manual_seed(0)
+    W = torch.randn(320, 320, dtype=torch.float64)
+    x = torch.randn(320, dtype=torch.float64)
+
+    def read_frag(img, row, s, h):  # what ds_read_b128 returns: 8 k-values
+        key = (row >> 1) & 7
+        c = (2 * s + h) ^ key
+        return img.view(-1, 64)[row, 8 * c: 8 * c + 8]
+
+    for permute in (False, True):
+        imgs = tchain.gemm_images(W, permute)  # [5, 320 * 64]
+        assert imgs.shape == (5, 320 * 64)
+        y = torch.zeros(320, dtype=torch.float64)
+        for kc in range(5):
+            for s in range(4):
+                for h in range(2):
+                    # operand registers of lane half h for k16 step 4 kc + s: logical k = 8 h + i
+                    base = 64 * kc + 16 * s
+                    if permute:
+                        ks = [base + tchain.KPERM16[8 * h + i] for i in range(8)]
+                    else:
+                        ks = [base + 8 * h + i for i in range(8)]
+                    xb = x[ks]
+                    for row in range(320):
+                        y[row] += (read_frag(imgs[kc], row, s, h) * xb).sum()
+        assert torch.allclose(y, W @ x, atol=1e-10)
+    # accumulator rows owned by lane half h of a 32-row block: 8 q + 4 h + r; its packed operand for step 2 t + g is
+    # i < 4: (q = 2 g, r = i), i >= 4: (q = 2 g + 1, r = i - 4)  ==  channel 32 t + 16 g + KPERM16[8 h + i]
+    for h in range(2):
+        for g_ in range(2):
+            ch = [8 * (2 * g_ + (i >> 2)) + 4 * h + (i & 3) for i in range(8)]
+            assert ch == [16 * g_ + tchain.KPERM16[8 * h + i] for i in range(8)]
+    # feed-forward images: value / gate rows and the hidden-axis order of the second matrix
+    W1, W2 = torch.randn(2560, 320, dtype=torch.float64), torch.randn(320, 1280, dtype=torch.float64)
+    ff = tchain.ff_images(W1, W2)
+    assert ff.shape == (60, 320 * 64)
+    j, half = 7, 1
+    a = ff[3 * j + half].view(5, 64, 64)  # [k chunk, row, swizzled k]
+    row, c, s, h = 37, 2, 3, 1            # a gate row: hidden 64 j + 32 half + 5
+    hid = 64 * j + 32 * half + (row - 32)
+    key = (row >> 1) & 7
+    got = a[c, row, 8 * ((2 * s + h) ^ key): 8 * ((2 * s + h) ^ key) + 8]
+    want = W1[1280 + hid, [64 * c + 16 * s + tchain.KPERM16[8 * h + i] for i in range(8)]]
+    assert torch.equal(got, want)
+    b = ff[3 * j + 2].view(320, 64)
+    row, s, h = 201, 2, 0
+    key = (row >> 1) & 7
+    got = b[row, 8 * ((2 * s + h) ^ key): 8 * ((2 * s + h) ^ key) + 8]
+    want = W2[row, [64 * j + 16 * s + tchain.KPERM16[8 * h + i] for i in range(8)]]
+    assert torch.equal(got, want)

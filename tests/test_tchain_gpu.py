@@ -1,0 +1,123 @@
+"""ur_tchain (csrc/tchain.hip): the row-local chains after the two attentions of a BasicTransformerBlock at the
+320-channel level, one launch each, against a plain fp32 PyTorch restatement of the same operations on the same
+(rounded) inputs and against the unfused product path (ops.linear / ops.layernorm) they replace."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+C = 320
+
+
+def _weights(dev, seed, S):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    r = lambda *s, sc=1.0: torch.randn(*s, device=dev, generator=g) * sc
+    W = []
+    for _ in range(S):
+        W.append(dict(wo=r(C, C, sc=C ** -0.5), bo=r(C, sc=0.1), g=1 + r(C, sc=0.1), b=r(C, sc=0.1), wq=r(C, C, sc=C ** -0.5),
+                      w1=r(8 * C, C, sc=C ** -0.5), b1=r(8 * C, sc=0.1), w2=r(C, 4 * C, sc=(4 * C) ** -0.5), b2=r(C, sc=0.1),
+                      wpo=r(C, C, sc=C ** -0.5), bpo=r(C, sc=0.1)))
+    return W
+
+
+def _stream(dev, dtype, M, S, seed, hilo):
+    from uni_renderer_amd import ops
+
+    g = torch.Generator(device=dev).manual_seed(seed)
+    v = torch.randn(S * M, C, device=dev, generator=g) * 1.5
+    t = v.to(dtype)
+    if hilo:
+        t.lo = ops.lo_encode(v - t.float(), dtype)
+    return t
+
+
+def _f(t):
+    from uni_renderer_amd import ops
+
+    lo = ops.lo_of(t)
+    return t.float() + (ops.lo_float(lo) if lo is not None else 0.0)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 1.5e-3), (torch.bfloat16, 1.2e-2)])
+@pytest.mark.parametrize("M,S", [(256, 1), (4096, 2), (200, 2)])
+def test_chain_q_vs_fp32_and_unfused(dev, dtype, tol, M, S):
+    from uni_renderer_amd import ops, tchain
+    from uni_renderer_amd.layers import f32, pack_matrix
+
+    W = _weights(dev, 3, S)
+    ao = _stream(dev, dtype, M, S, 10, False)
+    res = _stream(dev, dtype, M, S, 11, True)
+    scale = 40 ** -0.5 * 1.4426950408889634
+    packs = [tchain.pack_chain_q(w["wo"], w["bo"], w["g"], w["b"], w["wq"], scale, dtype) for w in W]
+    ws = torch.stack([p[0] for p in packs]).contiguous()
+    cs = torch.stack([p[1] for p in packs]).contiguous()
+    if S == 1:
+        ws, cs = ws[0], cs[0]
+    y, q = tchain.chain_q(ao, res, ws, cs, 1e-5, streams=S)
+    torch.cuda.synchronize()
+    for s in range(S):
+        w = W[s]
+        sl = slice(s * M, (s + 1) * M)
+        wo_r, wq_r = w["wo"].to(dtype).float(), (w["wq"] * scale).to(dtype).float()
+        y_ref = ao[sl].float() @ wo_r.t() + w["bo"] + _f(res)[sl]
+        xn = F.layer_norm(y_ref, (C,), w["g"], w["b"], 1e-5).to(dtype).float()
+        q_ref = xn @ wq_r.t()
+        ey, eq = rel_l2(_f(y)[sl], y_ref), rel_l2(q[sl], q_ref)
+        print(f"tchain_q {dtype} M={M} z={s}: y {ey:.2e} q {eq:.2e}")
+        assert ey < (2e-4 if dtype == torch.float16 else 2e-3) and eq < tol, (ey, eq)
+    # the unfused product path on the same operands
+    wo = torch.stack([pack_matrix(w["wo"], dtype) for w in W])
+    bo = torch.stack([f32(w["bo"]) for w in W])
+    wq = torch.stack([pack_matrix(w["wq"] * scale, dtype) for w in W])
+    gm, bt = torch.stack([f32(w["g"]) for w in W]), torch.stack([f32(w["b"]) for w in W])
+    y2 = ops.linear(ao.view(S, M, C), wo, bo, res=ops.view_hilo(res, S, M, C), streams=S, hilo=True)
+    q2 = ops.linear(ops.layernorm(y2, gm, bt, 1e-5, streams=S), wq, streams=S)
+    assert rel_l2(_f(y), _f(y2).view(S * M, C)) < (1e-4 if dtype == torch.float16 else 1e-3)
+    assert rel_l2(q, q2.view(S * M, C)) < tol
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 1.5e-3), (torch.bfloat16, 1.2e-2)])
+@pytest.mark.parametrize("M,S", [(256, 1), (4096, 2), (200, 2)])
+def test_chain_ff_vs_fp32(dev, dtype, tol, M, S):
+    from uni_renderer_amd import ops, tchain
+
+    W = _weights(dev, 5, S)
+    ao = _stream(dev, dtype, M, S, 20, False)
+    res = _stream(dev, dtype, M, S, 21, True)
+    blk = _stream(dev, dtype, M, S, 22, True)
+    packs = [tchain.pack_chain_ff(w["wo"], w["bo"], w["g"], w["b"], w["w1"], w["b1"], w["w2"], w["b2"], w["wpo"], w["bpo"], dtype)
+             for w in W]
+    ws = torch.stack([p[0] for p in packs]).contiguous()
+    cs = torch.stack([p[1] for p in packs]).contiguous()
+    if S == 1:
+        ws, cs = ws[0], cs[0]
+    out = tchain.chain_ff(ao, res, blk, ws, cs, 1e-5, streams=S)
+    torch.cuda.synchronize()
+    for s in range(S):
+        w = W[s]
+        sl = slice(s * M, (s + 1) * M)
+        r = lambda t: t.to(dtype).float()
+        y = ao[sl].float() @ r(w["wo"]).t() + w["bo"] + _f(res)[sl]
+        xn = r(F.layer_norm(y, (C,), w["g"], w["b"], 1e-5))
+        hcat = xn @ r(w["w1"]).t() + w["b1"]
+        h = r(hcat[:, : 4 * C] * F.gelu(hcat[:, 4 * C:]))
+        y3 = y + h @ r(w["w2"]).t() + w["b2"]
+        ref = r(y3) @ r(w["wpo"]).t() + w["bpo"] + _f(blk)[sl]
+        e = rel_l2(_f(out)[sl], ref)
+        print(f"tchain_ff {dtype} M={M} z={s}: out {e:.2e}")
+        assert e < tol, e
+        assert rel_l2(out[sl], ref) < tol  # the hi part alone is the ordinary rounded tensor
+
+
+def test_chain_rejects_other_widths(dev):
+    from uni_renderer_amd import tchain
+
+    x = torch.zeros(128, 640, device=dev, dtype=torch.float16)
+    assert not tchain.supported(x)
+    with pytest.raises(RuntimeError):
+        tchain.chain_q(x, x, torch.zeros(10 * 20480, device=dev, dtype=torch.float16), torch.zeros(960, device=dev), 1e-5)

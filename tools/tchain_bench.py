@@ -1,0 +1,99 @@
+#!/usr/bin/env python3
+"""Time the row-local chains (ur_tchain) against the launches they replace, at the 64x64 level of the headline step
+(M = 4 x 4096 rows per stream, 2 streams grouped): HIP events around graph replays of each variant.
+
+    python tools/tchain_bench.py [--iters 50]
+"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--M", type=int, default=16384)
+    ap.add_argument("--S", type=int, default=2)
+    ap.add_argument("--dtype", default="fp16")
+    args = ap.parse_args()
+    from uni_renderer_amd import ops, tchain
+    from uni_renderer_amd.layers import f32, geglu_perm, pack_matrix
+
+    dev = torch.device("cuda:0")
+    dt = torch.float16 if args.dtype == "fp16" else torch.bfloat16
+    C, M, S = 320, args.M, args.S
+    g = torch.Generator(device=dev).manual_seed(0)
+    r = lambda *s, sc=1.0: torch.randn(*s, device=dev, generator=g) * sc
+    W = [dict(wo=r(C, C, sc=C ** -0.5), bo=r(C, sc=0.1), g=1 + r(C, sc=0.1), b=r(C, sc=0.1), wq=r(C, C, sc=C ** -0.5),
+              w1=r(8 * C, C, sc=C ** -0.5), b1=r(8 * C, sc=0.1), w2=r(C, 4 * C, sc=(4 * C) ** -0.5), b2=r(C, sc=0.1),
+              wpo=r(C, C, sc=C ** -0.5), bpo=r(C, sc=0.1)) for _ in range(S)]
+
+    def stream(hilo):
+        v = r(S, M, C, sc=1.5)
+        t = v.to(dt)
+        if hilo:
+            t.lo = ops.lo_encode(v - t.float(), dt)
+        return t
+
+    ao, res, blk = stream(False), stream(True), stream(True)
+    pq = [tchain.pack_chain_q(w["wo"], w["bo"], w["g"], w["b"], w["wq"], 0.228, dt) for w in W]
+    pf = [tchain.pack_chain_ff(w["wo"], w["bo"], w["g"], w["b"], w["w1"], w["b1"], w["w2"], w["b2"], w["wpo"], w["bpo"], dt) for w in W]
+    wsq, csq = torch.stack([p[0] for p in pq]).contiguous(), torch.stack([p[1] for p in pq]).contiguous()
+    wsf, csf = torch.stack([p[0] for p in pf]).contiguous(), torch.stack([p[1] for p in pf]).contiguous()
+    stk = lambda k, fn: torch.stack([fn(w[k]) for w in W]).contiguous()
+    wo, bo, wq = stk("wo", lambda t: pack_matrix(t, dt)), stk("bo", f32), stk("wq", lambda t: pack_matrix(t * 0.228, dt))
+    gm, bt = stk("g", f32), stk("b", f32)
+    perm = geglu_perm(4 * C, dev)
+    w1, b1 = stk("w1", lambda t: pack_matrix(t, dt)[perm]), stk("b1", lambda t: f32(t)[perm])
+    w2, b2 = stk("w2", lambda t: pack_matrix(t, dt)), stk("b2", f32)
+    wpo, bpo = stk("wpo", lambda t: pack_matrix(t, dt)), stk("bpo", f32)
+
+    def unfused_q():
+        y = ops.linear(ao, wo, bo, res=res, streams=S, hilo=True)
+        return ops.linear(ops.layernorm(y, gm, bt, 1e-5, streams=S), wq, streams=S)
+
+    def unfused_ff():
+        y = ops.linear(ao, wo, bo, res=res, streams=S, hilo=True)
+        xn = ops.layernorm(y, gm, bt, 1e-5, streams=S)
+        gg = ops.linear(xn, w1, b1, act=ops.ACT_GEGLU, streams=S)
+        y3 = ops.linear(gg, w2, b2, res=y, streams=S, hilo=True)
+        return ops.linear(y3, wpo, bpo, res=blk, streams=S, hilo=True)
+
+    def fused_q():
+        return tchain.chain_q(ao.view(S * M, C), ops.view_hilo(res, S * M, C), wsq, csq, 1e-5, streams=S)
+
+    def fused_ff():
+        return tchain.chain_ff(ao.view(S * M, C), ops.view_hilo(res, S * M, C), ops.view_hilo(blk, S * M, C), wsf, csf, 1e-5, streams=S)
+
+    out = {}
+    for name, fn in (("unfused_q", unfused_q), ("fused_q", fused_q), ("unfused_ff", unfused_ff), ("fused_ff", fused_ff)):
+        fn()
+        torch.cuda.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            for _ in range(5):
+                fn()
+        gr.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.iters // 5):
+            gr.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        out[name + "_us"] = round(e0.elapsed_time(e1) / (args.iters // 5 * 5) * 1e3, 2)
+    rows = S * M
+    out["gflop_q"] = 2.0 * rows * C * C * 2 / 1e9
+    out["gflop_ff"] = 2.0 * rows * C * C * 14 / 1e9
+    out["fused_q_tflops"] = round(out["gflop_q"] / out["fused_q_us"] * 1e-3 * 1e3, 1)
+    out["fused_ff_tflops"] = round(out["gflop_ff"] / out["fused_ff_us"] * 1e-3 * 1e3, 1)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must be imported first, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("UR_LIB_PATH", os.path.join(_HERE, "liburhip.so"))  # override = kernel experiments only
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
@@ -69,6 +69,18 @@ class AttnBwdDesc(C.Structure):
     ]
 
 
+class TChainDesc(C.Structure):
+    """Mirror of ``ur_tchain_desc``."""
+
+    _fields_ = [
+        ("a0", vp), ("res", vp), ("res_lo", vp), ("blk", vp), ("blk_lo", vp), ("y_out", vp), ("y_out_lo", vp),
+        ("out", vp), ("out_lo", vp), ("wstream", vp), ("consts", vp),
+        ("z_wstream", i64), ("z_consts", i64),
+        ("M", i32), ("zbatch", i32), ("mode", i32), ("dtype", i32), ("channels", i32),
+        ("eps", f32),
+    ]
+
+
 # name -> (restype, argtypes): every symbol include/ur_kernels.h declares
 SYMBOLS = {
     "ur_igemm": (C.c_int, [C.POINTER(IGemmDesc), vp]),
@@ -116,6 +128,10 @@ SYMBOLS = {
     "ur_adamw_multi": (C.c_int, [vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, vp, vp, vp, vp]),
     "ur_silu_forward": (C.c_int, [vp, vp, C.c_int64, C.c_int, vp]),
     "ur_resample2x": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "ur_tchain": (C.c_int, [C.POINTER(TChainDesc), vp]),
+    "ur_tchain_stream_bytes": (C.c_int64, [C.c_int]),
+    "ur_tchain_const_floats": (C.c_int, [C.c_int]),
+    "ur_sizeof_tchain_desc": (C.c_int, []),
     "ur_abi_version": (C.c_int, []),
     "ur_build_info": (C.c_char_p, []),
     "ur_sizeof_igemm_desc": (C.c_int, []),
@@ -154,7 +170,7 @@ def load() -> C.CDLL:
     if lib.ur_abi_version() != ABI_VERSION:
         raise UrLibraryError(f"ABI version mismatch: library {lib.ur_abi_version()} vs binding {ABI_VERSION}")
     if (lib.ur_sizeof_igemm_desc() != C.sizeof(IGemmDesc) or lib.ur_sizeof_attn_desc() != C.sizeof(AttnDesc)
-            or lib.ur_sizeof_attn_bwd_desc() != C.sizeof(AttnBwdDesc)):
+            or lib.ur_sizeof_attn_bwd_desc() != C.sizeof(AttnBwdDesc) or lib.ur_sizeof_tchain_desc() != C.sizeof(TChainDesc)):
         raise UrLibraryError("descriptor layout mismatch between include/ur_kernels.h and _lib.py")
     _lib = lib
     return lib

@@ -1,0 +1,156 @@
+"""Host side of the row-local transformer chains (``ur_tchain``, csrc/tchain.hip; C ABI in include/ur_kernels.h).
+
+One BasicTransformerBlock of the reference (diffusers 0.24, instantiated by models/unet_2d_blocks.py:1115-1126) at the
+320-channel level is, after each attention, a chain of row-local operations:
+
+    x  = attn1_out . Wo1^T + bo1 + x ;  q = LN2(x) . Wq2^T                          -> ``chain_q``   (UR_TCHAIN_Q)
+    x  = attn2_out . Wo2^T + bo2 + x ;  x = x + FF(LN3(x)) ;  out = proj_out(x) + block input  -> ``chain_ff``  (UR_TCHAIN_FF)
+
+The kernel keeps the activations of 128 rows in registers and streams only weights; this module builds what it
+streams, once per (dtype, parameter version):
+
+* **stage images**: 40960-byte blocks in exactly the byte order of the LDS ring slot they are copied into.  An image
+  holds rows of 64 k-values (128 bytes); inside a row the eight 16-byte chunks are stored XOR-swizzled by
+  ``(row >> 1) & 7`` so that the ``ds_read_b128`` A-fragment reads of v_mfma_f32_32x32x16 (32 rows x two k halves per
+  instruction) are bank-conflict free (same key as csrc/igemm.hip's 32x32 build, tools/lds_bank_check.py).
+* **KPERM**: a matrix whose operand comes out of an MFMA accumulator (everything except the leading GEMM, whose operand
+  is loaded from memory) has its k columns permuted per group of 16 by [0 1 2 3 8 9 10 11 4 5 6 7 12 13 14 15]: lane
+  (pixel, half h) of an accumulator block owns rows 8 q + 4 h + r, so the 8 values it can hand to the next MFMA as
+  k = 8 h .. 8 h + 7 are the channels {4 h + r} of two consecutive 8-row blocks.
+* **const block**: the fp32 vectors the kernel reads from LDS: leading bias | LayerNorm gamma | beta
+  [| FF bias value half | gate half | FF-out bias | proj_out bias].
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib, ops
+from ._lib import TChainDesc, check
+
+MODE_Q, MODE_FF = 0, 1
+CH = 320           # the level the kernel is built for
+STAGE = 40960      # bytes per stage image
+KPERM16 = (0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15)
+
+
+def kperm(w: torch.Tensor) -> torch.Tensor:
+    """Columns of ``w`` [N, K] reordered so that packed column 16 g + kk holds original column 16 g + KPERM16[kk]."""
+    N, K = w.shape
+    idx = torch.tensor(KPERM16, device=w.device)
+    return w.reshape(N, K // 16, 16)[:, :, idx].reshape(N, K)
+
+
+def _swizzle_rows(img: torch.Tensor) -> torch.Tensor:
+    """img [R, 64] (k-values of one row) -> [R, 64] with the eight 8-element chunks of row r stored at chunk position
+    c ^ ((r >> 1) & 7)  (position c' holds logical chunk c' ^ key: XOR is its own inverse)."""
+    R = img.shape[0]
+    r = torch.arange(R, device=img.device)
+    key = (r >> 1) & 7
+    pos = torch.arange(8, device=img.device)[None, :] ^ key[:, None]          # [R, 8]: logical chunk stored at position c'
+    return torch.gather(img.reshape(R, 8, 8), 1, pos[:, :, None].expand(R, 8, 8)).reshape(R, 64)
+
+
+def gemm_images(w: torch.Tensor, permute_k: bool) -> torch.Tensor:
+    """w [320, K] (K % 64 == 0) -> [K // 64, 320 * 64]: one stage image per 64-wide k chunk."""
+    N, K = w.shape
+    assert N == CH and K % 64 == 0
+    wp = kperm(w) if permute_k else w
+    return torch.stack([_swizzle_rows(wp[:, 64 * c: 64 * c + 64]).reshape(-1) for c in range(K // 64)], 0)
+
+
+def ff_images(w1: torch.Tensor, w2: torch.Tensor) -> torch.Tensor:
+    """GEGLU feed-forward as the kernel walks it: per 64 hidden units j three images
+         A0 / A1: for hidden 64 j + 32 half .. + 31: five [64 rows, 64 k] sub-images (k chunk c of the 320 inputs), rows
+                  0..31 = value rows of w1 (``proj`` rows hid), rows 32..63 = gate rows (rows 1280 + hid);
+         B:       w2[:, 64 j .. 64 j + 63] as [320 rows, 64 k].
+       Both operands come out of accumulators -> KPERM on the k axis of both."""
+    nh = w2.shape[1]
+    assert w1.shape == (2 * nh, CH) and w2.shape == (CH, nh) and nh % 64 == 0
+    w1p, w2p = kperm(w1), kperm(w2)
+    out = []
+    for j in range(nh // 64):
+        for half in range(2):
+            hid = 64 * j + 32 * half
+            rows = torch.cat([w1p[hid: hid + 32], w1p[nh + hid: nh + hid + 32]], 0)          # [64, 320]
+            out.append(torch.cat([_swizzle_rows(rows[:, 64 * c: 64 * c + 64]).reshape(-1) for c in range(CH // 64)], 0))
+        out.append(_swizzle_rows(w2p[:, 64 * j: 64 * j + 64]).reshape(-1))
+    return torch.stack(out, 0)
+
+
+def pack_chain_q(wo: torch.Tensor, bo: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, wq: torch.Tensor,
+                 q_scale: float, dtype):
+    """(wstream [10 * 20480] dtype elements, consts [960] fp32) of one UR_TCHAIN_Q chain.  ``q_scale`` is folded into the
+    query weights in fp32 (the attention kernels take q.k in log2 units, layers.Attention)."""
+    w0 = wo.detach().float().reshape(CH, CH)
+    wq_ = wq.detach().float().reshape(CH, CH) * q_scale
+    stream = torch.cat([gemm_images(w0, False), gemm_images(wq_, True)], 0).to(dtype).reshape(-1).contiguous()
+    consts = torch.cat([bo.detach().float(), gamma.detach().float(), beta.detach().float()]).contiguous()
+    return stream, consts
+
+
+def pack_chain_ff(wo: torch.Tensor, bo: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, w1: torch.Tensor,
+                  b1: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor, wpo: torch.Tensor, bpo: torch.Tensor, dtype):
+    """(wstream, consts [3840] fp32) of one UR_TCHAIN_FF chain.  ``w1`` / ``b1`` are diffusers' GEGLU ``proj`` ([2 * 1280,
+    320]: value rows first, gate rows second), ``w2`` the FeedForward output Linear, ``wpo`` / ``bpo`` proj_out."""
+    f = lambda t, *s: t.detach().float().reshape(*s)
+    nh = w2.shape[1]
+    stream = torch.cat([gemm_images(f(wo, CH, CH), False), ff_images(f(w1, 2 * nh, CH), f(w2, CH, nh)),
+                        gemm_images(f(wpo, CH, CH), True)], 0).to(dtype).reshape(-1).contiguous()
+    b1f = b1.detach().float()
+    consts = torch.cat([f(bo, CH), f(gamma, CH), f(beta, CH), b1f[:nh], b1f[nh:], f(b2, CH), f(bpo, CH)]).contiguous()
+    return stream, consts
+
+
+def _launch(mode, a0, res, wstream, consts, eps, *, blk=None, y_out=None, out=None, streams=1):
+    ops._require_gpu(a0)
+    lib = _lib.load()
+    Cn = a0.shape[-1]
+    M = a0.numel() // Cn // streams
+    d = TChainDesc()
+    d.a0, d.res, d.out = a0.data_ptr(), res.data_ptr(), out.data_ptr()
+    d.res_lo = ops._ptr(ops.lo_of(res))
+    d.out_lo = ops._ptr(ops.lo_of(out))
+    if blk is not None:
+        d.blk, d.blk_lo = blk.data_ptr(), ops._ptr(ops.lo_of(blk))
+    if y_out is not None:
+        d.y_out, d.y_out_lo = y_out.data_ptr(), ops._ptr(ops.lo_of(y_out))
+    d.wstream, d.consts = wstream.data_ptr(), consts.data_ptr()
+    d.z_wstream = wstream.stride(0) * wstream.element_size() if streams > 1 else 0
+    d.z_consts = consts.stride(0) if streams > 1 else 0
+    if streams == 1:  # the C side still checks the per-z sizes
+        d.z_wstream, d.z_consts = wstream.numel() * wstream.element_size(), consts.numel()
+    d.M, d.zbatch, d.mode, d.dtype, d.channels, d.eps = M, streams, mode, ops.DT[a0.dtype], Cn, float(eps)
+    e0 = ops._prof_begin()
+    check(lib.ur_tchain(C.byref(d), ops._stream()), "ur_tchain")
+    if e0 is not None:
+        el = a0.element_size()
+        rows = M * streams
+        if mode == MODE_Q:
+            fl = 2.0 * rows * CH * CH * 2
+            by = rows * CH * (el * 4 + 2 * (1 if a0.dtype == torch.float16 else el)) + wstream.numel() * el
+        else:
+            fl = 2.0 * rows * CH * (CH + 8 * CH + 4 * CH + CH)
+            by = rows * CH * (el * 4 + 3 * (1 if a0.dtype == torch.float16 else el)) + wstream.numel() * el
+        ops._prof_end(e0, "tchain_q" if mode == MODE_Q else "tchain_ff", fl, by)
+
+
+def supported(x: torch.Tensor) -> bool:
+    return x.is_cuda and x.shape[-1] == CH and x.dtype in (torch.float16, torch.bfloat16)
+
+
+def chain_q(attn_out, residual, wstream, consts, eps, *, streams=1, hilo=True):
+    """Returns (y, q): y = attn_out Wo^T + bo + residual as a (hi, lo) tensor (``y.lo`` when ``hilo``), q = LN(y) Wq^T."""
+    y = ops._with_lo(torch.empty_like(attn_out), hilo)
+    q = torch.empty_like(attn_out)
+    _launch(MODE_Q, attn_out, residual, wstream, consts, eps, y_out=y, out=q, streams=streams)
+    return y, q
+
+
+def chain_ff(attn_out, residual, block_input, wstream, consts, eps, *, streams=1, hilo=True):
+    """out = proj_out(x + FF(LN3(x))) + block_input with x = attn_out Wo^T + bo + residual."""
+    out = ops._with_lo(torch.empty_like(attn_out), hilo)
+    _launch(MODE_FF, attn_out, residual, wstream, consts, eps, blk=block_input, out=out, streams=streams)
+    return out

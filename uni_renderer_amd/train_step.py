@@ -441,7 +441,9 @@ class GraphedTrainStep:
     Without ``buckets`` (one GPU) the whole step is a single graph.  One instance per objective branch (``inverse``):
     the branch is a host decision (train.py:445), so a training loop keeps one instance per branch over the same
     networks and optimizer.  ``warmup`` eager steps run first (REAL optimisation steps on ``batch``: allocator pools, lazy
-    optimizer state); 0 is allowed with optimizers whose state can be created up front (optim.FusedAdamW)."""
+    optimizer state); 0 is allowed with optimizers whose state can be created up front (optim.FusedAdamW).
+    The optimizer's lr / betas / eps / weight_decay are captured by value; ``step()`` notices when a scheduler or a resumed
+    checkpoint changed them and captures again."""
 
     def __init__(self, nets, batch: Dict[str, torch.Tensor], optimizer, buckets=None, dtype=torch.bfloat16,
                  max_grad_norm: Optional[float] = 1.0, inverse: Optional[bool] = None, warmup: int = 2):
@@ -473,12 +475,23 @@ class GraphedTrainStep:
                 self._eager(kw, max_grad_norm)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        self.max_grad_norm = max_grad_norm
+        self._kw = kw
+        self._capture()
+
+    def _hyper(self):
+        """The optimizer hyper-parameters the captured update holds BY VALUE (kernel arguments of ``ur_adamw_multi``)."""
+        return tuple((float(g["lr"]), tuple(float(b) for b in g["betas"]), float(g["eps"]), float(g["weight_decay"]))
+                     for g in self.optimizer.param_groups)
+
+    def _capture(self):
+        nets, optimizer, buckets, kw, max_grad_norm = self.nets, self.optimizer, self.buckets, self._kw, self.max_grad_norm
+        self._captured_hyper = self._hyper()
         self.g_fb = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.g_fb):
             self.stats["loss"] = _forward_backward(nets, self.batch, optimizer if buckets is None else None, buckets, **kw)
             if buckets is None:
                 _clip_and_update(nets, optimizer, None, max_grad_norm, self.stats)
-        self.max_grad_norm = max_grad_norm
         self.g_up = None
         if buckets is not None:
             buckets._reset()
@@ -498,6 +511,12 @@ class GraphedTrainStep:
         if batch is not None:
             for k, v in batch.items():
                 self.batch[k].copy_(v)
+        if self._hyper() != self._captured_hyper:
+            # an lr_scheduler step (train.py --lr_scheduler / --lr_warmup_steps) or resume_from_checkpoint changed lr /
+            # betas / eps / weight_decay: the captured update holds the old values as kernel arguments.  Capture again
+            # (tens of ms, once per change -- a per-step schedule should run the eager train_step instead)
+            torch.cuda.synchronize()
+            self._capture()
         self.g_fb.replay()
         if self.buckets is not None:
             if self._host_sync_before_collectives:
