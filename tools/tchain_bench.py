@@ -87,6 +87,21 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         out[name + "_us"] = round(e0.elapsed_time(e1) / (args.iters // 5 * 5) * 1e3, 2)
+    # per-phase s_memtime stamps (wave 0 of every workgroup): mean ticks between stamps (100 MHz constant clock or shader
+    # clock -- only the proportions matter)
+    nb = S * M // 128
+    for name, fn in (("q", lambda pr: tchain.chain_q(ao.view(S * M, C), ops.view_hilo(res, S * M, C), wsq, csq, 1e-5, streams=S, profile=pr)),
+                     ("ff", lambda pr: tchain.chain_ff(ao.view(S * M, C), ops.view_hilo(res, S * M, C), ops.view_hilo(blk, S * M, C), wsf, csf, 1e-5, streams=S, profile=pr))):
+        pr = torch.zeros(nb, 16, dtype=torch.int64, device=dev)
+        fn(pr); torch.cuda.synchronize(); pr.zero_(); fn(pr); torch.cuda.synchronize()
+        st = pr.double()
+        n = 8 if name == "q" else 10
+        d = (st[:, 1:n] - st[:, : n - 1]).mean(0)
+        if name == "ff":
+            out["profile_ff_iter5"] = dict(zip(["wait_A0", "mfma_A0", "geglu_A0+stageA1", "wait_B", "mfma_B"],
+                                               [round(float(v)) for v in (st[:, 11:16] - st[:, 10:15]).mean(0)]))
+        out["profile_" + name] = [round(float(v)) for v in d] + ["total", round(float((st[:, n - 1] - st[:, 0]).mean())),
+                                                                   "span", round(float(st[:, n - 1].max() - st[:, 0].min()))]
     rows = S * M
     out["gflop_q"] = 2.0 * rows * C * C * 2 / 1e9
     out["gflop_ff"] = 2.0 * rows * C * C * 14 / 1e9

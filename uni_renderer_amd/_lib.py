@@ -78,6 +78,7 @@ class TChainDesc(C.Structure):
         ("z_wstream", i64), ("z_consts", i64),
         ("M", i32), ("zbatch", i32), ("mode", i32), ("dtype", i32), ("channels", i32),
         ("eps", f32),
+        ("profile", vp),
     ]
 
 

@@ -23,6 +23,7 @@
 // register quad) is converted to / from 8 consecutive channels per lane with v_permlane32_swap.
 #include "ur_common.h"
 #include "../../include/ur_kernels.h"
+#include "tchain_asm.inc"
 
 namespace ur {
 
@@ -84,6 +85,13 @@ __global__ void __launch_bounds__(256, 1) tchain_kernel(const ur_tchain_desc p) 
     const bool row_ok = m < p.M;
     const int64_t mrow = (int64_t)z * p.M + (row_ok ? m : p.M - 1);  // clamped: every lane loads, only valid rows store
 
+    // optional diagnostics: s_memtime stamps of wave 0 of every workgroup ([blocks][16] int64), tools/tchain_bench.py --profile
+    long long* prof = p.profile ? reinterpret_cast<long long*>(p.profile) + (int64_t)blockIdx.x * 16 : nullptr;
+    auto stamp = [&](int i) __attribute__((always_inline)) {
+        if (prof && tid == 0) prof[i] = __builtin_amdgcn_s_memtime();
+    };
+    stamp(0);
+
     // ---- constants -> LDS (before any LDS-DMA is in flight: plain loads + ds_write + one ordinary barrier) ----
     {
         const float* src = p.consts + (int64_t)z * p.z_consts;
@@ -97,31 +105,41 @@ __global__ void __launch_bounds__(256, 1) tchain_kernel(const ur_tchain_desc p) 
     const int voff = lane * 16;
     int issued = 0;   // stages whose copies this wave has issued
     int cons = 0;     // stages consumed
+    // Every workgroup streams the SAME images in the same order, and the workgroups of an XCD run in lock step: issued in
+    // image order, all 32 CUs of an XCD would ask the same L2 channel for the same kilobyte at the same moment (measured:
+    // 4700 cycles per stage = 18 GB/s per CU).  So the 40 pieces of a stage are walked from a workgroup-specific starting
+    // point: wave w takes pieces (4 i + w + rot) mod 40.
+    const int rot = __builtin_amdgcn_readfirstlane((tile * 7 + z * 3) % 40);
     auto issue = [&]() __attribute__((always_inline)) {
         if (issued < NSTAGES) {
             const int slot = issued % TC_NSLOT;
-            const int sbase = issued * TC_STAGE + wave * (TC_PIECES * 1024);
-            char* dst = smem + slot * TC_STAGE + wave * (TC_PIECES * 1024);
+            const int sbase = issued * TC_STAGE;
+            char* dst = smem + slot * TC_STAGE;
+            int pc = rot + wave;
 #pragma unroll
-            for (int i = 0; i < TC_PIECES; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, voff,
-                                                         sbase + i * 1024, 0, 0);
+            for (int i = 0; i < TC_PIECES; ++i) {
+                if (pc >= 40) pc -= 40;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dst + pc * 1024), 16, voff,
+                                                         sbase + pc * 1024, 0, 0);
+                pc += 4;
+            }
         }
         issued += 1;
     };
     // wait until stage `cons` has landed for everybody, free the slot of stage cons - 1, refill it with stage cons + 2
-    auto next_stage = [&]() __attribute__((always_inline)) -> const char* {
+    auto next_stage = [&]() __attribute__((always_inline)) -> int {
         if (cons + 1 < NSTAGES) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TC_PIECES) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         issue();
-        const char* s = smem + (cons % TC_NSLOT) * TC_STAGE;
+        const int s = cons % TC_NSLOT;
         cons += 1;
         return s;
     };
     issue();
     issue();
+    stamp(1);
 
     // fragment address of (row l31 of a 32-row block, k16 step s of the stage's 64-k chunk)
     const int key = (l31 >> 1) & 7;
@@ -208,16 +226,47 @@ __global__ void __launch_bounds__(256, 1) tchain_kernel(const ur_tchain_desc p) 
 #pragma unroll
                 for (int i = 0; i < 8; ++i) bop[2 * t + g][i] = (T)acc.t[t][8 * g + i];
     };
-    // one N = 320 GEMM pass over 5 stages: acc[t] += W[32 t .. 32 t + 31][k] * operand[k]
+    // LDS byte address of this lane's A fragment for k16 step s inside ring slot `slot` (the row-tile / sub-image offset
+    // is an instruction immediate): loop invariant, 12 VGPRs
+    unsigned fa[TC_NSLOT][4];
+#pragma unroll
+    for (int sl = 0; sl < TC_NSLOT; ++sl)
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+            fa[sl][s4] = (unsigned)(size_t)((__attribute__((address_space(3))) char*)smem) + sl * TC_STAGE + l31 * 128 +
+                         (((2 * s4 + hh) ^ key) << 4);
+    // one N = 320 GEMM stage (rows x 64 k): acc[t] += W[32 t .. 32 t + 31][k] * operand[k], 40 MFMAs, as ONE hand-scheduled
+    // instruction stream (tchain_asm.inc): six fragment reads in flight, counted lgkmcnt, a read behind every MFMA
+    auto gemm_stage = [&](Acc<T>& acc, int slot, const vec8& b0, const vec8& b1, const vec8& b2, const vec8& b3) __attribute__((always_inline)) {
+        vec8 f0, f1, f2, f3, f4, f5, f6, f7;
+#define TC_GEMM_OPERANDS                                                                                                       \
+        : [c0] "+a"(acc.t[0]), [c1] "+a"(acc.t[1]), [c2] "+a"(acc.t[2]), [c3] "+a"(acc.t[3]), [c4] "+a"(acc.t[4]),             \
+          [c5] "+a"(acc.t[5]), [c6] "+a"(acc.t[6]), [c7] "+a"(acc.t[7]), [c8] "+a"(acc.t[8]), [c9] "+a"(acc.t[9]),             \
+          [f0] "=&v"(f0), [f1] "=&v"(f1), [f2] "=&v"(f2), [f3] "=&v"(f3), [f4] "=&v"(f4), [f5] "=&v"(f5), [f6] "=&v"(f6),      \
+          [f7] "=&v"(f7)                                                                                                       \
+        : [a0] "v"(fa[slot][0]), [a1] "v"(fa[slot][1]), [a2] "v"(fa[slot][2]), [a3] "v"(fa[slot][3]), [b0] "v"(b0),            \
+          [b1] "v"(b1), [b2] "v"(b2), [b3] "v"(b3)
+        if constexpr (sizeof(T) == 2 && __is_same(T, f16)) asm volatile(TC_ASM_GEMM_STAGE("f16") TC_GEMM_OPERANDS);
+        else asm volatile(TC_ASM_GEMM_STAGE("bf16") TC_GEMM_OPERANDS);
+#undef TC_GEMM_OPERANDS
+    };
+    // compiler code that touches the accumulators after an asm stage: an MFMA result may be read 12+ states after issue
+    auto acc_fence = [&](Acc<T>& acc) __attribute__((always_inline)) {
+        asm volatile("s_nop 15\n\ts_nop 15"
+                     : "+a"(acc.t[0]), "+a"(acc.t[1]), "+a"(acc.t[2]), "+a"(acc.t[3]), "+a"(acc.t[4]), "+a"(acc.t[5]),
+                       "+a"(acc.t[6]), "+a"(acc.t[7]), "+a"(acc.t[8]), "+a"(acc.t[9]));
+    };
     auto gemm320 = [&](Acc<T>& acc, const vec8 (&bop)[TC_KS]) __attribute__((always_inline)) {
 #pragma unroll
         for (int kc = 0; kc < TC_C / 64; ++kc) {
-            const char* st = next_stage();
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int t = 0; t < TC_NT; ++t) acc.t[t] = mfma32(afrag(st + t * 4096, s), bop[4 * kc + s], acc.t[t]);
+            const int slot = next_stage();
+            // the slot index is a compile-time constant only when the stage counter is; select the address set without
+            // dynamic register indexing
+            if (slot == 0) gemm_stage(acc, 0, bop[4 * kc], bop[4 * kc + 1], bop[4 * kc + 2], bop[4 * kc + 3]);
+            else if (slot == 1) gemm_stage(acc, 1, bop[4 * kc], bop[4 * kc + 1], bop[4 * kc + 2], bop[4 * kc + 3]);
+            else gemm_stage(acc, 2, bop[4 * kc], bop[4 * kc + 1], bop[4 * kc + 2], bop[4 * kc + 3]);
         }
+        acc_fence(acc);
     };
 
     // =============================== leading GEMM: y = a0 W0^T + bias0 + residual ===============================
@@ -228,7 +277,9 @@ __global__ void __launch_bounds__(256, 1) tchain_kernel(const ur_tchain_desc p) 
     zero(acc);
     add_stream(acc, p.res, p.res_lo);
     add_cvec(acc, TCC_BIAS0);
+    stamp(2);
     gemm320(acc, bop);
+    stamp(3);
     if constexpr (MODE == UR_TCHAIN_Q) {
         // the updated residual stream leaves here; the LDS-DMA queue is drained first so that the stores are the
         // only vector-memory operations counted between the two GEMM passes
@@ -236,6 +287,7 @@ __global__ void __launch_bounds__(256, 1) tchain_kernel(const ur_tchain_desc p) 
         store_stream(acc, p.y_out, p.y_out_lo);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    stamp(4);
 
     // =============================== LayerNorm (exact two-pass, fp32) -> operand ===============================
     {
@@ -268,11 +320,14 @@ __global__ void __launch_bounds__(256, 1) tchain_kernel(const ur_tchain_desc p) 
             }
     }
 
+    stamp(5);
     if constexpr (MODE == UR_TCHAIN_Q) {
         // =============================== q = LN(y) Wq^T (scale folded into Wq by the host) ===============================
         zero(acc);
         gemm320(acc, bop);
+        stamp(6);
         store_stream(acc, p.out, nullptr);
+        stamp(7);
     } else {
         // =============================== GEGLU feed-forward: acc = y + b2 + sum_j h_j W2_j^T ===============================
         add_cvec(acc, TCC_B2);
@@ -281,19 +336,27 @@ __global__ void __launch_bounds__(256, 1) tchain_kernel(const ur_tchain_desc p) 
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 // stage image: five [64 rows][64 k] sub-images; rows 0..31 = value rows, 32..63 = gate rows of 32 hidden units
-                const char* st = next_stage();
-                f32x16 hv[2], hg[2];
+                const int slot = next_stage();
+                f32x16 hv0, hg0, hv1, hg1;
 #pragma unroll
-                for (int u = 0; u < 2; ++u)
-#pragma unroll
-                    for (int v = 0; v < 16; ++v) { hv[u][v] = 0.f; hg[u][v] = 0.f; }
-#pragma unroll
-                for (int c = 0; c < TC_C / 64; ++c)
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        hv[s & 1] = mfma32(afrag(st + c * 8192, s), bop[4 * c + s], hv[s & 1]);
-                        hg[s & 1] = mfma32(afrag(st + c * 8192 + 4096, s), bop[4 * c + s], hg[s & 1]);
-                    }
+                for (int v = 0; v < 16; ++v) { hv0[v] = 0.f; hg0[v] = 0.f; hv1[v] = 0.f; hg1[v] = 0.f; }
+                {
+                    vec8 f0, f1, f2, f3, f4, f5, f6, f7;
+                    const unsigned a0_ = slot == 0 ? fa[0][0] : (slot == 1 ? fa[1][0] : fa[2][0]);
+                    const unsigned a1_ = slot == 0 ? fa[0][1] : (slot == 1 ? fa[1][1] : fa[2][1]);
+                    const unsigned a2_ = slot == 0 ? fa[0][2] : (slot == 1 ? fa[1][2] : fa[2][2]);
+                    const unsigned a3_ = slot == 0 ? fa[0][3] : (slot == 1 ? fa[1][3] : fa[2][3]);
+#define TC_FFA_OPERANDS                                                                                                        \
+        : [hv0] "+a"(hv0), [hg0] "+a"(hg0), [hv1] "+a"(hv1), [hg1] "+a"(hg1), [f0] "=&v"(f0), [f1] "=&v"(f1), [f2] "=&v"(f2), \
+          [f3] "=&v"(f3), [f4] "=&v"(f4), [f5] "=&v"(f5), [f6] "=&v"(f6), [f7] "=&v"(f7)                                      \
+        : [a0] "v"(a0_), [a1] "v"(a1_), [a2] "v"(a2_), [a3] "v"(a3_), [b0] "v"(bop[0]), [b1] "v"(bop[1]), [b2] "v"(bop[2]),    \
+          [b3] "v"(bop[3]), [b4] "v"(bop[4]), [b5] "v"(bop[5]), [b6] "v"(bop[6]), [b7] "v"(bop[7]), [b8] "v"(bop[8]),          \
+          [b9] "v"(bop[9]), [b10] "v"(bop[10]), [b11] "v"(bop[11]), [b12] "v"(bop[12]), [b13] "v"(bop[13]),                   \
+          [b14] "v"(bop[14]), [b15] "v"(bop[15]), [b16] "v"(bop[16]), [b17] "v"(bop[17]), [b18] "v"(bop[18]), [b19] "v"(bop[19])
+                    if constexpr (__is_same(T, f16)) asm volatile(TC_ASM_FFA_STAGE("f16") "s_nop 15\n\ts_nop 15" TC_FFA_OPERANDS);
+                    else asm volatile(TC_ASM_FFA_STAGE("bf16") "s_nop 15\n\ts_nop 15" TC_FFA_OPERANDS);
+#undef TC_FFA_OPERANDS
+                }
                 const int hid = 64 * j + 32 * half;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -302,25 +365,29 @@ __global__ void __launch_bounds__(256, 1) tchain_kernel(const ur_tchain_desc p) 
                     const float bvv[4] = {bv.x, bv.y, bv.z, bv.w}, bgg[4] = {bg.x, bg.y, bg.z, bg.w};
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float val = hv[0][4 * q + r] + hv[1][4 * q + r] + bvv[r];
-                        const float gate = hg[0][4 * q + r] + hg[1][4 * q + r] + bgg[r];
+                        const float val = hv0[4 * q + r] + hv1[4 * q + r] + bvv[r];
+                        const float gate = hg0[4 * q + r] + hg1[4 * q + r] + bgg[r];
                         hb[2 * half + (q >> 1)][4 * (q & 1) + r] = (T)(val * gelu_erf_f(gate));
                     }
                 }
             }
-            const char* st = next_stage();  // W2[:, 64 j .. 64 j + 63]
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int t = 0; t < TC_NT; ++t) acc.t[t] = mfma32(afrag(st + t * 4096, s), hb[s], acc.t[t]);
+            const int slot = next_stage();  // W2[:, 64 j .. 64 j + 63]
+            if (slot == 0) gemm_stage(acc, 0, hb[0], hb[1], hb[2], hb[3]);
+            else if (slot == 1) gemm_stage(acc, 1, hb[0], hb[1], hb[2], hb[3]);
+            else gemm_stage(acc, 2, hb[0], hb[1], hb[2], hb[3]);
         }
+        acc_fence(acc);
+        stamp(6);
         // =============================== out = y3 Wpo^T + bpo + block input ===============================
         to_operand(acc, bop);
         zero(acc);
         gemm320(acc, bop);
+        stamp(7);
         add_cvec(acc, TCC_BPO);
         add_stream(acc, p.blk, p.blk_lo);
+        stamp(8);
         store_stream(acc, p.out, p.out_lo);
+        stamp(9);
     }
 }
 

@@ -26,7 +26,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
 
-from . import ops
+from . import ops, tchain
 from .controlnet import CIN_PAD, _compute_dtype
 from .layers import (LOG2E, Attention, BasicTransformerBlock, ResnetBlock2D, Transformer2DModel, f32, geglu_perm,
                      pack_conv3x3, pack_matrix)
@@ -67,6 +67,8 @@ class GroupedDualStreamStep:
         if precise_residual is None:
             precise_residual = os.environ.get("UR_PRECISE_RESIDUAL", "1") != "0"
         self.hilo = bool(precise_residual)
+        # row-local chain kernels at the 320-channel level (tchain.py); UR_TCHAIN=0: the unfused GEMM / LayerNorm launches
+        self.use_tchain = os.environ.get("UR_TCHAIN", "1") != "0"
         # Independent work on a second HIP stream (= a parallel branch of the captured graph): the 13 exchange GEMMs
         # (each only needs its own skip pair, which phase 1 produces early), the up phase's time / prompt projections
         # (inputs only) and every self-attention's V^T projection (beside its q|k projection).  These launches are
@@ -228,6 +230,54 @@ class GroupedDualStreamStep:
         ops.set_site(None)
         return y
 
+    def _tblock_chain(self, bs: Sequence[BasicTransformerBlock], ts, x, blk_in, kc, vtc, kv_slice):
+        """The 320-channel level: everything row-local behind the two attentions runs as two ``ur_tchain`` launches
+        (tchain.py) -- attn1 out-projection + residual + LayerNorm2 + cross-attention query projection, then attn2
+        out-projection + residual + LayerNorm3 + GEGLU feed-forward + residual + proj_out + block input -- instead of six
+        GEMM and two LayerNorm launches.  Same arithmetic and the same rounding points as ``_tblock`` + proj_out."""
+        S, pk, dt = len(bs), self.pk, x.dtype
+        a1, a2 = [b.attn1 for b in bs], [b.attn2 for b in bs]
+        a0 = a1[0]
+        Bt, T, C = x.shape
+        H, d = a0.heads, a0.dim_head
+        cs = d ** -0.5 * LOG2E
+        g, b_ = (pk.get("t.n1.g", bs, [b.norm1.weight for b in bs], dt, lambda: _stk(f32(b.norm1.weight) for b in bs)),
+                 pk.get("t.n1.b", bs, [b.norm1.bias for b in bs], dt, lambda: _stk(f32(b.norm1.bias) for b in bs)))
+        xn = ops.layernorm(x, g, b_, bs[0].norm1.eps, streams=S)
+        wqk = pk.get("a.wqk", a1, [p for a in a1 for p in (a.to_q.weight, a.to_k.weight)], dt,
+                     lambda: _stk(torch.cat([pack_matrix(a.to_q.weight, dt), pack_matrix(a.to_k.weight, dt)], 0) for a in a1))
+        wv = pk.get("a.wv", a1, [a.to_v.weight for a in a1], dt, lambda: _stk(pack_matrix(a.to_v.weight, dt) for a in a1))
+        ops.set_site("vt")
+        vt = ops.vt_proj(xn, wv, streams=S)
+        ops.set_site("qk")
+        qk = ops.linear(xn, wqk, streams=S, out_scale=math.sqrt(cs))
+        ops.set_site(None)
+        o1 = ops.attention(qk, qk, vt, B=Bt, H=H, Tq=T, Tk=T, d=d, ldq=2 * C, ldk=2 * C, q_off=0, k_off=C, scale=0.0)
+
+        def build_q():
+            packs = [tchain.pack_chain_q(b.attn1.to_out[0].weight, b.attn1.to_out[0].bias, b.norm2.weight, b.norm2.bias,
+                                         b.attn2.to_q.weight, cs, dt) for b in bs]
+            return _stk(p[0] for p in packs), _stk(p[1] for p in packs)
+
+        wsq, csq = pk.get("tc.q", bs, [p for b in bs for p in (b.attn1.to_out[0].weight, b.attn1.to_out[0].bias, b.norm2.weight,
+                                                               b.norm2.bias, b.attn2.to_q.weight)], dt, build_q)
+        y1, q2 = tchain.chain_q(o1.view(Bt * T, C), ops.view_hilo(x, Bt * T, C), wsq, csq, bs[0].norm2.eps, streams=S)
+        lo, hi = kv_slice
+        o2 = ops.attention(q2.view(Bt, T, C), kc[:, :, lo:hi], vtc[:, lo:hi], B=Bt, H=H, Tq=T, Tk=kc.shape[1], d=d, ldq=C,
+                           ldk=kc.stride(1), scale=0.0)
+
+        def build_ff():
+            packs = [tchain.pack_chain_ff(b.attn2.to_out[0].weight, b.attn2.to_out[0].bias, b.norm3.weight, b.norm3.bias,
+                                          b.ff.net[0].proj.weight, b.ff.net[0].proj.bias, b.ff.net[2].weight, b.ff.net[2].bias,
+                                          t.proj_out.weight, t.proj_out.bias, dt) for b, t in zip(bs, ts)]
+            return _stk(p[0] for p in packs), _stk(p[1] for p in packs)
+
+        wsf, csf = pk.get("tc.ff", bs, [p for b, t in zip(bs, ts) for p in (
+            b.attn2.to_out[0].weight, b.attn2.to_out[0].bias, b.norm3.weight, b.norm3.bias, b.ff.net[0].proj.weight,
+            b.ff.net[0].proj.bias, b.ff.net[2].weight, b.ff.net[2].bias, t.proj_out.weight, t.proj_out.bias)], dt, build_ff)
+        out = tchain.chain_ff(o2.view(Bt * T, C), y1, ops.view_hilo(blk_in, Bt * T, C), wsf, csf, bs[0].norm3.eps, streams=S)
+        return ops.view_hilo(out, Bt, T, C)
+
     def _transformer(self, ts: Sequence[Transformer2DModel], x, kc, vtc, kv_slices):
         S, pk, dt = len(ts), self.pk, x.dtype
         Bt, H, W, Cc = x.shape
@@ -241,6 +291,9 @@ class GroupedDualStreamStep:
         ops.set_site("pi")
         h = ops.linear(h.view(Bt, H * W, Cc), wi, bi, streams=S, hilo=self.hilo)
         ops.set_site(None)
+        if self.use_tchain and len(ts[0].transformer_blocks) == 1 and tchain.supported(h) and self.hilo:
+            return ops.view_hilo(self._tblock_chain([t.transformer_blocks[0] for t in ts], ts, h, ops.view_hilo(x, Bt, H * W, Cc),
+                                                    kc, vtc, kv_slices[0]), Bt, H, W, Cc)
         for j in range(len(ts[0].transformer_blocks)):
             h = self._tblock([t.transformer_blocks[j] for t in ts], h, kc, vtc, kv_slices[j])
         ops.set_site("po")

@@ -104,7 +104,7 @@ def pack_chain_ff(wo: torch.Tensor, bo: torch.Tensor, gamma: torch.Tensor, beta:
     return stream, consts
 
 
-def _launch(mode, a0, res, wstream, consts, eps, *, blk=None, y_out=None, out=None, streams=1):
+def _launch(mode, a0, res, wstream, consts, eps, *, blk=None, y_out=None, out=None, streams=1, profile=None):
     ops._require_gpu(a0)
     lib = _lib.load()
     Cn = a0.shape[-1]
@@ -123,6 +123,8 @@ def _launch(mode, a0, res, wstream, consts, eps, *, blk=None, y_out=None, out=No
     if streams == 1:  # the C side still checks the per-z sizes
         d.z_wstream, d.z_consts = wstream.numel() * wstream.element_size(), consts.numel()
     d.M, d.zbatch, d.mode, d.dtype, d.channels, d.eps = M, streams, mode, ops.DT[a0.dtype], Cn, float(eps)
+    if profile is not None:
+        d.profile = profile.data_ptr()
     e0 = ops._prof_begin()
     check(lib.ur_tchain(C.byref(d), ops._stream()), "ur_tchain")
     if e0 is not None:
@@ -141,16 +143,16 @@ def supported(x: torch.Tensor) -> bool:
     return x.is_cuda and x.shape[-1] == CH and x.dtype in (torch.float16, torch.bfloat16)
 
 
-def chain_q(attn_out, residual, wstream, consts, eps, *, streams=1, hilo=True):
+def chain_q(attn_out, residual, wstream, consts, eps, *, streams=1, hilo=True, profile=None):
     """Returns (y, q): y = attn_out Wo^T + bo + residual as a (hi, lo) tensor (``y.lo`` when ``hilo``), q = LN(y) Wq^T."""
     y = ops._with_lo(torch.empty_like(attn_out), hilo)
     q = torch.empty_like(attn_out)
-    _launch(MODE_Q, attn_out, residual, wstream, consts, eps, y_out=y, out=q, streams=streams)
+    _launch(MODE_Q, attn_out, residual, wstream, consts, eps, y_out=y, out=q, streams=streams, profile=profile)
     return y, q
 
 
-def chain_ff(attn_out, residual, block_input, wstream, consts, eps, *, streams=1, hilo=True):
+def chain_ff(attn_out, residual, block_input, wstream, consts, eps, *, streams=1, hilo=True, profile=None):
     """out = proj_out(x + FF(LN3(x))) + block_input with x = attn_out Wo^T + bo + residual."""
     out = ops._with_lo(torch.empty_like(attn_out), hilo)
-    _launch(MODE_FF, attn_out, residual, wstream, consts, eps, blk=block_input, out=out, streams=streams)
+    _launch(MODE_FF, attn_out, residual, wstream, consts, eps, blk=block_input, out=out, streams=streams, profile=profile)
     return out
