@@ -487,7 +487,7 @@ typedef struct ur_tchain_desc {
     int64_t z_consts;    /* floats between the constant blocks of two z */
     int M, zbatch, mode, dtype, channels;
     float eps;           /* LayerNorm epsilon */
-    void* profile;       /* diagnostics, normally NULL: int64 [workgroups][16] s_memtime stamps of each workgroup's wave 0 */
+    void* profile;       /* diagnostics, normally NULL: int64 [workgroups][64] s_memtime stamps (0..15 phases, 16..63 stage starts) of each workgroup's wave 0 */
 } ur_tchain_desc;
 int ur_tchain(const ur_tchain_desc* d, void* stream);
 int64_t ur_tchain_stream_bytes(int mode);

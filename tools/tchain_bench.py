@@ -20,10 +20,12 @@ def main():
     ap.add_argument("--M", type=int, default=16384)
     ap.add_argument("--S", type=int, default=2)
     ap.add_argument("--dtype", default="fp16")
+    ap.add_argument("--no-dma", action="store_true", help="timing ablation: negative eps = the kernel skips its weight copies")
     args = ap.parse_args()
     from uni_renderer_amd import ops, tchain
     from uni_renderer_amd.layers import f32, geglu_perm, pack_matrix
 
+    EPS = -1.0 if args.no_dma else 1e-5
     dev = torch.device("cuda:0")
     dt = torch.float16 if args.dtype == "fp16" else torch.bfloat16
     C, M, S = 320, args.M, args.S
@@ -65,10 +67,10 @@ def main():
         return ops.linear(y3, wpo, bpo, res=blk, streams=S, hilo=True)
 
     def fused_q():
-        return tchain.chain_q(ao.view(S * M, C), ops.view_hilo(res, S * M, C), wsq, csq, 1e-5, streams=S)
+        return tchain.chain_q(ao.view(S * M, C), ops.view_hilo(res, S * M, C), wsq, csq, EPS, streams=S)
 
     def fused_ff():
-        return tchain.chain_ff(ao.view(S * M, C), ops.view_hilo(res, S * M, C), ops.view_hilo(blk, S * M, C), wsf, csf, 1e-5, streams=S)
+        return tchain.chain_ff(ao.view(S * M, C), ops.view_hilo(res, S * M, C), ops.view_hilo(blk, S * M, C), wsf, csf, EPS, streams=S)
 
     out = {}
     for name, fn in (("unfused_q", unfused_q), ("fused_q", fused_q), ("unfused_ff", unfused_ff), ("fused_ff", fused_ff)):
@@ -90,16 +92,17 @@ def main():
     # per-phase s_memtime stamps (wave 0 of every workgroup): mean ticks between stamps (100 MHz constant clock or shader
     # clock -- only the proportions matter)
     nb = S * M // 128
-    for name, fn in (("q", lambda pr: tchain.chain_q(ao.view(S * M, C), ops.view_hilo(res, S * M, C), wsq, csq, 1e-5, streams=S, profile=pr)),
-                     ("ff", lambda pr: tchain.chain_ff(ao.view(S * M, C), ops.view_hilo(res, S * M, C), ops.view_hilo(blk, S * M, C), wsf, csf, 1e-5, streams=S, profile=pr))):
-        pr = torch.zeros(nb, 16, dtype=torch.int64, device=dev)
+    for name, fn in (("q", lambda pr: tchain.chain_q(ao.view(S * M, C), ops.view_hilo(res, S * M, C), wsq, csq, EPS, streams=S, profile=pr)),
+                     ("ff", lambda pr: tchain.chain_ff(ao.view(S * M, C), ops.view_hilo(res, S * M, C), ops.view_hilo(blk, S * M, C), wsf, csf, EPS, streams=S, profile=pr))):
+        pr = torch.zeros(nb, 64, dtype=torch.int64, device=dev)
         fn(pr); torch.cuda.synchronize(); pr.zero_(); fn(pr); torch.cuda.synchronize()
         st = pr.double()
         n = 8 if name == "q" else 10
         d = (st[:, 1:n] - st[:, : n - 1]).mean(0)
         if name == "ff":
-            out["profile_ff_iter5"] = dict(zip(["wait_A0", "mfma_A0", "geglu_A0+stageA1", "wait_B", "mfma_B"],
-                                               [round(float(v)) for v in (st[:, 11:16] - st[:, 10:15]).mean(0)]))
+            out["ff_stage_periods_16_to_46"] = [round(float(v)) for v in (st[:, 17:47] - st[:, 16:46]).mean(0)]
+            out["profile_ff_iter5"] = dict(zip(["next_stage_wait", "A0+G stream", "A1+G incl wait", "B incl wait"],
+                                               [round(float(v)) for v in (st[:, 11:15] - st[:, 10:14]).mean(0)]))
         out["profile_" + name] = [round(float(v)) for v in d] + ["total", round(float((st[:, n - 1] - st[:, 0]).mean())),
                                                                    "span", round(float(st[:, n - 1].max() - st[:, 0].min()))]
     rows = S * M

@@ -22,6 +22,7 @@
 // Global I/O happens only at the ends of a chain, 16 bytes per lane; the accumulator layout (4 consecutive channels per
 // register quad) is converted to / from 8 consecutive channels per lane with v_permlane32_swap.
 #include "ur_common.h"
+#include <type_traits>
 #include "../../include/ur_kernels.h"
 #include "tchain_asm.inc"
 
@@ -35,6 +36,13 @@ constexpr int TC_NSLOT = 3;                // LDS ring slots
 constexpr int TC_PIECES = TC_STAGE / 1024 / 4;  // LDS-DMA instructions (1 KiB each) per wave per stage
 constexpr int TC_FF = 4 * TC_C;            // GEGLU hidden width
 constexpr int TC_RING = TC_NSLOT * TC_STAGE;
+constexpr int TC_LDS = 160 * 1024;         // the whole CU's LDS: one workgroup per CU
+// I/O staging: a wave's 32-row tile is ONE contiguous 20-KiB block of global memory; it is moved with fully coalesced
+// 16-byte-per-lane accesses and transposed to / from the one-row-per-lane accumulator arrangement through a private LDS
+// region (rows padded by 16 bytes: conflict-free 16-byte reads down a column of rows).  The regions lie behind ring
+// slot 0 (which keeps prefetching), so staging happens only while slots 1 and 2 are not in use.
+constexpr int TC_IO_HI_ROW = TC_C * 2 + 16;          // padded row of the hi tile (bytes)
+constexpr int TC_IO_BASE = TC_STAGE;                 // first byte of the staging area
 
 // const-vector offsets (floats) inside the per-z block the host builds (tchain.py)
 constexpr int TCC_BIAS0 = 0, TCC_GAMMA = 320, TCC_BETA = 640, TCC_Q_END = 960;
@@ -74,10 +82,14 @@ __global__ void __launch_bounds__(256, 1) tchain_kernel(const ur_tchain_desc p) 
     constexpr int NSTAGES = MODE == UR_TCHAIN_Q ? 10 : 5 + 3 * (TC_FF / 64) + 5;
     constexpr int NCONST = MODE == UR_TCHAIN_Q ? TCC_Q_END : TCC_FF_END;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* cst = reinterpret_cast<float*>(smem + TC_RING);
+    float* cst = reinterpret_cast<float*>(smem + TC_LDS - NCONST * 4);  // the constant vectors sit at the very end
+    constexpr int IO_WAVE = ((TC_LDS - NCONST * 4 - TC_IO_BASE) / 4) & ~15;  // staging bytes per wave
+    static_assert(IO_WAVE >= 32 * TC_IO_HI_ROW, "staging region too small");
+
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hh = lane >> 5;
+    char* const io = smem + TC_IO_BASE + wave * IO_WAVE;  // this wave's staging slice
     const int tiles = (p.M + 127) >> 7;
     const int lid = xcd_remap(blockIdx.x, gridDim.x);  // an XCD works on one z (one weight stream in its L2)
     const int z = lid / tiles, tile = lid - z * tiles;
@@ -85,8 +97,8 @@ __global__ void __launch_bounds__(256, 1) tchain_kernel(const ur_tchain_desc p) 
     const bool row_ok = m < p.M;
     const int64_t mrow = (int64_t)z * p.M + (row_ok ? m : p.M - 1);  // clamped: every lane loads, only valid rows store
 
-    // optional diagnostics: s_memtime stamps of wave 0 of every workgroup ([blocks][16] int64), tools/tchain_bench.py --profile
-    long long* prof = p.profile ? reinterpret_cast<long long*>(p.profile) + (int64_t)blockIdx.x * 16 : nullptr;
+    // optional diagnostics: s_memtime stamps of wave 0 of every workgroup ([blocks][64] int64), tools/tchain_bench.py --profile
+    long long* prof = p.profile ? reinterpret_cast<long long*>(p.profile) + (int64_t)blockIdx.x * 64 : nullptr;
     auto stamp = [&](int i) __attribute__((always_inline)) {
         if (prof && tid == 0) prof[i] = __builtin_amdgcn_s_memtime();
     };
@@ -105,10 +117,10 @@ __global__ void __launch_bounds__(256, 1) tchain_kernel(const ur_tchain_desc p) 
     const int voff = lane * 16;
     int issued = 0;   // stages whose copies this wave has issued
     int cons = 0;     // stages consumed
-    // Every workgroup streams the SAME images in the same order, and the workgroups of an XCD run in lock step: issued in
-    // image order, all 32 CUs of an XCD would ask the same L2 channel for the same kilobyte at the same moment (measured:
-    // 4700 cycles per stage = 18 GB/s per CU).  So the 40 pieces of a stage are walked from a workgroup-specific starting
-    // point: wave w takes pieces (4 i + w + rot) mod 40.
+    // Every workgroup streams the SAME images in the same order; the 40 pieces of a stage are walked from a
+    // workgroup-specific starting point (wave w takes pieces (4 i + w + rot) mod 40) so that the CUs of an XCD do not all
+    // ask for the same kilobyte at the same moment.  (Compiler-issued copies: pipeline fill only; in steady state the
+    // copies of stage t + 2 ride inside the MFMA stream of stage t, tchain_asm.inc.)
     const int rot = __builtin_amdgcn_readfirstlane((tile * 7 + z * 3) % 40);
     auto issue = [&]() __attribute__((always_inline)) {
         if (issued < NSTAGES) {
@@ -123,22 +135,29 @@ __global__ void __launch_bounds__(256, 1) tchain_kernel(const ur_tchain_desc p) 
                                                          sbase + pc * 1024, 0, 0);
                 pc += 4;
             }
+            issued += 1;
         }
-        issued += 1;
     };
-    // wait until stage `cons` has landed for everybody, free the slot of stage cons - 1, refill it with stage cons + 2
+    // wait until stage `cons` has landed for everybody (that also frees the slot of stage cons - 1); returns its slot.
+    // The caller's stream then copies stage cons + 2 into the freed slot (dma_args) or nobody does (pipeline drain).
     auto next_stage = [&]() __attribute__((always_inline)) -> int {
-        if (cons + 1 < NSTAGES) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TC_PIECES) : "memory");
+        if (prof && tid == 0 && cons >= 16 && cons < 64) prof[cons] = __builtin_amdgcn_s_memtime();  // stage periods 16..63
+        if (issued > cons + 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TC_PIECES) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        issue();
         const int s = cons % TC_NSLOT;
         cons += 1;
         return s;
     };
-    issue();
-    issue();
+    const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) char*)smem);
+    // stream offset / LDS destination of this wave's ten pieces of the stage the running stream copies (stage `issued`)
+    auto dma_args = [&](unsigned& so, unsigned& ld) __attribute__((always_inline)) {
+        so = issued * TC_STAGE + wave * (TC_PIECES * 1024);
+        ld = lds0 + (issued % TC_NSLOT) * TC_STAGE + wave * (TC_PIECES * 1024);
+        issued += 1;
+    };
+    issue();  // stage 0 -> slot 0; slots 1 / 2 are the staging area until the leading operands are in registers
     stamp(1);
 
     // fragment address of (row l31 of a 32-row block, k16 step s of the stage's 64-k chunk)
@@ -152,53 +171,108 @@ __global__ void __launch_bounds__(256, 1) tchain_kernel(const ur_tchain_desc p) 
     };
 
     // ---- global I/O helpers (16 bytes per lane; rows are 320 channels wide) ----
-    const T* a0 = reinterpret_cast<const T*>(p.a0) + mrow * TC_C;
-    // residual-stream tensor (hi [+ lo]) -> fp32 in the accumulator arrangement, ADDED to acc
+    // ---- global I/O through the staging region ----
+    // Every I/O phase recomputes its addresses from a LAUNDERED copy of the lane id: otherwise the compiler shares the
+    // (loop-invariant) per-piece pointers of the first and the last phase and keeps ~60 registers alive across the whole
+    // kernel, spilling inside the feed-forward loop.
+    auto launder = [](int v) __attribute__((always_inline)) { asm volatile("" : "+v"(v)); return v; };
+    const int m0w = tile * 128 + wave * 32;  // first row of this wave
+    constexpr int HI_ROW = TC_C * (int)sizeof(T), LO_ROW = TC_C * (int)sizeof(lo_t<T>);
+    // 16-byte piece e = 64 k + ln of the wave's tile: row = e / CPR, chunk = e % CPR.  Global side: rows >= M clamped
+    // (loads) / skipped (stores); LDS side: rows padded by 16 bytes.
+    auto stage_in = [&](const void* base, int row_bytes) __attribute__((always_inline)) {
+        const int ln = launder(lane);
+        const int cpr = row_bytes / 16, np = 32 * row_bytes / 1024;
+#pragma unroll
+        for (int k0 = 0; k0 < 20; k0 += 5) {
+            u32x4 v[5];
+#pragma unroll
+            for (int k = k0; k < k0 + 5; ++k)
+                if (k < np) {
+                    const int e = 64 * k + ln, r = e / cpr, c = e - r * cpr;
+                    const int64_t row = (int64_t)z * p.M + min(m0w + r, p.M - 1);
+                    v[k - k0] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(base) + row * row_bytes + c * 16);
+                }
+#pragma unroll
+            for (int k = k0; k < k0 + 5; ++k)
+                if (k < np) {
+                    const int e = 64 * k + ln, r = e / cpr, c = e - r * cpr;
+                    *reinterpret_cast<u32x4*>(io + r * (row_bytes + 16) + c * 16) = v[k - k0];
+                }
+        }
+    };
+    auto stage_out = [&](void* base, int row_bytes) __attribute__((always_inline)) {
+        const int ln = launder(lane);
+        const int cpr = row_bytes / 16, np = 32 * row_bytes / 1024;
+#pragma unroll
+        for (int k = 0; k < 20; ++k)
+            if (k < np) {
+                const int e = 64 * k + ln, r = e / cpr, c = e - r * cpr;
+                const u32x4 v = *reinterpret_cast<const u32x4*>(io + r * (row_bytes + 16) + c * 16);
+                if (m0w + r < p.M)
+                    *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(base) + ((int64_t)z * p.M + m0w + r) * row_bytes + c * 16) = v;
+            }
+    };
+    // residual-stream tensor (hi [+ lo]) -> fp32 in the accumulator arrangement, ADDED to acc.  The staging region must
+    // be free (ring slots 1 / 2 idle); wave-private, so only the wave's own LDS ordering is needed.
     auto add_stream = [&](Acc<T>& acc, const void* hi_, const void* lo_) __attribute__((always_inline)) {
-        const T* hi = reinterpret_cast<const T*>(hi_) + mrow * TC_C;
-        const lo_t<T>* lo = lo_ ? reinterpret_cast<const lo_t<T>*>(lo_) + mrow * TC_C : nullptr;
+        stage_in(hi_, HI_ROW);
+        const int ln = launder(lane);
+        const int lrow = ln & 31, lh = ln >> 5;
 #pragma unroll
         for (int t = 0; t < TC_NT; ++t)
 #pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                const int c = 32 * t + 16 * g + 8 * hh;
-                float f[8];
-                load8(hi + c, f);
-                if (lo) {
-                    float l[8];
-                    load_lo<8>(lo + c, l);
+            for (int q = 0; q < 4; ++q) {
+                const T* src = reinterpret_cast<const T*>(io + lrow * (HI_ROW + 16)) + 32 * t + 8 * q + 4 * lh;
+                typedef T t4 __attribute__((ext_vector_type(4)));
+                const t4 v = *reinterpret_cast<const t4*>(src);
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) f[i] += l[i];
-                }
-                d_mem_swap(f);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    acc.t[t][8 * g + i] += f[i];
-                    acc.t[t][8 * g + 4 + i] += f[4 + i];
-                }
+                for (int r = 0; r < 4; ++r) acc.t[t][4 * q + r] += (float)v[r];
             }
+        if (lo_) {
+            stage_in(lo_, LO_ROW);
+#pragma unroll
+            for (int t = 0; t < TC_NT; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const lo_t<T>* src = reinterpret_cast<const lo_t<T>*>(io + lrow * (LO_ROW + 16)) + 32 * t + 8 * q + 4 * lh;
+                    float l[4];
+                    load_lo<4>(src, l);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc.t[t][4 * q + r] += l[r];
+                }
+        }
     };
     // accumulator -> global: hi (+ lo when asked)
     auto store_stream = [&](const Acc<T>& acc, void* hi_, void* lo_) __attribute__((always_inline)) {
-        T* hi = reinterpret_cast<T*>(hi_) + mrow * TC_C;
-        lo_t<T>* lo = lo_ ? reinterpret_cast<lo_t<T>*>(lo_) + mrow * TC_C : nullptr;
+        const int ln = launder(lane);
+        const int lrow = ln & 31, lh = ln >> 5;
 #pragma unroll
         for (int t = 0; t < TC_NT; ++t)
 #pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                const int c = 32 * t + 16 * g + 8 * hh;
-                float f[8];
+            for (int q = 0; q < 4; ++q) {
+                typedef T t4 __attribute__((ext_vector_type(4)));
+                t4 v;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    f[i] = acc.t[t][8 * g + i];
-                    f[4 + i] = acc.t[t][8 * g + 4 + i];
-                }
-                d_mem_swap(f);
-                if (row_ok) {
-                    store8(hi + c, f);
-                    if (lo) store_lo8<T>(lo + c, f);
-                }
+                for (int r = 0; r < 4; ++r) v[r] = (T)acc.t[t][4 * q + r];
+                *reinterpret_cast<t4*>(reinterpret_cast<T*>(io + lrow * (HI_ROW + 16)) + 32 * t + 8 * q + 4 * lh) = v;
             }
+        stage_out(hi_, HI_ROW);
+        if (lo_) {
+#pragma unroll
+            for (int t = 0; t < TC_NT; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    lo_t<T> b[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float y = acc.t[t][4 * q + r];
+                        b[r] = lo_from_f<lo_t<T>>(y - to_f(from_f<T>(y)));
+                    }
+                    __builtin_memcpy(reinterpret_cast<lo_t<T>*>(io + lrow * (LO_ROW + 16)) + 32 * t + 8 * q + 4 * lh, b, sizeof(b));
+                }
+            stage_out(lo_, LO_ROW);
+        }
     };
     auto add_cvec = [&](Acc<T>& acc, int off) __attribute__((always_inline)) {
 #pragma unroll
@@ -226,29 +300,44 @@ __global__ void __launch_bounds__(256, 1) tchain_kernel(const ur_tchain_desc p) 
 #pragma unroll
                 for (int i = 0; i < 8; ++i) bop[2 * t + g][i] = (T)acc.t[t][8 * g + i];
     };
-    // LDS byte address of this lane's A fragment for k16 step s inside ring slot `slot` (the row-tile / sub-image offset
-    // is an instruction immediate): loop invariant, 12 VGPRs
-    unsigned fa[TC_NSLOT][4];
+    // LDS byte address of this lane's A fragment for k16 step s inside ring slot 0 (+ slot * TC_STAGE at use; the
+    // row-tile / sub-image offset is an instruction immediate): loop invariant, 4 VGPRs
+    unsigned fa0[4];
 #pragma unroll
-    for (int sl = 0; sl < TC_NSLOT; ++sl)
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4)
-            fa[sl][s4] = (unsigned)(size_t)((__attribute__((address_space(3))) char*)smem) + sl * TC_STAGE + l31 * 128 +
-                         (((2 * s4 + hh) ^ key) << 4);
+    for (int s4 = 0; s4 < 4; ++s4)
+        fa0[s4] = (unsigned)(size_t)((__attribute__((address_space(3))) char*)smem) + l31 * 128 + (((2 * s4 + hh) ^ key) << 4);
     // one N = 320 GEMM stage (rows x 64 k): acc[t] += W[32 t .. 32 t + 31][k] * operand[k], 40 MFMAs, as ONE hand-scheduled
     // instruction stream (tchain_asm.inc): six fragment reads in flight, counted lgkmcnt, a read behind every MFMA
-    auto gemm_stage = [&](Acc<T>& acc, int slot, const vec8& b0, const vec8& b1, const vec8& b2, const vec8& b3) __attribute__((always_inline)) {
-        vec8 f0, f1, f2, f3, f4, f5, f6, f7;
-#define TC_GEMM_OPERANDS                                                                                                       \
-        : [c0] "+a"(acc.t[0]), [c1] "+a"(acc.t[1]), [c2] "+a"(acc.t[2]), [c3] "+a"(acc.t[3]), [c4] "+a"(acc.t[4]),             \
+    auto gemm_stage = [&](Acc<T>& acc, int slot, const vec8& b0, const vec8& b1, const vec8& b2, const vec8& b3, bool dma, auto b_in_agpr) __attribute__((always_inline)) {
+        vec8 f0, f1, f2, f3, f4, f5, f6, f7, f8, f9, f10, f11;
+        const unsigned so = slot * TC_STAGE;
+        const unsigned A0 = fa0[0] + so, A1 = fa0[1] + so, A2 = fa0[2] + so, A3 = fa0[3] + so;
+#define TC_GEMM_OUTS                                                                                                           \
+          [c0] "+a"(acc.t[0]), [c1] "+a"(acc.t[1]), [c2] "+a"(acc.t[2]), [c3] "+a"(acc.t[3]), [c4] "+a"(acc.t[4]),             \
           [c5] "+a"(acc.t[5]), [c6] "+a"(acc.t[6]), [c7] "+a"(acc.t[7]), [c8] "+a"(acc.t[8]), [c9] "+a"(acc.t[9]),             \
           [f0] "=&v"(f0), [f1] "=&v"(f1), [f2] "=&v"(f2), [f3] "=&v"(f3), [f4] "=&v"(f4), [f5] "=&v"(f5), [f6] "=&v"(f6),      \
-          [f7] "=&v"(f7)                                                                                                       \
-        : [a0] "v"(fa[slot][0]), [a1] "v"(fa[slot][1]), [a2] "v"(fa[slot][2]), [a3] "v"(fa[slot][3]), [b0] "v"(b0),            \
-          [b1] "v"(b1), [b2] "v"(b2), [b3] "v"(b3)
-        if constexpr (sizeof(T) == 2 && __is_same(T, f16)) asm volatile(TC_ASM_GEMM_STAGE("f16") TC_GEMM_OPERANDS);
-        else asm volatile(TC_ASM_GEMM_STAGE("bf16") TC_GEMM_OPERANDS);
-#undef TC_GEMM_OPERANDS
+          [f7] "=&v"(f7), [f8] "=&v"(f8), [f9] "=&v"(f9), [f10] "=&v"(f10), [f11] "=&v"(f11)
+        // B operands: the chain operand `bop` lives in AGPRs (the feed-forward streams read it there), the packed GEGLU
+        // words in VGPRs -- one constraint letter per call site, or the allocator copies 80 registers per stage
+#define TC_GEMM_INS(BC)                                                                                                        \
+          [a0] "v"(A0), [a1] "v"(A1), [a2] "v"(A2), [a3] "v"(A3), [b0] BC(b0), [b1] BC(b1), [b2] BC(b2), [b3] BC(b3)
+#define TC_GEMM_RUN(MT, BC)                                                                                                    \
+        if (dma) {                                                                                                             \
+            unsigned dso, dld, t_dso;                                                                                          \
+            dma_args(dso, dld);                                                                                                \
+            asm volatile(TC_ASM_GEMM_STAGE_DMA(MT) : TC_GEMM_OUTS, [dso] "=&s"(t_dso)                                          \
+                         : TC_GEMM_INS(BC), [vo] "v"(voff), [rs] "s"(rs), [so0] "s"(dso), [ld0] "s"(dld) : "memory");          \
+        } else {                                                                                                               \
+            asm volatile(TC_ASM_GEMM_STAGE(MT) : TC_GEMM_OUTS : TC_GEMM_INS(BC));                                              \
+        }
+        if constexpr (decltype(b_in_agpr)::value) {
+            if constexpr (__is_same(T, f16)) { TC_GEMM_RUN("f16", "a") } else { TC_GEMM_RUN("bf16", "a") }
+        } else {
+            if constexpr (__is_same(T, f16)) { TC_GEMM_RUN("f16", "v") } else { TC_GEMM_RUN("bf16", "v") }
+        }
+#undef TC_GEMM_RUN
+#undef TC_GEMM_OUTS
+#undef TC_GEMM_INS
     };
     // compiler code that touches the accumulators after an asm stage: an MFMA result may be read 12+ states after issue
     auto acc_fence = [&](Acc<T>& acc) __attribute__((always_inline)) {
@@ -256,15 +345,12 @@ __global__ void __launch_bounds__(256, 1) tchain_kernel(const ur_tchain_desc p) 
                      : "+a"(acc.t[0]), "+a"(acc.t[1]), "+a"(acc.t[2]), "+a"(acc.t[3]), "+a"(acc.t[4]), "+a"(acc.t[5]),
                        "+a"(acc.t[6]), "+a"(acc.t[7]), "+a"(acc.t[8]), "+a"(acc.t[9]));
     };
-    auto gemm320 = [&](Acc<T>& acc, const vec8 (&bop)[TC_KS]) __attribute__((always_inline)) {
+    // one N = 320 GEMM pass over 5 stages; the first `ndma` of them copy the stage two ahead
+    auto gemm320 = [&](Acc<T>& acc, const vec8 (&bop)[TC_KS], int ndma) __attribute__((always_inline)) {
 #pragma unroll
         for (int kc = 0; kc < TC_C / 64; ++kc) {
             const int slot = next_stage();
-            // the slot index is a compile-time constant only when the stage counter is; select the address set without
-            // dynamic register indexing
-            if (slot == 0) gemm_stage(acc, 0, bop[4 * kc], bop[4 * kc + 1], bop[4 * kc + 2], bop[4 * kc + 3]);
-            else if (slot == 1) gemm_stage(acc, 1, bop[4 * kc], bop[4 * kc + 1], bop[4 * kc + 2], bop[4 * kc + 3]);
-            else gemm_stage(acc, 2, bop[4 * kc], bop[4 * kc + 1], bop[4 * kc + 2], bop[4 * kc + 3]);
+            gemm_stage(acc, slot, bop[4 * kc], bop[4 * kc + 1], bop[4 * kc + 2], bop[4 * kc + 3], kc < ndma, std::true_type{});
         }
         acc_fence(acc);
     };
@@ -272,20 +358,29 @@ __global__ void __launch_bounds__(256, 1) tchain_kernel(const ur_tchain_desc p) 
     // =============================== leading GEMM: y = a0 W0^T + bias0 + residual ===============================
     Acc<T> acc;
     vec8 bop[TC_KS];
+    stage_in(p.a0, HI_ROW);
+    {
+        const int ln = launder(lane);
 #pragma unroll
-    for (int s = 0; s < TC_KS; ++s) bop[s] = *reinterpret_cast<const vec8*>(a0 + 16 * s + 8 * hh);
+        for (int s = 0; s < TC_KS; ++s)
+            bop[s] = *reinterpret_cast<const vec8*>(io + (ln & 31) * (HI_ROW + 16) + (2 * s + (ln >> 5)) * 16);
+    }
     zero(acc);
     add_stream(acc, p.res, p.res_lo);
     add_cvec(acc, TCC_BIAS0);
+    __syncthreads();  // every wave has read its staging slice: slots 1 / 2 belong to the weight stream from here on
+    issue();
     stamp(2);
-    gemm320(acc, bop);
+    gemm320(acc, bop, MODE == UR_TCHAIN_Q ? 3 : 5);
     stamp(3);
     if constexpr (MODE == UR_TCHAIN_Q) {
-        // the updated residual stream leaves here; the LDS-DMA queue is drained first so that the stores are the
-        // only vector-memory operations counted between the two GEMM passes
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // the updated residual stream leaves here through the staging area (no weight stage is in flight: `limit`)
+        __syncthreads();  // the other waves have left stage 4 (slot 1)
         store_stream(acc, p.y_out, p.y_out_lo);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores have left before LDS-DMA pieces are counted again
+        __syncthreads();  // staging slices read back: refill the ring
+        issue();
+        issue();
     }
     stamp(4);
 
@@ -324,64 +419,93 @@ __global__ void __launch_bounds__(256, 1) tchain_kernel(const ur_tchain_desc p) 
     if constexpr (MODE == UR_TCHAIN_Q) {
         // =============================== q = LN(y) Wq^T (scale folded into Wq by the host) ===============================
         zero(acc);
-        gemm320(acc, bop);
+        gemm320(acc, bop, 3);
         stamp(6);
         store_stream(acc, p.out, nullptr);
         stamp(7);
     } else {
         // =============================== GEGLU feed-forward: acc = y + b2 + sum_j h_j W2_j^T ===============================
         add_cvec(acc, TCC_B2);
-        for (int j = 0; j < TC_FF / 64; ++j) {
-            vec8 hb[4];
+        // Software-pipelined over 64 hidden units j (weight-stream order A0(0) A1(0) | A0(j) A1(j) B(j-1) ... | B(19),
+        // tchain.py):   A0(j) || GEGLU of (j-1, upper 32)  ->  A1(j) || GEGLU of (j, lower 32)  ->  B(j-1).
+        // A* = 40 MFMAs of the input projection (value + gate rows of 32 hidden units over all 320 k) into one of two
+        // accumulator pairs, with the GEGLU VALU program of the OTHER pair interleaved instruction by instruction
+        // (tchain_asm.inc); B = the 40 MFMAs of the output projection over the 64 packed h columns.
+        // pin the chain operand into AGPRs for the whole loop (its producers wrote VGPRs; without this the allocator keeps it
+        // there and copies all 80 registers in front of every stream)
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                // stage image: five [64 rows][64 k] sub-images; rows 0..31 = value rows, 32..63 = gate rows of 32 hidden units
-                const int slot = next_stage();
-                f32x16 hv0, hg0, hv1, hg1;
+        for (int k = 0; k < TC_KS; ++k) asm volatile("" : "+a"(bop[k]));
+        const float KS[3] = TC_GELU_KS;
+        const float KV[5] = TC_GELU_KV;
+        f32x16 hvA, hgA, hvB, hgB;
+        unsigned hbw[2][2][8];  // [j & 1][lower / upper 32 hidden][packed words]: B operands of B(j)
+        auto bias4 = [&](int hid, f32x4 (&BV)[4], f32x4 (&BG)[4]) __attribute__((always_inline)) {
 #pragma unroll
-                for (int v = 0; v < 16; ++v) { hv0[v] = 0.f; hg0[v] = 0.f; hv1[v] = 0.f; hg1[v] = 0.f; }
-                {
-                    vec8 f0, f1, f2, f3, f4, f5, f6, f7;
-                    const unsigned a0_ = slot == 0 ? fa[0][0] : (slot == 1 ? fa[1][0] : fa[2][0]);
-                    const unsigned a1_ = slot == 0 ? fa[0][1] : (slot == 1 ? fa[1][1] : fa[2][1]);
-                    const unsigned a2_ = slot == 0 ? fa[0][2] : (slot == 1 ? fa[1][2] : fa[2][2]);
-                    const unsigned a3_ = slot == 0 ? fa[0][3] : (slot == 1 ? fa[1][3] : fa[2][3]);
-#define TC_FFA_OPERANDS                                                                                                        \
-        : [hv0] "+a"(hv0), [hg0] "+a"(hg0), [hv1] "+a"(hv1), [hg1] "+a"(hg1), [f0] "=&v"(f0), [f1] "=&v"(f1), [f2] "=&v"(f2), \
-          [f3] "=&v"(f3), [f4] "=&v"(f4), [f5] "=&v"(f5), [f6] "=&v"(f6), [f7] "=&v"(f7)                                      \
-        : [a0] "v"(a0_), [a1] "v"(a1_), [a2] "v"(a2_), [a3] "v"(a3_), [b0] "v"(bop[0]), [b1] "v"(bop[1]), [b2] "v"(bop[2]),    \
-          [b3] "v"(bop[3]), [b4] "v"(bop[4]), [b5] "v"(bop[5]), [b6] "v"(bop[6]), [b7] "v"(bop[7]), [b8] "v"(bop[8]),          \
-          [b9] "v"(bop[9]), [b10] "v"(bop[10]), [b11] "v"(bop[11]), [b12] "v"(bop[12]), [b13] "v"(bop[13]),                   \
-          [b14] "v"(bop[14]), [b15] "v"(bop[15]), [b16] "v"(bop[16]), [b17] "v"(bop[17]), [b18] "v"(bop[18]), [b19] "v"(bop[19])
-                    if constexpr (__is_same(T, f16)) asm volatile(TC_ASM_FFA_STAGE("f16") "s_nop 15\n\ts_nop 15" TC_FFA_OPERANDS);
-                    else asm volatile(TC_ASM_FFA_STAGE("bf16") "s_nop 15\n\ts_nop 15" TC_FFA_OPERANDS);
-#undef TC_FFA_OPERANDS
-                }
-                const int hid = 64 * j + 32 * half;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float4 bv = *reinterpret_cast<const float4*>(cst + TCC_B1V + hid + 8 * q + 4 * hh);
-                    const float4 bg = *reinterpret_cast<const float4*>(cst + TCC_B1G + hid + 8 * q + 4 * hh);
-                    const float bvv[4] = {bv.x, bv.y, bv.z, bv.w}, bgg[4] = {bg.x, bg.y, bg.z, bg.w};
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float val = hv0[4 * q + r] + hv1[4 * q + r] + bvv[r];
-                        const float gate = hg0[4 * q + r] + hg1[4 * q + r] + bgg[r];
-                        hb[2 * half + (q >> 1)][4 * (q & 1) + r] = (T)(val * gelu_erf_f(gate));
-                    }
-                }
+            for (int q = 0; q < 4; ++q) {
+                BV[q] = *reinterpret_cast<const f32x4*>(cst + TCC_B1V + hid + 8 * q + 4 * hh);
+                BG[q] = *reinterpret_cast<const f32x4*>(cst + TCC_B1G + hid + 8 * q + 4 * hh);
             }
-            const int slot = next_stage();  // W2[:, 64 j .. 64 j + 63]
-            if (slot == 0) gemm_stage(acc, 0, hb[0], hb[1], hb[2], hb[3]);
-            else if (slot == 1) gemm_stage(acc, 1, hb[0], hb[1], hb[2], hb[3]);
-            else gemm_stage(acc, 2, hb[0], hb[1], hb[2], hb[3]);
+        };
+#define TC_TEMPS float t_g0, t_g1, t_g2, t_g3, t_e0, t_e1, t_e2, t_e3, t_t0, t_t1, t_t2, t_t3, t_p0, t_p1, t_p2, t_p3
+        auto ffa = [&](f32x16& HV, f32x16& HG) __attribute__((always_inline)) {
+            const unsigned so = next_stage() * TC_STAGE;
+            const unsigned A[4] = {fa0[0] + so, fa0[1] + so, fa0[2] + so, fa0[3] + so};
+            vec8 f0, f1, f2, f3, f4, f5, f6, f7, f8, f9, f10, f11;
+            unsigned dso, dld, t_dso;
+            dma_args(dso, dld);
+            if constexpr (__is_same(T, f16)) asm volatile(TC_ASM_FFA("f16") TC_OPS_FFA(HV, HG, A, bop, voff, rs, dso, dld));
+            else asm volatile(TC_ASM_FFA("bf16") TC_OPS_FFA(HV, HG, A, bop, voff, rs, dso, dld));
+        };
+        auto ffag = [&](f32x16& HV, f32x16& HG, const f32x16& PV, const f32x16& PG, unsigned (&O)[8], int hid) __attribute__((always_inline)) {
+            f32x4 BV[4], BG[4];
+            bias4(hid, BV, BG);
+            const unsigned so = next_stage() * TC_STAGE;
+            const unsigned A[4] = {fa0[0] + so, fa0[1] + so, fa0[2] + so, fa0[3] + so};
+            vec8 f0, f1, f2, f3, f4, f5, f6, f7, f8, f9, f10, f11;
+            TC_TEMPS;
+            unsigned dso, dld, t_dso;
+            dma_args(dso, dld);
+            if constexpr (__is_same(T, f16)) asm volatile(TC_ASM_FFAG("f16") TC_OPS_FFAG(HV, HG, PV, PG, O, A, bop, BV, BG, KS, KV, voff, rs, dso, dld));
+            else asm volatile(TC_ASM_FFAG("bf16") TC_OPS_FFAG(HV, HG, PV, PG, O, A, bop, BV, BG, KS, KV, voff, rs, dso, dld));
+        };
+        auto g_only = [&](const f32x16& PV, const f32x16& PG, unsigned (&O)[8], int hid) __attribute__((always_inline)) {
+            f32x4 BV[4], BG[4];
+            bias4(hid, BV, BG);
+            TC_TEMPS;
+            if constexpr (__is_same(T, f16)) asm volatile(TC_ASM_G("f16") TC_OPS_G(PV, PG, O, BV, BG, KS, KV));
+            else asm volatile(TC_ASM_G("bf16") TC_OPS_G(PV, PG, O, BV, BG, KS, KV));
+        };
+#undef TC_TEMPS
+        auto bstage = [&](const unsigned (&W)[2][8]) __attribute__((always_inline)) {
+            const int slot = next_stage();
+            vec8 b[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const u32x4 u = {W[k >> 1][4 * (k & 1)], W[k >> 1][4 * (k & 1) + 1], W[k >> 1][4 * (k & 1) + 2], W[k >> 1][4 * (k & 1) + 3]};
+                b[k] = __builtin_bit_cast(vec8, u);
+            }
+            gemm_stage(acc, slot, b[0], b[1], b[2], b[3], true, std::false_type{});
+        };
+        ffa(hvA, hgA);                                    // A0(0)
+        ffag(hvB, hgB, hvA, hgA, hbw[0][0], 0);           // A1(0) || G(0, lower)
+        for (int j = 1; j < TC_FF / 64; j += 2) {
+            ffag(hvA, hgA, hvB, hgB, hbw[0][1], 64 * (j - 1) + 32);  // A0(j) || G(j-1, upper)      (j odd: j-1 even -> set 0)
+            ffag(hvB, hgB, hvA, hgA, hbw[1][0], 64 * j);             // A1(j) || G(j, lower)
+            bstage(hbw[0]);                                          // B(j-1)
+            if (j + 1 < TC_FF / 64) {
+                ffag(hvA, hgA, hvB, hgB, hbw[1][1], 64 * j + 32);    // A0(j+1) || G(j, upper)
+                ffag(hvB, hgB, hvA, hgA, hbw[0][0], 64 * (j + 1));   // A1(j+1) || G(j+1, lower)
+                bstage(hbw[1]);                                      // B(j)
+            }
         }
+        g_only(hvB, hgB, hbw[1][1], TC_FF - 32);          // G(19, upper)
+        bstage(hbw[1]);                                   // B(19)
         acc_fence(acc);
         stamp(6);
         // =============================== out = y3 Wpo^T + bpo + block input ===============================
         to_operand(acc, bop);
         zero(acc);
-        gemm320(acc, bop);
+        gemm320(acc, bop, 3);
         stamp(7);
         add_cvec(acc, TCC_BPO);
         add_stream(acc, p.blk, p.blk_lo);
@@ -395,7 +519,7 @@ template <typename T, int MODE>
 static int launch_tchain(const ur_tchain_desc& d, hipStream_t s) {
     static std::atomic<uint64_t> done{0};
     const int nconst = MODE == UR_TCHAIN_Q ? TCC_Q_END : TCC_FF_END;
-    const int lds = TC_RING + nconst * 4;
+    const int lds = TC_LDS;  // ring + staging area + constants: the whole CU
     set_lds_limit_once(done, reinterpret_cast<const void*>(&tchain_kernel<T, MODE>), lds);
     const int tiles = (d.M + 127) / 128;
     hipLaunchKernelGGL((tchain_kernel<T, MODE>), dim3(tiles * d.zbatch), dim3(256), lds, s, d);

@@ -62,21 +62,32 @@ def gemm_images(w: torch.Tensor, permute_k: bool) -> torch.Tensor:
 
 
 def ff_images(w1: torch.Tensor, w2: torch.Tensor) -> torch.Tensor:
-    """GEGLU feed-forward as the kernel walks it: per 64 hidden units j three images
-         A0 / A1: for hidden 64 j + 32 half .. + 31: five [64 rows, 64 k] sub-images (k chunk c of the 320 inputs), rows
-                  0..31 = value rows of w1 (``proj`` rows hid), rows 32..63 = gate rows (rows 1280 + hid);
-         B:       w2[:, 64 j .. 64 j + 63] as [320 rows, 64 k].
+    """GEGLU feed-forward as the kernel walks it.  Per 64 hidden units j there are three images
+         A0(j) / A1(j): for hidden 64 j + 32 half .. + 31: five [64 rows, 64 k] sub-images (k chunk c of the 320 inputs),
+                  rows 0..31 = value rows of w1 (``proj`` rows hid), rows 32..63 = gate rows (rows 1280 + hid);
+         B(j):    0.5 * w2[:, 64 j .. 64 j + 63] as [320 rows, 64 k] -- the kernel's GEGLU program produces
+                  2 * value * gelu(gate) (it leaves the 0.5 of 0.5 x (1 + erf) out; a power of two, so folding it into
+                  the weights changes no rounding),
+       in the software-pipelined consumption order  A0(0) A1(0) | A0(j) A1(j) B(j-1) for j = 1 .. | B(last)
+       (csrc/tchain.hip: B lags one step so that the GEGLU of a half-chunk runs under the next stage's MFMAs).
        Both operands come out of accumulators -> KPERM on the k axis of both."""
     nh = w2.shape[1]
     assert w1.shape == (2 * nh, CH) and w2.shape == (CH, nh) and nh % 64 == 0
-    w1p, w2p = kperm(w1), kperm(w2)
-    out = []
-    for j in range(nh // 64):
-        for half in range(2):
-            hid = 64 * j + 32 * half
-            rows = torch.cat([w1p[hid: hid + 32], w1p[nh + hid: nh + hid + 32]], 0)          # [64, 320]
-            out.append(torch.cat([_swizzle_rows(rows[:, 64 * c: 64 * c + 64]).reshape(-1) for c in range(CH // 64)], 0))
-        out.append(_swizzle_rows(w2p[:, 64 * j: 64 * j + 64]).reshape(-1))
+    w1p, w2p = kperm(w1), kperm(w2 * 0.5)
+
+    def a_img(j, half):
+        hid = 64 * j + 32 * half
+        rows = torch.cat([w1p[hid: hid + 32], w1p[nh + hid: nh + hid + 32]], 0)          # [64, 320]
+        return torch.cat([_swizzle_rows(rows[:, 64 * c: 64 * c + 64]).reshape(-1) for c in range(CH // 64)], 0)
+
+    def b_img(j):
+        return _swizzle_rows(w2p[:, 64 * j: 64 * j + 64]).reshape(-1)
+
+    nj = nh // 64
+    out = [a_img(0, 0), a_img(0, 1)]
+    for j in range(1, nj):
+        out += [a_img(j, 0), a_img(j, 1), b_img(j - 1)]
+    out.append(b_img(nj - 1))
     return torch.stack(out, 0)
 
 
