@@ -294,11 +294,14 @@ def main():
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    dist_on = world > 1 or "RANK" in os.environ  # under a launcher even one rank times through RCCL's barrier / max-reduce
+    if dist_on:
         import torch.distributed as dist
 
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)  # RCCL
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # RCCL
     dtype = torch.float16 if args.dtype == "fp16" else torch.bfloat16
 
     from uni_renderer_amd import _lib
@@ -322,7 +325,7 @@ def main():
         one = runner.replay
 
     def barrier():
-        if world > 1:
+        if dist_on:
             torch.distributed.barrier()
 
     for _ in range(args.warmup):
@@ -335,7 +338,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
@@ -391,7 +394,7 @@ def main():
             del runner
             out["cpu_baseline"] = cpu_baseline(args.batch, args.latent)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_on:
         torch.distributed.barrier()  # rank 0 may still have been in its roofline leg
         torch.distributed.destroy_process_group()
 

@@ -1,0 +1,108 @@
+"""RCCL on the leased GPU (missing #2 / weak #11): the `nccl` backend with world_size 1 runs the same
+collectives the 8-GPU job issues -- all-reduce, reduce-scatter + in-place all-gather, bf16 transport, the barrier and
+max-reduce of bench.py -- on RCCL's own stream, so the stream ordering between the HIP kernels that produce the gradients
+and the collectives that consume them is exercised for real (the gloo tests cannot).  Plus: `python bench.py --gpus 1`
+and the self-spawn path (`--gpus N` with no launcher) start and print one JSON line."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from util_models import ROOT
+
+pytestmark = pytest.mark.gpu
+
+WORKER = r'''
+import os, sys, json
+import torch, torch.distributed as dist
+sys.path.insert(0, os.environ["UR_ROOT"])
+from uni_renderer_amd.parallel import GradientBuckets, init_distributed, max_over_ranks
+rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ["LOCAL_RANK"])
+dev = torch.device("cuda", local)
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+assert dist.get_backend() == "nccl"
+out = {}
+torch.manual_seed(0)
+def net():
+    torch.manual_seed(1)
+    return torch.nn.Sequential(torch.nn.Linear(256, 512), torch.nn.SiLU(), torch.nn.Linear(512, 300), torch.nn.SiLU(),
+                               torch.nn.Linear(300, 64)).to(dev)
+x = torch.randn(64, 256, device=dev)
+ref = net()
+ref(x).square().mean().backward()
+gref = [p.grad.clone() for p in ref.parameters()]
+for algo in ("all_reduce", "rs_ag"):
+    for comm in (None, torch.bfloat16):
+        for overlap in (True, False):
+            m = net()
+            gb = GradientBuckets([m], bucket_mb=0.25, comm_dtype=comm, algorithm=algo, overlap=overlap, force_collectives=True)
+            assert len(gb.buckets) >= 3
+            for it in range(2):  # second iteration: buffers reused, hooks re-armed
+                gb.zero_grad()
+                m(x).square().mean().backward()
+                gb.finish()
+                torch.cuda.synchronize()
+                err = max(float((p.grad - g).abs().max() / g.abs().max()) for p, g in zip(m.parameters(), gref))
+                tol = 1e-6 if comm is None else 1e-2
+                assert err < tol, (algo, comm, overlap, it, err)
+            out[f"{algo}/{comm}/{overlap}"] = dict(err=err, from_hooks=gb.launched_from_hooks, buckets=len(gb.buckets))
+            if overlap:
+                assert gb.launched_from_hooks > 0  # the collectives were enqueued while autograd was still running
+dist.barrier()
+out["max_over_ranks"] = max_over_ranks(0.25, device=dev)
+dist.destroy_process_group()
+print("RESULT " + json.dumps(out))
+'''
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_rccl_world1_collectives_of_the_gradient_buckets(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               UR_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    print(json.dumps(res))
+    assert res["max_over_ranks"] == 0.25
+    assert set(k.split("/")[0] for k in res if "/" in k) == {"all_reduce", "rs_ag"}
+
+
+def test_bench_runs_with_the_drivers_command_line_and_spawns_its_own_ranks():
+    """`python bench.py --gpus 1 ...` (the driver's N = 1 command) and, with no launcher around it, `--gpus N`: bench.py
+    must start its own N ranks (here N = visible GPUs = 1 is the only N the box can run; the spawn path is the same code
+    for every N and is exercised by forcing it through torch.distributed.run for N = 1)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+           "--no-roofline", "--batch", "1", "--latent", "16"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["steps"] == 3 and line["value"] > 0
+    # more GPUs than the box has: a clear refusal, not a hang and not the old "launch with torch.distributed.run" exit
+    n = torch.cuda.device_count() + 1
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and f"only {n - 1} GPU" in (r.stderr + r.stdout)
+    # the launcher path with one rank over RCCL (what `--gpus N` spawns for N > 1)
+    port = _free_port()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline", "--no-roofline", "--batch", "1", "--latent", "16"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1

@@ -109,7 +109,9 @@ class GradientBuckets:
     """
 
     def __init__(self, modules: Iterable[torch.nn.Module], bucket_mb: float = 256.0, comm_dtype=None,
-                 algorithm: str = "all_reduce", overlap: bool = True, process_group=None):
+                 algorithm: str = "all_reduce", overlap: bool = True, process_group=None, force_collectives: bool = False):
+        """``force_collectives``: issue the collectives even in a one-rank group (tests: drives RCCL's
+        all-reduce / reduce-scatter / all-gather and their stream ordering on a single GPU)."""
         mods = list(modules)
         mods.sort(key=lambda m: _FORWARD_ORDER.get(getattr(m, "module", m).__class__.__name__, 1))  # stable for others
         params = [p for m in mods for p in m.parameters() if p.requires_grad]
@@ -118,6 +120,7 @@ class GradientBuckets:
         self.algorithm = algorithm
         self.overlap = overlap
         self.group = process_group
+        self.force = bool(force_collectives)
         if algorithm not in ("all_reduce", "rs_ag"):
             raise ValueError(algorithm)
         cap = int(bucket_mb * (1 << 20))
@@ -169,8 +172,11 @@ class GradientBuckets:
     def _world(self) -> int:
         return dist.get_world_size(self.group) if dist.is_initialized() else 1
 
+    def _single(self) -> bool:
+        return self._world() == 1 and not (self.force and dist.is_initialized())
+
     def _on_grad(self, p):
-        if self._world() == 1:
+        if self._single():
             return
         bi = self._bucket_of[p]
         if p.grad is not None and p.grad.data_ptr() != self._view_ptr(p):  # someone re-created .grad: pull it back in
@@ -205,10 +211,15 @@ class GradientBuckets:
         else:
             buf = flat
             buf.mul_(1.0 / world)
-        if self.algorithm == "rs_ag" and buf.numel() % world == 0:
+        if self.algorithm == "rs_ag" and buf.numel() % world == 0 and dist.get_backend(self.group) != "gloo":
+            # reduce-scatter into this rank's slice of the bucket, then all-gather IN PLACE (the slice is the input): both
+            # are enqueued here, back to back on the process group's stream -- RCCL orders them -- so the all-gather also
+            # runs under the rest of the backward instead of inside finish().  (gloo has no reduce_scatter_tensor: the CPU
+            # test transport takes the all-reduce branch.)
             shard = buf.view(world, -1)[dist.get_rank(self.group)]
-            w1 = dist.reduce_scatter_tensor(shard, buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-            self._work.append((bi, w1, "rs"))
+            dist.reduce_scatter_tensor(shard, buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            w2 = dist.all_gather_into_tensor(buf, shard, group=self.group, async_op=True)
+            self._work.append((bi, w2, "rs_ag"))
         else:
             w = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             self._work.append((bi, w, "ar"))
@@ -219,7 +230,7 @@ class GradientBuckets:
     def finish(self):
         """After ``backward()``: launch the buckets the hooks could not (missing gradients on this rank), wait for all
         collectives, and leave the mean gradients in the flat buffers (= in every ``p.grad``)."""
-        if self._world() == 1:
+        if self._single():
             self._reset()
             return
         for p in self.params:  # a .grad re-created outside (set_to_none + a fresh backward): adopt it
@@ -232,10 +243,6 @@ class GradientBuckets:
         for bi, w, kind in self._work:
             w.wait()
             buf = self._comm[bi] if self._comm[bi] is not None else self.flat[bi]
-            if kind == "rs":
-                world = self._world()
-                shard = buf.view(world, -1)[dist.get_rank(self.group)]
-                dist.all_gather_into_tensor(buf, shard.clone(), group=self.group)
             if buf is not self.flat[bi]:
                 self.flat[bi].copy_(buf)
         self._reset()
