@@ -454,6 +454,9 @@ int ur_unpack_conv_weight_grad(const void* dwp, int64_t ld, float* out, int Co, 
  * reference) as ONE launch, with the activations of a 128-row tile resident in registers and
  * only the weights streamed through LDS.
  *
+ *   UR_TCHAIN_PRE y = a0 W0^T + b0                    (Transformer2DModel.proj_in of the GroupNorm output; y leaves as (hi, lo))
+ *                 xn = LayerNorm(y);  out = xn Wq^T,  out2 = xn Wk^T  ([zbatch][M][320], no bias),
+ *                 out3 = (xn Wv^T)^T per sample: [zbatch * M / rows_per_b][320][ld_vt] (the V^T layout ur_attention reads)
  *   UR_TCHAIN_Q   y = a0 W0^T + b0 + res              (attention out-projection + residual; y leaves as (hi, lo))
  *                 out = LayerNorm(y) Wq^T             (the query projection of the next attention; no bias)
  *   UR_TCHAIN_FF  y = a0 W0^T + b0 + res              (never stored)
@@ -471,6 +474,7 @@ int ur_unpack_conv_weight_grad(const void* dwp, int64_t ld, float* out, int Co, 
  */
 #define UR_TCHAIN_Q 0
 #define UR_TCHAIN_FF 1
+#define UR_TCHAIN_PRE 2
 typedef struct ur_tchain_desc {
     const void* a0;
     const void* res;
@@ -481,11 +485,15 @@ typedef struct ur_tchain_desc {
     void* y_out_lo;
     void* out;
     void* out_lo;
+    void* out2;          /* PRE: k */
+    void* out3;          /* PRE: V^T */
     const void* wstream;
     const float* consts;
     int64_t z_wstream;   /* bytes between the weight streams of two z (multiple of 16) */
     int64_t z_consts;    /* floats between the constant blocks of two z */
     int M, zbatch, mode, dtype, channels;
+    int rows_per_b;      /* PRE: tokens per sample (multiple of 32, divides M) */
+    int ld_vt;           /* PRE: row stride of V^T in elements (>= rows_per_b, multiple of 8) */
     float eps;           /* LayerNorm epsilon */
     void* profile;       /* diagnostics, normally NULL: int64 [workgroups][64] s_memtime stamps (0..15 phases, 16..63 stage starts) of each workgroup's wave 0 */
 } ur_tchain_desc;

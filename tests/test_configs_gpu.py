@@ -133,6 +133,45 @@ def test_cfg3_at_the_benchmarked_batch_4(dev, sd):
     assert max(errs["vs_fp32_weights"].values()) < 1.3e-3, errs
 
 
+def test_cfg3_five_step_ddim_loop_at_sd_size_batch_4(dev, sd):
+    """cfg 3 is a 50-step DDIM loop (models/pipeline.py:2629-2730): five of its steps at the benchmarked shape -- SD-size
+    networks, batch 4, 64x64 latent, fp16, the captured default executor -- with the attribute latents fed back through
+    the scheduler each step, against the same loop run by the CPU oracle networks and the independent DDIM restatement
+    (oracle/schedulers_oracle.py).  Measures how the per-step error compounds through the feedback."""
+    from util_models import OracleScheduler
+
+    from uni_renderer_amd.graph import GraphedDualStreamStep
+    from uni_renderer_amd.schedulers import DDIMScheduler
+
+    oracle, product = sd
+    unet, enc, dec = product(torch.float16)
+    x, c, ehs, ti, ta = O.make_inputs(4, 64, 768, seed=28, t_img=0)
+    steps = 5
+    so = OracleScheduler("ddim", 50)            # the 50-step grid; its first five steps
+    sp = DDIMScheduler()
+    sp.set_timesteps(50)
+    assert so.timesteps.tolist() == sp.timesteps.tolist()
+    # the LAST five steps of the grid (t = 81 .. 1): there the x0 prediction carries the update (sqrt(alpha_prev) ~ 0.9 ..
+    # 1); in the first steps it is weighted ~0.07 and the loop would compare little more than the initial noise
+    lat_o = c.clone()
+    for t in so.timesteps[-steps:]:
+        out = O.dual_stream_step(*oracle, x, lat_o, ehs, ti, t.expand(4))
+        lat_o = torch.cat([lat_o[:, :4], so.step(out["attr_pred"][:, 4:], t, lat_o[:, 4:])[0]], 1)
+    runner = GraphedDualStreamStep(unet, enc, dec, batch=4, latent_hw=64, cross_dim=768, dtype=torch.float16, device=dev)
+    lat = c.to(dev).float()
+    xg, eg, tig = x.to(dev).half(), ehs.to(dev).half(), ti.to(dev)
+    errs = []
+    for k, t in enumerate(sp.timesteps[-steps:]):
+        out = runner.step(xg, lat.half(), eg, tig, t.expand(4).to(dev))
+        nxt = sp.step(out["attr_pred"][:, 4:].float(), t, lat[:, 4:])[0]
+        lat = torch.cat([lat[:, :4], nxt], 1)
+    e = rel_l2(lat[:, 4:], lat_o[:, 4:])
+    e_upd = rel_l2(lat[:, 4:].cpu() - c[:, 4:], lat_o[:, 4:] - c[:, 4:])  # relative to what the five steps changed
+    print(json.dumps(dict(cfg=3, loop="last 5 of 50 DDIM steps, batch 4, SD size, fp16", rel_l2_latents_after_5_steps=e,
+                          rel_l2_of_the_update=e_upd)))
+    assert e < 3e-3 and e_upd < 5e-3, (e, e_upd)
+
+
 def test_cfg5_relighting_1024_bs1_fp16(dev, sd):
     """cfg 5 (1024x1024 -> 128x128 latent, bs 1, fp16): both executors against the CPU fp32 oracle (same fp16-rounded
     parameters: 1e-3; fp32 parameters: 1.3e-3, see the batch-4 test) and against each other."""

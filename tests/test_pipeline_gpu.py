@@ -27,14 +27,11 @@ def _setup(dev, seed=21):
 
 
 def _oracle_inverse(models, img, mask, ehs, noise, steps, guidance):
-    from uni_renderer_amd.schedulers import DDIMScheduler
+    from util_models import OracleScheduler  # independent restatement (oracle/schedulers_oracle.py), not the product's class
 
     unet_o, enc_o, dec_o = models
-    sched = {n: DDIMScheduler() for n in GROUPS}
-    s_attr = DDIMScheduler()
-    s_attr.set_timesteps(steps)
-    for s in sched.values():
-        s.set_timesteps(steps)
+    sched = {n: OracleScheduler("ddim", steps) for n in GROUPS}
+    s_attr = OracleScheduler("ddim", steps)
     lat = {n: noise.clone() for n in GROUPS}
     cfg = guidance != 0
     e = ehs.repeat(img.shape[0], 1, 1)
@@ -159,8 +156,9 @@ def test_rendering_loop_matches_oracle_loop(dev):
     attr = torch.randn(2, 28, 16, 16, generator=g)
     out = pipe.mask2image_3mod_albedo(prompt_embeds=ehs.to(dev).half(), attr_latents=attr.to(dev), latents=noise,
                                       num_inference_steps=3, guidance_scale=0.0, output_type="latent")
-    s = DDIMScheduler()
-    s.set_timesteps(3)
+    from util_models import OracleScheduler
+
+    s = OracleScheduler("ddim", 3)
     lat = noise.clone()
     e = ehs.repeat(2, 1, 1)
     for t in s.timesteps:
@@ -284,10 +282,10 @@ def test_unipc_fused_loop_vs_step_by_step_and_oracle_loop(dev, guidance):
     b32 = pipe.real_image2mask_3mod_albedo(**kw32)
     for x, z in zip(a32, b32):
         assert x.dtype == torch.float32 and rel_l2(x, z) < (3e-3 if guidance == 0 else 8e-3), rel_l2(x, z)
-    # oracle-driven loop, same scheduler class on the host
-    sched = {n: UniPCMultistepScheduler() for n in GROUPS}
-    for s in sched.values():
-        s.set_timesteps(steps)
+    # oracle-driven loop: CPU oracle networks + the independent UniPC restatement (oracle/schedulers_oracle.py)
+    from util_models import OracleScheduler
+
+    sched = {n: OracleScheduler("unipc", steps) for n in GROUPS}
     lat = {n: noise.clone() for n in GROUPS}
     cfg = guidance != 0
     e = ehs.repeat(img.shape[0], 1, 1)
@@ -352,6 +350,16 @@ def test_unipc_update_kernel_matches_the_host_scheduler(dev):
     assert int(step) == n and float(t_out[0]) == float(tvals[-1])
     assert rel_l2(master, ref16) < 2e-6
     assert rel_l2(lat[:, 4:], ref16) < 1e-3
+    # and against the independent float64 restatement (diffusers' D1s / einsum form): the kernel's fp32 recurrence with a
+    # host-built coefficient table must land on the same trajectory
+    from util_models import OracleScheduler
+
+    so = OracleScheduler("unipc", n)
+    assert so.timesteps.tolist() == s.timesteps.tolist()
+    ref64 = x0.double()
+    for i, t in enumerate(so.timesteps):
+        ref64 = so.step(preds[i].half().double()[..., 4:].permute(0, 3, 1, 2), t, ref64)[0]
+    assert rel_l2(master, ref64) < 2e-5, rel_l2(master, ref64)
 
 
 def test_repeat_averaging_folds_into_one_batch(dev):

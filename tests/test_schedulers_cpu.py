@@ -102,3 +102,109 @@ def test_epsilon_prediction_is_converted_to_data_prediction():
     x, eps = torch.randn(4, 4, generator=g), torch.randn(4, 4, generator=g)
     a, sg = s._alpha_sigma(s.sigmas[0])
     assert float((s.step(eps, s.timesteps[0], x)[0] - q.step((x - sg * eps) / a, q.timesteps[0], x)[0]).abs().max()) < 1e-5
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the independent restatement (oracle/schedulers_oracle.py) is itself pinned by the closed-form Gaussian solution, and
+# the product's host schedulers / coefficient table are checked against it
+# ---------------------------------------------------------------------------------------------------------------------
+def _run_oracle_unipc(n, order, s2=0.25, frac=0.8):
+    import numpy as np
+
+    from oracle.schedulers_oracle import UniPCOracle
+
+    s = UniPCOracle(solver_order=order, lower_order_final=False)
+    s.set_timesteps(n)
+    asg = lambda i: s._sigma_to_alpha_sigma_t(s.sigmas[i])
+    a0, g0 = asg(0)
+    x = np.linspace(-2, 2, 9) * (a0 * a0 * s2 + g0 * g0) ** 0.5
+    x_start = x.copy()
+    k = int(n * frac)
+    for i, t in enumerate(s.timesteps[:k]):
+        a, sg = asg(i)
+        x = s.step(x * (a * s2 / (a * a * s2 + sg * sg)), t, x)
+    a1, g1 = asg(k)
+    exact = x_start * ((a1 * a1 * s2 + g1 * g1) / (a0 * a0 * s2 + g0 * g0)) ** 0.5
+    return float(np.abs(x - exact).max() / np.abs(exact).max())
+
+
+def test_oracle_unipc_converges_with_its_order_on_the_closed_form_gaussian_flow():
+    e1 = [_run_oracle_unipc(n, 1) for n in (20, 40, 80)]
+    e2 = [_run_oracle_unipc(n, 2) for n in (20, 40, 80)]
+    e3 = [_run_oracle_unipc(n, 3) for n in (20, 40, 80)]
+    assert e2[0] / e2[1] > 3.5 and e2[1] / e2[2] > 3.5          # predictor order 2 + corrector: at least second order
+    assert e1[0] / e1[1] > 1.8                                   # order 1 + corrector
+    assert e2[0] < 0.2 * e1[0] and e3[1] < e2[1]                 # higher order = smaller error on the same grid
+    assert e2[2] < 1e-4
+
+
+def test_oracle_ddim_is_first_order_on_the_gaussian_flow_and_exact_for_a_perfect_predictor():
+    import numpy as np
+
+    from oracle.schedulers_oracle import DDIMOracle
+
+    def run(n, s2=0.25):
+        s = DDIMOracle()
+        s.set_timesteps(n)
+        t0 = int(s.timesteps[0])
+        a0 = s.ac[t0]
+        x = np.linspace(-2, 2, 9) * (a0 * s2 + 1 - a0) ** 0.5
+        x_start = x.copy()
+        k = int(n * 0.8)
+        for t in s.timesteps[:k]:
+            a = s.ac[int(t)]
+            x = s.step(x * (a ** 0.5 * s2 / (a * s2 + 1 - a)), t, x)
+        a1 = s.ac[int(s.timesteps[k])]
+        exact = x_start * ((a1 * s2 + 1 - a1) / (a0 * s2 + 1 - a0)) ** 0.5
+        return float(np.abs(x - exact).max() / np.abs(exact).max())
+
+    e = [run(n) for n in (25, 50, 100)]
+    assert 1.6 < e[0] / e[1] < 2.6 and 1.6 < e[1] / e[2] < 2.6
+    # a predictor that always returns the true x0 reaches it exactly at the last step (alpha_prev = alpha_0 form)
+    s = DDIMOracle(set_alpha_to_one=True)
+    s.set_timesteps(10)
+    x0 = np.linspace(-1, 1, 5)
+    x = x0 * 0 + 3.0
+    for t in s.timesteps:
+        x = s.step(x0, t, x)
+    assert np.allclose(x, x0, atol=1e-12)
+
+
+def test_product_host_schedulers_and_coefficient_table_match_the_independent_oracle():
+    import numpy as np
+
+    from oracle.schedulers_oracle import DDIMOracle, UniPCOracle
+    from uni_renderer_amd.schedulers import DDIMScheduler, UniPCMultistepScheduler
+
+    g = torch.Generator().manual_seed(3)
+    for n in (6, 20):
+        x0 = torch.randn(2, 4, 8, 8, generator=g, dtype=torch.float64)
+        outs = [torch.randn(2, 4, 8, 8, generator=g, dtype=torch.float64) for _ in range(n)]
+        # UniPC: host step() and the coefficient-table recurrence the fused kernel runs
+        sp, so = UniPCMultistepScheduler(), UniPCOracle()
+        sp.set_timesteps(n)
+        so.set_timesteps(n)
+        assert sp.timesteps.tolist() == so.timesteps.tolist()
+        assert np.allclose(sp.sigmas.double().numpy(), so.sigmas, rtol=5e-6)  # float32 cumprod: torch vs numpy summation order
+        xp, xo = x0.clone(), x0.numpy().copy()
+        tab = sp.coefficient_table().double()
+        L, m1, m2, xt = x0.clone(), torch.zeros_like(x0), torch.zeros_like(x0), x0.clone()
+        for i, t in enumerate(sp.timesteps):
+            xp = sp.step(outs[i], t, xp)[0]
+            xo = so.step(outs[i].numpy(), int(t), xo)
+            c = tab[i]
+            L = c[0] * L + c[1] * m1 + c[2] * m2 + c[3] * outs[i] if i > 0 else xt
+            xt = c[4] * L + c[5] * outs[i] + c[6] * m1
+            m2, m1 = m1, outs[i]
+            assert np.abs(xp.numpy() - xo).max() < 1e-4 * np.abs(xo).max(), (n, i)
+            assert np.abs(xt.numpy() - xo).max() < 1e-4 * np.abs(xo).max(), (n, i)
+        # DDIM
+        dp, do = DDIMScheduler(), DDIMOracle()
+        dp.set_timesteps(n)
+        do.set_timesteps(n)
+        assert dp.timesteps.tolist() == do.timesteps.tolist()
+        xp, xo = x0.clone(), x0.numpy().copy()
+        for i, t in enumerate(dp.timesteps):
+            xp = dp.step(outs[i], t, xp)[0]
+            xo = do.step(outs[i].numpy(), int(t), xo)
+        assert np.abs(xp.numpy() - xo).max() < 1e-4 * np.abs(xo).max()

@@ -114,6 +114,45 @@ def test_chain_ff_vs_fp32(dev, dtype, tol, M, S):
         assert rel_l2(out[sl], ref) < tol  # the hi part alone is the ordinary rounded tensor
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 1.5e-3), (torch.bfloat16, 1.2e-2)])
+@pytest.mark.parametrize("B,T,S", [(2, 128, 1), (2, 1024, 2), (3, 96, 2)])
+def test_chain_pre_vs_fp32(dev, dtype, tol, B, T, S):
+    """proj_in + LayerNorm1 + q / k / V^T projections in one launch (UR_TCHAIN_PRE)."""
+    from uni_renderer_amd import tchain
+
+    W = _weights(dev, 7, S)
+    g = torch.Generator(device=dev).manual_seed(30)
+    for w in W:
+        w["wk"] = torch.randn(C, C, device=dev, generator=g) * C ** -0.5
+        w["wv"] = torch.randn(C, C, device=dev, generator=g) * C ** -0.5
+    M = B * T
+    h0 = _stream(dev, dtype, M, S, 31, False)
+    sc = math.sqrt(40 ** -0.5 * 1.4426950408889634)
+    packs = [tchain.pack_chain_pre(w["wo"].view(C, C, 1, 1), w["bo"], w["g"], w["b"], w["wq"], w["wk"], w["wv"], sc, dtype) for w in W]
+    ws = torch.stack([p[0] for p in packs]).contiguous()
+    cs = torch.stack([p[1] for p in packs]).contiguous()
+    if S == 1:
+        ws, cs = ws[0], cs[0]
+    y, q, k, vt = tchain.chain_pre(h0, ws, cs, 1e-5, tokens_per_sample=T, streams=S)
+    torch.cuda.synchronize()
+    Tpad = (T + 63) // 64 * 64
+    assert vt.shape == (S * B, C, Tpad)
+    r = lambda t: t.to(dtype).float()
+    for s in range(S):
+        w = W[s]
+        sl = slice(s * M, (s + 1) * M)
+        y_ref = h0[sl].float() @ r(w["wo"]).t() + w["bo"]
+        xn = r(F.layer_norm(y_ref, (C,), w["g"], w["b"], 1e-5))
+        q_ref, k_ref, v_ref = xn @ r(w["wq"] * sc).t(), xn @ r(w["wk"] * sc).t(), xn @ r(w["wv"]).t()
+        vt_ref = v_ref.view(B, T, C).transpose(1, 2)
+        errs = dict(y=rel_l2(_f(y)[sl], y_ref), q=rel_l2(q[sl], q_ref), k=rel_l2(k[sl], k_ref),
+                    vt=rel_l2(vt[s * B:(s + 1) * B, :, :T], vt_ref))
+        print(f"tchain_pre {dtype} B={B} T={T} z={s}: {errs}")
+        assert errs["y"] < (2e-4 if dtype == torch.float16 else 2e-3) and max(errs["q"], errs["k"], errs["vt"]) < tol, errs
+        if Tpad != T:
+            assert float(vt[s * B:(s + 1) * B, :, T:].abs().max()) == 0.0
+
+
 def test_chain_rejects_other_widths(dev):
     from uni_renderer_amd import tchain
 

@@ -69,7 +69,8 @@ def test_train_step_loss_and_gradients_match_oracle_autograd(dev, dtype, tol):
             worst = (name, e)
     print({"dtype": str(dtype), "loss": float(loss), "loss_oracle": float(loss_o), "grad_rel_l2_all": total,
            "worst_param": worst})
-    assert total < tol / 2 and worst[1] < tol * 3
+    # measured (r02): fp16 3.2e-3 total, bf16 2.6e-2 total / 5.4e-2 worst parameter: bounds ~2x that
+    assert total < tol / 2 and worst[1] < (tol * 3 if dtype == torch.float16 else tol)
 
 
 def test_few_optimizer_steps_reduce_the_loss(dev):
@@ -125,8 +126,8 @@ def test_train_step_gradients_sd_size(dev):
             den += float((go * go).sum())
     err = (num / den) ** 0.5
     print({"sd_size_bf16": True, "loss": float(loss.detach()), "loss_oracle": float(loss_o.detach()), "grad_rel_l2_all": err})
-    assert abs(float(loss.detach()) - float(loss_o.detach())) / float(loss_o.detach()) < 2e-2
-    assert err < 8e-2
+    assert abs(float(loss.detach()) - float(loss_o.detach())) / float(loss_o.detach()) < 1e-2
+    assert err < 4.5e-2  # measured 2.2e-2 (r02)
 
 
 @pytest.mark.parametrize("inverse", [True, False])
@@ -382,8 +383,37 @@ def test_cfg4_per_gpu_training_step_vs_oracle(dev):
     err = _grad_error(oracle, nets, sample_every=7)
     print({"cfg4_per_gpu_shape": "B=4, 64x64 latent, bf16 autocast, SD size", "loss": float(loss.detach()), "loss_oracle": loss_o,
            "grad_rel_l2_sampled": err})
-    assert abs(float(loss.detach()) - loss_o) / abs(loss_o) < 2e-2
-    assert err < 8e-2
+    assert abs(float(loss.detach()) - loss_o) / abs(loss_o) < 2e-3  # measured 1e-5 (11.1493 vs 11.1494)
+    assert err < 2e-2  # measured 0.9e-2 (r02)
+
+
+def test_cfg4_inverse_branch_at_sd_size_vs_oracle(dev):
+    """cfg 4's OTHER branch at SD size (train/train.py:1388-1416): the cycle-consistency pass -- a second encoder + UNet
+    forward conditioned on [mask | the decoder's own prediction] with the gradient flowing through the prediction --
+    SD-1.x-size networks, batch 2, 64x64 latent, bf16 autocast over fp32 master parameters, through the module call
+    surface.  Loss and sampled parameter gradients against the CPU oracle's autograd of the same function."""
+    oracle = O.build_triplet(O.SD15_CONFIG, seed=43)
+    b = _train_batch(2, 64, 768, seed=27)
+    for m in oracle:
+        m.requires_grad_(True)
+    unet_o, enc_o, dec_o = oracle
+    loss_o = _reference_step_losses(enc_o, unet_o, dec_o, dict(b, oracle=True, weight_dtype=torch.float32), inverse=True)
+    loss_o.backward()
+    loss_o = float(loss_o.detach())
+    nets = build_product_from_oracle(*oracle, torch.float32, dev)
+    for m in nets:
+        m.train()
+        m.requires_grad_(True)
+    unet, enc, dec = nets
+    bg = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in b.items()}
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        loss = _reference_step_losses(enc, unet, dec, dict(bg, weight_dtype=torch.bfloat16), inverse=True)
+    loss.backward()
+    err = _grad_error(oracle, nets, sample_every=7)
+    print({"cfg4_inverse_branch": "B=2, 64x64 latent, bf16 autocast, SD size", "loss": float(loss.detach()), "loss_oracle": loss_o,
+           "grad_rel_l2_sampled": err})
+    assert abs(float(loss.detach()) - loss_o) / abs(loss_o) < 5e-3
+    assert err < 3e-2
 
 
 def _ddp_worker(rank, world, port, q):

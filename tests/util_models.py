@@ -56,3 +56,20 @@ def product_step(unet, enc, dec, x_t, cond, ehs, t_img, t_attr, run_decoder=True
                         mid_block_additional_residual=raw_mid_unet, return_dict=False)
     return dict(img_pred=img_pred, attr_pred=attr_pred, enc_res=res, enc_mid=mid, raw_enc=raw_enc,
                 raw_mid_enc=raw_mid_enc, raw_unet=raw_unet, raw_mid_unet=raw_mid_unet, up_res=up_res)
+
+
+class OracleScheduler:
+    """torch-tensor adapter over oracle/schedulers_oracle.py (numpy float64, diffusers' D1s / einsum form): the host
+    reference of the sampling-loop tests, so that the product's scheduler, its coefficient table and the fused HIP update
+    kernels are all compared against code they share nothing with."""
+
+    def __init__(self, kind: str, steps: int, **kw):
+        from oracle import schedulers_oracle as S
+
+        self.o = (S.UniPCOracle if kind == "unipc" else S.DDIMOracle)(**kw)
+        self.o.set_timesteps(steps)
+        self.timesteps = torch.from_numpy(self.o.timesteps.copy())
+
+    def step(self, model_output, t, sample):
+        out = self.o.step(model_output.detach().double().cpu().numpy(), int(t), sample.detach().double().cpu().numpy())
+        return (torch.from_numpy(out).to(sample.dtype),)

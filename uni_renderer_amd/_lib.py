@@ -74,9 +74,10 @@ class TChainDesc(C.Structure):
 
     _fields_ = [
         ("a0", vp), ("res", vp), ("res_lo", vp), ("blk", vp), ("blk_lo", vp), ("y_out", vp), ("y_out_lo", vp),
-        ("out", vp), ("out_lo", vp), ("wstream", vp), ("consts", vp),
+        ("out", vp), ("out_lo", vp), ("out2", vp), ("out3", vp), ("wstream", vp), ("consts", vp),
         ("z_wstream", i64), ("z_consts", i64),
         ("M", i32), ("zbatch", i32), ("mode", i32), ("dtype", i32), ("channels", i32),
+        ("rows_per_b", i32), ("ld_vt", i32),
         ("eps", f32),
         ("profile", vp),
     ]

@@ -79,8 +79,8 @@ __device__ __forceinline__ typename Vec8<T>::type pack8(const float (&f)[8]) {
 template <typename T, int MODE>
 __global__ void __launch_bounds__(256, 1) tchain_kernel(const ur_tchain_desc p) {
     typedef typename Vec8<T>::type vec8;
-    constexpr int NSTAGES = MODE == UR_TCHAIN_Q ? 10 : 5 + 3 * (TC_FF / 64) + 5;
-    constexpr int NCONST = MODE == UR_TCHAIN_Q ? TCC_Q_END : TCC_FF_END;
+    constexpr int NSTAGES = MODE == UR_TCHAIN_Q ? 10 : (MODE == UR_TCHAIN_PRE ? 20 : 5 + 3 * (TC_FF / 64) + 5);
+    constexpr int NCONST = MODE == UR_TCHAIN_FF ? TCC_FF_END : TCC_Q_END;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* cst = reinterpret_cast<float*>(smem + TC_LDS - NCONST * 4);  // the constant vectors sit at the very end
     constexpr int IO_WAVE = ((TC_LDS - NCONST * 4 - TC_IO_BASE) / 4) & ~15;  // staging bytes per wave
@@ -366,13 +366,24 @@ __global__ void __launch_bounds__(256, 1) tchain_kernel(const ur_tchain_desc p) 
             bop[s] = *reinterpret_cast<const vec8*>(io + (ln & 31) * (HI_ROW + 16) + (2 * s + (ln >> 5)) * 16);
     }
     zero(acc);
-    add_stream(acc, p.res, p.res_lo);
+    if (MODE != UR_TCHAIN_PRE) add_stream(acc, p.res, p.res_lo);  // PRE: proj_in has no residual
     add_cvec(acc, TCC_BIAS0);
     __syncthreads();  // every wave has read its staging slice: slots 1 / 2 belong to the weight stream from here on
     issue();
     stamp(2);
-    gemm320(acc, bop, MODE == UR_TCHAIN_Q ? 3 : 5);
+    gemm320(acc, bop, MODE == UR_TCHAIN_FF ? 5 : 3);
     stamp(3);
+    // a tile leaves through the staging area in the middle of the chain: the last two stages before it copied nothing
+    // (slots 1 / 2 stay free), the ring is refilled afterwards
+    auto store_mid = [&](const Acc<T>& a, void* hi_, void* lo_) __attribute__((always_inline)) {
+        __syncthreads();  // the other waves have left the last stage (slot 1 or 2)
+        store_stream(a, hi_, lo_);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores have left before LDS-DMA pieces are counted again
+        __syncthreads();  // staging slices read back: refill the ring
+        issue();
+        issue();
+    };
+    if constexpr (MODE == UR_TCHAIN_PRE) store_mid(acc, p.y_out, p.y_out_lo);
     if constexpr (MODE == UR_TCHAIN_Q) {
         // the updated residual stream leaves here through the staging area (no weight stage is in flight: `limit`)
         __syncthreads();  // the other waves have left stage 4 (slot 1)
@@ -416,7 +427,38 @@ __global__ void __launch_bounds__(256, 1) tchain_kernel(const ur_tchain_desc p) 
     }
 
     stamp(5);
-    if constexpr (MODE == UR_TCHAIN_Q) {
+    if constexpr (MODE == UR_TCHAIN_PRE) {
+        // =============================== q, k, V^T of the self-attention from one normalised operand ===============================
+        zero(acc);
+        gemm320(acc, bop, 3);
+        store_mid(acc, p.out, nullptr);         // q  (softmax scale * log2(e) split evenly over q and k by the host)
+        zero(acc);
+        gemm320(acc, bop, 3);
+        store_mid(acc, p.out2, nullptr);        // k
+        zero(acc);
+        gemm320(acc, bop, 3);
+        // V^T[b][channel][token]: a wave's 32 tokens are 64 contiguous bytes of every channel row.  Stage [channel][32
+        // tokens] in the wave's slice, then 16 bytes per lane = 8 tokens of one channel.
+        {
+            const int ln = launder(lane);
+            const int lrow = ln & 31, lh = ln >> 5;
+#pragma unroll
+            for (int t = 0; t < TC_NT; ++t)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int ch = 32 * t + 8 * (v >> 2) + 4 * lh + (v & 3);
+                    reinterpret_cast<T*>(io)[ch * 32 + lrow] = (T)acc.t[t][v];
+                }
+            const int b = m0w / p.rows_per_b, tok0 = m0w - b * p.rows_per_b;  // a wave never straddles two samples
+            char* vt = reinterpret_cast<char*>(p.out3) + (((int64_t)z * (p.M / p.rows_per_b) + b) * TC_C * p.ld_vt + tok0) * (int64_t)sizeof(T);
+#pragma unroll
+            for (int k = 0; k < 20; ++k) {
+                const int e = 64 * k + ln, ch = e >> 2, c = e & 3;
+                const u32x4 val = *reinterpret_cast<const u32x4*>(io + ch * 64 + c * 16);
+                if (m0w + 8 * c < p.M) *reinterpret_cast<u32x4*>(vt + (int64_t)ch * p.ld_vt * sizeof(T) + c * 16) = val;
+            }
+        }
+    } else if constexpr (MODE == UR_TCHAIN_Q) {
         // =============================== q = LN(y) Wq^T (scale folded into Wq by the host) ===============================
         zero(acc);
         gemm320(acc, bop, 3);
@@ -518,7 +560,7 @@ __global__ void __launch_bounds__(256, 1) tchain_kernel(const ur_tchain_desc p) 
 template <typename T, int MODE>
 static int launch_tchain(const ur_tchain_desc& d, hipStream_t s) {
     static std::atomic<uint64_t> done{0};
-    const int nconst = MODE == UR_TCHAIN_Q ? TCC_Q_END : TCC_FF_END;
+    const int nconst = MODE == UR_TCHAIN_FF ? TCC_FF_END : TCC_Q_END;
     const int lds = TC_LDS;  // ring + staging area + constants: the whole CU
     set_lds_limit_once(done, reinterpret_cast<const void*>(&tchain_kernel<T, MODE>), lds);
     const int tiles = (d.M + 127) / 128;
@@ -533,11 +575,16 @@ extern "C" int ur_tchain(const ur_tchain_desc* din, void* stream) {
     using namespace ur;
     if (!din) return UR_E_BADARG;
     ur_tchain_desc d = *din;
-    if (!d.a0 || !d.res || !d.out || !d.wstream || !d.consts || d.M <= 0) return UR_E_BADARG;
+    if (!d.a0 || !d.out || !d.wstream || !d.consts || d.M <= 0) return UR_E_BADARG;
+    if (d.mode != UR_TCHAIN_PRE && !d.res) return UR_E_BADARG;
     if (d.zbatch < 1) d.zbatch = 1;
     if (d.mode == UR_TCHAIN_Q) {
         if (!d.y_out) return UR_E_BADARG;
         if (d.z_consts < TCC_Q_END || d.z_wstream < 10 * (int64_t)TC_STAGE) return UR_E_BADARG;
+    } else if (d.mode == UR_TCHAIN_PRE) {
+        if (!d.y_out || !d.out2 || !d.out3) return UR_E_BADARG;
+        if (d.rows_per_b <= 0 || (d.rows_per_b % 32) || (d.M % d.rows_per_b) || d.ld_vt < d.rows_per_b || (d.ld_vt % 8)) return UR_E_BADARG;
+        if (d.z_consts < TCC_Q_END || d.z_wstream < 20 * (int64_t)TC_STAGE) return UR_E_BADARG;
     } else if (d.mode == UR_TCHAIN_FF) {
         if (!d.blk) return UR_E_BADARG;
         if (d.z_consts < TCC_FF_END || d.z_wstream < (10 + 3 * (TC_FF / 64)) * (int64_t)TC_STAGE) return UR_E_BADARG;
@@ -547,13 +594,17 @@ extern "C" int ur_tchain(const ur_tchain_desc* din, void* stream) {
     if (d.channels != TC_C) return UR_E_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(d.wstream) | (uintptr_t)d.z_wstream) & 15) return UR_E_BADARG;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (d.dtype == UR_DT_F16) return d.mode == UR_TCHAIN_Q ? launch_tchain<f16, UR_TCHAIN_Q>(d, s) : launch_tchain<f16, UR_TCHAIN_FF>(d, s);
-    if (d.dtype == UR_DT_BF16) return d.mode == UR_TCHAIN_Q ? launch_tchain<bf16, UR_TCHAIN_Q>(d, s) : launch_tchain<bf16, UR_TCHAIN_FF>(d, s);
+    if (d.dtype == UR_DT_F16)
+        return d.mode == UR_TCHAIN_Q ? launch_tchain<f16, UR_TCHAIN_Q>(d, s)
+               : (d.mode == UR_TCHAIN_PRE ? launch_tchain<f16, UR_TCHAIN_PRE>(d, s) : launch_tchain<f16, UR_TCHAIN_FF>(d, s));
+    if (d.dtype == UR_DT_BF16)
+        return d.mode == UR_TCHAIN_Q ? launch_tchain<bf16, UR_TCHAIN_Q>(d, s)
+               : (d.mode == UR_TCHAIN_PRE ? launch_tchain<bf16, UR_TCHAIN_PRE>(d, s) : launch_tchain<bf16, UR_TCHAIN_FF>(d, s));
     return UR_E_BADARG;
 }
 
 extern "C" int ur_sizeof_tchain_desc(void) { return (int)sizeof(ur_tchain_desc); }
 extern "C" int64_t ur_tchain_stream_bytes(int mode) {
-    return (int64_t)ur::TC_STAGE * (mode == UR_TCHAIN_Q ? 10 : 10 + 3 * (ur::TC_FF / 64));
+    return (int64_t)ur::TC_STAGE * (mode == UR_TCHAIN_Q ? 10 : (mode == UR_TCHAIN_PRE ? 20 : 10 + 3 * (ur::TC_FF / 64)));
 }
-extern "C" int ur_tchain_const_floats(int mode) { return mode == UR_TCHAIN_Q ? ur::TCC_Q_END : ur::TCC_FF_END; }
+extern "C" int ur_tchain_const_floats(int mode) { return mode == UR_TCHAIN_FF ? ur::TCC_FF_END : ur::TCC_Q_END; }

@@ -231,28 +231,30 @@ class GroupedDualStreamStep:
         return y
 
     def _tblock_chain(self, bs: Sequence[BasicTransformerBlock], ts, x, blk_in, kc, vtc, kv_slice):
-        """The 320-channel level: everything row-local behind the two attentions runs as two ``ur_tchain`` launches
-        (tchain.py) -- attn1 out-projection + residual + LayerNorm2 + cross-attention query projection, then attn2
-        out-projection + residual + LayerNorm3 + GEGLU feed-forward + residual + proj_out + block input -- instead of six
-        GEMM and two LayerNorm launches.  Same arithmetic and the same rounding points as ``_tblock`` + proj_out."""
+        """The 320-channel level: everything row-local around the two attentions runs as three ``ur_tchain`` launches
+        (tchain.py) -- proj_in + LayerNorm1 + q / k / V^T projections; attn1 out-projection + residual + LayerNorm2 +
+        cross-attention query projection; attn2 out-projection + residual + LayerNorm3 + GEGLU feed-forward + residual +
+        proj_out + block input -- instead of ten GEMM and three LayerNorm launches.  ``x`` = the GroupNorm output, ``blk_in``
+        the transformer's input.  Same arithmetic and the same rounding points as ``_tblock`` + proj_in / proj_out."""
         S, pk, dt = len(bs), self.pk, x.dtype
         a1, a2 = [b.attn1 for b in bs], [b.attn2 for b in bs]
         a0 = a1[0]
         Bt, T, C = x.shape
         H, d = a0.heads, a0.dim_head
         cs = d ** -0.5 * LOG2E
-        g, b_ = (pk.get("t.n1.g", bs, [b.norm1.weight for b in bs], dt, lambda: _stk(f32(b.norm1.weight) for b in bs)),
-                 pk.get("t.n1.b", bs, [b.norm1.bias for b in bs], dt, lambda: _stk(f32(b.norm1.bias) for b in bs)))
-        xn = ops.layernorm(x, g, b_, bs[0].norm1.eps, streams=S)
-        wqk = pk.get("a.wqk", a1, [p for a in a1 for p in (a.to_q.weight, a.to_k.weight)], dt,
-                     lambda: _stk(torch.cat([pack_matrix(a.to_q.weight, dt), pack_matrix(a.to_k.weight, dt)], 0) for a in a1))
-        wv = pk.get("a.wv", a1, [a.to_v.weight for a in a1], dt, lambda: _stk(pack_matrix(a.to_v.weight, dt) for a in a1))
-        ops.set_site("vt")
-        vt = ops.vt_proj(xn, wv, streams=S)
-        ops.set_site("qk")
-        qk = ops.linear(xn, wqk, streams=S, out_scale=math.sqrt(cs))
-        ops.set_site(None)
-        o1 = ops.attention(qk, qk, vt, B=Bt, H=H, Tq=T, Tk=T, d=d, ldq=2 * C, ldk=2 * C, q_off=0, k_off=C, scale=0.0)
+        def build_pre():
+            packs = [tchain.pack_chain_pre(t.proj_in.weight, t.proj_in.bias, b.norm1.weight, b.norm1.bias, b.attn1.to_q.weight,
+                                           b.attn1.to_k.weight, b.attn1.to_v.weight, math.sqrt(cs), dt) for b, t in zip(bs, ts)]
+            return _stk(p[0] for p in packs), _stk(p[1] for p in packs)
+
+        wsp, csp = pk.get("tc.pre", bs, [p for b, t in zip(bs, ts) for p in (
+            t.proj_in.weight, t.proj_in.bias, b.norm1.weight, b.norm1.bias, b.attn1.to_q.weight, b.attn1.to_k.weight,
+            b.attn1.to_v.weight)], dt, build_pre)
+        # x = the GroupNorm output: proj_in + LayerNorm1 + q / k / V^T projections in one launch
+        xr, q1, k1, vt = tchain.chain_pre(x.reshape(Bt * T, C), wsp, csp, bs[0].norm1.eps, tokens_per_sample=T, streams=S)
+        o1 = ops.attention(q1, k1, vt, B=Bt, H=H, Tq=T, Tk=T, d=d, ldq=C, ldk=C, scale=0.0)
+        x = xr.view(Bt, T, C)
+        x.lo = xr.lo.view(Bt, T, C)
 
         def build_q():
             packs = [tchain.pack_chain_q(b.attn1.to_out[0].weight, b.attn1.to_out[0].bias, b.norm2.weight, b.norm2.bias,
@@ -288,12 +290,13 @@ class GroupedDualStreamStep:
         wo = pk.get("x.wo", ts, [t.proj_out.weight for t in ts], dt, lambda: _stk(pack_matrix(t.proj_out.weight, dt) for t in ts))
         bo = pk.get("x.bo", ts, [t.proj_out.bias for t in ts], dt, lambda: _stk(f32(t.proj_out.bias) for t in ts))
         h = ops.groupnorm(x, g, b_, ts[0].norm.eps, groups=ts[0].groups, silu=False, streams=S)
+        if (self.use_tchain and len(ts[0].transformer_blocks) == 1 and tchain.supported(h) and self.hilo
+                and (H * W) % 32 == 0 and ts[0].transformer_blocks[0].attn1.dim_head == 40):
+            return ops.view_hilo(self._tblock_chain([t.transformer_blocks[0] for t in ts], ts, h.view(Bt, H * W, Cc),
+                                                    ops.view_hilo(x, Bt, H * W, Cc), kc, vtc, kv_slices[0]), Bt, H, W, Cc)
         ops.set_site("pi")
         h = ops.linear(h.view(Bt, H * W, Cc), wi, bi, streams=S, hilo=self.hilo)
         ops.set_site(None)
-        if self.use_tchain and len(ts[0].transformer_blocks) == 1 and tchain.supported(h) and self.hilo:
-            return ops.view_hilo(self._tblock_chain([t.transformer_blocks[0] for t in ts], ts, h, ops.view_hilo(x, Bt, H * W, Cc),
-                                                    kc, vtc, kv_slices[0]), Bt, H, W, Cc)
         for j in range(len(ts[0].transformer_blocks)):
             h = self._tblock([t.transformer_blocks[j] for t in ts], h, kc, vtc, kv_slices[j])
         ops.set_site("po")

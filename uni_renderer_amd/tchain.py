@@ -30,7 +30,7 @@ import torch
 from . import _lib, ops
 from ._lib import TChainDesc, check
 
-MODE_Q, MODE_FF = 0, 1
+MODE_Q, MODE_FF, MODE_PRE = 0, 1, 2
 CH = 320           # the level the kernel is built for
 STAGE = 40960      # bytes per stage image
 KPERM16 = (0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15)
@@ -102,6 +102,18 @@ def pack_chain_q(wo: torch.Tensor, bo: torch.Tensor, gamma: torch.Tensor, beta: 
     return stream, consts
 
 
+def pack_chain_pre(wpi: torch.Tensor, bpi: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, wq: torch.Tensor,
+                   wk: torch.Tensor, wv: torch.Tensor, qk_scale: float, dtype):
+    """(wstream [20 stages], consts [960]) of one UR_TCHAIN_PRE chain: proj_in (1x1 conv [320, 320, 1, 1]) | LayerNorm1 | q, k,
+    v projections of the self-attention.  ``qk_scale`` = sqrt(d^-0.5 * log2(e)) multiplies BOTH q and k weights (the
+    attention kernel takes q.k in log2 units, layers.Attention)."""
+    f = lambda t: t.detach().float().reshape(CH, CH)
+    stream = torch.cat([gemm_images(f(wpi), False), gemm_images(f(wq) * qk_scale, True), gemm_images(f(wk) * qk_scale, True),
+                        gemm_images(f(wv), True)], 0).to(dtype).reshape(-1).contiguous()
+    consts = torch.cat([bpi.detach().float(), gamma.detach().float(), beta.detach().float()]).contiguous()
+    return stream, consts
+
+
 def pack_chain_ff(wo: torch.Tensor, bo: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, w1: torch.Tensor,
                   b1: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor, wpo: torch.Tensor, bpo: torch.Tensor, dtype):
     """(wstream, consts [3840] fp32) of one UR_TCHAIN_FF chain.  ``w1`` / ``b1`` are diffusers' GEGLU ``proj`` ([2 * 1280,
@@ -115,14 +127,18 @@ def pack_chain_ff(wo: torch.Tensor, bo: torch.Tensor, gamma: torch.Tensor, beta:
     return stream, consts
 
 
-def _launch(mode, a0, res, wstream, consts, eps, *, blk=None, y_out=None, out=None, streams=1, profile=None):
+def _launch(mode, a0, res, wstream, consts, eps, *, blk=None, y_out=None, out=None, streams=1, profile=None, out2=None,
+            out3=None, rows_per_b=0):
     ops._require_gpu(a0)
     lib = _lib.load()
     Cn = a0.shape[-1]
     M = a0.numel() // Cn // streams
     d = TChainDesc()
-    d.a0, d.res, d.out = a0.data_ptr(), res.data_ptr(), out.data_ptr()
-    d.res_lo = ops._ptr(ops.lo_of(res))
+    d.a0, d.out = a0.data_ptr(), out.data_ptr()
+    if res is not None:
+        d.res, d.res_lo = res.data_ptr(), ops._ptr(ops.lo_of(res))
+    if out2 is not None:
+        d.out2, d.out3, d.rows_per_b, d.ld_vt = out2.data_ptr(), out3.data_ptr(), rows_per_b, out3.shape[-1]
     d.out_lo = ops._ptr(ops.lo_of(out))
     if blk is not None:
         d.blk, d.blk_lo = blk.data_ptr(), ops._ptr(ops.lo_of(blk))
@@ -141,17 +157,34 @@ def _launch(mode, a0, res, wstream, consts, eps, *, blk=None, y_out=None, out=No
     if e0 is not None:
         el = a0.element_size()
         rows = M * streams
-        if mode == MODE_Q:
+        if mode == MODE_PRE:
+            fl = 2.0 * rows * CH * CH * 4
+            by = rows * CH * (el * 5 + (1 if a0.dtype == torch.float16 else el)) + wstream.numel() * el
+        elif mode == MODE_Q:
             fl = 2.0 * rows * CH * CH * 2
             by = rows * CH * (el * 4 + 2 * (1 if a0.dtype == torch.float16 else el)) + wstream.numel() * el
         else:
             fl = 2.0 * rows * CH * (CH + 8 * CH + 4 * CH + CH)
             by = rows * CH * (el * 4 + 3 * (1 if a0.dtype == torch.float16 else el)) + wstream.numel() * el
-        ops._prof_end(e0, "tchain_q" if mode == MODE_Q else "tchain_ff", fl, by)
+        ops._prof_end(e0, {MODE_Q: "tchain_q", MODE_FF: "tchain_ff", MODE_PRE: "tchain_pre"}[mode], fl, by)
 
 
 def supported(x: torch.Tensor) -> bool:
     return x.is_cuda and x.shape[-1] == CH and x.dtype in (torch.float16, torch.bfloat16)
+
+
+def chain_pre(x_norm, wstream, consts, eps, *, tokens_per_sample, streams=1, hilo=True, profile=None):
+    """x_norm [S*B*T, 320] (the GroupNorm output).  Returns (y, q, k, vt): y = proj_in(x_norm) as a (hi, lo) tensor, q / k
+    [S*B*T, 320] already carrying sqrt(scale * log2 e) each, vt [S*B, 320, Tpad] (columns >= T zero)."""
+    T = tokens_per_sample
+    rows = x_norm.shape[0]
+    Tpad = (T + 63) // 64 * 64
+    y = ops._with_lo(torch.empty_like(x_norm), hilo)
+    q, k = torch.empty_like(x_norm), torch.empty_like(x_norm)
+    vt = (torch.zeros if Tpad != T else torch.empty)(rows // T, CH, Tpad, dtype=x_norm.dtype, device=x_norm.device)
+    _launch(MODE_PRE, x_norm, None, wstream, consts, eps, y_out=y, out=q, out2=k, out3=vt, rows_per_b=T, streams=streams,
+            profile=profile)
+    return y, q, k, vt
 
 
 def chain_q(attn_out, residual, wstream, consts, eps, *, streams=1, hilo=True, profile=None):
