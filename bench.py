@@ -164,6 +164,10 @@ def measure_roofline(step_fn, by_shape=False):
         if a["flop"] > 0:
             row["tflops"] = round(a["flop"] / (a["ms"] * 1e-3) / 1e12, 2)
             row["alg_flop_per_launch"] = round(a["flop"] / a["calls"])
+            if key == "attention_d40":
+                # the head dim is zero-padded for the MFMA: Q.K^T contracts over 48, P.V produces 64 rows; `tflops`
+                # counts the USEFUL 40 + 40, the matrix pipe also executes the padding (MFMA-busy counts both)
+                row["useful_frac_of_mfma_flops"] = round((40 + 40) / (48 + 64), 3)
         else:
             row["gbs"] = round(a["bytes"] / (a["ms"] * 1e-3) / 1e9, 1)
         table.append(row)

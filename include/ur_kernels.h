@@ -101,7 +101,8 @@ extern "C" {
 #define UR_TILE_256x128_L2 38
 #define UR_TILE_256x256_L0 39   /* reserved: not instantiated (UR_E_UNSUPPORTED) */
 #define UR_TILE_128x256_L2 40
-#define UR_TILE_COUNT 41
+#define UR_TILE_128x256_S3 41   /* 8 waves, 3-deep ring (144 KB): does a deeper prefetch help a big tile? */
+#define UR_TILE_COUNT 42
 
 /*
  * Implicit GEMM:  out[m][n] = epilogue( sum_k X[m][k] * W[n][k] )

@@ -19,14 +19,14 @@ OUT, PROF = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
     src = os.path.join(OUT, f"prof_{tag}")
     for f in sorted(os.listdir(src)):
         if f.endswith((".json", ".csv")):
             shutil.copy(os.path.join(src, f), os.path.join(PROF, f"{tag}_{f}"))
     shutil.copy(os.path.join(src, "pmc_traffic.json"), os.path.join(PROF, "pmc_traffic.json"))  # bench.py reads this one
     for f in sorted(os.listdir(OUT)):
-        if f.startswith("final_") and f.endswith((".json", ".csv")):
+        if f.startswith("final_") and f.endswith((".json", ".csv", ".txt")):
             shutil.copy(os.path.join(OUT, f), os.path.join(PROF, f"{tag}_{f[len('final_'):]}"))
     for f in ("ab_final.txt", "ab_knobs.txt"):
         if os.path.exists(os.path.join(OUT, f)):

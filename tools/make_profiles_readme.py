@@ -60,15 +60,20 @@ commands below and keeps the summaries; this file is `python tools/make_profiles
 round 1 (first complete collection / end of round), kept for the history of the numbers; `{tag}_*` = the state at the
 end of round {tag[1:3].lstrip("0")}.
 
-Other round-2 summaries: `r02_parity_numbers.json` (every rel-L2 the `-m gpu` suite printed: cfg 3 at batch 2 and 4, cfg 5
-vs the oracle, the 16384-token attention, UpRes, the module-surface and cfg-4 training steps, the VAE),
-`r02_bench_cfg2/cfg5/b5/b8/b10/b20.json` (the other configurations and the repeat batches through `bench.py`),
-`r02_loop_bench.json` (50-step DDIM loops; 20-step UniPC x 5 repeats as five calls vs one folded batch),
-`r02_train_graph/eager.json` (`tools/train_bench.py`; `r02_train_graph_torch_adamw.json`: the same with torch's fused AdamW instead
-of `optim.FusedAdamW`), `r02_attn_bwd_bench.json` (flash vs materialised-P attention backward per transformer level,
-`tools/attn_bwd_bench.py`), `r02_ab_final.txt` / `r02_ab_knobs.txt` (same-box alternations of the tile table before / after the
-in-situ passes), `r02_train_ab.txt` (same-box alternation of the training-path switches), `r02_vae_bench.json` (`tools/vae_bench.py`), `r02_insitu_tuning_log.json` (whole-step coordinate descent over
-tile choices, `tools/tune_in_situ.py`).
+Round-3 additions: `{tag}_tchain_bench.json` (`tools/tchain_bench.py`: the three row-local chain launches of the
+320-channel transformer blocks against the GEMM / LayerNorm launches they replace, graph-timed, plus s_memtime phase and
+per-stage stamps of the kernels), `{tag}_pmc_conv_sq.json` / `{tag}_pmc_gemm320_sq.json` (`tools/pmc_conv_sq.sh`: three SQ-counter
+passes over the level-0 conv / a K = 320 GEMM replayed alone: parked, issue-stalled and active wave cycles, LDS activity,
+bank conflicts), `{tag}_mfma_rate.txt` (`tools/ubench/mfma_rate.hip`, the corrected MFMA issue-rate micro-benchmark: random
+operands, distinct A / B registers, 1 / 2 / 4 waves per SIMD), `{tag}_ring_depth_ab.txt` (`tools/r03_run6.sh`: a 3-deep LDS ring
+on the 128x256 tile against the 2-deep one: no difference, the conv loop is not waiting for its copies).
+Other summaries: `{tag}_parity_numbers.json` (every rel-L2 the `-m gpu` suite printed: the chain kernels, cfg 3 at batch 2 and 4
+and as a 5-step DDIM loop, cfg 5 vs the oracle, the 16384-token attention, UpRes, the module-surface and cfg-4 training steps
+incl. the inverse branch at SD size, the VAE, the RCCL world-size-1 collectives),
+`{tag}_bench_cfg2/cfg5/b5/b8/b10/b20.json` (the other configurations and the repeat batches through `bench.py`),
+`{tag}_loop_bench.json` (50-step DDIM loops; 20-step UniPC x 5 repeats as five calls vs one folded batch),
+`{tag}_train_graph/eager.json` (`tools/train_bench.py`; `{tag}_train_graph_torch_adamw.json`: the same with torch's fused AdamW instead
+of `optim.FusedAdamW`), `{tag}_vae_bench.json` (`tools/vae_bench.py`); round 2's A/B logs stay as `r02_*`.
 
 | file | what |
 |---|---|
@@ -86,11 +91,11 @@ rocprofv3 --kernel-trace --stats -d <out> -o {tag} --output-format csv -- python
 ## Headline (un-profiled, `{tag}_bench_default.json`)
 
 {d['value']:.2f} denoise-steps/s = {d['ms_per_step']:.2f} ms per dual-stream step (enc + unet + dec, SD-1.x size, B=4, 512x512, fp16,
-default (hi, lo) residual stream) on one MI355X (boxes of the pool differ by +-4 %: 12.1 .. 12.9 ms were seen for this
-build in round 2, about 0.5 ms less with the plain fp16 residual stream `UR_PRECISE_RESIDUAL=0`); CPU oracle on the same
+default (hi, lo) residual stream) on one MI355X (boxes of the pool differ by +-4 %: 11.7 .. 12.2 ms were seen for this
+build, 12.1 .. 12.9 ms for round 2's; same-box A/B of the chain kernels `UR_TCHAIN=0/1`: 12.16 -> 11.75 ms); CPU oracle on the same
 host ({cpu['cores']}-core cgroup quota) {cpu['value']:.4f} steps/s (median of 3 timed steps).  6.49 TFLOP/step => {6.49 / d['ms_per_step']:.3f} PFLOP/s
-algorithmic = {100 * 6.49 / d['ms_per_step'] / 2.5:.0f} % of the dense fp16 MFMA roofline for the whole step (round 1 ended at 12.3 .. 13.1 ms; what was
-tried on the step time in round 2 and why it did not move: DESIGN.md section 4, "Round 2").
+algorithmic = {100 * 6.49 / d['ms_per_step'] / 2.5:.0f} % of the dense fp16 MFMA roofline for the whole step (round 1 ended at 12.3 .. 13.1 ms, round 2 at 12.0 .. 12.9 ms;
+DESIGN.md section 4, "Round 3").
 
 Dominant kernel (by symbol; plain + split-K launches {100 * roof.get('share_of_step_incl_splitk_launches', roof['share_of_step']):.0f} % of the step):
 `{roof['kernel']}` at {roof['achieved']:.0f} TFLOP/s = {100 * roof['frac']:.0f} % of peak over its {roof['calls_per_step']} plain launches/step

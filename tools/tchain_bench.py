@@ -20,12 +20,11 @@ def main():
     ap.add_argument("--M", type=int, default=16384)
     ap.add_argument("--S", type=int, default=2)
     ap.add_argument("--dtype", default="fp16")
-    ap.add_argument("--no-dma", action="store_true", help="timing ablation: negative eps = the kernel skips its weight copies")
     args = ap.parse_args()
     from uni_renderer_amd import ops, tchain
     from uni_renderer_amd.layers import f32, geglu_perm, pack_matrix
 
-    EPS = -1.0 if args.no_dma else 1e-5
+    EPS = 1e-5
     dev = torch.device("cuda:0")
     dt = torch.float16 if args.dtype == "fp16" else torch.bfloat16
     C, M, S = 320, args.M, args.S
@@ -73,7 +72,24 @@ def main():
         return tchain.chain_ff(ao.view(S * M, C), ops.view_hilo(res, S * M, C), ops.view_hilo(blk, S * M, C), wsf, csf, EPS, streams=S)
 
     out = {}
-    for name, fn in (("unfused_q", unfused_q), ("fused_q", fused_q), ("unfused_ff", unfused_ff), ("fused_ff", fused_ff)):
+    Tn = 4096 if M % 4096 == 0 else M
+    wk_, wv_ = [r(C, C, sc=C ** -0.5) for _ in range(S)], [r(C, C, sc=C ** -0.5) for _ in range(S)]
+    pp = [tchain.pack_chain_pre(w["wo"].view(C, C, 1, 1), w["bo"], w["g"], w["b"], w["wq"], wk_[i], wv_[i], 0.4777, dt) for i, w in enumerate(W)]
+    wsp, csp = torch.stack([p[0] for p in pp]).contiguous(), torch.stack([p[1] for p in pp]).contiguous()
+    wqk = torch.stack([torch.cat([pack_matrix(w["wq"], dt), pack_matrix(wk_[i], dt)], 0) for i, w in enumerate(W)]).contiguous()
+    wvv = torch.stack([pack_matrix(t, dt) for t in wv_]).contiguous()
+
+    def unfused_pre():
+        y = ops.linear(ao, wo, bo, streams=S, hilo=True)
+        xn = ops.layernorm(y, gm, bt, 1e-5, streams=S)
+        vt = ops.vt_proj(xn.view(S * M // Tn, Tn, C), wvv, streams=S)
+        return ops.linear(xn, wqk, streams=S, out_scale=0.4777), vt
+
+    def fused_pre():
+        return tchain.chain_pre(ao.view(S * M, C), wsp, csp, 1e-5, tokens_per_sample=Tn, streams=S)
+
+    for name, fn in (("unfused_pre", unfused_pre), ("fused_pre", fused_pre), ("unfused_q", unfused_q), ("fused_q", fused_q),
+                     ("unfused_ff", unfused_ff), ("fused_ff", fused_ff)):
         fn()
         torch.cuda.synchronize()
         gr = torch.cuda.CUDAGraph()

@@ -674,7 +674,8 @@ static const TileCfg kTiles[UR_TILE_COUNT] = {{0, 0, 0},      {128, 128, 2}, {12
                                               {64, 64, 3},   {256, 256, 2}, {256, 128, 2}, {128, 256, 2},
                                               // wave-specialised builds: dedicated loader waves (UR_TILE_*_L<n>)
                                               {128, 320, 2}, {128, 320, 2}, {128, 128, 2}, {128, 128, 3}, {128, 64, 2},
-                                              {128, 64, 3},  {64, 64, 3},   {256, 128, 2}, {256, 256, 2}, {128, 256, 2}};
+                                              {128, 64, 3},  {64, 64, 3},   {256, 128, 2}, {256, 256, 2}, {128, 256, 2},
+                                              {128, 256, 3}};
 
 static int pick_tile(const ur_igemm_desc& d) {
     // Cost model: the busiest CU runs ceil(workgroups / 256) tiles; bigger tiles have a better
@@ -767,6 +768,7 @@ static int launch_dtype(ur_igemm_desc& d, hipStream_t s) {
         case UR_TILE_256x128_L2: return launch_cfg<T, 256, 128, 4, 2, 2, 16, 2>(d, s);
         case UR_TILE_256x256_L0: return UR_E_UNSUPPORTED;  /* 16 consumer waves already fill the 1024-thread limit */
         case UR_TILE_128x256_L2: return launch_cfg<T, 128, 256, 2, 4, 2, 16, 2>(d, s);
+        case UR_TILE_128x256_S3: return launch_cfg<T, 128, 256, 2, 4, 3>(d, s);
     }
     return UR_E_BADARG;
 }

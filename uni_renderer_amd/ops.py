@@ -38,7 +38,7 @@ _TILES = {TILE_128x128: (128, 128, 1.0, 2), TILE_128x64: (128, 64, 0.85, 3), TIL
           # wave-specialised builds: n dedicated loader waves (UR_TILE_*_L<n>); 39 is reserved / not instantiated
           31: (128, 320, 1.3, "2L2"), 32: (128, 320, 1.3, "2L4"), 33: (128, 128, 1.2, "2L2"), 34: (128, 128, 1.2, "3L2"),
           35: (128, 64, 1.0, "2L1"), 36: (128, 64, 1.0, "3L2"), 37: (64, 64, 0.8, "3L1"), 38: (256, 128, 1.3, "2L2"),
-          40: (128, 256, 1.3, "2L2")}
+          40: (128, 256, 1.3, "2L2"), 41: (128, 256, 1.2, 3)}
 _PLANNER_TILES = (TILE_128x128, TILE_128x64, TILE_64x64)
 
 _zero_pages = {}
