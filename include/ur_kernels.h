@@ -78,8 +78,7 @@ extern "C" {
 #define UR_TILE_64x64_W1_S3 19
 #define UR_TILE_64x128_W2 20
 #define UR_TILE_64x64_W1_S4 21
-/* the same tiles on v_mfma_f32_32x32x16 (csrc/igemm.hip: half the MFMA instructions per chunk; this chip issues the
- * 16x16x32 shape at ~27 cycles against its nominal 16) */
+/* the same tiles on v_mfma_f32_32x32x16 (csrc/igemm.hip: half the MFMA instructions per chunk) */
 #define UR_TILE_128x320_M32 22
 #define UR_TILE_128x128_M32 23
 #define UR_TILE_128x64_M32 24    /* 2-deep */

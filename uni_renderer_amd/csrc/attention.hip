@@ -312,9 +312,10 @@ __global__ void __launch_bounds__(256) attention_kernel(const ur_attn_desc p) {
 
 // ---------------------------------------------------------------------------------------------------------------
 // Head dims <= 64 (SD-1.x level 0: d = 40, the 4096-token self-attention that dominates the step) run on the
-// 32x32x16 MFMA: the 16x16x32 shape issues at ~27 cycles per instruction on this chip against its nominal 16
-// (tools/ubench/mfma_rate.hip), which made the kernel above MFMA-issue bound at d = 40; the 32x32x16 shape does the
-// same work in half the instructions at its nominal 32 cycles.
+// 32x32x16 MFMA: the same matrix work in half the instructions (7 per 32 keys instead of 14), i.e. half the MFMA issue
+// slots competing with the softmax VALU stream; measured 280 -> 272 us at B.H = 64, T = 4096.  (An
+// earlier comment blamed a "27-cycle" 16x16x32: that was a micro-benchmark artefact -- both shapes issue at their nominal
+// 16 / 32 cycles, profiles/r03_mfma_rate.txt.)
 //
 // Same transposed formulation, one 32-query block per wave:
 //   S^T[key][query] = K . Q^T : A = 32 key rows, B = Q rows.  Lane (query j = l&31, h = l>>5) receives, in register

@@ -502,8 +502,8 @@ __global__ void __launch_bounds__(256) attn_bwd_fold_kernel(const AttnBwdArgs p,
 
 // ---------------------------------------------------------------------------------------------------------------
 // The same two kernels on the 32x32x16 MFMA for the 64-wide padded head dim (d = 40, the 4096-token level where the
-// time is).  The 16x16x32 shape issues at ~27 cycles per instruction on this chip (tools/ubench/mfma_rate.hip), the
-// 32x32x16 shape does twice the work in its nominal 32; LDS bytes per FLOP are the same as the NB = 2 kernels above.
+// time is).  The 32x32x16 shape does the same work in half the MFMA issue slots (both shapes run at their nominal 16 / 32
+// cycles, profiles/r03_mfma_rate.txt); LDS bytes per FLOP are the same as the NB = 2 kernels above.
 // A wave owns 32 columns (queries / keys); lane (j = lane & 31, hh = lane >> 5) receives, in register v, row
 // 8 (v >> 2) + 4 hh + (v & 3) of column j: registers 8t .. 8t+7 ARE the B operand of k step t of the next MFMA when its k
 // index is read as k = 8 hh + i -> row 16 t + 4 hh + i (i < 4), 16 t + 8 + 4 hh + i - 4 (i >= 4); the transposed tile is

@@ -167,10 +167,10 @@ __device__ __forceinline__ void epilogue16(const ur_igemm_desc& p, T* __restrict
 }
 
 // MF = 16: v_mfma_f32_16x16x32 (the original formulation, described above).
-// MF = 32: v_mfma_f32_32x32x16.  On this chip the 16x16x32 shape issues at ~27 cycles against its nominal 16
-// (tools/ubench/mfma_rate.hip: 1.16 vs 1.91 PFLOP/s), and the big conv tiles run at 85 % of THAT ceiling, so the
-// same wave tiles are also built on the 32x32x16 shape: per 64-deep K chunk a wave issues (BM/WM/32) x (BN/WN/32) x 4
-// MFMAs of 32 nominal cycles instead of twice as many of 16.  Same LDS image except for two details: a fragment
+// MF = 32: v_mfma_f32_32x32x16: the same wave tiles with half the MFMA instructions: per 64-deep K chunk a wave issues
+// (BM/WM/32) x (BN/WN/32) x 4 MFMAs of 32 cycles instead of twice as many of 16.  (Both shapes sustain the same
+// 1.6-1.85 PFLOP/s on random operands, profiles/r03_mfma_rate.txt; round 2's "27-cycle 16x16x32" was a micro-benchmark
+// artefact.  The M32 builds measure 4-13 % SLOWER on the heavy problems: the loop is not MFMA-issue bound.)  Same LDS image except for two details: a fragment
 // read now spans 32 consecutive tile rows per half-wave, so the 16-byte chunk swizzle key is ((row >> 1) & 7) instead
 // of (row & 7) (conflict-free for ds_read_b128's 16-lane service groups, tools/lds_bank_check.py), and the weight
 // rows of a 32-row block are permuted so that the 16 accumulator registers of a lane (MFMA rows 8g + 4h + r) are 16

@@ -32,9 +32,9 @@ __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
 }
 
 // 32x32x16: lane l feeds A[l&31][8*(l>>5)..+7] and B[8*(l>>5)..+7][l&31] and receives, for v = 0..15,
-// D[8*(v>>2) + 4*(l>>5) + (v&3)][l&31].  Issue-bound rates measured on MI355X (tools/ubench/mfma_rate.hip): 1.9 PFLOP/s
-// against 1.16 PFLOP/s for the 16x16x32 shape -- but the igemm tiles are not MFMA-issue bound: a 32x32x16 build of
-// them measured 9 % slower over the step's heaviest problems, so they stay on mfma16.
+// D[8*(v>>2) + 4*(l>>5) + (v&3)][l&31].  Both shapes sustain 1.6-1.85 PFLOP/s on random operands (tools/ubench/mfma_rate.hip,
+// profiles/r03_mfma_rate.txt); the igemm tiles are not MFMA-issue bound: a 32x32x16 build of them measured 9 % slower
+// over the step's heaviest problems, so they stay on mfma16.
 __device__ __forceinline__ f32x16 mfma32(f16x8 a, f16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
