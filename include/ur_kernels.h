@@ -101,7 +101,14 @@ extern "C" {
 #define UR_TILE_256x256_L0 39   /* reserved: not instantiated (UR_E_UNSUPPORTED) */
 #define UR_TILE_128x256_L2 40
 #define UR_TILE_128x256_S3 41   /* 8 waves, 3-deep ring (144 KB): does a deeper prefetch help a big tile? */
-#define UR_TILE_COUNT 42
+#define UR_TILE_128x320_W8_M32 42 /* 8 waves (4 x 2, 32 x 160 each) on the 32x32x16 MFMA: two waves per SIMD, balanced */
+#define UR_TILE_256x320_W16_M32 43 /* 16 waves (8 x 2, 32 x 160 each) */
+#define UR_TILE_128x160_M32 44    /* 4 waves (4 x 1, 32 x 160 each), 2-deep: N = 640 / 1280 layers in 4 / 8 column tiles without split-K */
+#define UR_TILE_128x160_S3_M32 45 /* the same, 3-deep */
+#define UR_TILE_64x320_M32 46     /* 4 waves (2 x 2, 32 x 160 each), 2-deep */
+#define UR_TILE_WS320 47          /* weight-streaming 3x3 conv, 128 pixels x 320 channels per workgroup (csrc/wsconv.hip):\
+                                     `w` is the stage-image stream of tchain.py wsconv_images, channels multiples of 320 */
+#define UR_TILE_COUNT 48
 
 /*
  * Implicit GEMM:  out[m][n] = epilogue( sum_k X[m][k] * W[n][k] )

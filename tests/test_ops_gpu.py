@@ -21,7 +21,7 @@ def _rand(shape, dtype, dev, scale=1.0, seed=0):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("tile", [t for t in range(1, 41) if t != 39])
+@pytest.mark.parametrize("tile", [t for t in range(1, 47) if t != 39])
 @pytest.mark.parametrize("shape", [(256, 320, 320), (300, 64, 128), (1000, 448, 640), (4, 1280, 320)])
 def test_linear_bias_res(dev, dtype, tile, shape):
     from uni_renderer_amd import ops
@@ -61,7 +61,7 @@ def test_linear_two_sources(dev, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("tile", [t for t in range(1, 41) if t != 39])
+@pytest.mark.parametrize("tile", [t for t in range(1, 47) if t != 39])
 def test_geglu(dev, dtype, tile):
     from uni_renderer_amd import ops
     from uni_renderer_amd.layers import geglu_perm
@@ -86,7 +86,7 @@ def _conv_ref(x_nhwc, w_oihw, b, stride=1, ups=False):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("tile", [t for t in range(1, 41) if t != 39])
+@pytest.mark.parametrize("tile", [t for t in range(1, 47) if t != 39])
 @pytest.mark.parametrize("mode", ["s1", "s2", "ups"])
 def test_conv3x3(dev, dtype, tile, mode):
     from uni_renderer_amd import ops

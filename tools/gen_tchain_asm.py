@@ -29,7 +29,18 @@ def dma_ops():
     return ops
 
 
-def stream(n, acc_of, frag_addr, b_of, valu=(), dma=False, c0=lambda m: None):
+def operand_dma_ops(n):
+    """LDS-DMA pieces of the NEXT operand block of csrc/wsconv.hip (n per stage): a `buffer_load ... lds` through the
+    source tensor's descriptor %[ors] with the per-lane byte offsets %[q<j>] (bit 31 set = zero padding: out of range
+    reads deliver 0), wave-uniform tap / channel-block offset %[oso], LDS destination %[ob] + j KiB."""
+    ops = []
+    for j in range(n):
+        pre = ["s_mov_b32 m0, %[ob]"] if j == 0 else [f"s_add_u32 m0, %[ob], 0x{j * 0x400:x}"]
+        ops.append(pre + ["s_nop 0", f"buffer_load_dwordx4 %[q{j}], %[ors], %[oso] offen lds"])
+    return ops
+
+
+def stream(n, acc_of, frag_addr, b_of, valu=(), dma=False, c0=lambda m: None, opieces=0):
     """n MFMAs; MFMA m multiplies fragment m (read from frag_addr(m) = (address operand, immediate offset)) with B operand
     b_of(m) into accumulator acc_of(m) (c0(m): literal C operand of a first MFMA).  `valu`: a VALU program spread evenly
     behind the MFMAs; `dma`: the LDS-DMA pieces of the next-but-one stage, one behind every fourth MFMA."""
@@ -44,6 +55,11 @@ def stream(n, acc_of, frag_addr, b_of, valu=(), dma=False, c0=lambda m: None):
     for m in range(min(AHEAD, n)):
         out.append(rd(m))
     pieces = dma_ops() if dma else []
+    where = {4 * i + 1: p for i, p in enumerate(pieces)}
+    if opieces:  # weight pieces first (every third MFMA), the operand pieces last: `s_waitcnt vmcnt(opieces)` then
+        # guarantees the weights of the next stage while the operand pieces may still be in flight
+        where = {3 * i + 1: p for i, p in enumerate(pieces)}
+        where.update({31 + (8 // opieces) * j: p for j, p in enumerate(operand_dma_ops(opieces))})
     per = -(-len(valu) // (n - 1)) if valu else 0
     pi = 0
     for m in range(n):
@@ -52,8 +68,8 @@ def stream(n, acc_of, frag_addr, b_of, valu=(), dma=False, c0=lambda m: None):
         out.append(f"v_mfma_f32_32x32x16_\" MT \" %[{acc_of(m)}], %[f{m % RD}], %[{b_of(m)}], {c}")
         if m + AHEAD < n:
             out.append(rd(m + AHEAD))
-        if pieces and m % 4 == 1 and m // 4 < len(pieces):
-            out += pieces[m // 4]
+        if m in where:
+            out += where[m]
         if m >= 1 and valu:
             out += valu[pi: pi + per]
             pi += per
@@ -154,6 +170,8 @@ def main():
         f.write("// N = 320 GEMM stage, without / with the LDS-DMA pieces of the stage two ahead\n")
         f.write("#define TC_ASM_GEMM_STAGE(MT) \\\n" + cstr(stream(*gargs)) + "\n\n")
         f.write("#define TC_ASM_GEMM_STAGE_DMA(MT) \\\n" + cstr(stream(*gargs, dma=True)) + "\n\n")
+        f.write("// conv stage (csrc/wsconv.hip): weights of the next stage + 5 pieces of the next operand block\n")
+        f.write("#define TC_ASM_CONV_STAGE(MT) \\\n" + cstr(stream(*gargs, dma=True, opieces=5)) + "\n\n")
         f.write("// feed-forward input stage + the GEGLU program of the previous half-chunk + LDS-DMA (tools/gen_tchain_asm.py)\n")
         f.write("#define TC_ASM_FFAG(MT) \\\n" + cstr(ffa_stream(True, True)) + "\n\n")
         f.write("#define TC_ASM_FFA(MT) \\\n" + cstr(ffa_stream(True, False)) + "\n\n")

@@ -39,6 +39,8 @@ def main():
     ap.add_argument("--broad", action="store_true", help="candidates = a fixed broad tile list (x current split-K, x2, /2) instead "
                     "of the isolated report's best few: the isolated ranking missed in-situ winners (a 128x64 tile for the "
                     "level-0 feed-forward GEMM whose isolated optimum is 256x256)")
+    ap.add_argument("--tiles", default="9,10,1,5,7,2,3,11,8,32,24,13", help="--broad: the tile ids tried per problem")
+    ap.add_argument("--min-rows", type=int, default=0, help="--broad: only problems with M >= this")
     ap.add_argument("--train", action="store_true", help="tune the captured TRAINING step (tools/train_bench.py --graph: cfg 4's "
                     "per-GPU shape, bf16) instead of the inference step; candidates = a fixed tile list at the current split-K")
     args = ap.parse_args()
@@ -89,7 +91,7 @@ def main():
     finally:
         ops.igemm = orig
     rep = {(r["M"], r["N"], r["K"], r["taps"], r["z"]): r for r in json.load(open(args.report))}
-    share = sorted(((rep[k[:5]]["best_us"] * n, k) for k, n in calls.items() if k[:5] in rep and (k[5] or not args.sites)),
+    share = sorted(((rep[k[:5]]["best_us"] * n, k) for k, n in calls.items() if k[:5] in rep and (k[5] or not args.sites) and k[0] >= args.min_rows),
                    reverse=True)[: args.top]
     base = measure()
     base2 = measure()
@@ -106,7 +108,7 @@ def main():
         if args.broad:
             sks = [cur[1]] + ([cur[1] * 2] if key[2] // 64 >= 8 * cur[1] and key[4] <= 4 else []) + ([cur[1] // 2] if cur[1] > 1 else [])
             for sk in sks:
-                for t in (9, 10, 1, 5, 7, 2, 3, 11, 8, 32, 24, 13):
+                for t in [int(v) for v in args.tiles.split(",")]:
                     if (t, sk) != cur and (t, sk) not in cands:
                         cands.append((t, sk))
         else:

@@ -675,7 +675,10 @@ static const TileCfg kTiles[UR_TILE_COUNT] = {{0, 0, 0},      {128, 128, 2}, {12
                                               // wave-specialised builds: dedicated loader waves (UR_TILE_*_L<n>)
                                               {128, 320, 2}, {128, 320, 2}, {128, 128, 2}, {128, 128, 3}, {128, 64, 2},
                                               {128, 64, 3},  {64, 64, 3},   {256, 128, 2}, {256, 256, 2}, {128, 256, 2},
-                                              {128, 256, 3}};
+                                              {128, 256, 3}, {128, 320, 2}, {256, 320, 2}, {128, 160, 2},
+                                              {128, 160, 3}, {64, 320, 2},
+                                              // weight-streaming conv (wsconv.hip)
+                                              {128, 320, 2}};
 
 static int pick_tile(const ur_igemm_desc& d) {
     // Cost model: the busiest CU runs ceil(workgroups / 256) tiles; bigger tiles have a better
@@ -725,6 +728,24 @@ static int launch_cfg(const ur_igemm_desc& d, hipStream_t s) {
     return 0;
 }
 
+int wsconv_launch(const ur_igemm_desc& d, hipStream_t s);  // wsconv.hip
+
+// weight-streaming conv main pass + the shared split-K second pass
+template <typename T>
+static int launch_ws(const ur_igemm_desc& d, hipStream_t s) {
+    const int rc = wsconv_launch(d, s);
+    if (rc) return rc;
+    if (d.splitk > 1) {
+        const int64_t total = (int64_t)d.M * (d.ldp / 16);
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL((igemm_splitk_reduce<T>), dim3(blocks, d.zbatch), dim3(256), 0, s, d);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return -(int)e;
+    }
+    return 0;
+}
+
 template <typename T>
 static int launch_dtype(ur_igemm_desc& d, hipStream_t s) {
     switch (d.tile) {
@@ -769,6 +790,12 @@ static int launch_dtype(ur_igemm_desc& d, hipStream_t s) {
         case UR_TILE_256x256_L0: return UR_E_UNSUPPORTED;  /* 16 consumer waves already fill the 1024-thread limit */
         case UR_TILE_128x256_L2: return launch_cfg<T, 128, 256, 2, 4, 2, 16, 2>(d, s);
         case UR_TILE_128x256_S3: return launch_cfg<T, 128, 256, 2, 4, 3>(d, s);
+        case UR_TILE_128x320_W8_M32: return launch_cfg<T, 128, 320, 4, 2, 2, 32>(d, s);
+        case UR_TILE_256x320_W16_M32: return launch_cfg<T, 256, 320, 8, 2, 2, 32>(d, s);
+        case UR_TILE_128x160_M32: return launch_cfg<T, 128, 160, 4, 1, 2, 32>(d, s);
+        case UR_TILE_128x160_S3_M32: return launch_cfg<T, 128, 160, 4, 1, 3, 32>(d, s);
+        case UR_TILE_64x320_M32: return launch_cfg<T, 64, 320, 2, 2, 2, 32>(d, s);
+        case UR_TILE_WS320: return launch_ws<T>(d, s);
     }
     return UR_E_BADARG;
 }

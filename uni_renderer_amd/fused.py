@@ -140,7 +140,8 @@ class GroupedDualStreamStep:
         c2 = pk.get("r.c2", rs, [r.conv2.bias for r in rs], dt, lambda: _stk(f32(r.conv2.bias) for r in rs))
         lo, hi = slice_
         h = ops.groupnorm(x, g1, b1, r0.eps, x1=x1, groups=r0.groups, silu=True, streams=S)
-        h = ops.conv3x3(h, w1, c1, rowadd=temb[:, lo:hi], streams=S, cblock=ops.conv_cblock(h.shape[-1]))
+        h = ops.conv3x3(h, w1, c1, rowadd=temb[:, lo:hi], streams=S, cblock=ops.conv_cblock(h.shape[-1]),
+                        ws=self._ws("r.w1ws", rs, [r.conv1.weight for r in rs], w1, h, streams=S))
         h = ops.groupnorm(h, g2, b2, r0.eps, groups=r0.groups, silu=True, streams=S)
         if r0.conv_shortcut is not None and ops.FOLD_SHORTCUT:
             # the 1x1 conv_shortcut over (x | x1) rides in conv2's K loop (ur_igemm_desc.t0 / t1): one launch less and no
@@ -151,7 +152,9 @@ class GroupedDualStreamStep:
             c2s = pk.get("r.c2s", rs, [t for r in rs for t in (r.conv2.bias, r.conv_shortcut.bias)], dt,
                          lambda: _stk(f32(r.conv2.bias) + f32(r.conv_shortcut.bias) for r in rs))
             return ops.conv3x3(h, w2s, c2s, tail=(x, x1), out_scale=1.0 / r0.output_scale_factor, streams=S, hilo=self.hilo,
-                               cblock=ops.conv_cblock(h.shape[-1]))
+                               cblock=ops.conv_cblock(h.shape[-1]),
+                               ws=self._ws("r.w2sws", rs, [t for r in rs for t in (r.conv2.weight, r.conv_shortcut.weight)], w2s, h,
+                                           tail=(x, x1), streams=S))
         if r0.conv_shortcut is not None:
             ws = pk.get("r.ws", rs, [r.conv_shortcut.weight for r in rs], dt,
                         lambda: _stk(pack_matrix(r.conv_shortcut.weight, dt) for r in rs))
@@ -160,7 +163,16 @@ class GroupedDualStreamStep:
         else:
             sc = x
         return ops.conv3x3(h, w2, c2, res=sc, out_scale=1.0 / r0.output_scale_factor, streams=S, hilo=self.hilo,
-                           cblock=ops.conv_cblock(h.shape[-1]))
+                           cblock=ops.conv_cblock(h.shape[-1]),
+                           ws=self._ws("r.w2ws", rs, [r.conv2.weight for r in rs], w2, h, streams=S))
+
+    def _ws(self, name, mods, params, w, x, tail=None, streams=1):
+        """Stage-image copy of the packed conv weights ``w`` [S, N, K] for the weight-streaming kernel, or None where the
+        LDS-tiled build is used (ops.wsconv_prefer)."""
+        N, K = w.shape[-2], w.shape[-1]
+        if not ops.wsconv_prefer(x, N, K, tail=tail, streams=streams):
+            return None
+        return self.pk.get(name, mods, params, x.dtype, lambda: _stk(ops.wsconv_images(w[i]) for i in range(w.shape[0])))
 
     def _attn(self, as_: Sequence[Attention], xn, residual, kc, vtc, kv_slice):
         S, pk, dt = len(as_), self.pk, xn.dtype

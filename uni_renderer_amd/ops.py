@@ -38,7 +38,11 @@ _TILES = {TILE_128x128: (128, 128, 1.0, 2), TILE_128x64: (128, 64, 0.85, 3), TIL
           # wave-specialised builds: n dedicated loader waves (UR_TILE_*_L<n>); 39 is reserved / not instantiated
           31: (128, 320, 1.3, "2L2"), 32: (128, 320, 1.3, "2L4"), 33: (128, 128, 1.2, "2L2"), 34: (128, 128, 1.2, "3L2"),
           35: (128, 64, 1.0, "2L1"), 36: (128, 64, 1.0, "3L2"), 37: (64, 64, 0.8, "3L1"), 38: (256, 128, 1.3, "2L2"),
-          40: (128, 256, 1.3, "2L2"), 41: (128, 256, 1.2, 3)}
+          40: (128, 256, 1.3, "2L2"), 41: (128, 256, 1.2, 3), 42: (128, 320, 1.2, "2w8m32"), 43: (256, 320, 1.2, "2w16m32"), 44: (128, 160, 1.0, "2m32"), 45: (128, 160, 1.0, "3m32"),
+          46: (64, 320, 0.9, "2m32"),
+          # weight-streaming conv (csrc/wsconv.hip): ``w`` is the stage-image stream of wsconv_images()
+          47: (128, 320, 1.4, "ws")}
+TILE_WS320 = 47
 _PLANNER_TILES = (TILE_128x128, TILE_128x64, TILE_64x64)
 
 _zero_pages = {}
@@ -325,14 +329,79 @@ def conv_cblock(cin: int) -> int:
     return CONV_CBLOCK if (CONV_CBLOCK > 0 and cin > CONV_CBLOCK and cin % CONV_CBLOCK == 0) else 0
 
 
+# Weight-streaming conv kernel (csrc/wsconv.hip) in the executors: OFF by default.  Isolated it matches or beats the tuned
+# LDS-tiled build by 2-6 % from K = 5760 up (tools/wsconv_bench.py), but inside the step -- weights cold in L2, one stage
+# of prefetch with one wave per SIMD -- the same launches are ~10 % slower: 11.88 -> 12.20 ms per step with it on for
+# K >= 5000 (tools/r03_run13.sh, two alternating repetitions on one box).  ``conv3x3(..., ws=...)`` still takes it
+# explicitly (tests/test_wsconv_gpu.py).
+WSCONV = os.environ.get("UR_WSCONV", "0") != "0"
+WS_C = 320
+
+
+def wsconv_images(w: torch.Tensor, n_out: Optional[int] = None) -> torch.Tensor:
+    """Packed conv weights [Npad >= N, K] (the cblock = 320 K order of pack_conv3x3, tail columns appended) -> the weight
+    stream of csrc/wsconv.hip: [N / 320][K / 64] stage images of 320 rows x 64 k (40960 bytes), the eight 16-byte chunks
+    of row r stored at position c ^ ((r >> 1) & 7) (tchain.py, ``_swizzle_rows``)."""
+    N = n_out if n_out is not None else w.shape[0]
+    K = w.shape[1]
+    if N % WS_C or K % WS_C:
+        raise RuntimeError("wsconv_images: N and K must be multiples of 320")
+    v = w[:N].reshape(N // WS_C, WS_C, K // 64, 8, 8).permute(0, 2, 1, 3, 4)      # [nt, stage, row, chunk, 8]
+    r = torch.arange(WS_C, device=w.device)
+    pos = torch.arange(8, device=w.device)[None, :] ^ ((r >> 1) & 7)[:, None]     # position c' holds chunk c' ^ key
+    idx = pos[None, None, :, :, None].expand(v.shape[0], v.shape[1], WS_C, 8, 8)
+    return torch.gather(v, 3, idx).reshape(-1).contiguous()
+
+
+def wsconv_ok(x, N, *, x1=None, stride=1, ups=False, pad=1, tail=None, streams=1) -> bool:
+    """Whether conv3x3 over ``x`` can take the weight-streaming kernel (mirror of wsconv_supported, csrc/wsconv.hip)."""
+    if x1 is not None or stride != 1 or ups or pad != 1:
+        return False
+    Bt, H, W, C0 = x.shape
+    if (H * W) % 128 or N % WS_C or C0 % WS_C or (C0 > WS_C and conv_cblock(C0) != WS_C):
+        return False
+    if tail is not None and any(t is not None and t.shape[-1] % WS_C for t in tail):
+        return False
+    cmax = max([C0] + [t.shape[-1] for t in (tail or ()) if t is not None])
+    return (Bt // streams * H * W + W + 2) * cmax * 2 < 2 ** 31
+
+
+WSCONV_MIN_K = int(os.environ.get("UR_WSCONV_MIN_K", "5000"))
+
+
+def wsconv_prefer(x, N, K, **kw) -> bool:
+    """Policy: the weight-streaming kernel where it measured faster than the tuned LDS-tiled build (tools/wsconv_bench.py:
+    +2 .. +6 % from K = 5760 up, -2 .. -20 % below: its per-workgroup prologue / epilogue is longer)."""
+    return WSCONV and K >= WSCONV_MIN_K and wsconv_ok(x, N, **kw)
+
+
+def wsconv_splitk(M, N, K, zbatch) -> int:
+    """Split-K of the weight-streaming conv: enough workgroups (128 pixels x 320 channels each) for the 256 CUs, never
+    fewer than three 320-channel K blocks per slice."""
+    t = _ws_table.get((M, N, K, zbatch))
+    if t is not None:
+        return t
+    wgs = (M // 128) * (N // WS_C) * zbatch
+    nblk = K // WS_C
+    sk = 1
+    while wgs * sk < 200 and nblk // (sk * 2) >= 3:
+        sk *= 2
+    return sk
+
+
+_ws_table: dict = {}
+
+
 def conv3x3(x, w, bias=None, *, x1=None, stride=1, ups=False, rowadd=None, res=None, out_scale=1.0, n_out=None,
-            tile=None, splitk=None, streams=1, hilo=False, cblock=0, tail=None, pad=1):
+            tile=None, splitk=None, streams=1, hilo=False, cblock=0, tail=None, pad=1, ws=None):
     """3x3 conv, pad 1, over NHWC ``x`` (optionally cat(x, x1) on channels, optionally after a nearest-2x
     upsample).  ``w`` is [Npad >= n_out, 9*Cin] with k = (ky*3+kx)*Cin + c, or, with ``cblock`` > 0, in the
     block-outer order k = (c // cblock)*9*cblock + (ky*3+kx)*cblock + c % cblock.  Output [B, Ho, Wo, n_out].
     ``tail=(t0, t1 | None)``: a 1x1 conv over cat(t0, t1) (NHWC, the OUTPUT's spatial size) added in the same K loop;
     its [N, Ct0 + Ct1] weight matrix is appended to ``w`` along K (stride 1, no upsampling only).
-    ``streams=S``: x is [S*B, H, W, C] (stream-major), ``w`` [S, N, 9*Cin], ``bias`` [S, N]: one grouped launch."""
+    ``streams=S``: x is [S*B, H, W, C] (stream-major), ``w`` [S, N, 9*Cin], ``bias`` [S, N]: one grouped launch.
+    ``ws``: the same weights as stage images (``wsconv_images``; [S, N*K] with streams): when given and the shape fits
+    (``wsconv_ok``) the weight-streaming kernel runs instead of the LDS-tiled one."""
     Bt, H, W, C0 = x.shape
     B = Bt // streams
     C1 = x1.shape[-1] if x1 is not None else 0
@@ -358,9 +427,20 @@ def conv3x3(x, w, bias=None, *, x1=None, stride=1, ups=False, rowadd=None, res=N
         ca, cb_ = ta.shape[-1], (tb.shape[-1] if tb is not None else 0)
         tl = dict(t0=ta, t1=tb, ldt0=ca, ldt1=cb_, ct0=ca, ct1=cb_,
                   zt0=(M * ca if streams > 1 else 0), zt1=(M * cb_ if streams > 1 else 0))
-    igemm(x0=x, x1=x1, w=w, out=out, M=M, N=N, K=9 * (C0 + C1) + sum(tl.get(k, 0) for k in ("ct0", "ct1")), c0=C0, c1=C1, ldx0=C0, ldx1=C1,
-          ldw=w.stride(-2), ldc=N, taps=9, conv=(B, H, W, Ho, Wo), stride=stride, ups=int(ups), bias=bias,
+    Kt = 9 * (C0 + C1) + sum(tl.get(k, 0) for k in ("ct0", "ct1"))
+    ldw = w.stride(-2)
+    if ws is not None and tile in (None, TILE_WS320) and wsconv_ok(x, N, x1=x1, stride=stride, ups=ups, pad=pad, tail=tail, streams=streams):
+        if C0 > WS_C and cblock != WS_C:
+            raise RuntimeError("conv3x3: the weight-streaming kernel walks K in the cblock = 320 order")
+        w, tile, ldw = ws, TILE_WS320, 8
+        if streams > 1:
+            z["zw"] = ws.stride(0)
+        if splitk is None:
+            splitk = wsconv_splitk(M, N, Kt, streams)
+    igemm(x0=x, x1=x1, w=w, out=out, M=M, N=N, K=Kt, c0=C0, c1=C1, ldx0=C0, ldx1=C1,
+          ldw=ldw, ldc=N, taps=9, conv=(B, H, W, Ho, Wo), stride=stride, ups=int(ups), bias=bias,
           rowadd=rowadd, rows_per_b=Ho * Wo, res=res, ldres=(N if res is not None else 0), out_scale=out_scale,
+          act=(int(os.environ.get("UR_WS_DEBUG_ACT", "0")) if tile == TILE_WS320 else ACT_NONE),
           tile=tile, splitk=splitk, res_lo=lo_of(res), out_lo=lo_of(out), cblock=cblock, pad=pad, **tl, **z)
     return out
 
