@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define UR_ABI_VERSION 5
+#define UR_ABI_VERSION 6
 
 #define UR_E_BADARG (-1001)   /* inconsistent descriptor (shape / alignment / null pointer)   */
 #define UR_E_UNSUPPORTED (-1002) /* shape outside what the kernels are instantiated for       */
@@ -346,6 +346,9 @@ int ur_transpose2d(const void* src, int64_t ld_src, int64_t bs_src, void* dst, i
                    int C, int batch, int dtype, void* stream);
 int ur_im2col3x3_t(const void* x, int B, int H, int W, int C, int stride, void* out, int64_t ld_out, int dtype,
                    void* stream);
+/* out[k][c] = sum over b < B of in[b][c][k], k = 0, 1 (fp32): the per-sample (sum dz, sum dz * xhat) pairs of the GroupNorm
+ * backward reduced over the batch straight into two contiguous parameter-gradient rows (dbeta = out[0], dgamma = out[1]). */
+int ur_pairsum_rows(const float* in, int B, int C, float* out, void* stream);
 int64_t ur_colsum_workspace_floats(int M, int N, int rows_per_group);
 int ur_colsum(const void* x, int64_t ldx, int M, int N, int rows_per_group, float* out, float* workspace, int dtype,
               void* stream);
@@ -365,6 +368,12 @@ typedef struct ur_transpose_desc {
     void* dst;
     int64_t ld_src, bs_src, ld_dst, bs_dst;
     int32_t R, C, batch, pad_;
+    /* optional fused column sums of the source (batch == 1): colsum[c] = sum_r src[r][c] in fp32, deterministic.
+     * colsum_ws: ceil(R / 64) * C floats of scratch; colsum_cnt: ceil(C / 64) zero-initialised counters that the launch
+     * leaves zero again (one buffer can serve every call on a stream). */
+    float* colsum;
+    float* colsum_ws;
+    uint32_t* colsum_cnt;
 } ur_transpose_desc;
 int ur_transpose2d_multi(const ur_transpose_desc* descs, int n, int dtype, void* stream);
 

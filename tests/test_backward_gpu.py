@@ -318,6 +318,26 @@ def test_transpose2d_many(dev):
         assert torch.equal(o, bw.transpose2d(x))
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("R,C", [(77, 320), (16384, 320), (4096, 1280), (100, 8), (1000, 136), (64, 64), (2, 5120)])
+def test_transpose2d_many_fused_colsum(dev, dtype, R, C):
+    """the bias gradient computed by the transpose launch (ur_transpose_desc.colsum): == fp64 column sums of the same
+    rounded values to fp32 accuracy, bitwise reproducible, transposes unchanged, counters left at zero."""
+    from uni_renderer_amd import backward as bw
+    g = torch.Generator().manual_seed(R + C)
+    y = (torch.randn(R, C, generator=g) + 0.25).to(dtype).to(dev)
+    other = torch.randn(40, 72, generator=g).to(dtype).to(dev)
+    (ot, yt), s = bw.transpose2d_many([other, y], colsum_of=1)
+    assert torch.equal(yt, bw.transpose2d(y)) and torch.equal(ot, bw.transpose2d(other))
+    want = y.double().sum(0)
+    assert s.dtype == torch.float32 and s.shape == (C,)
+    assert float((s.double() - want).abs().max()) <= 2e-6 * float(y.double().abs().sum(0).max())
+    (_, _), s2 = bw.transpose2d_many([other, y], colsum_of=1)
+    assert torch.equal(s, s2)
+    assert int(bw._colsum_counter(y.device).abs().sum()) == 0
+    assert float((bw.colsum(y).double() - want).abs().max()) <= 2e-6 * float(y.double().abs().sum(0).max())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("shape", [(2, 2, 40, 128, 128), (1, 2, 40, 100, 77), (1, 2, 80, 64, 64), (1, 2, 160, 96, 40)])
 def test_attention_forward_lse(dev, dtype, shape):
     """ur_attn_desc.lse: the forward kernels' row log-sum-exp (log2 units) against fp32 logsumexp of the scaled scores."""

@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must be imported first, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("UR_LIB_PATH", os.path.join(_HERE, "liburhip.so"))  # override = kernel experiments only
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
@@ -112,6 +112,7 @@ SYMBOLS = {
     "ur_im2col3x3_t": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int64, C.c_int, vp]),
     "ur_colsum_workspace_floats": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
     "ur_colsum": (C.c_int, [vp, C.c_int64, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp]),
+    "ur_pairsum_rows": (C.c_int, [vp, C.c_int, C.c_int, vp, vp]),
     "ur_silu_backward": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int, vp]),
     "ur_geglu_forward": (C.c_int, [vp, vp, C.c_int64, C.c_int, C.c_int, vp]),
     "ur_geglu_backward": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int, C.c_int, vp]),

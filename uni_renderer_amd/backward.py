@@ -46,17 +46,38 @@ def transpose2d(x: torch.Tensor) -> torch.Tensor:
 class _TransposeDesc(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("ld_src", C.c_int64), ("bs_src", C.c_int64),
                 ("ld_dst", C.c_int64), ("bs_dst", C.c_int64), ("R", C.c_int32), ("C", C.c_int32), ("batch", C.c_int32),
-                ("pad_", C.c_int32)]
+                ("pad_", C.c_int32), ("colsum", C.c_void_p), ("colsum_ws", C.c_void_p), ("colsum_cnt", C.c_void_p)]
+
+
+# Bias gradients inside the transpose launch (ur_transpose_desc.colsum): correct and deterministic, removes ~650 launches per
+# step, but every transposing workgroup then pays a memory-side store + counter round trip: 84.7 vs 84.6 ms per graphed
+# step (tools/r03_run14.sh) -- no gain, so off by default.
+FUSED_COLSUM = os.environ.get("UR_FUSED_COLSUM", "0") != "0"
+_colsum_counters: dict = {}
+
+
+def _colsum_counter(device) -> torch.Tensor:
+    """Per-device counter block of the fused column sums (``ur_transpose_desc.colsum_cnt``): zero between launches by
+    construction, shared by every call on the (single) training stream."""
+    t = _colsum_counters.get(device)
+    if t is None:
+        t = _colsum_counters[device] = torch.zeros(4096, dtype=torch.int32, device=device)
+    return t
 
 
 MULTI_TRANSPOSE = os.environ.get("UR_MULTI_TRANSPOSE", "1") != "0"
 
 
-def transpose2d_many(xs) -> list:
+def transpose2d_many(xs, colsum_of: Optional[int] = None):
     """``[transpose2d(x) for x in xs]`` in one launch per four tensors (``ur_transpose2d_multi``): same dtype, each
-    [..., R, C] -> [..., C, ceil8(R)]."""
+    [..., R, C] -> [..., C, ceil8(R)].  ``colsum_of = i``: also the fp32 column sums of the 2-D tensor xs[i], computed by
+    the same launch from the tiles it reads anyway (the bias gradient of a linear / conv backward); returns
+    (outs, sums)."""
     xs = list(xs)
-    if not MULTI_TRANSPOSE or len(xs) == 1:
+    if colsum_of is not None and not (FUSED_COLSUM and MULTI_TRANSPOSE and xs[colsum_of].dim() == 2
+                                      and xs[colsum_of].shape[1] <= 64 * 4096):
+        return transpose2d_many(xs), colsum(xs[colsum_of])
+    if colsum_of is None and (not MULTI_TRANSPOSE or len(xs) == 1):
         return [transpose2d(x) for x in xs]
     lib = _lib.load()
     outs, descs = [], []
@@ -75,6 +96,7 @@ def transpose2d_many(xs) -> list:
     if len({x.dtype for x in xs}) != 1:
         raise ValueError("transpose2d_many: one dtype per call")
     nmax = 4
+    sums = ws = None
     for i in range(0, len(descs), nmax):
         part = descs[i:i + nmax]
         arr = (_TransposeDesc * len(part))()
@@ -82,8 +104,13 @@ def transpose2d_many(xs) -> list:
             arr[k].src, arr[k].dst = x.data_ptr(), out.data_ptr()
             arr[k].ld_src, arr[k].bs_src, arr[k].ld_dst, arr[k].bs_dst = ld, bs, ldd, bsd
             arr[k].R, arr[k].C, arr[k].batch = R, Cc, batch
+            if colsum_of is not None and i + k == colsum_of:
+                sums = torch.empty(Cc, dtype=torch.float32, device=x.device)
+                ws = torch.empty((R + 63) // 64 * Cc, dtype=torch.float32, device=x.device)
+                arr[k].colsum, arr[k].colsum_ws = sums.data_ptr(), ws.data_ptr()
+                arr[k].colsum_cnt = _colsum_counter(x.device).data_ptr()
         check(lib.ur_transpose2d_multi(arr, len(part), DT[xs[0].dtype], _stream()), "ur_transpose2d_multi")
-    return outs
+    return outs if colsum_of is None else (outs, sums)
 
 
 class _CastDesc(C.Structure):
@@ -150,11 +177,13 @@ def linear_backward(x: torch.Tensor, w: torch.Tensor, dy: torch.Tensor, need_bia
     K, N = x.shape[-1], w.shape[0]
     x2, dy2 = x.reshape(-1, K), dy.reshape(-1, N)
     dy2p = dy2  # transpose2d zero-pads the row count (M = batch rows in the time-embedding GEMMs) to a multiple of 8
-    wt, dyt, xt = transpose2d_many([w, dy2p, x2])         # [K, N], [N, M], [K, M]: one launch
+    if need_bias:  # db rides in the transpose launch: dy is read there anyway
+        (wt, dyt, xt), db = transpose2d_many([w, dy2p, x2], colsum_of=1)
+    else:
+        (wt, dyt, xt), db = transpose2d_many([w, dy2p, x2]), None   # [K, N], [N, M], [K, M]: one launch
     dx = ops.linear(dy2, wt).view(x.shape)                # [M, N] @ [K, N]^T
     dyt, xt = _pad_rows64(dyt), _pad_rows64(xt)
     dw = ops.linear(dyt, xt)                              # [N, M] @ [K, M]^T = [N, K]
-    db = colsum(dy2) if need_bias else None
     return dx, dw, db
 
 
@@ -222,9 +251,13 @@ def conv3x3_backward(x: torch.Tensor, w_packed: torch.Tensor, dy: torch.Tensor, 
     xcol_t = torch.empty(9 * Cc, Pp, dtype=x.dtype, device=x.device)
     check(lib.ur_im2col3x3_t(x.contiguous().data_ptr(), B, H, W, Cc, stride, xcol_t.data_ptr(), Pp, DT[x.dtype], _stream()),
           "ur_im2col3x3_t")
-    dyt = _pad_rows64(transpose2d(dyp.reshape(P, Np)))        # [Np, Pp]
+    if need_bias:
+        (dyt,), db = transpose2d_many([dyp.reshape(P, Np)], colsum_of=0)
+        db = db[:N].contiguous()
+    else:
+        dyt, db = transpose2d(dyp.reshape(P, Np)), None
+    dyt = _pad_rows64(dyt)                                    # [Np, Pp]
     dw = ops.linear(dyt, xcol_t)[:N]                          # [Np, Pp] @ [9C, Pp]^T = [Np, 9C]
-    db = colsum(dyp.reshape(P, Np))[:N].contiguous() if need_bias else None
     return dx, dw, db
 
 
@@ -276,8 +309,9 @@ def groupnorm_backward(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, b
     check(lib.ur_groupnorm_backward(x.data_ptr(), dy.data_ptr(), Cc, B, rows, groups, nstat, part.data_ptr(),
                                     gamma.data_ptr(), beta.data_ptr(), float(eps), int(silu), nred, chan_part.data_ptr(),
                                     chan_sum.data_ptr(), nchunks, dx.data_ptr(), DT[x.dtype], s), "ur_groupnorm_backward")
-    sums = (chan_sum[0] if B == 1 else colsum(chan_sum.view(B, 2 * Cc)).view(Cc, 2))  # (sum dz, sum dz*xhat) per channel
-    return dx, sums[:, 1].contiguous(), sums[:, 0].contiguous()
+    sums = torch.empty(2, Cc, dtype=torch.float32, device=x.device)  # rows: sum dz (= dbeta), sum dz * xhat (= dgamma)
+    check(lib.ur_pairsum_rows(chan_sum.data_ptr(), B, Cc, sums.data_ptr(), s), "ur_pairsum_rows")
+    return dx, sums[1], sums[0]
 
 
 def layernorm_backward(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, eps: float = 1e-5
@@ -289,7 +323,7 @@ def layernorm_backward(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, e
     rows = x.numel() // Cc
     rpw = max(1, min(64, rows // 2048))  # rows per wave: enough waves to fill the chip, few partial rows
     waves = (rows + rpw - 1) // rpw
-    part = torch.zeros(waves, 2, Cc, dtype=torch.float32, device=x.device)
+    part = torch.empty(waves, 2, Cc, dtype=torch.float32, device=x.device)  # every wave writes its whole row
     dx = torch.empty_like(x)
     check(lib.ur_layernorm_backward(x.data_ptr(), dy.data_ptr(), gamma.data_ptr(), float(eps), rows, Cc, rpw, dx.data_ptr(),
                                     part.data_ptr(), DT[x.dtype], _stream()), "ur_layernorm_backward")

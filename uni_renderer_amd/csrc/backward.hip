@@ -21,6 +21,13 @@ namespace ur {
 // 2-byte accesses).  Word index inside a column is XOR-swizzled in 4-word groups to spread the banks.
 __device__ __forceinline__ int tp_word(int c, int r2) { return c * 32 + ((((r2 >> 2) ^ (c >> 3)) & 7) << 2 | (r2 & 3)); }
 
+template <typename T>
+__device__ __forceinline__ float bits_to_f(uint16_t b) {
+    T v;
+    __builtin_memcpy(&v, &b, 2);
+    return (float)v;
+}
+
 template <typename T, typename LoadRow>
 __device__ __forceinline__ void transpose_tile_64x64(LoadRow load_row, uint32_t* tile, T* __restrict__ dst, int64_t ld_dst,
                                                      int c_valid, int r_valid8, int t) {
@@ -103,6 +110,56 @@ __global__ void __launch_bounds__(256) transpose2d_multi_kernel(const TransposeM
         return v;
     };
     transpose_tile_64x64<T>(load_row, tile, dst + (int64_t)c0 * d.ld_dst + r0, d.ld_dst, C - c0, ((R + 7) & ~7) - r0, t);
+    if (!d.colsum) return;
+    // ---- fused column sums of the source (the bias gradient of a linear / conv backward: dy is read here anyway) ----
+    // The tile in LDS holds column c as 32 packed words (rows 2 w, 2 w + 1; rows >= R are zeros).  Thread c < 64 adds them
+    // in fp32, starting at word c & 31 (bank spread; the order is fixed per column), and writes the tile's partial to
+    // ws[row tile][column].  The last workgroup of a column tile (device-scope counter, reset for the next launch) adds
+    // the partials in row-tile order: deterministic, no separate reduction launch.
+    // Cross-workgroup visibility WITHOUT a fence: an agent-scope release (__threadfence) writes back the XCD's whole L2
+    // -- measured +110 us per launch with 256+ workgroups doing it.  Instead the partials are stored / loaded with
+    // relaxed AGENT-scope atomics (they bypass the non-coherent L2s), each storing thread waits for its store to be
+    // acknowledged (vmcnt) before the workgroup barrier, and only then is the counter bumped.
+    __shared__ float red[4][64];
+    __shared__ int last;
+    const int ct = c0 >> 6, rt = r0 >> 6;
+    if (t < 64) {
+        float acc = 0.f;
+#pragma unroll 8
+        for (int j = 0; j < 32; ++j) {
+            const uint32_t w = tile[t * 32 + ((j + t) & 31)];
+            acc += bits_to_f<T>((uint16_t)(w & 0xffffu)) + bits_to_f<T>((uint16_t)(w >> 16));
+        }
+        if (c0 + t < C) __hip_atomic_store(d.colsum_ws + (int64_t)rt * C + c0 + t, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    if (t == 0) {
+        const unsigned prev = __hip_atomic_fetch_add(d.colsum_cnt + ct, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = prev == (unsigned)(tr - 1);
+        if (last) __hip_atomic_store(d.colsum_cnt + ct, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // all others have arrived
+    }
+    __syncthreads();
+    if (!last) return;
+    const int nl = t & 63, q = t >> 6, n = c0 + nl;
+    const int len = (tr + 3) >> 2, k0 = q * len, k1 = min(tr, k0 + len);
+    float fs = 0.f;
+    if (n < C) {
+        // eight partials in flight per round trip (an agent-scope load goes to the memory side: ~1.5 us each way)
+        int k = k0;
+        for (; k + 8 <= k1; k += 8) {
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                v[i] = __hip_atomic_load(d.colsum_ws + (int64_t)(k + i) * C + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) fs += v[i];
+        }
+        for (; k < k1; ++k) fs += __hip_atomic_load(d.colsum_ws + (int64_t)k * C + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    red[q][nl] = fs;
+    __syncthreads();
+    if (q == 0 && n < C) d.colsum[n] = ((red[0][nl] + red[1][nl]) + red[2][nl]) + red[3][nl];
 }
 
 // Transposed im2col of a 3x3 / pad 1 convolution: out[(tap*C + c)][p] = x[pixel(p, tap)][c] (0 outside the image),
@@ -764,6 +821,7 @@ extern "C" int ur_transpose2d_multi(const ur_transpose_desc* descs, int n, int d
         if (!d.src || !d.dst || d.R <= 0 || d.C <= 0 || d.batch <= 0 || (d.C & 7) || (d.ld_src & 7) || (d.ld_dst & 7) ||
             (d.bs_src & 7) || (d.bs_dst & 7) || d.ld_dst < ((d.R + 7) & ~7))
             return UR_E_BADARG;
+        if (d.colsum && (d.batch != 1 || !d.colsum_ws || !d.colsum_cnt)) return UR_E_BADARG;
         a.d[i] = d;
         a.tile0[i] = (int)tiles;
         tiles += (int64_t)((d.C + 63) / 64) * ((d.R + 63) / 64) * d.batch;
@@ -786,6 +844,25 @@ extern "C" int ur_im2col3x3_t(const void* x, int B, int H, int W, int C, int str
     dim3 grid((C + 63) / 64, (int)((ld_out + 63) / 64), 9);
     UR_DISPATCH(dtype, hipLaunchKernelGGL((im2col3x3_t_kernel<T>), grid, dim3(256), 0, s, (const T*)x, B, H, W, C, Ho, Wo,
                                           stride, (T*)out, ld_out));
+    return last_error();
+}
+
+__global__ void __launch_bounds__(256) pairsum_rows_kernel(const float* __restrict__ in, int B, int C, float* __restrict__ out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float a = 0.f, b2 = 0.f;
+    for (int b = 0; b < B; ++b) {  // fixed order
+        const float2 v = *reinterpret_cast<const float2*>(in + ((int64_t)b * C + c) * 2);
+        a += v.x;
+        b2 += v.y;
+    }
+    out[c] = a;
+    out[C + c] = b2;
+}
+
+extern "C" int ur_pairsum_rows(const float* in, int B, int C, float* out, void* stream) {
+    if (!in || !out || B <= 0 || C <= 0) return UR_E_BADARG;
+    hipLaunchKernelGGL(pairsum_rows_kernel, dim3((C + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), in, B, C, out);
     return last_error();
 }
 

@@ -77,12 +77,10 @@ def _temb_projections(resnets, temb_act, dt):
     w = torch.cat([_wc(r.time_emb_proj.weight, dt) for r in resnets], 0)
     b = torch.cat([r.time_emb_proj.bias for r in resnets], 0)
     t_all = A.linear(temb_act, w, b)
-    out, off = {}, 0
-    for r in resnets:
-        n = r.time_emb_proj.weight.shape[0]
-        out[id(r)] = t_all[:, off:off + n]
-        off += n
-    return out
+    # torch.split, not per-resnet slicing: its backward is ONE cat of the slice gradients, where every SliceBackward
+    # allocates a zero-filled full-width tensor, copies its slice in and adds it to the running sum (3 launches each)
+    parts = torch.split(t_all, [r.time_emb_proj.weight.shape[0] for r in resnets], dim=1)
+    return {id(r): part for r, part in zip(resnets, parts)}
 
 
 def _resnets_of(blocks, mid=None):
@@ -116,7 +114,8 @@ def _cross_attn(a, xn, kv, res, dt):
     """``kv`` [B, 77, 2C]: this block's columns of the phase-wide prompt projection (_context_projections)."""
     Cc = a.to_q.weight.shape[0]
     q = A.linear(xn, _w2(a.to_q, dt))
-    o = A.Attention.apply(q, kv[..., :Cc], kv[..., Cc:], a.heads)
+    k_, v_ = torch.split(kv, Cc, dim=-1)
+    o = A.Attention.apply(q, k_, v_, a.heads)
     return A.linear(o, _w2(a.to_out[0], dt), a.to_out[0].bias, res=res)
 
 
@@ -128,12 +127,8 @@ def _context_projections(blocks, ehs, dt):
         return {}
     w = torch.cat([_wc(w_, dt) for tb in tbs for w_ in (tb.attn2.to_k.weight, tb.attn2.to_v.weight)], 0)
     kv_all = A.linear(ehs, w)
-    out, off = {}, 0
-    for tb in tbs:
-        n = 2 * tb.attn2.to_k.weight.shape[0]
-        out[id(tb)] = kv_all[..., off:off + n]
-        off += n
-    return out
+    parts = torch.split(kv_all, [2 * tb.attn2.to_k.weight.shape[0] for tb in tbs], dim=-1)  # one cat in the backward
+    return {id(tb): part for tb, part in zip(tbs, parts)}
 
 
 def _tblock(b, x, kvs, dt):
