@@ -361,13 +361,15 @@ int ur_groupnorm_backward(const void* x, const void* dy, int C, int B, int rows,
 int ur_layernorm_backward(const void* x, const void* dy, const float* gamma, float eps, int rows, int C,
                           int rows_per_wave, void* dx, float* part, int dtype, void* stream);
 /* Up to UR_TRANSPOSE_MAX independent batched transposes (each as ur_transpose2d: dst[b][c][r] = src[b][r][c], rows
- * R .. ceil8(R) of the source read as zeros) in one launch; same dtype for all. */
+ * R .. ceil8(R) -- or rows_out -- of the source read as zeros) in one launch; same dtype for all. */
 #define UR_TRANSPOSE_MAX 4
 typedef struct ur_transpose_desc {
     const void* src;
     void* dst;
     int64_t ld_src, bs_src, ld_dst, bs_dst;
-    int32_t R, C, batch, pad_;
+    int32_t R, C, batch;
+    int32_t rows_out;  /* 0: ceil8(R) destination columns are written (zeros past R); else a multiple of 8 in
+                          [R, ceil64(R)]: the zero padding a following GEMM needs on its contraction dimension */
     /* optional fused column sums of the source (batch == 1): colsum[c] = sum_r src[r][c] in fp32, deterministic.
      * colsum_ws: ceil(R / 64) * C floats of scratch; colsum_cnt: ceil(C / 64) zero-initialised counters that the launch
      * leaves zero again (one buffer can serve every call on a stream). */

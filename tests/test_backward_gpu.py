@@ -317,6 +317,21 @@ def test_transpose2d_many(dev):
         assert torch.equal(o[..., :R], x.transpose(-1, -2)) and float(o[..., R:].abs().sum()) == 0.0
         assert torch.equal(o, bw.transpose2d(x))
 
+def test_transpose2d_many_pad64(dev):
+    """rows_out: the launch itself zero-pads the transposed row length to the dW GEMM's 64-granularity"""
+    from uni_renderer_amd import backward as bw
+    g = torch.Generator().manual_seed(9)
+    xs = [torch.randn(308, 320, generator=g).to(torch.bfloat16).to(dev), torch.randn(4, 1280, generator=g).to(torch.bfloat16).to(dev),
+          torch.randn(128, 64, generator=g).to(torch.bfloat16).to(dev)]
+    outs = bw.transpose2d_many(xs, pad64=(0, 1))
+    assert outs[0].shape == (320, 320) and outs[1].shape == (1280, 64) and outs[2].shape == (64, 128)
+    for x, o in zip(xs, outs):
+        R = x.shape[0]
+        assert torch.equal(o[:, :R], x.t()) and float(o[:, R:].abs().sum()) == 0.0
+    (o2, _, _), s = bw.transpose2d_many(xs, colsum_of=1, pad64=(0, 1))
+    assert torch.equal(o2, outs[0]) and float((s - xs[1].float().sum(0)).abs().max()) < 1e-5
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("R,C", [(77, 320), (16384, 320), (4096, 1280), (100, 8), (1000, 136), (64, 64), (2, 5120)])
 def test_transpose2d_many_fused_colsum(dev, dtype, R, C):

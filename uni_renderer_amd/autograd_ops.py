@@ -71,13 +71,14 @@ class GroupNorm(Function):
     def forward(ctx, x, gamma, beta, eps, groups, silu):
         ctx.save_for_backward(x, gamma, beta)
         ctx.cfg = (float(eps), int(groups), bool(silu))
-        return ops.groupnorm(x, gamma, beta, eps, groups=groups, silu=silu)
+        y, ctx.stats = ops.groupnorm(x, gamma, beta, eps, groups=groups, silu=silu, return_stats=True)
+        return y
 
     @staticmethod
     def backward(ctx, dy):
         x, gamma, beta = ctx.saved_tensors
         eps, groups, silu = ctx.cfg
-        dx, dg, db = bw.groupnorm_backward(x, dy.contiguous(), gamma, beta, eps, groups=groups, silu=silu)
+        dx, dg, db = bw.groupnorm_backward(x, dy.contiguous(), gamma, beta, eps, groups=groups, silu=silu, stats=ctx.stats)
         return dx, dg, db, None, None, None
 
 
@@ -104,9 +105,14 @@ class Attention(Function):
         B, Tq, Cc = q.shape
         Tk = k.shape[1]
         d = Cc // heads
-        vt = bw._pad_rows64(bw.transpose2d(v.contiguous()))  # [B, C, Tk_pad]
+        # column slices of a wider projection (the [B, 77, 2C] k | v of a cross-attention) are read in place: the kernels
+        # take a leading dimension, transpose2d a strided source
+        inplace = lambda t: (t.stride(-1) == 1 and t.stride(0) == t.shape[1] * t.stride(1) and t.stride(1) % 8 == 0
+                             and t.storage_offset() % 8 == 0)
+        k_ = k if inplace(k) else k.contiguous()
+        vt = bw._pad_rows64(bw.transpose2d(v if inplace(v) else v.contiguous()))  # [B, C, Tk_pad]
         stats = bw.flash_stats(B, heads, Tq, Tk, d, q.device)  # [2, B*H, T] when the flash backward will run, else None
-        o = ops.attention(q.contiguous(), k.contiguous(), vt, B=B, H=heads, Tq=Tq, Tk=Tk, d=d, ldq=Cc, ldk=Cc,
+        o = ops.attention(q.contiguous(), k_, vt, B=B, H=heads, Tq=Tq, Tk=Tk, d=d, ldq=Cc, ldk=k_.stride(1),
                           lse=None if stats is None else stats[0])
         ctx.save_for_backward(q, k, v, o)  # o: rowsum(do * o) of the flash backward (the out projection keeps it anyway)
         ctx.heads, ctx.stats = heads, stats

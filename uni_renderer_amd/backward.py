@@ -46,7 +46,7 @@ def transpose2d(x: torch.Tensor) -> torch.Tensor:
 class _TransposeDesc(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("ld_src", C.c_int64), ("bs_src", C.c_int64),
                 ("ld_dst", C.c_int64), ("bs_dst", C.c_int64), ("R", C.c_int32), ("C", C.c_int32), ("batch", C.c_int32),
-                ("pad_", C.c_int32), ("colsum", C.c_void_p), ("colsum_ws", C.c_void_p), ("colsum_cnt", C.c_void_p)]
+                ("rows_out", C.c_int32), ("colsum", C.c_void_p), ("colsum_ws", C.c_void_p), ("colsum_cnt", C.c_void_p)]
 
 
 # Bias gradients inside the transpose launch (ur_transpose_desc.colsum): correct and deterministic, removes ~650 launches per
@@ -68,23 +68,29 @@ def _colsum_counter(device) -> torch.Tensor:
 MULTI_TRANSPOSE = os.environ.get("UR_MULTI_TRANSPOSE", "1") != "0"
 
 
-def transpose2d_many(xs, colsum_of: Optional[int] = None):
+def transpose2d_many(xs, colsum_of: Optional[int] = None, pad64=()):
     """``[transpose2d(x) for x in xs]`` in one launch per four tensors (``ur_transpose2d_multi``): same dtype, each
     [..., R, C] -> [..., C, ceil8(R)].  ``colsum_of = i``: also the fp32 column sums of the 2-D tensor xs[i], computed by
     the same launch from the tiles it reads anyway (the bias gradient of a linear / conv backward); returns
-    (outs, sums)."""
+    (outs, sums).  ``pad64``: indices of the tensors whose transposed row length is zero-padded to a multiple of 64 by the
+    launch itself (the contraction dimension of the dW GEMM) instead of by a zero fill + copy afterwards."""
     xs = list(xs)
+    if pad64 and not MULTI_TRANSPOSE:
+        outs = transpose2d_many(xs, colsum_of=colsum_of)
+        o, rest = (outs if colsum_of is None else outs[0]), (None if colsum_of is None else outs[1])
+        o = [_pad_rows64(t) if i in pad64 else t for i, t in enumerate(o)]
+        return o if colsum_of is None else (o, rest)
     if colsum_of is not None and not (FUSED_COLSUM and MULTI_TRANSPOSE and xs[colsum_of].dim() == 2
                                       and xs[colsum_of].shape[1] <= 64 * 4096):
-        return transpose2d_many(xs), colsum(xs[colsum_of])
-    if colsum_of is None and (not MULTI_TRANSPOSE or len(xs) == 1):
+        return transpose2d_many(xs, pad64=pad64), colsum(xs[colsum_of])
+    if colsum_of is None and not pad64 and (not MULTI_TRANSPOSE or len(xs) == 1):
         return [transpose2d(x) for x in xs]
     lib = _lib.load()
     outs, descs = [], []
-    for x in xs:
+    for i, x in enumerate(xs):
         _require_gpu(x)
         R, Cc = x.shape[-2:]
-        Rp = (R + 7) // 8 * 8
+        Rp = (R + 63) // 64 * 64 if i in pad64 else (R + 7) // 8 * 8
         if x.dim() == 3 and x.stride(2) == 1 and x.stride(1) % 8 == 0 and x.stride(0) % 8 == 0 and x.storage_offset() % 8 == 0:
             ld, bs, batch = x.stride(1), x.stride(0), x.shape[0]
         else:
@@ -104,6 +110,7 @@ def transpose2d_many(xs, colsum_of: Optional[int] = None):
             arr[k].src, arr[k].dst = x.data_ptr(), out.data_ptr()
             arr[k].ld_src, arr[k].bs_src, arr[k].ld_dst, arr[k].bs_dst = ld, bs, ldd, bsd
             arr[k].R, arr[k].C, arr[k].batch = R, Cc, batch
+            arr[k].rows_out = ldd if (i + k) in pad64 else 0
             if colsum_of is not None and i + k == colsum_of:
                 sums = torch.empty(Cc, dtype=torch.float32, device=x.device)
                 ws = torch.empty((R + 63) // 64 * Cc, dtype=torch.float32, device=x.device)
@@ -177,12 +184,12 @@ def linear_backward(x: torch.Tensor, w: torch.Tensor, dy: torch.Tensor, need_bia
     K, N = x.shape[-1], w.shape[0]
     x2, dy2 = x.reshape(-1, K), dy.reshape(-1, N)
     dy2p = dy2  # transpose2d zero-pads the row count (M = batch rows in the time-embedding GEMMs) to a multiple of 8
-    if need_bias:  # db rides in the transpose launch: dy is read there anyway
-        (wt, dyt, xt), db = transpose2d_many([w, dy2p, x2], colsum_of=1)
+    # [K, N], [N, Mp], [K, Mp]: one launch; the last two zero-padded to the 64-granularity of the dW contraction
+    if need_bias:
+        (wt, dyt, xt), db = transpose2d_many([w, dy2p, x2], colsum_of=1, pad64=(1, 2))
     else:
-        (wt, dyt, xt), db = transpose2d_many([w, dy2p, x2]), None   # [K, N], [N, M], [K, M]: one launch
+        (wt, dyt, xt), db = transpose2d_many([w, dy2p, x2], pad64=(1, 2)), None
     dx = ops.linear(dy2, wt).view(x.shape)                # [M, N] @ [K, N]^T
-    dyt, xt = _pad_rows64(dyt), _pad_rows64(xt)
     dw = ops.linear(dyt, xt)                              # [N, M] @ [K, M]^T = [N, K]
     return dx, dw, db
 
@@ -290,18 +297,23 @@ def geglu_backward(h: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
 
 
 def groupnorm_backward(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float,
-                       groups: int = 32, silu: bool = False) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+                       groups: int = 32, silu: bool = False, stats: Optional[torch.Tensor] = None
+                       ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """x, dy NHWC [B,H,W,C]; y = act(GN(x)*gamma + beta).  -> (dx, dgamma, dbeta) (the last two fp32).
-    The forward statistics are recomputed with ``ur_groupnorm_stats`` (one read of x) instead of being saved."""
+    ``stats``: the forward pass's partial statistics when it kept them; otherwise they are recomputed with
+    ``ur_groupnorm_stats`` (one more read of x)."""
     _require_gpu(x)
     lib = _lib.load()
     B, Cc = x.shape[0], x.shape[-1]
     rows = x.numel() // (B * Cc)
     nstat, nchunks = ops._gn_chunks_bytes(B, rows, Cc, x.element_size())
-    part = torch.empty(B * nstat * groups * 2, dtype=torch.float32, device=x.device)
     s = _stream()
-    check(lib.ur_groupnorm_stats(x.data_ptr(), None, None, None, Cc, 0, B, rows, groups, nstat, part.data_ptr(), DT[x.dtype],
-                                 s), "ur_groupnorm_stats")
+    if stats is not None and stats.numel() == B * nstat * groups * 2:
+        part = stats  # the forward's partial statistics (ops.groupnorm(return_stats=True)): same chunking, x not re-read
+    else:
+        part = torch.empty(B * nstat * groups * 2, dtype=torch.float32, device=x.device)
+        check(lib.ur_groupnorm_stats(x.data_ptr(), None, None, None, Cc, 0, B, rows, groups, nstat, part.data_ptr(), DT[x.dtype],
+                                     s), "ur_groupnorm_stats")
     nred = max(1, min(nchunks, 512 // B))  # the reduction pass needs ~512 workgroups, not one per 20 KB
     chan_part = torch.empty(B * nred, Cc, 2, dtype=torch.float32, device=x.device)
     chan_sum = torch.empty(B, Cc, 2, dtype=torch.float32, device=x.device)

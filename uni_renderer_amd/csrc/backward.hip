@@ -109,7 +109,8 @@ __global__ void __launch_bounds__(256) transpose2d_multi_kernel(const TransposeM
         if (r0 + r < R && c0 + cv < C) v = *reinterpret_cast<const vec8*>(src + (int64_t)(r0 + r) * ld_src + c0 + cv);
         return v;
     };
-    transpose_tile_64x64<T>(load_row, tile, dst + (int64_t)c0 * d.ld_dst + r0, d.ld_dst, C - c0, ((R + 7) & ~7) - r0, t);
+    transpose_tile_64x64<T>(load_row, tile, dst + (int64_t)c0 * d.ld_dst + r0, d.ld_dst, C - c0,
+                            (d.rows_out > 0 ? d.rows_out : ((R + 7) & ~7)) - r0, t);
     if (!d.colsum) return;
     // ---- fused column sums of the source (the bias gradient of a linear / conv backward: dy is read here anyway) ----
     // The tile in LDS holds column c as 32 packed words (rows 2 w, 2 w + 1; rows >= R are zeros).  Thread c < 64 adds them
@@ -822,6 +823,7 @@ extern "C" int ur_transpose2d_multi(const ur_transpose_desc* descs, int n, int d
             (d.bs_src & 7) || (d.bs_dst & 7) || d.ld_dst < ((d.R + 7) & ~7))
             return UR_E_BADARG;
         if (d.colsum && (d.batch != 1 || !d.colsum_ws || !d.colsum_cnt)) return UR_E_BADARG;
+        if (d.rows_out && ((d.rows_out & 7) || d.rows_out < d.R || d.rows_out > ((d.R + 63) & ~63) || d.ld_dst < d.rows_out)) return UR_E_BADARG;
         a.d[i] = d;
         a.tile0[i] = (int)tiles;
         tiles += (int64_t)((d.C + 63) / 64) * ((d.R + 63) / 64) * d.batch;

@@ -499,9 +499,12 @@ def resize_nearest(x, size):
 GN_FUSED_MAX_ROWS = int(os.environ.get("UR_GN_FUSED_MAX_ROWS", "256"))
 
 
-def groupnorm(x, gamma, beta, eps, *, x1=None, groups=32, silu=False, nstat=None, napply=None, streams=1, fused=None):
+def groupnorm(x, gamma, beta, eps, *, x1=None, groups=32, silu=False, nstat=None, napply=None, streams=1, fused=None,
+              return_stats=False):
     """GroupNorm over NHWC x (or over cat(x, x1)); returns one contiguous [B,H,W,C0+C1] tensor.
-    ``fused``: one launch (ur_groupnorm_fused) instead of stats + apply; default: maps of <= GN_FUSED_MAX_ROWS pixels."""
+    ``fused``: one launch (ur_groupnorm_fused) instead of stats + apply; default: maps of <= GN_FUSED_MAX_ROWS pixels.
+    ``return_stats``: (out, partial statistics of the stats pass | None on the one-launch path) -- the training backward
+    reuses them instead of reading x once more."""
     _require_gpu(x)
     lib = _lib.load()
     B = x.shape[0]
@@ -519,7 +522,7 @@ def groupnorm(x, gamma, beta, eps, *, x1=None, groups=32, silu=False, nstat=None
                                      (B // streams if streams > 1 else 0), (C0 + C1 if streams > 1 else 0), out.data_ptr(),
                                      DT[x.dtype], _stream()), "ur_groupnorm_fused")
         _prof_end(e0, "gn_fused", 0.0, 2.0 * out.numel() * out.element_size())
-        return out
+        return (out, None) if return_stats else out
     _ns, _na = _gn_chunks_bytes(B, rows, C0 + C1, x.element_size())
     nstat, napply = (nstat or _ns), (napply or _na)
     part = torch.empty(B * nstat * groups * 2, dtype=torch.float32, device=x.device)
@@ -539,7 +542,7 @@ def groupnorm(x, gamma, beta, eps, *, x1=None, groups=32, silu=False, nstat=None
                                  DT[x.dtype], s),
           "ur_groupnorm_apply")
     _prof_end(e1, "gn_apply", 0.0, 2.0 * out.numel() * out.element_size())
-    return out
+    return (out, part) if return_stats else out
 
 
 def layernorm(x, gamma, beta, eps=1e-5, streams=1):
