@@ -133,6 +133,30 @@ def test_cfg3_at_the_benchmarked_batch_4(dev, sd):
     assert max(errs["vs_fp32_weights"].values()) < 1.3e-3, errs
 
 
+def test_cfg3_batch_4_step_is_bitwise_reproducible(dev, sd):
+    """No kernel of the step accumulates in a run-dependent order, and none reads a buffer another wave is still
+    writing: 60 graph replays and 20 eager runs of the benchmarked configuration give bit-identical outputs.  (Regression
+    for the LDS race of the UR_TCHAIN_PRE chain, DESIGN.md section 5: one step in seven used to differ by ~2e-3.)"""
+    from uni_renderer_amd.fused import GroupedDualStreamStep
+    from uni_renderer_amd.graph import GraphedDualStreamStep
+
+    _, product = sd
+    unet, enc, dec = product(torch.float16)
+    x, c, ehs, ti, ta = [t.to(dev) for t in O.make_inputs(4, 64, 768, seed=18)]
+    runner = GraphedDualStreamStep(unet, enc, dec, batch=4, latent_hw=64, cross_dim=768, dtype=torch.float16, device=dev)
+    ref = {k: v.clone() for k, v in runner.step(x.half(), c.half(), ehs.half(), ti, ta).items()}
+    for i in range(60):
+        out = runner.step(x.half(), c.half(), ehs.half(), ti, ta)
+        for k in ref:
+            assert torch.equal(out[k], ref[k]), f"graph replay {i}: {k} differs"
+    eager = GroupedDualStreamStep(unet, enc, dec)
+    with torch.no_grad():
+        for i in range(20):
+            out = eager(x.half(), c.half(), ehs.half(), ti, ta)
+            for k in ref:
+                assert torch.equal(out[k], ref[k]), f"eager run {i}: {k} differs from the graph replay"
+
+
 def test_cfg3_five_step_ddim_loop_at_sd_size_batch_4(dev, sd):
     """cfg 3 is a 50-step DDIM loop (models/pipeline.py:2629-2730): five of its steps at the benchmarked shape -- SD-size
     networks, batch 4, 64x64 latent, fp16, the captured default executor -- with the attribute latents fed back through

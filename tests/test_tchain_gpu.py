@@ -153,6 +153,35 @@ def test_chain_pre_vs_fp32(dev, dtype, tol, B, T, S):
             assert float(vt[s * B:(s + 1) * B, :, T:].abs().max()) == 0.0
 
 
+def test_chain_pre_is_reproducible_at_the_benchmarked_size(dev):
+    """Regression: the V^T staging of UR_TCHAIN_PRE used to start while slower waves were still reading the last weight
+    stage out of the same LDS bytes (ring slot 1 = the staging slices of waves 0 / 1): ~1 launch in 300 stored a few wrong
+    V^T channels for one wave, i.e. one grouped step in seven differed from the next.  400 launches at the benchmarked size
+    (2 streams x 4 x 4096 rows) must be bit-identical."""
+    from uni_renderer_amd import ops, tchain
+
+    dtype, S, B, T = torch.float16, 2, 4, 4096
+    W = _weights(dev, 7, S)
+    g = torch.Generator(device=dev).manual_seed(30)
+    for w in W:
+        w["wk"] = torch.randn(C, C, device=dev, generator=g) * C ** -0.5
+        w["wv"] = torch.randn(C, C, device=dev, generator=g) * C ** -0.5
+    h0 = _stream(dev, dtype, B * T, S, 31, False)
+    packs = [tchain.pack_chain_pre(w["wo"].view(C, C, 1, 1), w["bo"], w["g"], w["b"], w["wq"], w["wk"], w["wv"], 0.4777, dtype) for w in W]
+    ws = torch.stack([p[0] for p in packs]).contiguous()
+    cs = torch.stack([p[1] for p in packs]).contiguous()
+
+    def run():
+        y, q, k, vt = tchain.chain_pre(h0, ws, cs, 1e-5, tokens_per_sample=T, streams=S)
+        return [y, ops.lo_of(y), q, k, vt]
+
+    ref = [t.clone() for t in run()]
+    for i in range(400):
+        cur = run()
+        for name, a, b in zip(("y", "y.lo", "q", "k", "vt"), cur, ref):
+            assert torch.equal(a, b), f"launch {i}: {name} differs from the first launch"
+
+
 def test_chain_rejects_other_widths(dev):
     from uni_renderer_amd import tchain
 

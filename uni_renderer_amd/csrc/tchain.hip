@@ -439,6 +439,10 @@ __global__ void __launch_bounds__(256, 1) tchain_kernel(const ur_tchain_desc p) 
         gemm320(acc, bop, 3);
         // V^T[b][channel][token]: a wave's 32 tokens are 64 contiguous bytes of every channel row.  Stage [channel][32
         // tokens] in the wave's slice, then 16 bytes per lane = 8 tokens of one channel.
+        // The last weight stage (19) sits in ring slot 1 = the staging slices of waves 0 / 1: nobody may write there until
+        // every wave has left that stage (without this barrier 1 launch in ~300 stored a few wrong V^T channels of one
+        // wave -- tools/tchain_determinism.py).
+        __syncthreads();
         {
             const int ln = launder(lane);
             const int lrow = ln & 31, lh = ln >> 5;
