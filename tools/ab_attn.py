@@ -42,12 +42,17 @@ def main():
             Tkp = (Tk + 63) // 64 * 64
             vt = torch.zeros(B, C, Tkp, device=dev, dtype=dt)
             vt[:, :, :Tk] = v.transpose(1, 2)
-            o = ops.attention(q, k, vt, B=B, H=H, Tq=T, Tk=Tk, d=d, ldq=C, ldk=C)
+            kw = {}
+            if os.environ.get("AB_ATTN_SCALE0"):  # the step's form: q.k pre-scaled to log2 units by the projections (SLOT kernel)
+                f = (d ** -0.5 * 1.4426950408889634) ** 0.5
+                q, k = (q.float() * f).to(dt), (k.float() * f).to(dt)
+                kw = dict(scale=0.0)
+            o = ops.attention(q, k, vt, B=B, H=H, Tq=T, Tk=Tk, d=d, ldq=C, ldk=C, **kw)
             ref = torch.nn.functional.scaled_dot_product_attention(
                 q.view(B, T, H, d).transpose(1, 2).float(), k.view(B, Tk, H, d).transpose(1, 2).float(),
                 v.view(B, Tk, H, d).transpose(1, 2).float()).transpose(1, 2).reshape(B, T, C)
             err = float((o.float() - ref).norm() / ref.norm())
-            us = timeit(lambda: ops.attention(q, k, vt, B=B, H=H, Tq=T, Tk=Tk, d=d, ldq=C, ldk=C))
+            us = timeit(lambda: ops.attention(q, k, vt, B=B, H=H, Tq=T, Tk=Tk, d=d, ldq=C, ldk=C, **kw))
             # the modules' path: scale * log2(e) folded into q by the projection epilogue, kernel called with scale 0
             cs = d ** -0.5 * 1.4426950408889634
             qs = (q.float() * cs).to(dt)
