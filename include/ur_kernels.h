@@ -527,6 +527,7 @@ int ur_sizeof_igemm_desc(void);
 int ur_sizeof_attn_desc(void);
 int ur_sizeof_attn_bwd_desc(void);
 int ur_sizeof_tchain_desc(void);
+int ur_sizeof_transpose_desc(void);
 
 #ifdef __cplusplus
 }

@@ -287,3 +287,68 @@ def test_tchain_stage_images_are_the_lds_layout_the_kernel_reads():
     got = b[row, 8 * ((2 * s + h) ^ key): 8 * ((2 * s + h) ^ key) + 8]
     want = 0.5 * W2[row, [64 * j + 16 * s + tchain.KPERM16[8 * h + i] for i in range(8)]]
     assert torch.equal(got, want)
+
+
+def test_wsconv_stream_is_the_conv_in_block_order():
+    """ops.wsconv_images: the weight stream of csrc/wsconv.hip.  Emulate the kernel on the CPU -- K blocks of 320 in the
+    order (channel block, tap) then the tail blocks, five 64-k stage images per block, fragment reads with the LDS
+    swizzle, operand = the 320 channels of the shifted pixel (zero outside the image) -- and compare with F.conv2d + the
+    1x1 tail."""
+    import torch.nn.functional as F
+
+    from uni_renderer_amd import ops
+    from uni_renderer_amd.layers import pack_conv3x3, pack_matrix
+
+    torch.manual_seed(1)
+    Cin, N, Ct, H, W = 640, 320, 320, 4, 5
+    wt = torch.randn(N, Cin, 3, 3, dtype=torch.float64)
+    wtail = torch.randn(N, Ct, dtype=torch.float64)
+    x = torch.randn(H, W, Cin, dtype=torch.float64)
+    t0 = torch.randn(H, W, Ct, dtype=torch.float64)
+    packed = torch.cat([pack_conv3x3(wt, torch.float64, cblock=320), pack_matrix(wtail, torch.float64)], 1)
+    stream = ops.wsconv_images(packed, N).view(N // 320, packed.shape[1] // 64, 320, 64)   # [n tile][stage][row][64]
+
+    def unswizzle(img):  # logical [row][k] of a stage image
+        out = torch.empty_like(img)
+        for r in range(320):
+            key = (r >> 1) & 7
+            for c in range(8):
+                out[r, 8 * c: 8 * c + 8] = img[r, 8 * (c ^ key): 8 * (c ^ key) + 8]
+        return out
+
+    stages = [unswizzle(stream[0, s]) for s in range(stream.shape[1])]
+    y, x_, p = 2, 0, None  # one output pixel on the image border
+    acc = torch.zeros(N, dtype=torch.float64)
+    blocks = [(0, cb, t) for cb in range(Cin // 320) for t in range(9)] + [(1, cb, 4) for cb in range(Ct // 320)]
+    for bi, (src, cb, t) in enumerate(blocks):
+        yy, xx = y + t // 3 - 1, x_ + t % 3 - 1
+        if src == 0:
+            op = x[yy, xx, 320 * cb: 320 * cb + 320] if (0 <= yy < H and 0 <= xx < W) else torch.zeros(320, dtype=torch.float64)
+        else:
+            op = t0[y, x_, 320 * cb: 320 * cb + 320]
+        for kc in range(5):
+            acc += stages[5 * bi + kc] @ op[64 * kc: 64 * kc + 64]
+    ref = F.conv2d(x.permute(2, 0, 1)[None], wt, padding=1)[0, :, y, x_] + wtail @ t0[y, x_]
+    assert float((acc - ref).abs().max()) < 1e-9
+
+
+def test_wsconv_policy_and_eligibility():
+    from uni_renderer_amd import ops
+
+    x = torch.zeros(8, 64, 64, 640)
+    assert ops.wsconv_ok(x, 320, streams=2) and not ops.wsconv_ok(x, 256, streams=2)
+    assert not ops.wsconv_ok(torch.zeros(8, 8, 8, 320), 320)            # 64 pixels per sample
+    assert not ops.wsconv_ok(x, 320, stride=2) and not ops.wsconv_ok(x, 320, ups=True)
+    assert not ops.wsconv_ok(x, 320, tail=(torch.zeros(8, 64, 64, 192), None))
+    assert ops.wsconv_splitk(16384, 320, 2880, 2) == 1                  # 256 workgroups already
+    assert ops.wsconv_splitk(4096, 640, 11520, 2) == 2 and ops.wsconv_splitk(1024, 1280, 23040, 2) == 4
+    assert not ops.WSCONV and not ops.wsconv_prefer(x, 320, 5760, streams=2)   # off in the executors by default
+
+
+def test_transpose_descriptor_mirror_matches_the_library():
+    import ctypes as C
+
+    from uni_renderer_amd import _lib
+    from uni_renderer_amd.backward import _TransposeDesc
+
+    assert _lib.load().ur_sizeof_transpose_desc() == C.sizeof(_TransposeDesc)

@@ -13,6 +13,8 @@ python tools/train_bench.py --steps 3 > gpurun_out/final_train_eager.json 2>/dev
 python tools/loop_bench.py > gpurun_out/final_loop_bench.json 2>/dev/null
 python tools/vae_bench.py > gpurun_out/final_vae_bench.json 2>/dev/null
 python tools/tchain_bench.py > gpurun_out/final_tchain_bench.json 2>/dev/null
+{ echo "== step, latent 64 batch 4"; python tools/determinism_check.py --n 200 2>&1 | tail -1; echo "== step, latent 128 batch 1"; python tools/determinism_check.py --latent 128 --batch 1 --n 60 2>&1 | tail -1; echo "== chains"; python tools/tchain_determinism.py --iters 1000 2>&1 | tail -3; } > gpurun_out/final_determinism.txt 2>&1
+python tools/wsconv_bench.py --iters 20 > gpurun_out/final_wsconv_bench.txt 2>&1
 bash tools/pmc_conv_sq.sh gpurun_out/final_pmc_conv_sq.json > /dev/null 2>&1
 ./tools/ubench/mfma_rate > gpurun_out/final_mfma_rate.txt 2>&1
 bash tools/r03_run6.sh > gpurun_out/final_ring_depth_ab.txt 2>&1

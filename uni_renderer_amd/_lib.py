@@ -135,6 +135,7 @@ SYMBOLS = {
     "ur_tchain_stream_bytes": (C.c_int64, [C.c_int]),
     "ur_tchain_const_floats": (C.c_int, [C.c_int]),
     "ur_sizeof_tchain_desc": (C.c_int, []),
+    "ur_sizeof_transpose_desc": (C.c_int, []),
     "ur_abi_version": (C.c_int, []),
     "ur_build_info": (C.c_char_p, []),
     "ur_sizeof_igemm_desc": (C.c_int, []),

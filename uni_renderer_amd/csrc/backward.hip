@@ -813,6 +813,8 @@ extern "C" int ur_transpose2d(const void* src, int64_t ld_src, int64_t bs_src, v
     return last_error();
 }
 
+extern "C" int ur_sizeof_transpose_desc(void) { return (int)sizeof(ur_transpose_desc); }
+
 extern "C" int ur_transpose2d_multi(const ur_transpose_desc* descs, int n, int dtype, void* stream) {
     if (!descs || n <= 0 || n > UR_TRANSPOSE_MAX) return UR_E_BADARG;
     TransposeMultiArgs a;
