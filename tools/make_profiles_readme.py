@@ -67,6 +67,13 @@ passes over the level-0 conv / a K = 320 GEMM replayed alone: parked, issue-stal
 bank conflicts), `{tag}_mfma_rate.txt` (`tools/ubench/mfma_rate.hip`, the corrected MFMA issue-rate micro-benchmark: random
 operands, distinct A / B registers, 1 / 2 / 4 waves per SIMD), `{tag}_ring_depth_ab.txt` (`tools/r03_run6.sh`: a 3-deep LDS ring
 on the 128x256 tile against the 2-deep one: no difference, the conv loop is not waiting for its copies).
+Second half of round 3: `{tag}_determinism.txt` (`tools/determinism_check.py`, `tools/tchain_determinism.py`: the grouped step
+and the three chain kernels repeated on fixed inputs, bitwise comparison -- after the LDS race of the first chain kernel was
+fixed), `{tag}_gap_analysis.txt` (`tools/gap_analysis.py` over a `rocprofv3 --kernel-trace` of the graph
+replay: 393 kernels per step, 0.1 % idle between them), `{tag}_wsconv_bench.txt` (`tools/wsconv_bench.py`: the weight-streaming
+conv kernel against the tuned LDS-tiled one on the 18 resnet conv shapes of the step), `{tag}_pmc_attn_slot.txt`
+(`tools/pmc_attn.sh`: SQ counters of the d = 40 self-attention on the pre-scaled path), `{tag}_ab_collections.txt` (same-box
+A/B of the commits of the round's two collections: the 11.67 vs 12.01 ms of their bench lines is the box, not the code).
 Other summaries: `{tag}_parity_numbers.json` (every rel-L2 the `-m gpu` suite printed: the chain kernels, cfg 3 at batch 2 and 4
 and as a 5-step DDIM loop, cfg 5 vs the oracle, the 16384-token attention, UpRes, the module-surface and cfg-4 training steps
 incl. the inverse branch at SD size, the VAE, the RCCL world-size-1 collectives),
