@@ -135,7 +135,7 @@ def make_inputs(B, L, dev, dtype, seed):
     return x_t, cond, ehs, t_img, t_attr
 
 
-def measure_roofline(step_fn, by_shape=False):
+def measure_roofline(step_fn, by_shape=False, live_traffic=False, extra_args=()):
     """One eager step (same executor as the timed mode, launched serially on one stream) with every launch
     bracketed by HIP events on the launch stream; per kernel class sums."""
     from uni_renderer_amd import ops
@@ -189,6 +189,10 @@ def measure_roofline(step_fn, by_shape=False):
                 algorithmic_bytes_per_launch=dom["alg_bytes_per_launch"],
                 algorithmic_flop_per_launch=dom.get("alg_flop_per_launch"),
                 share_of_step_incl_splitk_launches=round(sym_share[dom_sym], 4), traffic=None)
+    live = measure_traffic_live(dom["kernel"].replace("_splitk", ""), extra_args) if live_traffic else None
+    if live is not None:
+        roof["traffic"], roof["traffic_source"] = live
+        return roof, table, total_ms
     tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")  # HBM bytes/launch from a separate rocprofv3 --pmc pass
     if os.path.exists(tf):
         try:
@@ -200,6 +204,55 @@ def measure_roofline(step_fn, by_shape=False):
         except Exception:
             pass
     return roof, table, total_ms
+
+
+def measure_traffic_live(klass, extra_args, steps=2, timeout=300):
+    """HBM bytes per launch of kernel class ``klass`` measured NOW: two child runs of this script under
+    ``rocprofv3 --pmc FETCH_SIZE`` / ``--pmc WRITE_SIZE`` (separate passes: the two counters do not fit the TCC's four
+    slots together; only --kernel-trace beside them), reduced exactly as tools/pmc_traffic.py does (FETCH_SIZE in KiB and
+    doubled on gfx950 for 16-B-per-lane reads, WRITE_SIZE in KiB as reported: MI355X_MICROARCH.md, HBM section).
+    Returns (bytes per launch, description) or None when rocprofv3 is missing or a pass fails."""
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    if shutil.which("rocprofv3") is None:
+        return None
+    if any(k.startswith(("ROCPROF", "ROCPROFILER", "ROCP_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        return None  # this process is itself being profiled (tools/collect_profiles.sh): no nested profiler
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import pmc_traffic
+    except Exception:
+        return None
+    tmp = tempfile.mkdtemp(prefix="ur_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    got = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "-d", out, "-o", "p", "--output-format", "csv", "--",
+                   sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(steps), "--warmup", "1", "--no-cpu-baseline",
+                   "--no-roofline"] + list(extra_args)
+            r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout)
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None
+            agg = pmc_traffic.per_class(files[0], counter)
+            if klass not in agg or agg[klass][1] == 0:
+                return None
+            got[counter] = agg[klass][0] / agg[klass][1], agg[klass][1]
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    rd, wr = 2.0 * 1024.0 * got["FETCH_SIZE"][0], 1024.0 * got["WRITE_SIZE"][0]
+    return round(rd + wr), (f"LIVE: two rocprofv3 passes of this command (--pmc FETCH_SIZE, --pmc WRITE_SIZE; --kernel-trace only beside "
+                            f"them) right after the timed region, {got['FETCH_SIZE'][1]} launches of the class averaged; "
+                            f"FETCH_SIZE x 2 x 1024 = {round(rd)} B read + WRITE_SIZE x 1024 = {round(wr)} B written per launch")
 
 
 def cpu_baseline(B, L):
@@ -281,6 +334,8 @@ def main():
                     help="inverse: enc+unet+dec (headline, cfg 3/5); render: enc+unet only (cfg 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="roofline.traffic from profiles/pmc_traffic.json instead of two rocprofv3 --pmc child runs (~1 min)")
     ap.add_argument("--eager", action="store_true", help="time eager launches instead of the HIP graph")
     ap.add_argument("--no-concurrent", action="store_true", help="capture the three networks serially on one stream")
     ap.add_argument("--mode", default=None, choices=["grouped", "concurrent", "serial"],
@@ -380,7 +435,11 @@ def main():
         }
         if not args.no_roofline:  # rank 0 only (this block), at every N: the kernels are the same on every rank
             side, runner.side = runner.side, None  # serial launches for per-kernel timing
-            roof, table, total_ms = measure_roofline(runner._run)
+            # HBM traffic of the dominant kernel: measured live (one GPU, headline-style run) by two PMC child runs of the
+            # same workload; the committed profile is the fallback
+            child = ["--batch", str(args.batch), "--latent", str(args.latent), "--dtype", args.dtype, "--direction", args.direction]
+            roof, table, total_ms = measure_roofline(runner._run, live_traffic=(world == 1 and not args.no_live_traffic
+                                                                                and not args.eager), extra_args=child)
             out["roofline"] = roof
             # the whole step against the MFMA roofline: algorithmic FLOP of the step / measured step time / dense peak
             out["step_frac_of_mfma_peak"] = round(out["config"]["algorithmic_tflop_per_step"] / out["ms_per_step"]

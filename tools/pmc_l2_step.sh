@@ -3,7 +3,7 @@
 # split-K launches of a symbol filed separately (tools/pmc_traffic.py rules).  Output: gpurun_out/pmc_l2_step.json
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-(cd $R && rocprofv3 --pmc TCC_HIT TCC_MISS TCC_REQ --kernel-trace -d $R/gpurun_out/pmc_l2s -o p --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1)
+(cd $R && rocprofv3 --pmc TCC_HIT TCC_MISS TCC_REQ --kernel-trace -d $R/gpurun_out/pmc_l2s -o p --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-live-traffic > /dev/null 2>&1)
 cd $R && python - <<'PY'
 import glob, json, sys
 sys.path.insert(0, "tools")
