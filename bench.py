@@ -206,7 +206,7 @@ def measure_roofline(step_fn, by_shape=False, live_traffic=False, extra_args=())
     return roof, table, total_ms
 
 
-def measure_traffic_live(klass, extra_args, steps=2, timeout=300):
+def measure_traffic_live(klass, extra_args, steps=2, timeout=150):
     """HBM bytes per launch of kernel class ``klass`` measured NOW: two child runs of this script under
     ``rocprofv3 --pmc FETCH_SIZE`` / ``--pmc WRITE_SIZE`` (separate passes: the two counters do not fit the TCC's four
     slots together; only --kernel-trace beside them), reduced exactly as tools/pmc_traffic.py does (FETCH_SIZE in KiB and
