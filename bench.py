@@ -237,9 +237,16 @@ def measure_traffic_live(klass, extra_args, steps=2, timeout=150):
             cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "-d", out, "-o", "p", "--output-format", "csv", "--",
                    sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(steps), "--warmup", "1", "--no-cpu-baseline",
                    "--no-roofline"] + list(extra_args)
-            r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout)
+            proc = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = proc.wait(timeout=timeout)
+            except subprocess.TimeoutExpired:
+                import signal
+                os.killpg(proc.pid, signal.SIGKILL)  # the process group this call started (rocprofv3 + its python child)
+                proc.wait()
+                return None
             files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
-            if r.returncode != 0 or not files:
+            if rc != 0 or not files:
                 return None
             agg = pmc_traffic.per_class(files[0], counter)
             if klass not in agg or agg[klass][1] == 0:
