@@ -108,7 +108,8 @@ extern "C" {
 #define UR_TILE_64x320_M32 46     /* 4 waves (2 x 2, 32 x 160 each), 2-deep */
 #define UR_TILE_WS320 47          /* weight-streaming 3x3 conv, 128 pixels x 320 channels per workgroup (csrc/wsconv.hip):\
                                      `w` is the stage-image stream of tchain.py wsconv_images, channels multiples of 320 */
-#define UR_TILE_COUNT 48
+#define UR_TILE_WS320_W8 48       /* the same with 8 waves per workgroup = 2 per SIMD (a wave: 32 pixels x 160 channels) */
+#define UR_TILE_COUNT 49
 
 /*
  * Implicit GEMM:  out[m][n] = epilogue( sum_k X[m][k] * W[n][k] )

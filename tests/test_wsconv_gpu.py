@@ -30,10 +30,11 @@ def _mk(shape, dt, s=1.0):
     return (torch.randn(*shape, device="cuda") * s).to(dt)
 
 
+@pytest.mark.parametrize("wtile", [47, 48])
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("B,H,W,Cin,N,splitk", [(2, 16, 16, 320, 320, 1), (1, 16, 8, 640, 320, 1), (2, 16, 16, 320, 640, 2),
                                                 (1, 32, 32, 960, 320, 3), (1, 16, 16, 1280, 640, 4), (3, 8, 16, 320, 320, 1)])
-def test_wsconv_vs_fp32_and_igemm(dt, B, H, W, Cin, N, splitk):
+def test_wsconv_vs_fp32_and_igemm(dt, B, H, W, Cin, N, splitk, wtile):
     torch.manual_seed(B * 1000 + Cin + N + splitk)
     x = _mk((B, H, W, Cin), dt)
     wt = _mk((N, Cin, 3, 3), dt, (9 * Cin) ** -0.5)
@@ -42,7 +43,7 @@ def test_wsconv_vs_fp32_and_igemm(dt, B, H, W, Cin, N, splitk):
     cb = ops.conv_cblock(Cin)
     w = pack_conv3x3(wt, dt, cblock=cb)
     ws = ops.wsconv_images(w, N)
-    y = ops.conv3x3(x, w, b, rowadd=ra, cblock=cb, ws=ws, splitk=splitk)
+    y = ops.conv3x3(x, w, b, rowadd=ra, cblock=cb, ws=ws, splitk=splitk, tile=wtile)
     y0 = ops.conv3x3(x, w, b, rowadd=ra, cblock=cb)
     ref = _ref(x, wt, b, rowadd=ra)
     tol = 2e-3 if dt == torch.float16 else 1.5e-2
@@ -50,8 +51,9 @@ def test_wsconv_vs_fp32_and_igemm(dt, B, H, W, Cin, N, splitk):
     assert (y.float() - y0.float()).abs().max() <= tol * ref.abs().max()
 
 
+@pytest.mark.parametrize("wtile", [47, 48])
 @pytest.mark.parametrize("splitk", [1, 2])
-def test_wsconv_residual_hilo_and_scale(splitk):
+def test_wsconv_residual_hilo_and_scale(splitk, wtile):
     torch.manual_seed(5)
     dt, B, H, W, C = torch.float16, 2, 16, 16, 320
     x = _mk((B, H, W, C), dt)
@@ -61,15 +63,16 @@ def test_wsconv_residual_hilo_and_scale(splitk):
     res = resf.to(dt)
     res.lo = ops.lo_encode(resf - res.float(), dt)
     w = pack_conv3x3(wt, dt)
-    y = ops.conv3x3(x, w, b, res=res, out_scale=0.5, hilo=True, ws=ops.wsconv_images(w), splitk=splitk)
+    y = ops.conv3x3(x, w, b, res=res, out_scale=0.5, hilo=True, ws=ops.wsconv_images(w), splitk=splitk, tile=wtile)
     ref = _ref(x, wt, b, res=res, out_scale=0.5)
     got = y.float() + ops.lo_float(y.lo)
     assert (got - ref).abs().max() <= 3e-4 * ref.abs().max()      # the (hi, lo) pair carries ~2^-14 relative
     assert (y.float() - ref).abs().max() <= 1e-3 * ref.abs().max()
 
 
+@pytest.mark.parametrize("wtile", [47, 48])
 @pytest.mark.parametrize("Ct0,Ct1,splitk", [(320, 0, 1), (640, 320, 1), (320, 320, 2)])
-def test_wsconv_shortcut_tail(Ct0, Ct1, splitk):
+def test_wsconv_shortcut_tail(Ct0, Ct1, splitk, wtile):
     torch.manual_seed(7 + Ct0 + Ct1)
     dt, B, H, W, C, N = torch.float16, 2, 16, 16, 640, 640
     x = _mk((B, H, W, C), dt)
@@ -80,15 +83,16 @@ def test_wsconv_shortcut_tail(Ct0, Ct1, splitk):
     b = torch.randn(N, device="cuda")
     cb = ops.conv_cblock(C)
     w = torch.cat([pack_conv3x3(wt, dt, cblock=cb), pack_matrix(wtail, dt)], 1).contiguous()
-    y = ops.conv3x3(x, w, b, tail=(t0, t1), cblock=cb, ws=ops.wsconv_images(w), splitk=splitk, hilo=True)
+    y = ops.conv3x3(x, w, b, tail=(t0, t1), cblock=cb, ws=ops.wsconv_images(w), splitk=splitk, hilo=True, tile=wtile)
     y0 = ops.conv3x3(x, w, b, tail=(t0, t1), cblock=cb, hilo=True)
     ref = _ref(x, wt, b, tail=(t0, t1), wtail=wtail)
     assert (y.float() - ref).abs().max() <= 2e-3 * ref.abs().max()
     assert (y.float() - y0.float()).abs().max() <= 2e-3 * ref.abs().max()
 
 
+@pytest.mark.parametrize("wtile", [47, 48])
 @pytest.mark.parametrize("splitk", [1, 2])
-def test_wsconv_two_streams(splitk):
+def test_wsconv_two_streams(splitk, wtile):
     """grouped launch: stream-major batch, per-stream weights / bias / time-embedding rows"""
     torch.manual_seed(11)
     dt, S, B, H, W, C, N = torch.float16, 2, 2, 16, 16, 640, 320
@@ -99,7 +103,7 @@ def test_wsconv_two_streams(splitk):
     cb = ops.conv_cblock(C)
     w = torch.stack([pack_conv3x3(t, dt, cblock=cb) for t in wts])
     ws = torch.stack([ops.wsconv_images(w[i]) for i in range(S)])
-    y = ops.conv3x3(x, w, bs, rowadd=ra, streams=S, cblock=cb, ws=ws, splitk=splitk)
+    y = ops.conv3x3(x, w, bs, rowadd=ra, streams=S, cblock=cb, ws=ws, splitk=splitk, tile=wtile)
     for s_ in range(S):
         ref = _ref(x[s_ * B:(s_ + 1) * B], wts[s_], bs[s_], rowadd=ra[s_ * B:(s_ + 1) * B])
         assert (y[s_ * B:(s_ + 1) * B].float() - ref).abs().max() <= 2e-3 * ref.abs().max()

@@ -40,7 +40,7 @@ def operand_dma_ops(n):
     return ops
 
 
-def stream(n, acc_of, frag_addr, b_of, valu=(), dma=False, c0=lambda m: None, opieces=0):
+def stream(n, acc_of, frag_addr, b_of, valu=(), dma=False, c0=lambda m: None, opieces=0, wpieces=NPIECE):
     """n MFMAs; MFMA m multiplies fragment m (read from frag_addr(m) = (address operand, immediate offset)) with B operand
     b_of(m) into accumulator acc_of(m) (c0(m): literal C operand of a first MFMA).  `valu`: a VALU program spread evenly
     behind the MFMAs; `dma`: the LDS-DMA pieces of the next-but-one stage, one behind every fourth MFMA."""
@@ -54,12 +54,19 @@ def stream(n, acc_of, frag_addr, b_of, valu=(), dma=False, c0=lambda m: None, op
         return out + list(valu)
     for m in range(min(AHEAD, n)):
         out.append(rd(m))
-    pieces = dma_ops() if dma else []
+    pieces = dma_ops()[:wpieces] if dma else []
     where = {4 * i + 1: p for i, p in enumerate(pieces)}
-    if opieces:  # weight pieces first (every third MFMA), the operand pieces last: `s_waitcnt vmcnt(opieces)` then
-        # guarantees the weights of the next stage while the operand pieces may still be in flight
+    if n == 20:  # half-width conv stage (8-wave workgroup): 5 weight pieces behind every third MFMA, then the operand pieces
         where = {3 * i + 1: p for i, p in enumerate(pieces)}
-        where.update({31 + (8 // opieces) * j: p for j, p in enumerate(operand_dma_ops(opieces))})
+        where.update({3 * len(pieces) + 1 + j: p for j, p in enumerate(operand_dma_ops(opieces))})
+    elif opieces:  # weight pieces first, the operand pieces last: `s_waitcnt vmcnt(opieces)` then guarantees the
+        # weights of the next stage while the operand pieces may still be in flight.  EARLY: the ring is only two slots
+        # deep (the rest of the LDS stages operands), so the copies of stage g + 1 have just the rest of stage g to land
+        # (issue -> landed is ~1.1 us on a loaded chip): one behind each of the first ten MFMAs, not spread over thirty.
+        step = int(os.environ.get("UR_GEN_CONV_WSTEP", "3"))
+        where = {step * i + 1: p for i, p in enumerate(pieces)}
+        o0 = step * (len(pieces) - 1) + 3
+        where.update({o0 + 2 * j: p for j, p in enumerate(operand_dma_ops(opieces))})
     per = -(-len(valu) // (n - 1)) if valu else 0
     pi = 0
     for m in range(n):
@@ -172,6 +179,11 @@ def main():
         f.write("#define TC_ASM_GEMM_STAGE_DMA(MT) \\\n" + cstr(stream(*gargs, dma=True)) + "\n\n")
         f.write("// conv stage (csrc/wsconv.hip): weights of the next stage + 5 pieces of the next operand block\n")
         f.write("#define TC_ASM_CONV_STAGE(MT) \\\n" + cstr(stream(*gargs, dma=True, opieces=5)) + "\n\n")
+        f.write("// half-width conv stage (8 waves per workgroup, 2 per SIMD: a wave owns 32 pixels x 160 channels = tiles c0..c4):\n")
+        f.write("// 20 MFMAs, 5 weight pieces, 0 / 3 / 4 operand pieces\n")
+        hargs = (20, lambda m: f"c{m % 5}", lambda m: (f"a{m // 5}", (m % 5) * 4096), lambda m: f"b{m // 5}")
+        for npc in (0, 3, 4):
+            f.write(f"#define TC_ASM_CONV8_STAGE_O{npc}(MT) \\\n" + cstr(stream(*hargs, dma=True, opieces=npc, wpieces=5)) + "\n\n")
         f.write("// feed-forward input stage + the GEGLU program of the previous half-chunk + LDS-DMA (tools/gen_tchain_asm.py)\n")
         f.write("#define TC_ASM_FFAG(MT) \\\n" + cstr(ffa_stream(True, True)) + "\n\n")
         f.write("#define TC_ASM_FFA(MT) \\\n" + cstr(ffa_stream(True, False)) + "\n\n")

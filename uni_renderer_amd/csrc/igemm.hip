@@ -677,8 +677,8 @@ static const TileCfg kTiles[UR_TILE_COUNT] = {{0, 0, 0},      {128, 128, 2}, {12
                                               {128, 64, 3},  {64, 64, 3},   {256, 128, 2}, {256, 256, 2}, {128, 256, 2},
                                               {128, 256, 3}, {128, 320, 2}, {256, 320, 2}, {128, 160, 2},
                                               {128, 160, 3}, {64, 320, 2},
-                                              // weight-streaming conv (wsconv.hip)
-                                              {128, 320, 2}};
+                                              // weight-streaming conv (wsconv.hip): 4 and 8 waves
+                                              {128, 320, 2}, {128, 320, 2}};
 
 static int pick_tile(const ur_igemm_desc& d) {
     // Cost model: the busiest CU runs ceil(workgroups / 256) tiles; bigger tiles have a better
@@ -796,6 +796,7 @@ static int launch_dtype(ur_igemm_desc& d, hipStream_t s) {
         case UR_TILE_128x160_S3_M32: return launch_cfg<T, 128, 160, 4, 1, 3, 32>(d, s);
         case UR_TILE_64x320_M32: return launch_cfg<T, 64, 320, 2, 2, 2, 32>(d, s);
         case UR_TILE_WS320: return launch_ws<T>(d, s);
+        case UR_TILE_WS320_W8: return launch_ws<T>(d, s);
     }
     return UR_E_BADARG;
 }

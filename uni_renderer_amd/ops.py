@@ -41,8 +41,10 @@ _TILES = {TILE_128x128: (128, 128, 1.0, 2), TILE_128x64: (128, 64, 0.85, 3), TIL
           40: (128, 256, 1.3, "2L2"), 41: (128, 256, 1.2, 3), 42: (128, 320, 1.2, "2w8m32"), 43: (256, 320, 1.2, "2w16m32"), 44: (128, 160, 1.0, "2m32"), 45: (128, 160, 1.0, "3m32"),
           46: (64, 320, 0.9, "2m32"),
           # weight-streaming conv (csrc/wsconv.hip): ``w`` is the stage-image stream of wsconv_images()
-          47: (128, 320, 1.4, "ws")}
-TILE_WS320 = 47
+          47: (128, 320, 1.4, "ws"), 48: (128, 320, 1.4, "ws8")}
+TILE_WS320, TILE_WS320_W8 = 47, 48
+# which build ``conv3x3(ws=...)`` launches: 8 waves per workgroup (two instruction streams per SIMD) or 4 (one)
+WSCONV_TILE = TILE_WS320_W8 if os.environ.get("UR_WSCONV_WAVES", "8") == "8" else TILE_WS320
 _PLANNER_TILES = (TILE_128x128, TILE_128x64, TILE_64x64)
 
 _zero_pages = {}
@@ -429,10 +431,10 @@ def conv3x3(x, w, bias=None, *, x1=None, stride=1, ups=False, rowadd=None, res=N
                   zt0=(M * ca if streams > 1 else 0), zt1=(M * cb_ if streams > 1 else 0))
     Kt = 9 * (C0 + C1) + sum(tl.get(k, 0) for k in ("ct0", "ct1"))
     ldw = w.stride(-2)
-    if ws is not None and tile in (None, TILE_WS320) and wsconv_ok(x, N, x1=x1, stride=stride, ups=ups, pad=pad, tail=tail, streams=streams):
+    if ws is not None and tile in (None, TILE_WS320, TILE_WS320_W8) and wsconv_ok(x, N, x1=x1, stride=stride, ups=ups, pad=pad, tail=tail, streams=streams):
         if C0 > WS_C and cblock != WS_C:
             raise RuntimeError("conv3x3: the weight-streaming kernel walks K in the cblock = 320 order")
-        w, tile, ldw = ws, TILE_WS320, 8
+        w, tile, ldw = ws, (WSCONV_TILE if tile is None else tile), 8
         if streams > 1:
             z["zw"] = ws.stride(0)
         if splitk is None:
@@ -440,7 +442,7 @@ def conv3x3(x, w, bias=None, *, x1=None, stride=1, ups=False, rowadd=None, res=N
     igemm(x0=x, x1=x1, w=w, out=out, M=M, N=N, K=Kt, c0=C0, c1=C1, ldx0=C0, ldx1=C1,
           ldw=ldw, ldc=N, taps=9, conv=(B, H, W, Ho, Wo), stride=stride, ups=int(ups), bias=bias,
           rowadd=rowadd, rows_per_b=Ho * Wo, res=res, ldres=(N if res is not None else 0), out_scale=out_scale,
-          act=(int(os.environ.get("UR_WS_DEBUG_ACT", "0")) if tile == TILE_WS320 else ACT_NONE),
+          act=(int(os.environ.get("UR_WS_DEBUG_ACT", "0")) if tile in (TILE_WS320, TILE_WS320_W8) else ACT_NONE),
           tile=tile, splitk=splitk, res_lo=lo_of(res), out_lo=lo_of(out), cblock=cblock, pad=pad, **tl, **z)
     return out
 
