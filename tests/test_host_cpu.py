@@ -352,3 +352,28 @@ def test_transpose_descriptor_mirror_matches_the_library():
     from uni_renderer_amd.backward import _TransposeDesc
 
     assert _lib.load().ur_sizeof_transpose_desc() == C.sizeof(_TransposeDesc)
+
+
+def test_pmc_traffic_reduction_rule(tmp_path):
+    """tools/pmc_traffic.per_class (also what bench.py's live roofline.traffic uses): kernel symbol -> class, split-K launches
+    recognised by the reduce dispatch that follows them, per-class sums and launch counts."""
+    import csv
+    import sys as _sys
+
+    _sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pmc_traffic
+
+    conv = "_ZN2ur12igemm_kernelIDF16_Li128ELi320ELi2ELi5ELi2ELb1ELi16ELi0EEEv13ur_igemm_desc"
+    red = "_ZN2ur19igemm_splitk_reduceIDF16_EEv13ur_igemm_desc"
+    attn = "_ZN2ur18attention32_kernelIDF16_Li40ELb1EEEv12ur_attn_desc"
+    rows = [(1, conv, 100.0), (2, conv, 300.0), (3, red, 7.0), (4, attn, 50.0), (5, conv, 110.0)]
+    path = tmp_path / "p_counter_collection.csv"
+    with open(path, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Dispatch_Id", "Kernel_Name", "Counter_Name", "Counter_Value"])
+        for did, name, val in rows:
+            w.writerow([did, name, "FETCH_SIZE", val])
+    agg = pmc_traffic.per_class(str(path), "FETCH_SIZE")
+    assert agg["igemm_128x320s2_conv3x3"] == [210.0, 2]          # dispatches 1 and 5: plain launches
+    assert agg["igemm_128x320s2_conv3x3_splitk"] == [300.0, 1]   # dispatch 2: followed by the reduce kernel
+    assert agg["igemm_splitk_reduce"] == [7.0, 1] and agg["attention_d40"] == [50.0, 1]
