@@ -1087,17 +1087,22 @@ __global__ void __launch_bounds__(256) adamw_multi_kernel(const AdamwArgs a) {
     const bool vec = ((((uintptr_t)t.p) | ((uintptr_t)t.g) | ((uintptr_t)t.m) | ((uintptr_t)t.v)) & 15) == 0;
     if (vec) {
         const int64_t end4 = beg + ((end - beg) & ~(int64_t)3);
+        // every byte is touched once per step and 48 GB pass before it is touched again: non-temporal both ways
+        typedef float f4 __attribute__((ext_vector_type(4)));
         for (int64_t i = beg + 4 * threadIdx.x; i < end4; i += 1024) {
-            float4 p = *reinterpret_cast<float4*>(t.p + i), m = *reinterpret_cast<float4*>(t.m + i),
-                   v = *reinterpret_cast<float4*>(t.v + i);
-            const float4 g = *reinterpret_cast<const float4*>(t.g + i);
-            adamw_one(p.x, g.x, m.x, v.x, ginv, decay, a.beta1, a.beta2, step_size, rbc2, a.eps);
-            adamw_one(p.y, g.y, m.y, v.y, ginv, decay, a.beta1, a.beta2, step_size, rbc2, a.eps);
-            adamw_one(p.z, g.z, m.z, v.z, ginv, decay, a.beta1, a.beta2, step_size, rbc2, a.eps);
-            adamw_one(p.w, g.w, m.w, v.w, ginv, decay, a.beta1, a.beta2, step_size, rbc2, a.eps);
-            *reinterpret_cast<float4*>(t.p + i) = p;
-            *reinterpret_cast<float4*>(t.m + i) = m;
-            *reinterpret_cast<float4*>(t.v + i) = v;
+            f4 p = __builtin_nontemporal_load(reinterpret_cast<const f4*>(t.p + i));
+            f4 m = __builtin_nontemporal_load(reinterpret_cast<const f4*>(t.m + i));
+            f4 v = __builtin_nontemporal_load(reinterpret_cast<const f4*>(t.v + i));
+            const f4 g = __builtin_nontemporal_load(reinterpret_cast<const f4*>(t.g + i));
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float pk = p[k], mk = m[k], vk = v[k];
+                adamw_one(pk, g[k], mk, vk, ginv, decay, a.beta1, a.beta2, step_size, rbc2, a.eps);
+                p[k] = pk; m[k] = mk; v[k] = vk;
+            }
+            __builtin_nontemporal_store(p, reinterpret_cast<f4*>(t.p + i));
+            __builtin_nontemporal_store(m, reinterpret_cast<f4*>(t.m + i));
+            __builtin_nontemporal_store(v, reinterpret_cast<f4*>(t.v + i));
         }
         for (int64_t i = end4 + threadIdx.x; i < end; i += 256)
             adamw_one(t.p[i], t.g[i], t.m[i], t.v[i], ginv, decay, a.beta1, a.beta2, step_size, rbc2, a.eps);
