@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define UR_ABI_VERSION 6
+#define UR_ABI_VERSION 7
 
 #define UR_E_BADARG (-1001)   /* inconsistent descriptor (shape / alignment / null pointer)   */
 #define UR_E_UNSUPPORTED (-1002) /* shape outside what the kernels are instantiated for       */
@@ -389,6 +389,11 @@ typedef struct ur_cast_tensor {
     int64_t n;
 } ur_cast_tensor;
 int ur_cast_multi(const ur_cast_tensor* tensors, int n_tensors, int to_f32, int dtype, void* stream);
+/* The same (to_f32 = 1 only) that also leaves, per workgroup, the sum of squares of the fp32 values it wrote in
+ * sumsq[0 .. ur_cast_multi_blocks()) -- fixed order inside a workgroup, no atomics: the gradient norm of train/train.py:1422
+ * (clip_grad_norm_) without a second sweep over the gradients (ABI 7). */
+int64_t ur_cast_multi_blocks(const ur_cast_tensor* tensors, int n_tensors);
+int ur_cast_multi_sumsq(const ur_cast_tensor* tensors, int n_tensors, int to_f32, int dtype, float* sumsq, void* stream);
 
 /* AdamW over many parameter tensors per launch (the optimizer step of the training loop, train/train.py:1082-1100
  * torch.optim.AdamW, 1425 optimizer.step()).  Decoupled weight decay, bias correction, no amsgrad, fp32 everywhere; the
@@ -466,6 +471,10 @@ int ur_resample2x(const void* in, void* out, int B, int Hout, int Wout, int C, i
  * the cast / permute / contiguous chain of torch kernels the autocast of train/train.py:1324-1354 amounts to. */
 int ur_pack_conv_weight(const float* w, void* out, int Co, int Ci, int Cpad, int dtype, void* stream);
 int ur_unpack_conv_weight_grad(const void* dwp, int64_t ld, float* out, int Co, int Ci, int Cpad, int dtype, void* stream);
+/* ... with per-workgroup sums of squares of the gradient written, sumsq[0 .. ur_unpack_conv_weight_grad_blocks(Co, Ci)) (ABI 7) */
+int ur_unpack_conv_weight_grad_blocks(int Co, int Ci);
+int ur_unpack_conv_weight_grad_sumsq(const void* dwp, int64_t ld, float* out, int Co, int Ci, int Cpad, float* sumsq, int dtype,
+                                     void* stream);
 
 /*
  * Row-local transformer chains at C = 320 (csrc/tchain.hip): the GEMMs, LayerNorm, GEGLU and residual adds that follow an

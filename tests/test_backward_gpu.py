@@ -418,3 +418,65 @@ def test_cast_many(dev):
         back = bw.cast_many(outs, torch.float32)
         for a, b in zip(outs, back):
             assert b.dtype == torch.float32 and torch.equal(b, a.float())
+
+
+def test_gradient_sums_of_squares_from_the_writing_kernels(dev):
+    """ur_cast_multi_sumsq / ur_unpack_conv_weight_grad_sumsq: the per-workgroup partial sums add up to the sum of squares of
+    exactly what was written (fp64 reference), the outputs are unchanged, and the result is reproducible bit for bit."""
+    import ctypes as C
+
+    from uni_renderer_amd import _lib, autograd_ops as A, backward as bw
+    g = torch.Generator().manual_seed(13)
+    srcs = [(torch.randn(n, generator=g) * 3).to(torch.bfloat16).to(dev) for n in (1, 7, 8193, 100003, 320 * 1280)] * 30
+    outs, part = bw.cast_many(srcs, torch.float32, sumsq=True)
+    want = sum((s.double() ** 2).sum() for s in srcs)
+    assert all(torch.equal(o, s.float()) for o, s in zip(outs, srcs))
+    assert abs(float(part.double().sum()) - float(want)) <= 1e-6 * float(want)
+    _, part2 = bw.cast_many(srcs, torch.float32, sumsq=True)
+    assert torch.equal(part, part2)
+    lib = _lib.load()
+    for co, ci, cp in ((320, 320, 320), (4, 28, 64), (1280, 2560, 2560)):
+        dwp = (torch.randn(co, 9 * cp, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+        ref = torch.empty(co, ci, 3, 3, dtype=torch.float32, device=dev)
+        bw.check(lib.ur_unpack_conv_weight_grad(dwp.data_ptr(), dwp.stride(0), ref.data_ptr(), co, ci, cp, bw.DT[dwp.dtype], None),
+                 "ur_unpack_conv_weight_grad")
+        out = torch.empty_like(ref)
+        ps = torch.empty(int(lib.ur_unpack_conv_weight_grad_blocks(co, ci)), dtype=torch.float32, device=dev)
+        bw.check(lib.ur_unpack_conv_weight_grad_sumsq(dwp.data_ptr(), dwp.stride(0), out.data_ptr(), co, ci, cp, ps.data_ptr(),
+                                                      bw.DT[dwp.dtype], None), "ur_unpack_conv_weight_grad_sumsq")
+        torch.cuda.synchronize()
+        w = float((ref.double() ** 2).sum())
+        assert torch.equal(out, ref) and abs(float(ps.double().sum()) - w) <= 1e-6 * w
+
+
+def test_clipping_norm_from_the_backward_matches_the_sweep(dev):
+    """train_step's clipping norm assembled from the per-launch sums of squares (backward.GradSquares) equals
+    torch's norm over the same gradients; a parameter with two contributions (one conv weight packed twice) makes the
+    registry unusable, so the step falls back to the sweep."""
+    import torch.nn as nn
+
+    from uni_renderer_amd import autograd_ops as A, backward as bw
+    torch.manual_seed(3)
+    conv = nn.Conv2d(64, 64, 3, padding=1).to(dev)
+    lin = nn.Linear(64, 128).to(dev)
+    x = torch.randn(2, 16, 16, 64, device=dev, dtype=torch.bfloat16)
+
+    def run(twice):
+        for p in list(conv.parameters()) + list(lin.parameters()):
+            p.grad = None
+        bw.grad_squares.begin()
+        (wl,) = A.CastParams.apply(torch.bfloat16, lin.weight)
+        h = A.conv3x3(x, A.pack_conv_weight(conv.weight, torch.bfloat16), conv.bias)
+        if twice:
+            h = A.conv3x3(h, A.pack_conv_weight(conv.weight, torch.bfloat16), conv.bias)
+        y = A.linear(h, wl, lin.bias)
+        (y.float() ** 2).mean().backward()
+
+    run(False)
+    gs = bw.grad_squares
+    assert gs.usable() and set(gs.count) == {id(conv.weight), id(lin.weight)}
+    fused = torch.cat(gs.parts).double().sum() + sum((p.grad.double() ** 2).sum() for p in (conv.bias, lin.bias))
+    ref = sum((p.grad.double() ** 2).sum() for p in list(conv.parameters()) + list(lin.parameters()))
+    assert abs(float(fused) - float(ref)) <= 1e-6 * float(ref)
+    run(True)
+    assert not bw.grad_squares.usable() and bw.grad_squares.count[id(conv.weight)] == 2

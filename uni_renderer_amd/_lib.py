@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must be imported first, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("UR_LIB_PATH", os.path.join(_HERE, "liburhip.so"))  # override = kernel experiments only
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
@@ -106,6 +106,8 @@ SYMBOLS = {
     "ur_prefetch": (C.c_int, [vp, C.c_int64, C.c_int, vp]),
     "ur_pack_conv_weight": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "ur_unpack_conv_weight_grad": (C.c_int, [vp, C.c_int64, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "ur_unpack_conv_weight_grad_blocks": (C.c_int, [C.c_int, C.c_int]),
+    "ur_unpack_conv_weight_grad_sumsq": (C.c_int, [vp, C.c_int64, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]),
     "ur_unipc_update": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int64, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp,
                                   vp, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, vp]),
     "ur_transpose2d": (C.c_int, [vp, C.c_int64, C.c_int64, vp, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
@@ -128,6 +130,8 @@ SYMBOLS = {
     "ur_attention_backward_splits": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "ur_transpose2d_multi": (C.c_int, [vp, C.c_int, C.c_int, vp]),
     "ur_cast_multi": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp]),
+    "ur_cast_multi_blocks": (C.c_int64, [vp, C.c_int]),
+    "ur_cast_multi_sumsq": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp]),
     "ur_adamw_multi": (C.c_int, [vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, vp, vp, vp, vp]),
     "ur_silu_forward": (C.c_int, [vp, vp, C.c_int64, C.c_int, vp]),
     "ur_resample2x": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),

@@ -209,6 +209,7 @@ class PackConvWeight(Function):
         co, ci = weight.shape[:2]
         cp = ci if cin_pad is None else cin_pad
         ctx.geom = (co, ci, cp)
+        ctx.pid = id(weight)
         w = weight.detach().contiguous()
         out = torch.empty(co, 9 * cp, dtype=dtype, device=weight.device)
         check(lib.ur_pack_conv_weight(w.data_ptr(), out.data_ptr(), co, ci, cp, DT[dtype], _stream()), "ur_pack_conv_weight")
@@ -221,8 +222,14 @@ class PackConvWeight(Function):
         if dwp.stride(-1) != 1:
             dwp = dwp.contiguous()
         g = torch.empty(co, ci, 3, 3, dtype=torch.float32, device=dwp.device)
-        check(lib.ur_unpack_conv_weight_grad(dwp.data_ptr(), dwp.stride(0), g.data_ptr(), co, ci, cp, DT[dwp.dtype], _stream()),
-              "ur_unpack_conv_weight_grad")
+        if bw.FUSED_GRADNORM:
+            part = torch.empty(int(lib.ur_unpack_conv_weight_grad_blocks(co, ci)), dtype=torch.float32, device=dwp.device)
+            check(lib.ur_unpack_conv_weight_grad_sumsq(dwp.data_ptr(), dwp.stride(0), g.data_ptr(), co, ci, cp, part.data_ptr(),
+                                                       DT[dwp.dtype], _stream()), "ur_unpack_conv_weight_grad_sumsq")
+            bw.grad_squares.add(part, [ctx.pid])
+        else:
+            check(lib.ur_unpack_conv_weight_grad(dwp.data_ptr(), dwp.stride(0), g.data_ptr(), co, ci, cp, DT[dwp.dtype], _stream()),
+                  "ur_unpack_conv_weight_grad")
         return g, None, None
 
 
@@ -245,6 +252,7 @@ class CastParams(Function):
     @staticmethod
     def forward(ctx, dtype, *params):
         ctx.set_materialize_grads(False)
+        ctx.pids = [id(p) for p in params]
         return tuple(bw.cast_many([p.detach() for p in params], dtype))
 
     @staticmethod
@@ -252,6 +260,12 @@ class CastParams(Function):
         idx = [i for i, g in enumerate(grads) if g is not None]
         res = [None] * len(grads)
         if idx:
-            for i, o_ in zip(idx, bw.cast_many([grads[i] for i in idx], torch.float32)):
+            if bw.FUSED_GRADNORM:  # the sums of squares of what is written here feed the clipping norm (bw.GradSquares)
+                outs, part = bw.cast_many([grads[i] for i in idx], torch.float32, sumsq=True)
+                if part is not None:
+                    bw.grad_squares.add(part, [ctx.pids[i] for i in idx if grads[i].numel()])
+            else:
+                outs = bw.cast_many([grads[i] for i in idx], torch.float32)
+            for i, o_ in zip(idx, outs):
                 res[i] = o_
         return (None, *res)

@@ -124,9 +124,36 @@ class _CastDesc(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("n", C.c_int64)]
 
 
-def cast_many(srcs, dtype) -> list:
+class GradSquares:
+    """Sum of squares of the fp32 parameter gradients, collected where they are WRITTEN (the multi-tensor cast of the weight
+    gradients, the conv-weight unpack) instead of by a second sweep over 7 GB at clipping time (train.py:1422).  Every
+    contributing launch leaves per-workgroup partial sums; a parameter is *covered* when exactly one launch of the step
+    produced its whole gradient.  If any parameter received two contributions (the cycle-consistency branch runs enc + unet
+    twice) the partials do not describe the accumulated gradients and the step falls back to ``_foreach_norm``."""
+
+    def __init__(self):
+        self.begin()
+
+    def begin(self):
+        self.parts, self.count = [], {}
+
+    def add(self, partial: torch.Tensor, pids):
+        self.parts.append(partial)
+        for pid in pids:
+            self.count[pid] = self.count.get(pid, 0) + 1
+
+    def usable(self) -> bool:
+        return bool(self.parts) and all(c == 1 for c in self.count.values())
+
+
+grad_squares = GradSquares()
+FUSED_GRADNORM = os.environ.get("UR_FUSED_GRADNORM", "1") != "0"
+
+
+def cast_many(srcs, dtype, sumsq: bool = False):
     """``[s.to(dtype) for s in srcs]`` for fp32 -> fp16 / bf16 or fp16 / bf16 -> fp32, 128 tensors per launch
-    (``ur_cast_multi``)."""
+    (``ur_cast_multi``).  ``sumsq`` (to fp32 only): also returns the per-workgroup sums of squares of everything written,
+    one 1-D fp32 tensor (``ur_cast_multi_sumsq``)."""
     lib = _lib.load()
     srcs = [s_.contiguous() for s_ in srcs]
     outs = [torch.empty_like(s_, dtype=dtype) for s_ in srcs]
@@ -139,6 +166,7 @@ def cast_many(srcs, dtype) -> list:
         if s_.dtype != (low if to_f32 else torch.float32):
             raise ValueError("cast_many: one source dtype per call (fp32 -> half or half -> fp32)")
     st = _stream()
+    partials = []
     for i in range(0, len(srcs), 128):
         part = list(zip(srcs[i:i + 128], outs[i:i + 128]))
         part = [(a, b) for a, b in part if a.numel()]
@@ -147,7 +175,14 @@ def cast_many(srcs, dtype) -> list:
         arr = (_CastDesc * len(part))()
         for k, (a, b) in enumerate(part):
             arr[k].src, arr[k].dst, arr[k].n = a.data_ptr(), b.data_ptr(), a.numel()
-        check(lib.ur_cast_multi(arr, len(part), int(to_f32), DT[low], st), "ur_cast_multi")
+        if sumsq and to_f32:
+            ps = torch.empty(int(lib.ur_cast_multi_blocks(arr, len(part))), dtype=torch.float32, device=srcs[0].device)
+            check(lib.ur_cast_multi_sumsq(arr, len(part), 1, DT[low], ps.data_ptr(), st), "ur_cast_multi_sumsq")
+            partials.append(ps)
+        else:
+            check(lib.ur_cast_multi(arr, len(part), int(to_f32), DT[low], st), "ur_cast_multi")
+    if sumsq:
+        return outs, (torch.cat(partials) if len(partials) > 1 else (partials[0] if partials else None))
     return outs
 
 

@@ -777,18 +777,34 @@ __global__ void __launch_bounds__(256) pack_conv_weight_kernel(const float* __re
     }
 }
 
+// sum of a per-thread value over the workgroup in a fixed order (wave sums, then waves 0..3): the per-workgroup partial of
+// the fused gradient-norm (ur_*_sumsq entry points)
+__device__ __forceinline__ void block_partial_store(float v, float* dst) {
+    __shared__ float wsum[4];
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) dst[blockIdx.x] = ((wsum[0] + wsum[1]) + wsum[2]) + wsum[3];
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256) unpack_conv_weight_kernel(const T* __restrict__ dwp, int64_t ld, float* __restrict__ out,
-                                                                 int Co, int Ci, int Cpad) {
+                                                                 int Co, int Ci, int Cpad, float* __restrict__ sumsq) {
     const int64_t total = (int64_t)Co * Ci;
+    float sq = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int c = (int)(i % Ci);
         const int64_t co = i / Ci;
         const T* src = dwp + co * ld + c;
         float* o = out + i * 9;
 #pragma unroll
-        for (int t = 0; t < 9; ++t) o[t] = (float)src[(int64_t)t * Cpad];
+        for (int t = 0; t < 9; ++t) {
+            const float g = (float)src[(int64_t)t * Cpad];
+            o[t] = g;
+            sq = fmaf(g, g, sq);
+        }
     }
+    if (sumsq) block_partial_store(sq, sumsq);
 }
 
 #define UR_DISPATCH(dtype, CALL)                          \
@@ -1034,15 +1050,24 @@ extern "C" int ur_pack_conv_weight(const float* w, void* out, int Co, int Ci, in
     return last_error();
 }
 
-extern "C" int ur_unpack_conv_weight_grad(const void* dwp, int64_t ld, float* out, int Co, int Ci, int Cpad, int dtype,
-                                          void* stream) {
+extern "C" int ur_unpack_conv_weight_grad_blocks(int Co, int Ci) {
+    const int64_t total = (int64_t)Co * Ci;
+    return (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+}
+
+extern "C" int ur_unpack_conv_weight_grad_sumsq(const void* dwp, int64_t ld, float* out, int Co, int Ci, int Cpad, float* sumsq,
+                                                int dtype, void* stream) {
     if (!dwp || !out || Co <= 0 || Ci <= 0 || Cpad < Ci || ld < 9 * (int64_t)Cpad) return UR_E_BADARG;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const int64_t total = (int64_t)Co * Ci;
-    const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    const int grid = ur_unpack_conv_weight_grad_blocks(Co, Ci);
     UR_DISPATCH(dtype, hipLaunchKernelGGL((unpack_conv_weight_kernel<T>), dim3(grid), dim3(256), 0, s, (const T*)dwp, ld, out,
-                                          Co, Ci, Cpad));
+                                          Co, Ci, Cpad, sumsq));
     return last_error();
+}
+
+extern "C" int ur_unpack_conv_weight_grad(const void* dwp, int64_t ld, float* out, int Co, int Ci, int Cpad, int dtype,
+                                          void* stream) {
+    return ur_unpack_conv_weight_grad_sumsq(dwp, ld, out, Co, Ci, Cpad, nullptr, dtype, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1142,6 +1167,7 @@ struct CastArgs {
     ur_cast_tensor t[UR_CAST_MAX_TENSORS];
     int chunk0[UR_CAST_MAX_TENSORS + 1];
     int n;
+    float* sumsq;  // to_f32 only: per-workgroup sum of squares of the values written (NULL: none)
 };
 constexpr int CAST_CHUNK = 8192;
 
@@ -1160,13 +1186,21 @@ __global__ void __launch_bounds__(256) cast_multi_kernel(const CastArgs a) {
     if constexpr (TO_F32) {
         const T* src = reinterpret_cast<const T*>(t.src);
         float* dst = reinterpret_cast<float*>(t.dst);
+        float sq = 0.f;
         for (int64_t i = beg + 8 * threadIdx.x; i < end8; i += 2048) {
             float v[8];
             load8(src + i, v);
             *reinterpret_cast<float4*>(dst + i) = make_float4(v[0], v[1], v[2], v[3]);
             *reinterpret_cast<float4*>(dst + i + 4) = make_float4(v[4], v[5], v[6], v[7]);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) sq = fmaf(v[k], v[k], sq);
         }
-        for (int64_t i = end8 + threadIdx.x; i < end; i += 256) dst[i] = (float)src[i];
+        for (int64_t i = end8 + threadIdx.x; i < end; i += 256) {
+            const float g = (float)src[i];
+            dst[i] = g;
+            sq = fmaf(g, g, sq);
+        }
+        if (a.sumsq) block_partial_store(sq, a.sumsq);
     } else {
         const float* src = reinterpret_cast<const float*>(t.src);
         T* dst = reinterpret_cast<T*>(t.dst);
@@ -1179,9 +1213,21 @@ __global__ void __launch_bounds__(256) cast_multi_kernel(const CastArgs a) {
     }
 }
 
+extern "C" int ur_cast_multi_sumsq(const ur_cast_tensor* tensors, int n_tensors, int to_f32, int dtype, float* sumsq, void* stream);
 extern "C" int ur_cast_multi(const ur_cast_tensor* tensors, int n_tensors, int to_f32, int dtype, void* stream) {
-    if (!tensors || n_tensors <= 0 || n_tensors > UR_CAST_MAX_TENSORS) return UR_E_BADARG;
+    return ur_cast_multi_sumsq(tensors, n_tensors, to_f32, dtype, nullptr, stream);
+}
+
+extern "C" int64_t ur_cast_multi_blocks(const ur_cast_tensor* tensors, int n_tensors) {
+    int64_t chunks = 0;
+    for (int i = 0; tensors && i < n_tensors; ++i) chunks += (tensors[i].n + CAST_CHUNK - 1) / CAST_CHUNK;
+    return chunks;
+}
+
+extern "C" int ur_cast_multi_sumsq(const ur_cast_tensor* tensors, int n_tensors, int to_f32, int dtype, float* sumsq, void* stream) {
+    if (!tensors || n_tensors <= 0 || n_tensors > UR_CAST_MAX_TENSORS || (sumsq && !to_f32)) return UR_E_BADARG;
     CastArgs a;
+    a.sumsq = sumsq;
     int64_t chunks = 0;
     for (int i = 0; i < n_tensors; ++i) {
         if (!tensors[i].src || !tensors[i].dst || tensors[i].n <= 0) return UR_E_BADARG;

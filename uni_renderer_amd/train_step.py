@@ -20,6 +20,7 @@ from typing import Dict, List, Optional, Sequence
 import torch
 
 from . import autograd_ops as A
+from . import backward as B
 from . import ops
 from .controlnet import CIN_PAD
 
@@ -358,6 +359,7 @@ def _forward_backward(nets, batch, optimizer, buckets, dtype, inverse):
         buckets.zero_grad()  # gradients live in the buckets' flat buffers (views): zero in place, keep the views
     elif optimizer is not None:
         optimizer.zero_grad(set_to_none=True)
+    B.grad_squares.begin()  # per-launch sums of squares of the fp32 gradients written by this backward (clipping norm)
     loss.backward()  # with ``buckets``: complete buckets are all-reduced (async) while the backward is still running
     return loss.detach()
 
@@ -389,6 +391,15 @@ def _clip_and_update(nets, optimizer, buckets, max_grad_norm, stats):
                 # _foreach_norm, not vector_norm per bucket: a CAPTURED vector_norm over a 32 MB tensor returns wrong
                 # values on replay in this torch / ROCm build (tools/graph_norm_repro.py)
                 norm = torch.linalg.vector_norm(torch.stack(torch._foreach_norm(list(buckets.flat))))
+            elif B.FUSED_GRADNORM and B.grad_squares.usable():
+                # the big gradients' sums of squares came out of the kernels that wrote them; only the parameters those
+                # launches do not cover (norm / bias vectors, a few small matrices) are swept here
+                cov = B.grad_squares.count
+                rest = [p.grad for p in _parameters(nets) if p.grad is not None and id(p) not in cov]
+                sq = torch.cat(B.grad_squares.parts).sum()
+                if rest:
+                    sq = sq + torch.stack(torch._foreach_norm(rest)).square().sum()
+                norm = sq.sqrt()
             else:
                 grads = [p.grad for p in _parameters(nets) if p.grad is not None]
                 norm = torch.linalg.vector_norm(torch.stack(torch._foreach_norm(grads)))
