@@ -28,9 +28,6 @@ def main():
     for f in sorted(os.listdir(OUT)):
         if f.startswith("final_") and f.endswith((".json", ".csv", ".txt")):
             shutil.copy(os.path.join(OUT, f), os.path.join(PROF, f"{tag}_{f[len('final_'):]}"))
-    for f in ("ab_final.txt", "ab_knobs.txt"):
-        if os.path.exists(os.path.join(OUT, f)):
-            shutil.copy(os.path.join(OUT, f), os.path.join(PROF, f"{tag}_{f}"))
     rows, test = [], None
     log = os.path.join(OUT, "final_pytest.log")
     if os.path.exists(log):
