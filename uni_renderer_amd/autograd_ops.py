@@ -110,7 +110,7 @@ class Attention(Function):
         inplace = lambda t: (t.stride(-1) == 1 and t.stride(0) == t.shape[1] * t.stride(1) and t.stride(1) % 8 == 0
                              and t.storage_offset() % 8 == 0)
         k_ = k if inplace(k) else k.contiguous()
-        vt = bw._pad_rows64(bw.transpose2d(v if inplace(v) else v.contiguous()))  # [B, C, Tk_pad]
+        vt = bw.transpose2d_many([v if inplace(v) else v.contiguous()], pad64=(0,))[0]  # [B, C, Tk_pad]: padded by the launch
         stats = bw.flash_stats(B, heads, Tq, Tk, d, q.device)  # [2, B*H, T] when the flash backward will run, else None
         o = ops.attention(q.contiguous(), k_, vt, B=B, H=heads, Tq=Tq, Tk=Tk, d=d, ldq=Cc, ldk=k_.stride(1),
                           lse=None if stats is None else stats[0])
@@ -137,7 +137,7 @@ class AttentionQKV(Function):
         qkv = qkv.contiguous()
         B, T, C3 = qkv.shape
         Cc = C3 // 3
-        vt = bw._pad_rows64(bw.transpose2d(qkv[..., 2 * Cc:]))  # [B, C, T_pad], read in place (strided)
+        vt = bw.transpose2d_many([qkv[..., 2 * Cc:]], pad64=(0,))[0]  # [B, C, T_pad], read in place (strided), padded by the launch
         stats = bw.flash_stats(B, heads, T, T, Cc // heads, qkv.device)
         o = ops.attention(qkv, qkv, vt, B=B, H=heads, Tq=T, Tk=T, d=Cc // heads, ldq=C3, ldk=C3, q_off=0, k_off=Cc,
                           lse=None if stats is None else stats[0])

@@ -437,9 +437,10 @@ def _flash_attention_backward(q, k, v, o, do, H, scale, fused_qkv, oq, ok, ov, C
         for t in (q, k, v, o, do):
             if t.stride(2) != 1 or t.stride(0) != t.shape[1] * t.stride(1):
                 raise RuntimeError("flash attention backward: [B, T, ld] operands with contiguous batches")
-        qt, kt, dot_ = transpose2d_many([q[..., oq:oq + Cc], k[..., ok:ok + Cc], do])  # [B, C, T], one launch
+        # [B, C, T], one launch; the key side zero-padded to the 64-key tiles by the launch itself
+        qt, kt, dot_ = transpose2d_many([q[..., oq:oq + Cc], k[..., ok:ok + Cc], do], pad64=((1,) if Tk % 64 else ()))
         if kt.shape[-1] != Tkp:
-            kt = _pad_rows64(kt)                                                      # zero columns for the padded keys
+            kt = _pad_rows64(kt)
         if fused_qkv:
             g = torch.empty(B, Tq, 3 * Cc, dtype=q.dtype, device=q.device)
             outs, ldg, offs = (g, g, g), 3 * Cc, (oq, ok, ov)
