@@ -351,6 +351,11 @@ int ur_im2col3x3_t(const void* x, int B, int H, int W, int C, int stride, void* 
  * backward reduced over the batch straight into two contiguous parameter-gradient rows (dbeta = out[0], dgamma = out[1]). */
 int ur_pairsum_rows(const float* in, int B, int C, float* out, void* stream);
 int64_t ur_colsum_workspace_floats(int M, int N, int rows_per_group);
+/* One-launch form (ABI 7): `counters` = ur_colsum_counters() zero-initialised 32-bit device counters, left at zero; the
+ * last workgroup of a (group, column block) adds the slice sums in the order of the two-launch form (identical bits). */
+int ur_colsum_counters(int M, int N, int rows_per_group);
+int ur_colsum_fused(const void* x, int64_t ldx, int M, int N, int rows_per_group, float* out, float* workspace,
+                    uint32_t* counters, int dtype, void* stream);
 int ur_colsum(const void* x, int64_t ldx, int M, int N, int rows_per_group, float* out, float* workspace, int dtype,
               void* stream);
 int ur_silu_backward(const void* x, const void* dy, void* dx, int64_t n, int dtype, void* stream);

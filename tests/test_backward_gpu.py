@@ -480,3 +480,22 @@ def test_clipping_norm_from_the_backward_matches_the_sweep(dev):
     assert abs(float(fused) - float(ref)) <= 1e-6 * float(ref)
     run(True)
     assert not bw.grad_squares.usable() and bw.grad_squares.count[id(conv.weight)] == 2
+
+
+@pytest.mark.parametrize("dtype", DTYPES + [torch.float32])
+@pytest.mark.parametrize("M,N,rpg", [(16384, 320, 0), (600, 136, 0), (8192, 1280, 4096), (77 * 4, 768, 0), (64, 8, 0), (100000, 64, 0)])
+def test_colsum_one_launch_equals_two_launches(dev, dtype, M, N, rpg, monkeypatch):
+    """the last-arriver fold inside ur_colsum_fused gives the bits of partial sums + colsum_fold_kernel, run after run, and
+    leaves its counters at zero"""
+    from uni_renderer_amd import backward as bw
+    g = torch.Generator().manual_seed(M + N)
+    x = (torch.randn(M, N, generator=g) + 0.1).to(dtype).to(dev)
+    monkeypatch.setattr(bw, "COLSUM_ONE_LAUNCH", False)
+    two = bw.colsum(x, rows_per_group=rpg)
+    monkeypatch.setattr(bw, "COLSUM_ONE_LAUNCH", True)
+    for _ in range(20):
+        one = bw.colsum(x, rows_per_group=rpg)
+        assert torch.equal(one, two)
+    assert int(bw._colsum_counter(x.device).abs().sum()) == 0
+    want = x.double().sum(0) if rpg == 0 else x.double().view(-1, rpg, N).sum(1)
+    assert float((one.double() - want).abs().max()) <= 2e-6 * float(x.double().abs().sum(0).max())

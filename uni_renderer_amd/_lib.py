@@ -114,6 +114,8 @@ SYMBOLS = {
     "ur_im2col3x3_t": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int64, C.c_int, vp]),
     "ur_colsum_workspace_floats": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
     "ur_colsum": (C.c_int, [vp, C.c_int64, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp]),
+    "ur_colsum_counters": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "ur_colsum_fused": (C.c_int, [vp, C.c_int64, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp]),
     "ur_pairsum_rows": (C.c_int, [vp, C.c_int, C.c_int, vp, vp]),
     "ur_silu_backward": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int, vp]),
     "ur_geglu_forward": (C.c_int, [vp, vp, C.c_int64, C.c_int, C.c_int, vp]),

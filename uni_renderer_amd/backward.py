@@ -53,6 +53,10 @@ class _TransposeDesc(C.Structure):
 # step, but every transposing workgroup then pays a memory-side store + counter round trip: 84.7 vs 84.6 ms per graphed
 # step (tools/r03_run14.sh) -- no gain, so off by default.
 FUSED_COLSUM = os.environ.get("UR_FUSED_COLSUM", "0") != "0"
+# Column sums folded in the same launch by the last-arriving workgroup (ur_colsum_fused; identical bits, 476 launches fewer
+# per step): measured 81.4 vs 81.1 ms per step (tools/r03_run35.sh) -- the agent-scope hand-off costs what the fold launch
+# did -- so off by default.
+COLSUM_ONE_LAUNCH = os.environ.get("UR_COLSUM_ONE_LAUNCH", "0") != "0"
 _colsum_counters: dict = {}
 
 
@@ -197,8 +201,9 @@ def colsum(x: torch.Tensor, rows_per_group: int = 0) -> torch.Tensor:
     dt = 2 if x.dtype == torch.float32 else DT[x.dtype]
     nws = lib.ur_colsum_workspace_floats(M, N, rows_per_group)
     ws = torch.empty(nws, dtype=torch.float32, device=x.device) if nws else None
-    check(lib.ur_colsum(x.data_ptr(), N, M, N, rows_per_group, out.data_ptr(), ws.data_ptr() if nws else None, dt,
-                        _stream()), "ur_colsum")
+    cnt = _colsum_counter(x.device) if (COLSUM_ONE_LAUNCH and nws and lib.ur_colsum_counters(M, N, rows_per_group) <= 4096) else None
+    check(lib.ur_colsum_fused(x.data_ptr(), N, M, N, rows_per_group, out.data_ptr(), ws.data_ptr() if nws else None,
+                              cnt.data_ptr() if cnt is not None else None, dt, _stream()), "ur_colsum_fused")
     return out if rows_per_group > 0 else out[0]
 
 

@@ -204,7 +204,8 @@ __device__ __forceinline__ void load8f<float>(const float* p, float (&v)[8]) {
 
 template <typename T>
 __global__ void __launch_bounds__(256) colsum_kernel(const T* __restrict__ x, int64_t ldx, int M, int N, int rpg,
-                                                     int slices, float* __restrict__ dst) {
+                                                     int slices, float* __restrict__ dst, float* __restrict__ out,
+                                                     unsigned* __restrict__ counters) {
     __shared__ float red[32][64 + 1];
     const int t = threadIdx.x, cv = (t & 7) * 8, rl = t >> 3;  // 8 vector columns x 32 row lanes
     const int n0 = blockIdx.x * 64, sl = blockIdx.y, g = blockIdx.z;
@@ -235,11 +236,45 @@ __global__ void __launch_bounds__(256) colsum_kernel(const T* __restrict__ x, in
 #pragma unroll
     for (int i = 0; i < 8; ++i) red[rl][cv + i] = s[i];
     __syncthreads();
+    if (!counters) {  // two-launch form: colsum_fold_kernel adds the slices
+        if (t < 64 && n0 + t < N) {
+            float a = 0.f;
+            for (int k = 0; k < 32; ++k) a += red[k][t];  // fixed order
+            dst[((int64_t)g * slices + sl) * N + n0 + t] = a;
+        }
+        return;
+    }
+    // one-launch form: the slice sums go to the workspace with agent-scope stores (they bypass the non-coherent L2s), the
+    // last workgroup of a (group, column block) -- device-scope counter, left at zero -- adds them exactly as
+    // colsum_fold_kernel would.  (The same hand-off cost every one of the thousands of small transposing workgroups a
+    // memory round trip, tools/r03_run14.sh; here there are <= 512 long-running workgroups and the fold launch goes away.)
+    __shared__ int last;
     if (t < 64 && n0 + t < N) {
         float a = 0.f;
         for (int k = 0; k < 32; ++k) a += red[k][t];  // fixed order
-        dst[((int64_t)g * slices + sl) * N + n0 + t] = a;
+        __hip_atomic_store(dst + ((int64_t)g * slices + sl) * N + n0 + t, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    __syncthreads();
+    if (t == 0) {
+        unsigned* c = counters + (int64_t)g * gridDim.x + blockIdx.x;
+        const unsigned prev = __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = prev == (unsigned)(slices - 1);
+        if (last) __hip_atomic_store(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!last) return;
+    float (*r4)[64] = reinterpret_cast<float (*)[64]>(&red[0][0]);  // red is free again: [4][64] of it
+    const int nl = t & 63, q = t >> 6, n = n0 + nl;
+    const int len = (slices + 3) >> 2, k0 = q * len, k1 = min(slices, k0 + len);
+    float a = 0.f;
+    if (n < N)
+        for (int k = k0; k < k1; ++k)
+            a += __hip_atomic_load(dst + ((int64_t)g * slices + k) * N + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    r4[q][nl] = a;
+    __syncthreads();
+    if (q == 0 && n < N) out[(int64_t)g * N + n] = ((r4[0][nl] + r4[1][nl]) + r4[2][nl]) + r4[3][nl];
 }
 
 // 64 columns per workgroup, four 64-lane groups over contiguous quarters of the slices, partial sums added in group order
@@ -903,8 +938,16 @@ extern "C" int64_t ur_colsum_workspace_floats(int M, int N, int rows_per_group) 
     return sl > 1 ? (int64_t)((M + rpg - 1) / rpg) * sl * N : 0;
 }
 
-extern "C" int ur_colsum(const void* x, int64_t ldx, int M, int N, int rows_per_group, float* out, float* workspace,
-                         int dtype, void* stream) {
+extern "C" int ur_colsum_counters(int M, int N, int rows_per_group) {
+    if (M <= 0 || N <= 0) return 0;
+    const int rpg = rows_per_group > 0 ? rows_per_group : M;
+    return ((M + rpg - 1) / rpg) * ((N + 63) / 64);
+}
+
+// counters: NULL = partial sums + a second (fold) launch; else ur_colsum_counters() zero-initialised device counters that
+// the launch leaves zero again: ONE launch, the last workgroup of every column block folds (same order, same bits)
+extern "C" int ur_colsum_fused(const void* x, int64_t ldx, int M, int N, int rows_per_group, float* out, float* workspace,
+                               unsigned* counters, int dtype, void* stream) {
     if (!x || !out || M <= 0 || N <= 0 || (N & 7) || (ldx & 7)) return UR_E_BADARG;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int rpg = rows_per_group > 0 ? rows_per_group : M;
@@ -912,14 +955,20 @@ extern "C" int ur_colsum(const void* x, int64_t ldx, int M, int N, int rows_per_
     const int sl = colsum_slices(M, N, rpg);
     if (sl > 1 && !workspace) return UR_E_BADARG;
     float* dst = sl > 1 ? workspace : out;
+    unsigned* cnt = sl > 1 ? counters : nullptr;
     dim3 grid((N + 63) / 64, sl, groups);
     if (dtype == UR_DT_F32) {
-        hipLaunchKernelGGL((colsum_kernel<float>), grid, dim3(256), 0, s, (const float*)x, ldx, M, N, rpg, sl, dst);
+        hipLaunchKernelGGL((colsum_kernel<float>), grid, dim3(256), 0, s, (const float*)x, ldx, M, N, rpg, sl, dst, out, cnt);
     } else {
-        UR_DISPATCH(dtype, hipLaunchKernelGGL((colsum_kernel<T>), grid, dim3(256), 0, s, (const T*)x, ldx, M, N, rpg, sl, dst));
+        UR_DISPATCH(dtype, hipLaunchKernelGGL((colsum_kernel<T>), grid, dim3(256), 0, s, (const T*)x, ldx, M, N, rpg, sl, dst, out, cnt));
     }
-    if (sl > 1) hipLaunchKernelGGL(colsum_fold_kernel, dim3((N + 63) / 64, groups), dim3(256), 0, s, workspace, N, sl, out);
+    if (sl > 1 && !cnt) hipLaunchKernelGGL(colsum_fold_kernel, dim3((N + 63) / 64, groups), dim3(256), 0, s, workspace, N, sl, out);
     return last_error();
+}
+
+extern "C" int ur_colsum(const void* x, int64_t ldx, int M, int N, int rows_per_group, float* out, float* workspace,
+                         int dtype, void* stream) {
+    return ur_colsum_fused(x, ldx, M, N, rows_per_group, out, workspace, nullptr, dtype, stream);
 }
 
 extern "C" int ur_silu_backward(const void* x, const void* dy, void* dx, int64_t n, int dtype, void* stream) {
