@@ -499,3 +499,22 @@ def test_colsum_one_launch_equals_two_launches(dev, dtype, M, N, rpg, monkeypatc
     assert int(bw._colsum_counter(x.device).abs().sum()) == 0
     want = x.double().sum(0) if rpg == 0 else x.double().view(-1, rpg, N).sum(1)
     assert float((one.double() - want).abs().max()) <= 2e-6 * float(x.double().abs().sum(0).max())
+
+
+def test_packed_casts_concatenate_without_a_copy(dev):
+    """CastParams lays its copies out back to back; cat_adjacent over neighbours is the same matrix as torch.cat, shares their
+    storage, and routes every row slice of the gradient back to its parameter."""
+    from uni_renderer_amd import autograd_ops as A
+    torch.manual_seed(5)
+    ws = [torch.randn(n, 64, device=dev, requires_grad=True) for n in (32, 48, 16, 8)]
+    cs = A.CastParams.apply(torch.bfloat16, *ws)
+    cat = A.cat_adjacent(cs[:3])
+    assert cat.shape == (96, 64) and cat.data_ptr() == cs[0].data_ptr()
+    assert torch.equal(cat, torch.cat([w.detach().to(torch.bfloat16) for w in ws[:3]], 0))
+    up = torch.randn(96, 64, device=dev).to(torch.bfloat16)
+    (cat.float() * up.float()).sum().backward()
+    for w, g in zip(ws[:3], torch.split(up.float(), [32, 48, 16], 0)):
+        assert torch.equal(w.grad, g)
+    assert ws[3].grad is None
+    other = A.cat_adjacent([cs[0], cs[2]])   # not neighbours: falls back to a copy
+    assert other.data_ptr() != cs[0].data_ptr() and torch.equal(other, torch.cat([cs[0], cs[2]], 0))

@@ -199,6 +199,39 @@ def conv3x3(x, wp, b=None, res=None, rowadd=None, stride=1):
     return Conv3x3.apply(x, wp, b, res, rowadd, stride)
 
 
+class CatAdjacent(Function):
+    """``torch.cat(ts, 0)`` for matrices that already lie back to back in memory (the packed outputs of CastParams): the
+    result is a view-like tensor over their storage, no copy; the backward hands every input its row slice of the gradient."""
+
+    @staticmethod
+    def forward(ctx, *ts):
+        ctx.rows = [t.shape[0] for t in ts]
+        n = sum(ctx.rows)
+        t0 = ts[0]
+        # a NEW tensor object over the same storage (not an autograd view of an input: its gradient is defined below)
+        return torch.empty(0, dtype=t0.dtype, device=t0.device).set_(t0.untyped_storage(), t0.storage_offset(),
+                                                                     (n,) + tuple(t0.shape[1:]), t0.stride())
+
+    @staticmethod
+    def backward(ctx, g):
+        return tuple(torch.split(g, ctx.rows, 0))
+
+
+def cat_adjacent(ts):
+    """Row-wise concatenation of 2-D tensors; free when they are adjacent slices of one buffer, ``torch.cat`` otherwise."""
+    ts = list(ts)
+    ok = len(ts) > 1 and all(t.dim() == 2 and t.is_contiguous() and t.shape[1:] == ts[0].shape[1:] and t.dtype == ts[0].dtype
+                             and t.untyped_storage().data_ptr() == ts[0].untyped_storage().data_ptr() for t in ts)
+    if ok:
+        off = ts[0].storage_offset()
+        for t in ts:
+            ok = ok and t.storage_offset() == off
+            off += t.numel()
+    if not ok:
+        return torch.cat(ts, 0)
+    return CatAdjacent.apply(*ts)
+
+
 class PackConvWeight(Function):
     """fp32 master [Co, Ci, 3, 3] -> compute-dtype [Co][(ky, kx, ci_pad)] (ur_pack_conv_weight) and the packed weight
     gradient back to an fp32 [Co, Ci, 3, 3] gradient (ur_unpack_conv_weight_grad): one kernel each way."""
@@ -253,7 +286,7 @@ class CastParams(Function):
     def forward(ctx, dtype, *params):
         ctx.set_materialize_grads(False)
         ctx.pids = [id(p) for p in params]
-        return tuple(bw.cast_many([p.detach() for p in params], dtype))
+        return tuple(bw.cast_many([p.detach() for p in params], dtype, packed=True))
 
     @staticmethod
     def backward(ctx, *grads):

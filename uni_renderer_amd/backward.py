@@ -154,13 +154,22 @@ grad_squares = GradSquares()
 FUSED_GRADNORM = os.environ.get("UR_FUSED_GRADNORM", "1") != "0"
 
 
-def cast_many(srcs, dtype, sumsq: bool = False):
+def cast_many(srcs, dtype, sumsq: bool = False, packed: bool = False):
     """``[s.to(dtype) for s in srcs]`` for fp32 -> fp16 / bf16 or fp16 / bf16 -> fp32, 128 tensors per launch
     (``ur_cast_multi``).  ``sumsq`` (to fp32 only): also returns the per-workgroup sums of squares of everything written,
     one 1-D fp32 tensor (``ur_cast_multi_sumsq``)."""
     lib = _lib.load()
     srcs = [s_.contiguous() for s_ in srcs]
-    outs = [torch.empty_like(s_, dtype=dtype) for s_ in srcs]
+    if packed and srcs:
+        # one flat buffer, the copies back to back in the order given: consecutive tensors with the same trailing shape can
+        # then be used as ONE matrix without a torch.cat (autograd_ops.cat_adjacent)
+        flat = torch.empty(sum(s_.numel() for s_ in srcs), dtype=dtype, device=srcs[0].device)
+        outs, off = [], 0
+        for s_ in srcs:
+            outs.append(flat[off: off + s_.numel()].view(s_.shape))
+            off += s_.numel()
+    else:
+        outs = [torch.empty_like(s_, dtype=dtype) for s_ in srcs]
     if not srcs:
         return outs
     to_f32 = dtype == torch.float32

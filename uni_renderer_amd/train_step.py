@@ -23,6 +23,7 @@ from . import autograd_ops as A
 from . import backward as B
 from . import ops
 from .controlnet import CIN_PAD
+from .layers import BasicTransformerBlock, ResnetBlock2D
 
 
 BATCH_CASTS = os.environ.get("UR_BATCH_CASTS", "1") != "0"
@@ -45,6 +46,15 @@ class _batched_casts:
         if hit is None or hit[0] is not self.net:
             ws = [m.weight for m in self.net.modules()
                   if isinstance(m, torch.nn.Linear) or (isinstance(m, torch.nn.Conv2d) and m.kernel_size == (1, 1))]
+            # order = memory order of the packed copies (CastParams): the weights this file concatenates into one GEMM
+            # operand come first and in the order of their use, so the "concatenation" is a view (A.cat_adjacent):
+            # all time_emb_proj, then the to_k / to_v pairs of the cross-attentions; q | k | v of a self-attention are
+            # neighbours in module order already
+            temb = [m.time_emb_proj.weight for m in self.net.modules() if isinstance(m, ResnetBlock2D) and m.time_emb_proj is not None]
+            ctxw = [w for m in self.net.modules() if isinstance(m, BasicTransformerBlock) and getattr(m, "attn2", None) is not None
+                    for w in (m.attn2.to_k.weight, m.attn2.to_v.weight)]
+            first = {id(w) for w in temb + ctxw}
+            ws = temb + ctxw + [w for w in ws if id(w) not in first]
             hit = _castable[id(self.net)] = (self.net, [w for w in ws if w.dtype == torch.float32])
         ws = [w for w in hit[1] if w.requires_grad]
         if ws:
@@ -75,7 +85,7 @@ def _temb_projections(resnets, temb_act, dt):
     """All ``time_emb_proj`` of a network phase as ONE GEMM (what the inference path does too): the M = batch-size
     linears, their two backward GEMMs, three transposes and the bias column sum per resnet are launch-bound, ~25
     launches per resnet.  Returns {id(resnet): [B, C_out] column slice}; autograd splits the gradients back."""
-    w = torch.cat([_wc(r.time_emb_proj.weight, dt) for r in resnets], 0)
+    w = A.cat_adjacent([_wc(r.time_emb_proj.weight, dt) for r in resnets])
     b = torch.cat([r.time_emb_proj.bias for r in resnets], 0)
     t_all = A.linear(temb_act, w, b)
     # torch.split, not per-resnet slicing: its backward is ONE cat of the slice gradients, where every SliceBackward
@@ -106,7 +116,7 @@ def _resnet(r, x, temb, dt, x1=None):
 def _self_attn(a, xn, res, dt):
     """q | k | v as ONE projection (one forward and two backward GEMMs instead of three of each)."""
     Cc = a.to_q.weight.shape[0]
-    qkv = A.linear(xn, torch.cat([_wc(a.to_q.weight, dt), _wc(a.to_k.weight, dt), _wc(a.to_v.weight, dt)], 0))
+    qkv = A.linear(xn, A.cat_adjacent([_wc(a.to_q.weight, dt), _wc(a.to_k.weight, dt), _wc(a.to_v.weight, dt)]))
     o = A.AttentionQKV.apply(qkv, a.heads)
     return A.linear(o, _w2(a.to_out[0], dt), a.to_out[0].bias, res=res)
 
@@ -126,7 +136,7 @@ def _context_projections(blocks, ehs, dt):
     tbs = [tb for blk in blocks for t in getattr(blk, "attentions", []) for tb in t.transformer_blocks]
     if not tbs:
         return {}
-    w = torch.cat([_wc(w_, dt) for tb in tbs for w_ in (tb.attn2.to_k.weight, tb.attn2.to_v.weight)], 0)
+    w = A.cat_adjacent([_wc(w_, dt) for tb in tbs for w_ in (tb.attn2.to_k.weight, tb.attn2.to_v.weight)])
     kv_all = A.linear(ehs, w)
     parts = torch.split(kv_all, [2 * tb.attn2.to_k.weight.shape[0] for tb in tbs], dim=-1)  # one cat in the backward
     return {id(tb): part for tb, part in zip(tbs, parts)}
