@@ -364,6 +364,9 @@ int ur_geglu_backward(const void* h, const void* dy, void* dh, int64_t M, int D,
 int ur_groupnorm_backward(const void* x, const void* dy, int C, int B, int rows, int groups, int nstat,
                           const float* partial, const float* gamma, const float* beta, float eps, int silu, int nred,
                           float* chan_part, float* chan_sum, int nchunks, void* dx, int dtype, void* stream);
+/* ... with `skip` (NULL or [rows][C] dtype): dx += skip -- the gradient of a residual connection around the norm (ABI 7) */
+int ur_layernorm_backward_skip(const void* x, const void* dy, const float* gamma, float eps, int rows, int C,
+                               int rows_per_wave, void* dx, float* part, const void* skip, int dtype, void* stream);
 int ur_layernorm_backward(const void* x, const void* dy, const float* gamma, float eps, int rows, int C,
                           int rows_per_wave, void* dx, float* part, int dtype, void* stream);
 /* Up to UR_TRANSPOSE_MAX independent batched transposes (each as ur_transpose2d: dst[b][c][r] = src[b][r][c], rows

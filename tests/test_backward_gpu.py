@@ -518,3 +518,36 @@ def test_packed_casts_concatenate_without_a_copy(dev):
     assert ws[3].grad is None
     other = A.cat_adjacent([cs[0], cs[2]])   # not neighbours: falls back to a copy
     assert other.data_ptr() != cs[0].data_ptr() and torch.equal(other, torch.cat([cs[0], cs[2]], 0))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_layernorm_skip_node(dev, dtype):
+    """LayerNormSkip: x + f(LN(x)) with the residual's gradient added inside the LayerNorm backward kernel == the two-node
+    form (LayerNorm + autograd's accumulation) up to the rounding of that one addition, and == fp32 autograd."""
+    from uni_renderer_amd import autograd_ops as A
+    C = 640
+    x0 = _rand((3, 50, C), dtype, dev, 1)
+    g_ = (1 + 0.1 * torch.randn(C)).to(dev)
+    b_ = (0.1 * torch.randn(C)).to(dev)
+    w = _rand((C, C), dtype, dev, 2, C ** -0.5)
+    up = _rand((3, 50, C), dtype, dev, 3)
+
+    def run(skipnode):
+        x = x0.clone().requires_grad_()
+        g, b = g_.clone().requires_grad_(), b_.clone().requires_grad_()
+        if skipnode:
+            xs, xn = A.LayerNormSkip.apply(x, g, b, 1e-5)
+        else:
+            xs, xn = x, A.LayerNorm.apply(x, g, b, 1e-5)
+        y = A.linear(xn, w, None, res=xs)
+        y.backward(up)
+        return y.detach(), x.grad, g.grad, b.grad
+
+    y1, dx1, dg1, db1 = run(True)
+    y0, dx0, dg0, db0 = run(False)
+    assert torch.equal(y1, y0) and torch.equal(dg1, dg0) and torch.equal(db1, db0)
+    assert rel_l2(dx1, dx0.float()) < (1e-3 if dtype == torch.float16 else 6e-3)
+    xr = x0.float().cpu().requires_grad_()
+    yr = F.layer_norm(xr, (C,), g_.cpu(), b_.cpu(), 1e-5) @ w.float().cpu().t() + xr
+    yr.backward(up.float().cpu())
+    assert rel_l2(dx1, xr.grad) < TOL[dtype]

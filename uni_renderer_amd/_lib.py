@@ -123,6 +123,7 @@ SYMBOLS = {
     "ur_groupnorm_backward": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_float,
                                         C.c_int, C.c_int, vp, vp, C.c_int, vp, C.c_int, vp]),
     "ur_layernorm_backward": (C.c_int, [vp, vp, vp, C.c_float, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp]),
+    "ur_layernorm_backward_skip": (C.c_int, [vp, vp, vp, C.c_float, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp]),
     "ur_split_heads": (C.c_int, [vp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp]),
     "ur_merge_heads": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int64, C.c_int, C.c_int, vp]),
     "ur_softmax_rows": (C.c_int, [vp, C.c_int64, C.c_int64, C.c_int, C.c_int, vp]),

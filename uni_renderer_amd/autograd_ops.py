@@ -96,6 +96,28 @@ class LayerNorm(Function):
         return dx, dg, db, None
 
 
+class LayerNormSkip(Function):
+    """(x, LayerNorm(x)): the pre-norm residual pattern ``x + f(LN(x))`` as ONE autograd node, so that the gradient reaching x
+    around the norm and the norm's own input gradient are added by the LayerNorm backward kernel
+    (``ur_layernorm_backward_skip``) instead of by a separate accumulation launch."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        ctx.save_for_backward(x, gamma)
+        ctx.eps = float(eps)
+        ctx.set_materialize_grads(False)
+        return x.view_as(x), ops.layernorm(x, gamma, beta, eps)
+
+    @staticmethod
+    def backward(ctx, dskip, dy):
+        x, gamma = ctx.saved_tensors
+        if dy is None:
+            return dskip, None, None, None
+        skip = dskip.contiguous() if dskip is not None else None
+        dx, dg, db = bw.layernorm_backward(x, dy.contiguous(), gamma, ctx.eps, skip=skip)
+        return dx, dg, db, None
+
+
 class Attention(Function):
     """softmax(q k^T / sqrt(d)) v per head; q [B,Tq,H*d], k / v [B,Tk,H*d].  Forward: the flash kernel (nothing but
     q, k, v is kept); backward: backward.attention_backward."""

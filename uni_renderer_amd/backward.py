@@ -375,9 +375,10 @@ def groupnorm_backward(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, b
     return dx, sums[1], sums[0]
 
 
-def layernorm_backward(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, eps: float = 1e-5
-                       ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
-    """x, dy [..., C] -> (dx, dgamma, dbeta) (fp32 parameter gradients)."""
+def layernorm_backward(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, eps: float = 1e-5,
+                       skip: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """x, dy [..., C] -> (dx, dgamma, dbeta) (fp32 parameter gradients).  ``skip``: a gradient reaching x around the norm
+    (same shape), added to dx by the kernel."""
     _require_gpu(x)
     lib = _lib.load()
     Cc = x.shape[-1]
@@ -386,8 +387,9 @@ def layernorm_backward(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, e
     waves = (rows + rpw - 1) // rpw
     part = torch.empty(waves, 2, Cc, dtype=torch.float32, device=x.device)  # every wave writes its whole row
     dx = torch.empty_like(x)
-    check(lib.ur_layernorm_backward(x.data_ptr(), dy.data_ptr(), gamma.data_ptr(), float(eps), rows, Cc, rpw, dx.data_ptr(),
-                                    part.data_ptr(), DT[x.dtype], _stream()), "ur_layernorm_backward")
+    check(lib.ur_layernorm_backward_skip(x.data_ptr(), dy.data_ptr(), gamma.data_ptr(), float(eps), rows, Cc, rpw, dx.data_ptr(),
+                                         part.data_ptr(), skip.data_ptr() if skip is not None else None, DT[x.dtype], _stream()),
+          "ur_layernorm_backward_skip")
     sums = colsum(part.view(waves, 2 * Cc)).view(2, Cc)
     return dx, sums[0].contiguous(), sums[1].contiguous()
 

@@ -545,7 +545,8 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const T* __restrict__
 template <typename T, int MAXV>
 __global__ void __launch_bounds__(256) ln_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                      const float* __restrict__ gamma, float eps, int rows, int C,
-                                                     int rpw, T* __restrict__ dx, float* __restrict__ part) {
+                                                     int rpw, T* __restrict__ dx, float* __restrict__ part,
+                                                     const T* __restrict__ skip) {
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int nvec = C >> 3;
@@ -610,6 +611,12 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const T* __restrict__ x, co
                 float o[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) o[i] = rstd * (dv[k][i] - a - xv[k][i] * b2);
+                if (skip) {  // the gradient that reaches x around the norm (residual path): added here, not by a launch of its own
+                    float sk[8];
+                    load8(skip + (int64_t)row * C + cv * 8, sk);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) o[i] += sk[i];
+                }
                 store8(dx + (int64_t)row * C + cv * 8, o);
             }
         }
@@ -1014,8 +1021,8 @@ extern "C" int ur_groupnorm_backward(const void* x, const void* dy, int C, int B
     return last_error();
 }
 
-extern "C" int ur_layernorm_backward(const void* x, const void* dy, const float* gamma, float eps, int rows, int C,
-                                     int rows_per_wave, void* dx, float* part, int dtype, void* stream) {
+extern "C" int ur_layernorm_backward_skip(const void* x, const void* dy, const float* gamma, float eps, int rows, int C,
+                                          int rows_per_wave, void* dx, float* part, const void* skip, int dtype, void* stream) {
     if (!x || !dy || !gamma || !dx || !part || rows <= 0 || C <= 0 || (C & 7) || C > 2048 || rows_per_wave <= 0)
         return UR_E_BADARG;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -1023,15 +1030,20 @@ extern "C" int ur_layernorm_backward(const void* x, const void* dy, const float*
     dim3 grid((waves + 3) / 4);
     if (C <= 512) {
         UR_DISPATCH(dtype, hipLaunchKernelGGL((ln_bwd_kernel<T, 1>), grid, dim3(256), 0, s, (const T*)x, (const T*)dy, gamma,
-                                              eps, rows, C, rows_per_wave, (T*)dx, part));
+                                              eps, rows, C, rows_per_wave, (T*)dx, part, (const T*)skip));
     } else if (C <= 1024) {
         UR_DISPATCH(dtype, hipLaunchKernelGGL((ln_bwd_kernel<T, 2>), grid, dim3(256), 0, s, (const T*)x, (const T*)dy, gamma,
-                                              eps, rows, C, rows_per_wave, (T*)dx, part));
+                                              eps, rows, C, rows_per_wave, (T*)dx, part, (const T*)skip));
     } else {
         UR_DISPATCH(dtype, hipLaunchKernelGGL((ln_bwd_kernel<T, 4>), grid, dim3(256), 0, s, (const T*)x, (const T*)dy, gamma,
-                                              eps, rows, C, rows_per_wave, (T*)dx, part));
+                                              eps, rows, C, rows_per_wave, (T*)dx, part, (const T*)skip));
     }
     return last_error();
+}
+
+extern "C" int ur_layernorm_backward(const void* x, const void* dy, const float* gamma, float eps, int rows, int C,
+                                     int rows_per_wave, void* dx, float* part, int dtype, void* stream) {
+    return ur_layernorm_backward_skip(x, dy, gamma, eps, rows, C, rows_per_wave, dx, part, nullptr, dtype, stream);
 }
 
 extern "C" int ur_split_heads(const void* x, int64_t ld, int off, int B, int T_, int H, int d, void* out, int Tp, int dp,

@@ -143,11 +143,15 @@ def _context_projections(blocks, ehs, dt):
 
 
 def _tblock(b, x, kvs, dt):
-    x = _self_attn(b.attn1, A.LayerNorm.apply(x, b.norm1.weight, b.norm1.bias, b.norm1.eps), x, dt)
-    x = _cross_attn(b.attn2, A.LayerNorm.apply(x, b.norm2.weight, b.norm2.bias, b.norm2.eps), kvs[id(b)], x, dt)
+    # (x, LN(x)) as one autograd node: the residual's gradient is added inside the LayerNorm backward kernel
+    xs, xn = A.LayerNormSkip.apply(x, b.norm1.weight, b.norm1.bias, b.norm1.eps)
+    x = _self_attn(b.attn1, xn, xs, dt)
+    xs, xn = A.LayerNormSkip.apply(x, b.norm2.weight, b.norm2.bias, b.norm2.eps)
+    x = _cross_attn(b.attn2, xn, kvs[id(b)], xs, dt)
     proj, out = b.ff.net[0].proj, b.ff.net[2]
-    h = A.linear(A.LayerNorm.apply(x, b.norm3.weight, b.norm3.bias, b.norm3.eps), _w2(proj, dt), proj.bias)
-    return A.linear(A.GEGLU.apply(h), _w2(out, dt), out.bias, res=x)
+    xs, xn = A.LayerNormSkip.apply(x, b.norm3.weight, b.norm3.bias, b.norm3.eps)
+    h = A.linear(xn, _w2(proj, dt), proj.bias)
+    return A.linear(A.GEGLU.apply(h), _w2(out, dt), out.bias, res=xs)
 
 
 def _transformer(t, x, ehs, dt):
