@@ -106,3 +106,27 @@ def test_bench_runs_with_the_drivers_command_line_and_spawns_its_own_ranks():
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 1
+
+
+def test_bench_line_carries_the_contract_fields_with_a_live_roofline():
+    """One default-style run (roofline on, live PMC traffic attempted, CPU baseline off for time) at a small configuration:
+    the JSON line has every field of the bench contract, and the roofline object is self-consistent."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", TMPDIR="/tmp")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--batch", "2",
+           "--latent", "32"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline"):
+        assert k in line, k
+    assert line["steps"] == 3 and line["warmup"] == 1 and line["n_gpus"] == 1 and line["higher_is_better"] is True
+    assert line["scaling"] == "weak" and line["vs_baseline"] is None and "workload" in line["config"] and "model" not in line["config"]
+    roof = line["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in roof, k
+    assert roof["bound"] in ("hbm", "mfma") and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+    if roof["traffic"] is not None:
+        assert roof["traffic"] > 0 and roof["traffic_source"].startswith(("LIVE", "STATIC"))
