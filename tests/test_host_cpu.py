@@ -197,21 +197,34 @@ def test_algorithmic_flop_model_matches_the_survey():
     assert abs(bench.algorithmic_flops(64, 1, "inverse") / 1e12 - 1.622) < 0.005
 
 
-def test_eval_modules_keep_the_inference_path_and_train_selects_autograd():
-    """after from_pretrained() (eval mode, parameters still requires_grad) a plain call outside no_grad must
-    not silently take the activation-saving autograd path; train() -- what train.py:1050-1052 calls -- selects it."""
+def test_autograd_follows_torch_semantics_and_eval_mode_warns_once():
+    """ADVICE r3 (supersedes r2's choice): eval() never disables autograd in torch / diffusers.  A module with
+    requires_grad parameters called with autograd recording returns differentiable outputs whatever its train() flag --
+    a fine-tuning set-up that keeps a network in eval() must not silently lose its gradients; the inference mistake
+    (from_pretrained() module called outside no_grad) is told once that it took the activation-saving path."""
+    import warnings
+
     import uni_renderer_amd as U
 
     unet = U.UNet2DConditionModel(**{k: v for k, v in O.TINY_CONFIG.items()})
     x = torch.zeros(1, 4, 8, 8)
     unet.eval()
     assert any(p.requires_grad for p in unet.parameters())
-    assert unet._autograd_mode(x) is False
-    assert unet._autograd_mode(x.clone().requires_grad_()) is True   # an input that wants a gradient still does
+    type(unet)._warned_eval_autograd = False
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert unet._autograd_mode(x) is True
+        assert unet._autograd_mode(x) is True
+    assert len([m for m in w if "eval() mode" in str(m.message)]) == 1  # once
     unet.train()
     assert unet._autograd_mode(x) is True
     with torch.no_grad():
         assert unet._autograd_mode(x) is False
+    unet.requires_grad_(False)
+    assert unet._autograd_mode(x) is False                              # frozen network: the fused inference path
+    assert unet._autograd_mode(x.clone().requires_grad_()) is True      # unless an input wants a gradient
+    unet.eval()
+    assert unet._autograd_mode(x) is False
 
 
 def test_enable_gradient_checkpointing_tells_the_caller():

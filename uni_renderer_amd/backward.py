@@ -136,18 +136,26 @@ class GradSquares:
     twice) the partials do not describe the accumulated gradients and the step falls back to ``_foreach_norm``."""
 
     def __init__(self):
-        self.begin()
+        self.begin(trusted=False)
 
-    def begin(self):
+    def begin(self, token=None, trusted: bool = True):
+        """Start collecting for one backward.  ``token`` identifies whose gradients these are (the network triple of the
+        step); ``trusted`` is False when the caller knows the backward ADDS to older gradients (accumulation micro-steps,
+        a scaled loss, parameters that kept a ``.grad``): the partial sums would then not describe ``p.grad``."""
         self.parts, self.count = [], {}
+        self.token, self.trusted = token, bool(trusted)
+
+    def clear(self):
+        self.begin(trusted=False)
 
     def add(self, partial: torch.Tensor, pids):
         self.parts.append(partial)
         for pid in pids:
             self.count[pid] = self.count.get(pid, 0) + 1
 
-    def usable(self) -> bool:
-        return bool(self.parts) and all(c == 1 for c in self.count.values())
+    def usable(self, token=None) -> bool:
+        return (self.trusted and token == self.token and bool(self.parts)
+                and all(c == 1 for c in self.count.values()))
 
 
 grad_squares = GradSquares()

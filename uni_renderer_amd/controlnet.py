@@ -15,6 +15,8 @@ encoder_hid_proj, GLIGEN, LoRA scale, attention masks) rai
 """
 from __future__ import annotations
 
+import warnings
+
 from dataclasses import dataclass
 from typing import Any, Dict, List, Optional, Tuple, Union
 
@@ -110,8 +112,8 @@ class _DenoiserBase(ConfigModelMixin, nn.Module):
         """True when this call must be differentiable: autograd is recording and a parameter or an input wants a
         gradient -- the situation of train/train.py:1324-1354 (modules called, then ``accelerator.backward(loss)``).
         The forwards then run over ``autograd_ops`` (train_step.py: HIP forward AND backward kernels, same return
-        tuples); under ``torch.no_grad()``, with frozen parameters, or in ``eval()`` mode with no input that requires a
-        gradient, they take the fused inference path."""
+        tuples); under ``torch.no_grad()`` or with frozen parameters and no input that requires a gradient they take the
+        fused inference path.  ``train()`` / ``eval()`` does not enter the decision (as in torch)."""
         if not torch.is_grad_enabled():
             return False
         for t in tensors:
@@ -120,10 +122,20 @@ class _DenoiserBase(ConfigModelMixin, nn.Module):
                     return True
             elif isinstance(t, (list, tuple)) and any(torch.is_tensor(u) and u.requires_grad for u in t):
                 return True
-        # parameters alone select the training path only in train() mode (the reference calls controlnet.train() /
-        # unet.train(), train.py:1233-1235): an eval() module called outside torch.no_grad() -- the default state after
-        # from_pretrained() -- keeps the fused inference path instead of silently saving activations
-        return self.training and any(p.requires_grad for p in self.parameters())
+        # torch semantics: eval() never disables autograd.  A module whose parameters require a gradient, called with
+        # autograd recording, must return outputs with a grad_fn whatever its train() / eval() flag -- otherwise a
+        # fine-tuning set-up that leaves a network in eval() (frozen-statistics modes, partial training) would get NO
+        # gradients for it and no error.  The common inference mistake -- calling a from_pretrained() module
+        # (eval(), requires_grad parameters) outside torch.no_grad() -- therefore takes the slower differentiable path;
+        # it is told so once.  (The reference's sampling methods are all @torch.no_grad(), pipeline.py Appendix B.)
+        if not any(p.requires_grad for p in self.parameters()):
+            return False
+        if not self.training and not getattr(type(self), "_warned_eval_autograd", False):
+            type(self)._warned_eval_autograd = True
+            warnings.warn(f"{type(self).__name__} is in eval() mode but was called with autograd recording and parameters "
+                          "that require gradients: taking the differentiable path (activations are saved).  For "
+                          "inference wrap the call in torch.no_grad() or call .requires_grad_(False).", stacklevel=3)
+        return True
 
     @staticmethod
     def _tokens(ehs: torch.Tensor, dt) -> torch.Tensor:

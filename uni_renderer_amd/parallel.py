@@ -82,6 +82,60 @@ def max_over_ranks(seconds: float, device=None) -> float:
 _FORWARD_ORDER = {"AttributeEncoderModel": 0, "UNet2DConditionModel": 1, "AttributeDecoderModel": 2}
 
 
+@torch.no_grad()
+def broadcast_parameters(modules: Iterable[torch.nn.Module], src: int = 0, group=None, chunk_mb: float = 256.0) -> int:
+    """Make every rank start from rank ``src``'s parameters AND buffers -- what the constructor of each of the reference's
+    three ``DistributedDataParallel`` wrappers does (train/train.py:1140-1142; torch DDP ``_sync_module_states``).  Without
+    it ranks agree only if they were seeded identically; a rank that resumed from a different checkpoint would diverge
+    silently.  Tensors are packed per dtype into flat chunks of ``chunk_mb`` (xGMI: few large messages) and copied back in
+    place.  Returns the number of elements sent; a no-op without an initialised multi-rank group."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return 0
+    seen, tensors = set(), []
+    for m in modules:
+        for t in list(m.parameters()) + list(m.buffers()):
+            if id(t) not in seen:
+                seen.add(id(t))
+                tensors.append(t.data)
+    sent = 0
+    by_kind = {}
+    for t in tensors:
+        by_kind.setdefault((t.dtype, t.device), []).append(t)
+    for (dtype, dev), ts in by_kind.items():
+        if not (dtype.is_floating_point or dtype in (torch.int64, torch.int32, torch.uint8, torch.bool)):
+            continue
+        cap = max(1, int(chunk_mb * (1 << 20)) // max(1, torch.empty((), dtype=dtype).element_size()))
+        i = 0
+        while i < len(ts):
+            part, n = [], 0
+            while i < len(ts) and (not part or n + ts[i].numel() <= cap):
+                part.append(ts[i])
+                n += ts[i].numel()
+                i += 1
+            wire = torch.uint8 if dtype == torch.bool else dtype
+            flat = torch.empty(n, dtype=wire, device=dev)
+            off = 0
+            for t in part:
+                flat[off:off + t.numel()].copy_(t.reshape(-1))
+                off += t.numel()
+            dist.broadcast(flat, src=src, group=group)
+            off = 0
+            for t in part:
+                t.copy_(flat[off:off + t.numel()].view(t.shape))
+                off += t.numel()
+            sent += n
+    return sent
+
+
+def rs_ag_shard(buf: torch.Tensor, rank: int, world: int) -> torch.Tensor:
+    """Rank ``rank``'s slice of a flat bucket for reduce-scatter + all-gather: the bucket is ``world`` equal contiguous
+    slices in rank order (``reduce_scatter_tensor`` / ``all_gather_into_tensor`` semantics), returned as a VIEW so the
+    reduce-scatter lands in place and the all-gather reads it in place."""
+    if buf.dim() != 1 or buf.numel() % world:
+        raise ValueError(f"bucket of {tuple(buf.shape)} elements does not split over {world} ranks")
+    return buf.view(world, -1)[rank]
+
+
 class GradientBuckets:
     """Flat gradient buckets over several modules, all-reduced (mean) WHILE the backward pass is still running.
 
@@ -109,11 +163,15 @@ class GradientBuckets:
     """
 
     def __init__(self, modules: Iterable[torch.nn.Module], bucket_mb: float = 256.0, comm_dtype=None,
-                 algorithm: str = "all_reduce", overlap: bool = True, process_group=None, force_collectives: bool = False):
+                 algorithm: str = "all_reduce", overlap: bool = True, process_group=None, force_collectives: bool = False,
+                 broadcast: bool = True):
         """``force_collectives``: issue the collectives even in a one-rank group (tests: drives RCCL's
-        all-reduce / reduce-scatter / all-gather and their stream ordering on a single GPU)."""
+        all-reduce / reduce-scatter / all-gather and their stream ordering on a single GPU).
+        ``broadcast``: start every rank from rank 0's parameters and buffers, as each DDP constructor of the reference
+        does (train.py:1140-1142); see ``broadcast_parameters``."""
         mods = list(modules)
         mods.sort(key=lambda m: _FORWARD_ORDER.get(getattr(m, "module", m).__class__.__name__, 1))  # stable for others
+        self.broadcast_elements = broadcast_parameters(mods, 0, process_group) if broadcast else 0
         params = [p for m in mods for p in m.parameters() if p.requires_grad]
         self.params = list(reversed(params))
         self.comm_dtype = comm_dtype
@@ -162,6 +220,7 @@ class GradientBuckets:
         self._launched = 0
         self._work: List = []
         self._in_backward = True
+        self._sync = True  # False inside no_sync(): gradients accumulate locally, no collective is issued
         self.launched_from_hooks = 0  # diagnostics: buckets whose collective was enqueued during backward()
         self._hooks = []
         if overlap:
@@ -175,8 +234,28 @@ class GradientBuckets:
     def _single(self) -> bool:
         return self._world() == 1 and not (self.force and dist.is_initialized())
 
+    def no_sync(self):
+        """Context manager for gradient accumulation -- DDP's ``no_sync()``, which ``accelerator.accumulate(controlnet,
+        controldec, unet)`` enters on every micro-step but the last (train/train.py:1236, flag --gradient_accumulation_steps
+        at 621).  Inside it ``backward()`` only accumulates into the flat buffers (the ``p.grad`` views): no hook counts an
+        arrival, ``finish()`` issues nothing.  The first ``backward()`` + ``finish()`` outside it reduces the ACCUMULATED
+        gradients.  Do not call ``zero_grad()`` between the micro-steps of one optimisation step."""
+        buckets = self
+
+        class _NoSync:
+            def __enter__(self_inner):
+                self_inner.prev = buckets._sync
+                buckets._sync = False
+                return buckets
+
+            def __exit__(self_inner, *exc):
+                buckets._sync = self_inner.prev
+                return False
+
+        return _NoSync()
+
     def _on_grad(self, p):
-        if self._single():
+        if self._single() or not self._sync:
             return
         bi = self._bucket_of[p]
         if p.grad is not None and p.grad.data_ptr() != self._view_ptr(p):  # someone re-created .grad: pull it back in
@@ -216,7 +295,7 @@ class GradientBuckets:
             # are enqueued here, back to back on the process group's stream -- RCCL orders them -- so the all-gather also
             # runs under the rest of the backward instead of inside finish().  (gloo has no reduce_scatter_tensor: the CPU
             # test transport takes the all-reduce branch.)
-            shard = buf.view(world, -1)[dist.get_rank(self.group)]
+            shard = rs_ag_shard(buf, dist.get_rank(self.group), world)
             dist.reduce_scatter_tensor(shard, buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             w2 = dist.all_gather_into_tensor(buf, shard, group=self.group, async_op=True)
             self._work.append((bi, w2, "rs_ag"))
@@ -231,6 +310,12 @@ class GradientBuckets:
         """After ``backward()``: launch the buckets the hooks could not (missing gradients on this rank), wait for all
         collectives, and leave the mean gradients in the flat buffers (= in every ``p.grad``)."""
         if self._single():
+            self._reset()
+            return
+        if not self._sync:  # accumulation micro-step: keep the local sums, adopt gradients re-created outside the buckets
+            for p in self.params:
+                if p.grad is not None and p.grad.data_ptr() != self._view_ptr(p):
+                    self._adopt(p)
             self._reset()
             return
         for p in self.params:  # a .grad re-created outside (set_to_none + a fresh backward): adopt it

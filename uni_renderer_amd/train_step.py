@@ -359,26 +359,53 @@ def reference_losses(nets: Sequence[torch.nn.Module], batch: Dict[str, torch.Ten
     return res
 
 
-def _forward_backward(nets, batch, optimizer, buckets, dtype, inverse):
+def _forward_backward(nets, batch, optimizer, buckets, dtype, inverse, grad_accum=None, loss_scale=None, scaler=None):
     """forward, losses, backward; gradients end in ``buckets``' flat buffers (collectives of complete buckets already in
-    flight when the buckets were built with ``overlap=True``) or in fresh ``p.grad`` tensors."""
+    flight when the buckets were built with ``overlap=True``) or in fresh ``p.grad`` tensors.
+    ``grad_accum`` = (k, n): micro-step k of n of one optimisation step (train.py:1236 ``accelerator.accumulate``):
+    gradients are zeroed only at k = 0, the loss is divided by n (accelerate's ``backward``), and with ``buckets`` every
+    micro-step but the last runs under ``no_sync()``.  ``loss_scale``: a factor (device scalar or float) the loss is
+    multiplied with before ``backward()``; ``scaler``: a ``torch.amp.GradScaler`` whose ``scale(loss)`` is used instead
+    (train.sh:21 ``--mixed_precision="fp16"``: accelerate's ``backward`` does exactly that)."""
     unet, enc, dec = nets
+    k, n = grad_accum if grad_accum is not None else (0, 1)
     if inverse is None:
         out = dual_stream_forward(unet, enc, dec, batch["x_t"], batch["cond"], batch["ehs"], batch["t_img"],
                                   batch["t_attr"], dtype=dtype)
         loss = mse_losses(out, batch["target_img"], batch["target_attr"])
     else:
         loss = reference_losses(nets, batch, dtype=dtype, inverse=inverse)["loss"]
-    if buckets is not None:
-        buckets.zero_grad()  # gradients live in the buckets' flat buffers (views): zero in place, keep the views
-    elif optimizer is not None:
-        optimizer.zero_grad(set_to_none=True)
-    B.grad_squares.begin()  # per-launch sums of squares of the fp32 gradients written by this backward (clipping norm)
-    loss.backward()  # with ``buckets``: complete buckets are all-reduced (async) while the backward is still running
-    return loss.detach()
+    if k == 0:
+        if buckets is not None:
+            buckets.zero_grad()  # gradients live in the buckets' flat buffers (views): zero in place, keep the views
+        elif optimizer is not None:
+            optimizer.zero_grad(set_to_none=True)
+    # per-launch sums of squares of the fp32 gradients written by this backward (clipping norm).  They describe the
+    # gradients only if this backward produces them from scratch: one micro-step, no loss scaling, and no parameter of
+    # these networks holding an older gradient (an optimizer over a subset of the parameters zeroes only its own)
+    fresh = (n == 1 and loss_scale is None and scaler is None and buckets is None
+             and all(p.grad is None for p in _parameters(nets)))
+    B.grad_squares.begin(token=_nets_token(nets), trusted=fresh)
+    report = loss.detach()
+    if n > 1:
+        loss = loss / n
+    if loss_scale is not None:
+        loss = loss * loss_scale
+    if scaler is not None:
+        loss = scaler.scale(loss)
+    if buckets is not None and k + 1 < n:
+        with buckets.no_sync():
+            loss.backward()
+    else:
+        loss.backward()  # with ``buckets``: complete buckets are all-reduced (async) while the backward is still running
+    return report
 
 
 _param_cache: Dict[tuple, tuple] = {}
+
+
+def _nets_token(nets) -> tuple:
+    return tuple(id(n) for n in nets)
 
 
 def _parameters(nets) -> list:
@@ -391,8 +418,24 @@ def _parameters(nets) -> list:
     return hit[1]
 
 
-def _clip_and_update(nets, optimizer, buckets, max_grad_norm, stats):
-    """train.py:1422-1425: clip_grad_norm_ + optimizer.step(), the clipping folded into the optimizer pass when it can."""
+def _clip_and_update(nets, optimizer, buckets, max_grad_norm, stats, scaler=None):
+    """train.py:1422-1425: clip_grad_norm_ + optimizer.step(), the clipping folded into the optimizer pass when it can.
+    With ``scaler`` (fp16 AMP, train.sh:21): the reference's order -- ``unscale_`` (which also looks for inf / nan),
+    clip, ``scaler.step`` (skips the update when an overflow was found: parameters, moments and the step counter stay),
+    ``scaler.update``."""
+    if scaler is not None:
+        if optimizer is None:
+            raise ValueError("a GradScaler needs the optimizer whose gradients it unscales")
+        scaler.unscale_(optimizer)
+        if max_grad_norm is not None:
+            if buckets is not None:
+                stats["grad_norm"] = buckets.clip_grad_norm_(max_grad_norm)
+            else:
+                params = [p for p in _parameters(nets) if p.grad is not None]
+                stats["grad_norm"] = torch.nn.utils.clip_grad_norm_(params, max_grad_norm)
+        scaler.step(optimizer)
+        scaler.update()
+        return
     folded = False
     if max_grad_norm is not None:
         # torch's fused Adam / AdamW kernels (and optim.FusedAdamW) divide every gradient by ``optimizer.grad_scale`` on
@@ -405,7 +448,7 @@ def _clip_and_update(nets, optimizer, buckets, max_grad_norm, stats):
                 # _foreach_norm, not vector_norm per bucket: a CAPTURED vector_norm over a 32 MB tensor returns wrong
                 # values on replay in this torch / ROCm build (tools/graph_norm_repro.py)
                 norm = torch.linalg.vector_norm(torch.stack(torch._foreach_norm(list(buckets.flat))))
-            elif B.FUSED_GRADNORM and B.grad_squares.usable():
+            elif B.FUSED_GRADNORM and B.grad_squares.usable(_nets_token(nets)):
                 # the big gradients' sums of squares came out of the kernels that wrote them; only the parameters those
                 # launches do not cover (norm / bias vectors, a few small matrices) are swept here
                 cov = B.grad_squares.count
@@ -414,6 +457,7 @@ def _clip_and_update(nets, optimizer, buckets, max_grad_norm, stats):
                 if rest:
                     sq = sq + torch.stack(torch._foreach_norm(rest)).square().sum()
                 norm = sq.sqrt()
+                B.grad_squares.clear()  # consumed: stale partial sums must not describe a later step
             else:
                 grads = [p.grad for p in _parameters(nets) if p.grad is not None]
                 norm = torch.linalg.vector_norm(torch.stack(torch._foreach_norm(grads)))
@@ -434,18 +478,27 @@ def _clip_and_update(nets, optimizer, buckets, max_grad_norm, stats):
 
 def train_step(nets: Sequence[torch.nn.Module], batch: Dict[str, torch.Tensor], optimizer=None, buckets=None,
                dtype=torch.bfloat16, max_grad_norm: Optional[float] = 1.0, inverse: Optional[bool] = None,
-               as_tensors: bool = False) -> Dict[str, float]:
+               as_tensors: bool = False, grad_accum: Optional[tuple] = None, scaler=None) -> Dict[str, float]:
     """One optimisation step: forward, losses, backward (HIP kernels), gradient all-reduce (``buckets``: a
     parallel.GradientBuckets, no-op on one rank), clipping (train.py:1422-1424), optimizer step.
+    ``grad_accum`` = (k, n): micro-step k of n (``accelerator.accumulate``, train.py:1236): gradients are zeroed at
+    k = 0 only, the loss is divided by n, the collectives / clipping / update happen at k = n - 1 only.
+    ``scaler``: a ``torch.amp.GradScaler`` for the reference's fp16 AMP recipe (train.sh:21; pass ``dtype=torch.float16``).
     ``inverse``: None = the plain two-stream MSE objective (mse_losses); True / False = the reference's inverse-rendering
     (cycle consistency) / rendering (contrastive) objectives (reference_losses).  Ranks may pick different branches
     (compute_t, train.py:445): parameters without a gradient contribute zeros to the buckets.
     ``as_tensors``: return the statistics as device tensors (no host synchronisation: the step can then be captured
     into a HIP graph, tools/train_bench.py --graph)."""
-    stats = {"loss": _forward_backward(nets, batch, optimizer, buckets, dtype, inverse)}
+    stats = {"loss": _forward_backward(nets, batch, optimizer, buckets, dtype, inverse, grad_accum=grad_accum, scaler=scaler)}
+    last = grad_accum is None or grad_accum[0] + 1 == grad_accum[1]
     if buckets is not None:
-        buckets.finish()
-    _clip_and_update(nets, optimizer, buckets, max_grad_norm, stats)
+        if last:
+            buckets.finish()
+        else:
+            with buckets.no_sync():
+                buckets.finish()  # an accumulation micro-step: only adopts gradients re-created outside the buckets
+    if last:
+        _clip_and_update(nets, optimizer, buckets, max_grad_norm, stats, scaler=scaler)
     return stats if as_tensors else {k: float(v) for k, v in stats.items()}
 
 
