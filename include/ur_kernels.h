@@ -109,7 +109,17 @@ extern "C" {
 #define UR_TILE_WS320 47          /* weight-streaming 3x3 conv, 128 pixels x 320 channels per workgroup (csrc/wsconv.hip):\
                                      `w` is the stage-image stream of tchain.py wsconv_images, channels multiples of 320 */
 #define UR_TILE_WS320_W8 48       /* the same with 8 waves per workgroup = 2 per SIMD (a wave: 32 pixels x 160 channels) */
-#define UR_TILE_COUNT 49
+/* 8-wave PING-PONG builds (csrc/igemm_pp.hip): two groups of four waves half a phase apart -- one multiplies while the
+   other reads fragments and issues LDS-DMA copies; 32-deep stages in a 4- / 5-slot LDS ring, counted vmcnt, raw barriers;
+   32x32x16 MFMA.  Same descriptor, operand layouts, split-K slabs and epilogue as the lock-step tiles. */
+#define UR_TILE_PP_128x320 49     /* 4 x 2 waves of 32 x 160, 5-slot ring (140 KB) */
+#define UR_TILE_PP_128x320_S4 50  /* the same, 4 slots (112 KB) */
+#define UR_TILE_PP_256x128 51     /* 4 x 2 waves of 64 x 64, 5 slots (120 KB) */
+#define UR_TILE_PP_128x256 52     /* 2 x 4 waves of 64 x 64, 5 slots (120 KB) */
+#define UR_TILE_PP_256x256 53     /* 4 x 2 waves of 64 x 128, 4 slots (128 KB) */
+#define UR_TILE_PP_128x128 54     /* 4 x 2 waves of 32 x 64, 5 slots (80 KB) */
+#define UR_TILE_PP_256x320 55     /* 4 x 2 waves of 64 x 160, 4 slots (144 KB) */
+#define UR_TILE_COUNT 56
 
 /*
  * Implicit GEMM:  out[m][n] = epilogue( sum_k X[m][k] * W[n][k] )

@@ -13,6 +13,8 @@ pytestmark = pytest.mark.gpu
 
 TOL = {torch.float16: 2e-3, torch.bfloat16: 1.2e-2}
 DTYPES = [torch.float16, torch.bfloat16]
+PP_TILES = list(range(49, 56))  # 8-wave ping-pong builds (csrc/igemm_pp.hip)
+ALL_TILES = [t for t in range(1, 47) if t != 39] + PP_TILES
 
 
 def _rand(shape, dtype, dev, scale=1.0, seed=0):
@@ -21,7 +23,7 @@ def _rand(shape, dtype, dev, scale=1.0, seed=0):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("tile", [t for t in range(1, 47) if t != 39])
+@pytest.mark.parametrize("tile", ALL_TILES)
 @pytest.mark.parametrize("shape", [(256, 320, 320), (300, 64, 128), (1000, 448, 640), (4, 1280, 320)])
 def test_linear_bias_res(dev, dtype, tile, shape):
     from uni_renderer_amd import ops
@@ -61,7 +63,7 @@ def test_linear_two_sources(dev, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("tile", [t for t in range(1, 47) if t != 39])
+@pytest.mark.parametrize("tile", ALL_TILES)
 def test_geglu(dev, dtype, tile):
     from uni_renderer_amd import ops
     from uni_renderer_amd.layers import geglu_perm
@@ -86,7 +88,7 @@ def _conv_ref(x_nhwc, w_oihw, b, stride=1, ups=False):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("tile", [t for t in range(1, 47) if t != 39])
+@pytest.mark.parametrize("tile", ALL_TILES)
 @pytest.mark.parametrize("mode", ["s1", "s2", "ups"])
 def test_conv3x3(dev, dtype, tile, mode):
     from uni_renderer_amd import ops
@@ -436,7 +438,7 @@ def test_conv3x3_with_1x1_tail(dev, dtype, cfg):
         if S == 1:
             wp, bp = wp[0], bp[0]
         # tile None: the planner's choice; 2: 128x64 on the 16x16x32 MFMA; 24 / 22 / 26: 128x64 / 128x320 / 64x64 on 32x32x16
-        for tile in (None, 24, 22, 26, 31, 35, 36):
+        for tile in (None, 24, 22, 26, 31, 35, 36, 49, 50, 51, 54):
             y = ops.conv3x3(h, wp, bp, tail=(ta, tb), cblock=cblock, streams=S, hilo=True,
                             splitk=(sk if sk is not None else (None if tile is None else 1)),
                             tile=(tile if tile is not None else (None if sk is None else 2)))
@@ -448,3 +450,39 @@ def test_conv3x3_with_1x1_tail(dev, dtype, cfg):
                 assert rel_l2(y[sl], ref.permute(0, 2, 3, 1)) < TOL[dtype], (cfg, S, s_, tile)
                 full = y[sl].float() + ops.lo_float(y.lo[sl])  # (hi, lo) pair written by the same epilogue
                 assert rel_l2(full, ref.permute(0, 2, 3, 1)) < TOL[dtype], (cfg, S, s_, tile)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("tile", PP_TILES)
+def test_pingpong_tiles_long_k_splitk_concat_and_repeatability(dev, dtype, tile):
+    """The ping-pong main loop (csrc/igemm_pp.hip) where its ring protocol matters: K long enough to wrap the 4- / 5-slot
+    ring many times, split-K slices of uneven length (slices that END early exercise the tail of the counted waits), a
+    two-source concat, a ragged M and N tile, stride 2 -- against fp32 conv2d; then 200 launches of one problem must be
+    BIT-identical (a ring race shows as a rare differing launch, not as a tolerance failure: DESIGN.md section 5)."""
+    from uni_renderer_amd import ops
+    from uni_renderer_amd.layers import pack_conv3x3
+    for (B, H, W, C0, C1, Co, stride, sk) in [(2, 20, 18, 640, 0, 320, 1, 1), (2, 20, 18, 320, 320, 200, 1, 3),
+                                              (1, 16, 16, 1280, 0, 640, 2, 4), (3, 9, 7, 64, 0, 96, 1, 1),
+                                              (1, 8, 8, 1920, 640, 1280, 1, 7)]:
+        x0 = _rand((B, H, W, C0), dtype, dev, seed=1)
+        x1 = _rand((B, H, W, C1), dtype, dev, seed=2) if C1 else None
+        w = _rand((Co, C0 + C1, 3, 3), dtype, dev, 1 / math.sqrt(9 * (C0 + C1)), seed=3)
+        b = torch.randn(Co, generator=torch.Generator().manual_seed(4)).to(dev)
+        y = ops.conv3x3(x0, pack_conv3x3(w, dtype), b, x1=x1, stride=stride, tile=tile, splitk=sk)
+        xin = x0 if x1 is None else torch.cat([x0, x1], -1)
+        ref = _conv_ref(xin, w, b, stride)
+        assert y.shape == ref.shape
+        assert rel_l2(y, ref) < TOL[dtype], (B, H, W, C0, C1, Co, stride, sk)
+    # a GEMM with K = 5120 (160 stages), ragged M
+    M, N, K = 1000, 640, 5120
+    x = _rand((M, K), dtype, dev, seed=5)
+    wl = _rand((N, K), dtype, dev, 1 / math.sqrt(K), seed=6)
+    r = _rand((M, N), dtype, dev, seed=7)
+    y = ops.linear(x, wl, None, res=r, tile=tile, splitk=1)
+    assert rel_l2(y, x.float().cpu() @ wl.float().cpu().t() + r.float().cpu()) < TOL[dtype]
+    # bitwise repeatability of the level-0 conv shape (M = 8192 rows: 64 workgroups, every CU of an XCD busy)
+    x = _rand((2, 64, 64, 320), dtype, dev, seed=8)
+    w = pack_conv3x3(_rand((320, 320, 3, 3), dtype, dev, 1 / math.sqrt(2880), seed=9), dtype)
+    first = ops.conv3x3(x, w, None, tile=tile, splitk=1).clone()
+    diff = sum(int(not torch.equal(ops.conv3x3(x, w, None, tile=tile, splitk=1), first)) for _ in range(200))
+    assert diff == 0, f"{diff} of 200 launches differ"

@@ -17,154 +17,9 @@
 //     operand B, so a lane ends up with consecutive output channels of ONE pixel; the weight rows are
 //     permuted while loading so that those channels are 16 consecutive ones -> 32-byte vector
 //     stores/loads per lane and full 128-byte lines per pixel row in the epilogue.
-#include "ur_common.h"
-#include "../../include/ur_kernels.h"
+#include "igemm_epi.h"
 
 namespace ur {
-
-constexpr int BK = 64;  // elements per K chunk (128 bytes)
-
-struct V16 { float v[16]; };
-// the scalars of the descriptor the masked epilogue needs, passed BY VALUE: handing the kernel-argument struct to
-// an out-of-line function by reference would force a scratch copy of it and turn every p.field into a scratch load
-struct EpiArgs { int N, n_store, rows_per_b, ld_rowadd, act; int64_t ldc, ldres; float out_scale; };
-// low parts of the (hi, lo) residual stream (include/ur_kernels.h): same leading dimensions as res / out
-template <typename T> struct HiLo { const lo_t<T>* res_lo; lo_t<T>* out_lo; };  // low parts: e5m2 bytes (fp16) / bf16
-
-// Rare path (ragged N tile, conv_out with 4 / 28 channels, unaligned leading dimensions): element-wise with
-// masks.  Kept OUT OF LINE so that the hot kernels carry only the straight-line vector epilogue.
-template <typename T>
-__device__ __noinline__ void epilogue16_slow(EpiArgs p, T* __restrict__ outz, const float* biasz, const T* rowaddz,
-                                             const T* resz, int m, int nc, V16 a, HiLo<T> hl) {
-    float (&v)[16] = a.v;
-    if (biasz) {
-        for (int i = 0; i < 16; ++i)
-            if (nc + i < p.N) v[i] += biasz[nc + i];
-    }
-    if (rowaddz) {
-        const T* ra = rowaddz + (int64_t)(m / p.rows_per_b) * p.ld_rowadd + nc;
-        for (int i = 0; i < 16; ++i)
-            if (nc + i < p.N) v[i] += to_f(ra[i]);
-    }
-    if (p.act == ACT_GEGLU) {
-        const int oc = nc >> 1;
-        T* dst = outz + (int64_t)m * p.ldc + oc;
-        for (int i = 0; i < 8; ++i) {
-            const int src = (i < 4) ? i : 4 + i;  // value columns 0-3 / 8-11, gates 4 columns further
-            if (oc + i < (p.N >> 1)) dst[i] = from_f<T>(v[src] * gelu_erf_f(v[src + 4]));
-        }
-        return;
-    }
-    if (p.act == ACT_SILU)
-        for (int i = 0; i < 16; ++i) v[i] = silu_f(v[i]);
-    if (resz) {
-        const T* rp = resz + (int64_t)m * p.ldres + nc;
-        for (int i = 0; i < 16; ++i)
-            if (nc + i < p.N) v[i] += to_f(rp[i]);
-        if (hl.res_lo) {
-            const lo_t<T>* rl = hl.res_lo + (int64_t)m * p.ldres + nc;
-            for (int i = 0; i < 16; ++i)
-                if (nc + i < p.N) v[i] += lo_to_f(rl[i]);
-        }
-    }
-    T* dst = outz + (int64_t)m * p.ldc + nc;
-    lo_t<T>* dlo = hl.out_lo ? hl.out_lo + (int64_t)m * p.ldc + nc : nullptr;
-    for (int i = 0; i < 16; ++i)
-        if (nc + i < p.n_store) {
-            const float y = v[i] * p.out_scale;
-            const T h = from_f<T>(y);
-            dst[i] = h;
-            if (dlo) dlo[i] = lo_from_f<lo_t<T>>(y - to_f(h));
-        }
-}
-
-template <typename T>
-__device__ __forceinline__ void epilogue16(const ur_igemm_desc& p, T* __restrict__ outz, const float* biasz,
-                                           const T* rowaddz, const T* resz, int m, int nc, float (&v)[16], HiLo<T> hl) {
-    if (m >= p.M) return;
-    const bool vec = (((p.ldc | p.ldres | (int64_t)p.ld_rowadd) & 7) == 0);
-    const int n_out_end = (p.act == ACT_GEGLU) ? (nc >> 1) + 8 : nc + 16;
-    if (__builtin_expect(!(vec && nc + 16 <= p.N && n_out_end <= p.n_store), 0)) {
-        V16 a;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) a.v[i] = v[i];
-        const EpiArgs e{p.N, p.n_store, p.rows_per_b, p.ld_rowadd, p.act, p.ldc, p.ldres, p.out_scale};
-        epilogue16_slow<T>(e, outz, biasz, rowaddz, resz, m, nc, a, hl);
-        return;
-    }
-    if (biasz) {
-        const float4* b4 = reinterpret_cast<const float4*>(biasz + nc);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float4 b = b4[i];
-            v[4 * i + 0] += b.x; v[4 * i + 1] += b.y; v[4 * i + 2] += b.z; v[4 * i + 3] += b.w;
-        }
-    }
-    if (rowaddz) {
-        const T* ra = rowaddz + (int64_t)(m / p.rows_per_b) * p.ld_rowadd + nc;
-        float t[8];
-        load8(ra, t);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] += t[i];
-        load8(ra + 8, t);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[8 + i] += t[i];
-    }
-    if (p.act == ACT_GEGLU) {
-        float o[8];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            o[i] = v[i] * gelu_erf_f(v[4 + i]);
-            o[4 + i] = v[8 + i] * gelu_erf_f(v[12 + i]);
-        }
-        store8(outz + (int64_t)m * p.ldc + (nc >> 1), o);
-        return;
-    }
-    if (p.act == ACT_SILU) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) v[i] = silu_f(v[i]);
-    }
-    if (resz) {
-        const T* rp = resz + (int64_t)m * p.ldres + nc;
-        float t[8];
-        load8(rp, t);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] += t[i];
-        load8(rp + 8, t);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[8 + i] += t[i];
-        if (hl.res_lo) {
-            const lo_t<T>* rl = hl.res_lo + (int64_t)m * p.ldres + nc;
-            load_lo<8>(rl, t);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] += t[i];
-            load_lo<8>(rl + 8, t);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) v[8 + i] += t[i];
-        }
-    }
-    if (p.out_scale != 1.0f) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) v[i] *= p.out_scale;
-    }
-    T* dst = outz + (int64_t)m * p.ldc + nc;
-    float t[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) t[i] = v[i];
-    store8(dst, t);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) t[i] = v[8 + i];
-    store8(dst + 8, t);
-    if (hl.out_lo) {  // rounding remainders v - float(T(v)) (exact in fp32), stored as e5m2 bytes / bf16
-        lo_t<T>* dlo = hl.out_lo + (int64_t)m * p.ldc + nc;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) t[i] = v[i];
-        store_lo8<T>(dlo, t);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) t[i] = v[8 + i];
-        store_lo8<T>(dlo + 8, t);
-    }
-}
 
 // MF = 16: v_mfma_f32_16x16x32 (the original formulation, described above).
 // MF = 32: v_mfma_f32_32x32x16: the same wave tiles with half the MFMA instructions: per 64-deep K chunk a wave issues
@@ -678,7 +533,10 @@ static const TileCfg kTiles[UR_TILE_COUNT] = {{0, 0, 0},      {128, 128, 2}, {12
                                               {128, 256, 3}, {128, 320, 2}, {256, 320, 2}, {128, 160, 2},
                                               {128, 160, 3}, {64, 320, 2},
                                               // weight-streaming conv (wsconv.hip): 4 and 8 waves
-                                              {128, 320, 2}, {128, 320, 2}};
+                                              {128, 320, 2}, {128, 320, 2},
+                                              // 8-wave ping-pong builds (igemm_pp.hip)
+                                              {128, 320, 5}, {128, 320, 4}, {256, 128, 5}, {128, 256, 5}, {256, 256, 4},
+                                              {128, 128, 5}, {256, 320, 4}};
 
 static int pick_tile(const ur_igemm_desc& d) {
     // Cost model: the busiest CU runs ceil(workgroups / 256) tiles; bigger tiles have a better
@@ -729,6 +587,23 @@ static int launch_cfg(const ur_igemm_desc& d, hipStream_t s) {
 }
 
 int wsconv_launch(const ur_igemm_desc& d, hipStream_t s);  // wsconv.hip
+int igemm_pp_launch(const ur_igemm_desc& d, hipStream_t s);  // igemm_pp.hip
+
+// ping-pong main pass + the shared split-K second pass
+template <typename T>
+static int launch_pp(const ur_igemm_desc& d, hipStream_t s) {
+    const int rc = igemm_pp_launch(d, s);
+    if (rc) return rc;
+    if (d.splitk > 1) {
+        const int64_t total = (int64_t)d.M * (d.ldp / 16);
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL((igemm_splitk_reduce<T>), dim3(blocks, d.zbatch), dim3(256), 0, s, d);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return -(int)e;
+    }
+    return 0;
+}
 
 // weight-streaming conv main pass + the shared split-K second pass
 template <typename T>
@@ -797,6 +672,8 @@ static int launch_dtype(ur_igemm_desc& d, hipStream_t s) {
         case UR_TILE_64x320_M32: return launch_cfg<T, 64, 320, 2, 2, 2, 32>(d, s);
         case UR_TILE_WS320: return launch_ws<T>(d, s);
         case UR_TILE_WS320_W8: return launch_ws<T>(d, s);
+        case UR_TILE_PP_128x320: case UR_TILE_PP_128x320_S4: case UR_TILE_PP_256x128: case UR_TILE_PP_128x256:
+        case UR_TILE_PP_256x256: case UR_TILE_PP_128x128: case UR_TILE_PP_256x320: return launch_pp<T>(d, s);
     }
     return UR_E_BADARG;
 }

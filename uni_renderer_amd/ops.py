@@ -41,7 +41,11 @@ _TILES = {TILE_128x128: (128, 128, 1.0, 2), TILE_128x64: (128, 64, 0.85, 3), TIL
           40: (128, 256, 1.3, "2L2"), 41: (128, 256, 1.2, 3), 42: (128, 320, 1.2, "2w8m32"), 43: (256, 320, 1.2, "2w16m32"), 44: (128, 160, 1.0, "2m32"), 45: (128, 160, 1.0, "3m32"),
           46: (64, 320, 0.9, "2m32"),
           # weight-streaming conv (csrc/wsconv.hip): ``w`` is the stage-image stream of wsconv_images()
-          47: (128, 320, 1.4, "ws"), 48: (128, 320, 1.4, "ws8")}
+          47: (128, 320, 1.4, "ws"), 48: (128, 320, 1.4, "ws8"),
+          # 8-wave ping-pong builds (csrc/igemm_pp.hip): "pp<ring slots>"
+          49: (128, 320, 1.5, "pp5"), 50: (128, 320, 1.5, "pp4"), 51: (256, 128, 1.4, "pp5"), 52: (128, 256, 1.4, "pp5"),
+          53: (256, 256, 1.5, "pp4"), 54: (128, 128, 1.2, "pp5"), 55: (256, 320, 1.5, "pp4")}
+TILE_PP_128x320, TILE_PP_128x320_S4, TILE_PP_256x128, TILE_PP_128x256, TILE_PP_256x256, TILE_PP_128x128, TILE_PP_256x320 = range(49, 56)
 TILE_WS320, TILE_WS320_W8 = 47, 48
 # which build ``conv3x3(ws=...)`` launches: 8 waves per workgroup (two instruction streams per SIMD) or 4 (one)
 WSCONV_TILE = TILE_WS320_W8 if os.environ.get("UR_WSCONV_WAVES", "8") == "8" else TILE_WS320
