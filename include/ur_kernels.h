@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define UR_ABI_VERSION 7
+#define UR_ABI_VERSION 8
 
 #define UR_E_BADARG (-1001)   /* inconsistent descriptor (shape / alignment / null pointer)   */
 #define UR_E_UNSUPPORTED (-1002) /* shape outside what the kernels are instantiated for       */
@@ -195,6 +195,16 @@ typedef struct ur_igemm_desc {
      * taps beyond the image read zeros).  1 = the symmetric `padding=1` of every conv of the UNets; 0 with stride 2 =
      * the VAE encoder's Downsample2D, F.pad(x, (0, 1, 0, 1)) followed by a stride-2 conv with padding 0. */
     int32_t pad;
+    /* Transposed side output (ABI 8): with out_vt set, the columns n >= vt_n0 are NOT written to `out`; they leave, after
+     * +bias only (no activation, residual or out_scale), as
+     *     out_vt[z * zvt + (m / vt_rows) * vt_bstride + (n - vt_n0) * ldvt + m % vt_rows]
+     * i.e. as the matrix V^T[sample][channel][token] the attention kernels read, so that a self-attention's q | k | v
+     * projection is ONE launch instead of a q | k GEMM plus a transposed V GEMM (models/unet_2d_blocks.py:1115-1126: the
+     * Attention of every Transformer2DModel).  vt_n0 and N - vt_n0 are multiples of 16, n_store <= vt_n0, act == NONE and
+     * res == NULL; the caller zero-fills token columns >= vt_rows of a padded V^T itself. */
+    void* out_vt;
+    int64_t ldvt, vt_bstride, zvt;
+    int32_t vt_n0, vt_rows;
 } ur_igemm_desc;
 
 int ur_igemm(const ur_igemm_desc* d, void* stream);

@@ -486,3 +486,31 @@ def test_pingpong_tiles_long_k_splitk_concat_and_repeatability(dev, dtype, tile)
     first = ops.conv3x3(x, w, None, tile=tile, splitk=1).clone()
     diff = sum(int(not torch.equal(ops.conv3x3(x, w, None, tile=tile, splitk=1), first)) for _ in range(200))
     assert diff == 0, f"{diff} of 200 launches differ"
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("tile,splitk", [(None, None), (2, 1), (9, 1), (3, 2), (24, 1), (49, 1), (54, 2)])
+@pytest.mark.parametrize("S", [1, 2])
+def test_qkv_projection_with_transposed_value_output(dev, dtype, tile, splitk, S):
+    """ur_igemm_desc.out_vt (ABI 8): q | k | v = x @ [Wq; Wk; Wv]^T in ONE launch, q | k row-major (scaled by out_scale),
+    the value columns transposed to V^T[sample][channel][token] -- against the two-launch form it replaces (ops.linear +
+    ops.vt_proj) and against fp32; grouped (two streams), split-K (the reduce pass runs the same epilogue), 16x16x32 /
+    32x32x16 / ping-pong tiles."""
+    from uni_renderer_amd import ops
+    B, T, C = 3, 128, 320
+    x = _rand((S * B, T, C), dtype, dev, seed=1)
+    w = _rand((S, 3 * C, C), dtype, dev, 1 / math.sqrt(C), seed=2)
+    ws = w if S > 1 else w[0]
+    qk, vt = ops.linear(x, ws, streams=S, out_scale=0.5, vt_cols=C, vt_tokens=T, tile=tile, splitk=splitk)
+    assert qk.shape == (S * B, T, 2 * C) and vt.shape == (S * B, C, T)
+    for s_ in range(S):
+        xs = x[s_ * B:(s_ + 1) * B].float().cpu()
+        full = xs @ w[s_].float().cpu().t()
+        assert rel_l2(qk[s_ * B:(s_ + 1) * B], 0.5 * full[..., :2 * C]) < TOL[dtype]
+        assert rel_l2(vt[s_ * B:(s_ + 1) * B], full[..., 2 * C:].transpose(1, 2)) < TOL[dtype]
+    # bit-identical to the pair of launches it replaces when both use the same tile and no split-K (same MFMA order)
+    if tile == 2:
+        qk2 = ops.linear(x, (w[:, :2 * C].contiguous() if S > 1 else w[0, :2 * C].contiguous()), streams=S, out_scale=0.5, tile=2, splitk=1)
+        assert torch.equal(qk2, qk)
+    vt2 = ops.vt_proj(x, (w[:, 2 * C:].contiguous() if S > 1 else w[0, 2 * C:].contiguous()), streams=S)
+    assert rel_l2(vt, vt2.float().cpu()) < TOL[dtype]

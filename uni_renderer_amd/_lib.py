@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must be imported first, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("UR_LIB_PATH", os.path.join(_HERE, "liburhip.so"))  # override = kernel experiments only
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
@@ -39,6 +39,7 @@ class IGemmDesc(C.Structure):
         ("cblock", i32),
         ("t0", vp), ("t1", vp), ("ldt0", i64), ("ldt1", i64), ("zt0", i64), ("zt1", i64), ("ct0", i32), ("ct1", i32),
         ("pad", i32),
+        ("out_vt", vp), ("ldvt", i64), ("vt_bstride", i64), ("zvt", i64), ("vt_n0", i32), ("vt_rows", i32),
     ]
 
 

@@ -451,7 +451,8 @@ __global__ void __launch_bounds__((WM * WN + NL) * 64) igemm_kernel(const ur_ige
                           p.rowadd ? reinterpret_cast<const T*>(p.rowadd) + (int64_t)zb * p.zrow : nullptr,
                           p.res ? reinterpret_cast<const T*>(p.res) + (int64_t)zb * p.zres : nullptr, m, nc, v,
                           HiLo<T>{p.res_lo ? reinterpret_cast<const lo_t<T>*>(p.res_lo) + (int64_t)zb * p.zres : nullptr,
-                                  p.out_lo ? reinterpret_cast<lo_t<T>*>(p.out_lo) + (int64_t)zb * p.zout : nullptr});
+                                  p.out_lo ? reinterpret_cast<lo_t<T>*>(p.out_lo) + (int64_t)zb * p.zout : nullptr},
+                          p.out_vt ? reinterpret_cast<T*>(p.out_vt) + (int64_t)zb * p.zvt : nullptr);
         }
     };
     if constexpr (MF == 32) {
@@ -509,7 +510,8 @@ __global__ void __launch_bounds__(256) igemm_splitk_reduce(const ur_igemm_desc p
                           p.rowadd ? reinterpret_cast<const T*>(p.rowadd) + (int64_t)zb * p.zrow : nullptr,
                           p.res ? reinterpret_cast<const T*>(p.res) + (int64_t)zb * p.zres : nullptr, m, nc, v,
                           HiLo<T>{p.res_lo ? reinterpret_cast<const lo_t<T>*>(p.res_lo) + (int64_t)zb * p.zres : nullptr,
-                                  p.out_lo ? reinterpret_cast<lo_t<T>*>(p.out_lo) + (int64_t)zb * p.zout : nullptr});
+                                  p.out_lo ? reinterpret_cast<lo_t<T>*>(p.out_lo) + (int64_t)zb * p.zout : nullptr},
+                          p.out_vt ? reinterpret_cast<T*>(p.out_vt) + (int64_t)zb * p.zvt : nullptr);
     }
 }
 
@@ -726,6 +728,12 @@ extern "C" int ur_igemm(const ur_igemm_desc* din, void* stream) {
     if (d.splitk > 1 && !d.partial) return UR_E_BADARG;
     if (d.rowadd && d.rows_per_b <= 0) return UR_E_BADARG;
     if (d.act == UR_ACT_GEGLU && (d.N % 16)) return UR_E_BADARG;
+    if (d.out_vt) {  // transposed side output for the columns n >= vt_n0
+        if (d.vt_n0 <= 0 || d.vt_n0 >= d.N || (d.vt_n0 % 16) || ((d.N - d.vt_n0) % 16) || d.vt_rows <= 0 || d.ldvt <= 0) return UR_E_BADARG;
+        if (d.act != UR_ACT_NONE || d.res || d.rowadd) return UR_E_BADARG;
+        if (d.n_store <= 0) d.n_store = d.vt_n0;
+        if (d.n_store > d.vt_n0) return UR_E_BADARG;
+    }
     if (d.n_store <= 0) d.n_store = (d.act == UR_ACT_GEGLU) ? d.N / 2 : d.N;
     if (d.tile == UR_TILE_AUTO) d.tile = pick_tile(d);
     if (d.tile < 1 || d.tile >= UR_TILE_COUNT) return UR_E_BADARG;

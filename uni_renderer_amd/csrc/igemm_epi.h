@@ -65,8 +65,23 @@ __device__ __noinline__ void epilogue16_slow(EpiArgs p, T* __restrict__ outz, co
 
 template <typename T>
 __device__ __forceinline__ void epilogue16(const ur_igemm_desc& p, T* __restrict__ outz, const float* biasz,
-                                           const T* rowaddz, const T* resz, int m, int nc, float (&v)[16], HiLo<T> hl) {
+                                           const T* rowaddz, const T* resz, int m, int nc, float (&v)[16], HiLo<T> hl,
+                                           T* __restrict__ vtz = nullptr) {
     if (m >= p.M) return;
+    if (vtz != nullptr && nc >= p.vt_n0) {
+        // transposed side output (ur_igemm_desc.out_vt): this lane's 16 channels of token m go to 16 rows of V^T; the
+        // lanes of a 16- / 32-lane group hold consecutive tokens, so every store instruction writes 32- / 64-byte runs
+        if (nc + 16 > p.N) return;  // vt_n0 and N - vt_n0 are multiples of 16 (checked on the host)
+        if (biasz) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] += biasz[nc + i];
+        }
+        const int b = m / p.vt_rows, t = m - b * p.vt_rows;
+        T* dst = vtz + (int64_t)b * p.vt_bstride + (int64_t)(nc - p.vt_n0) * p.ldvt + t;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dst[(int64_t)i * p.ldvt] = from_f<T>(v[i]);
+        return;
+    }
     const bool vec = (((p.ldc | p.ldres | (int64_t)p.ld_rowadd) & 7) == 0);
     const int n_out_end = (p.act == ACT_GEGLU) ? (nc >> 1) + 8 : nc + 16;
     if (__builtin_expect(!(vec && nc + 16 <= p.N && n_out_end <= p.n_store), 0)) {

@@ -43,7 +43,7 @@ constexpr int BKS = 32;  // K elements per stage (64 bytes per row)
 //   bit 1: the LDS-DMA pieces are issued from INSIDE the MFMA block (one piece after every few MFMAs, in the shadow of
 //          the matrix pipe) instead of in the READ block, prefetch distance NS - 1 stages
 #ifndef UR_PP_VARIANT
-#define UR_PP_VARIANT 2
+#define UR_PP_VARIANT 1
 #endif
 
 template <int N>
@@ -398,7 +398,8 @@ __global__ void __launch_bounds__(512) igemm_pp_kernel(const ur_igemm_desc p) {
                           p.rowadd ? reinterpret_cast<const T*>(p.rowadd) + (int64_t)zb * p.zrow : nullptr,
                           p.res ? reinterpret_cast<const T*>(p.res) + (int64_t)zb * p.zres : nullptr, m, nc, v,
                           HiLo<T>{p.res_lo ? reinterpret_cast<const lo_t<T>*>(p.res_lo) + (int64_t)zb * p.zres : nullptr,
-                                  p.out_lo ? reinterpret_cast<lo_t<T>*>(p.out_lo) + (int64_t)zb * p.zout : nullptr});
+                                  p.out_lo ? reinterpret_cast<lo_t<T>*>(p.out_lo) + (int64_t)zb * p.zout : nullptr},
+                          p.out_vt ? reinterpret_cast<T*>(p.out_vt) + (int64_t)zb * p.zvt : nullptr);
         }
     };
 #pragma unroll

@@ -32,6 +32,11 @@ from .layers import (LOG2E, Attention, BasicTransformerBlock, ResnetBlock2D, Tra
                      pack_conv3x3, pack_matrix)
 
 
+# q | k | v of a self-attention as ONE grouped GEMM with a transposed side output for V (ur_igemm_desc.out_vt, ABI 8);
+# UR_QKV_ONE_LAUNCH=0 restores the q | k GEMM + transposed V projection pair (same-box A/B runs)
+QKV_ONE_LAUNCH = os.environ.get("UR_QKV_ONE_LAUNCH", "1") != "0"
+
+
 class _Packs:
     """Cache of stream-stacked packed tensors keyed by (name, module ids, dtype) + parameter versions."""
 
@@ -183,20 +188,30 @@ class GroupedDualStreamStep:
         wo = pk.get("a.wo", as_, [a.to_out[0].weight for a in as_], dt, lambda: _stk(pack_matrix(a.to_out[0].weight, dt) for a in as_))
         bo = pk.get("a.bo", as_, [a.to_out[0].bias for a in as_], dt, lambda: _stk(f32(a.to_out[0].bias) for a in as_))
         if not a0.is_cross:
-            wqk = pk.get("a.wqk", as_, [p for a in as_ for p in (a.to_q.weight, a.to_k.weight)], dt,
-                         lambda: _stk(torch.cat([pack_matrix(a.to_q.weight, dt), pack_matrix(a.to_k.weight, dt)], 0) for a in as_))
-            wv = pk.get("a.wv", as_, [a.to_v.weight for a in as_], dt, lambda: _stk(pack_matrix(a.to_v.weight, dt) for a in as_))
-            vt_first = os.environ.get("UR_VT_FIRST", "1") != "0"
-            ops.set_site("qk")
-            if not vt_first:
-                qk = ops.linear(xn, wqk, streams=S, out_scale=math.sqrt(cs))
-            with self._fork(xn, kind="vt") as f:  # V^T projection on the sibling branch, beside the q|k projection
-                ops.set_site("vt")
-                vt = ops.vt_proj(xn, wv, streams=S)
+            if QKV_ONE_LAUNCH and T % 64 == 0:
+                # q | k | v as ONE grouped GEMM: the value columns leave the epilogue transposed (ur_igemm_desc.out_vt), which
+                # retires the separate V^T projection launch of every self-attention of the 32x32 .. 8x8 levels
+                wqkv = pk.get("a.wqkv", as_, [p for a in as_ for p in (a.to_q.weight, a.to_k.weight, a.to_v.weight)], dt,
+                              lambda: _stk(torch.cat([pack_matrix(a.to_q.weight, dt), pack_matrix(a.to_k.weight, dt),
+                                                      pack_matrix(a.to_v.weight, dt)], 0) for a in as_))
+                ops.set_site("qkv")
+                qk, vt = ops.linear(xn, wqkv, streams=S, out_scale=math.sqrt(cs), vt_cols=C, vt_tokens=T)
+                ops.set_site(None)
+            else:
+                wqk = pk.get("a.wqk", as_, [p for a in as_ for p in (a.to_q.weight, a.to_k.weight)], dt,
+                             lambda: _stk(torch.cat([pack_matrix(a.to_q.weight, dt), pack_matrix(a.to_k.weight, dt)], 0) for a in as_))
+                wv = pk.get("a.wv", as_, [a.to_v.weight for a in as_], dt, lambda: _stk(pack_matrix(a.to_v.weight, dt) for a in as_))
+                vt_first = os.environ.get("UR_VT_FIRST", "1") != "0"
                 ops.set_site("qk")
-            if vt_first:
-                qk = ops.linear(xn, wqk, streams=S, out_scale=math.sqrt(cs))  # scale folded in, see layers.Attention
-            f.join(vt)
+                if not vt_first:
+                    qk = ops.linear(xn, wqk, streams=S, out_scale=math.sqrt(cs))
+                with self._fork(xn, kind="vt") as f:  # V^T projection on the sibling branch, beside the q|k projection
+                    ops.set_site("vt")
+                    vt = ops.vt_proj(xn, wv, streams=S)
+                    ops.set_site("qk")
+                if vt_first:
+                    qk = ops.linear(xn, wqk, streams=S, out_scale=math.sqrt(cs))  # scale folded in, see layers.Attention
+                f.join(vt)
             o = ops.attention(qk, qk, vt, B=Bt, H=H, Tq=T, Tk=T, d=d, ldq=2 * C, ldk=2 * C, q_off=0, k_off=C, scale=0.0)
         else:
             wq = pk.get("a.wq", as_, [a.to_q.weight for a in as_], dt, lambda: _stk(pack_matrix(a.to_q.weight, dt) for a in as_))

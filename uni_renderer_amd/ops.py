@@ -179,7 +179,8 @@ def plan_igemm(M: int, N: int, K: int, taps: int = 1, zbatch: int = 1) -> Tuple[
 def igemm(*, x0, w, out, M, N, K, c0, c1=0, x1=None, ldx0, ldx1=0, ldw, ldc, taps=1, conv=None, stride=1, ups=0,
           bias=None, rowadd=None, rows_per_b=0, res=None, ldres=0, n_store=0, act=ACT_NONE, out_scale=1.0,
           zbatch=1, zx=0, zw=0, zout=0, zx1=0, zbias=0, zrow=0, zres=0, zx_div=1, tile=None, splitk=None,
-          res_lo=None, out_lo=None, cblock=0, t0=None, t1=None, ldt0=0, ldt1=0, zt0=0, zt1=0, ct0=0, ct1=0, pad=1):
+          res_lo=None, out_lo=None, cblock=0, t0=None, t1=None, ldt0=0, ldt1=0, zt0=0, zt1=0, ct0=0, ct1=0, pad=1,
+          out_vt=None, vt_n0=0, vt_rows=0, zvt=0):
     _require_gpu(x0)
     lib = _lib.load()
     if tile is None or splitk is None:
@@ -202,6 +203,9 @@ def igemm(*, x0, w, out, M, N, K, c0, c1=0, x1=None, ldx0, ldx1=0, ldw, ldc, tap
         d.out_lo = out_lo.data_ptr()
     if cblock:
         d.cblock = cblock
+    if out_vt is not None:  # columns >= vt_n0 leave transposed: out_vt[sample][n - vt_n0][token] (include/ur_kernels.h)
+        d.out_vt, d.ldvt, d.vt_bstride, d.zvt = out_vt.data_ptr(), out_vt.stride(-2), out_vt.stride(0), zvt
+        d.vt_n0, d.vt_rows = vt_n0, vt_rows
     if t0 is not None or t1 is not None:
         d.t0, d.t1, d.ldt0, d.ldt1, d.zt0, d.zt1, d.ct0, d.ct1 = _ptr(t0), _ptr(t1), ldt0, ldt1, zt0, zt1, ct0, ct1
     d.zero_page = zero_page(x0.device).data_ptr()
@@ -293,8 +297,11 @@ def _with_lo(out, want: bool):
 
 
 def linear(x, w, bias=None, *, x1=None, res=None, act=ACT_NONE, out_scale=1.0, rowadd=None, rows_per_b=0, out=None,
-           tile=None, splitk=None, streams=1, res_zstride=None, hilo=False, res_lo=None):
+           tile=None, splitk=None, streams=1, res_zstride=None, hilo=False, res_lo=None, vt_cols=0, vt_tokens=0):
     """y[..., N] = epilogue(x[..., K] @ w[N, K]^T).  ``x1``: second source concatenated along K.
+    ``vt_cols`` = Cv > 0 (with ``vt_tokens`` = T rows per sample, a multiple of 64): the LAST Cv rows of ``w`` are a
+    value projection whose result leaves TRANSPOSED -- returns ``(y[..., N - Cv], vt[samples, Cv, T])`` from one launch
+    (``out_scale`` applies to y only): a self-attention's q | k | v projection.
     ``hilo``: also produce the rounding remainder (``y.lo``); the low part of ``res`` (``res.lo`` or ``res_lo``) is
     added when present.
 
@@ -307,6 +314,13 @@ def linear(x, w, bias=None, *, x1=None, res=None, act=ACT_NONE, out_scale=1.0, r
     M = x.numel() // K0 // streams
     N = w.shape[-2]
     n_out = N // 2 if act == ACT_GEGLU else N
+    vt, vkw = None, {}
+    if vt_cols:
+        if act != ACT_NONE or res is not None or rowadd is not None or vt_tokens <= 0 or vt_tokens % 64 or (M % vt_tokens):
+            raise ValueError("linear(vt_cols=...): plain projection of whole samples with a multiple of 64 tokens")
+        n_out = N - vt_cols
+        vt = torch.empty(streams * (M // vt_tokens), vt_cols, vt_tokens, dtype=x.dtype, device=x.device)
+        vkw = dict(out_vt=vt, vt_n0=n_out, vt_rows=vt_tokens, zvt=(M // vt_tokens) * vt_cols * vt_tokens, n_store=n_out)
     if out is None:
         out = torch.empty(*x.shape[:-1], n_out, dtype=x.dtype, device=x.device)
     _with_lo(out, hilo and act != ACT_GEGLU)
@@ -320,8 +334,8 @@ def linear(x, w, bias=None, *, x1=None, res=None, act=ACT_NONE, out_scale=1.0, r
                  zrow=(rowadd.stride(0) * (rowadd.shape[0] // streams)) if rowadd is not None else 0)
     igemm(x0=x, x1=x1, w=w, out=out, M=M, N=N, K=K0 + K1, c0=K0, c1=K1, ldx0=K0, ldx1=K1, ldw=w.stride(-2), ldc=n_out,
           bias=bias, res=res, ldres=(n_out if res is not None else 0), act=act, out_scale=out_scale, rowadd=rowadd,
-          rows_per_b=rows_per_b, tile=tile, splitk=splitk, res_lo=res_lo, out_lo=lo_of(out), **z)
-    return out
+          rows_per_b=rows_per_b, tile=tile, splitk=splitk, res_lo=res_lo, out_lo=lo_of(out), **z, **vkw)
+    return out if vt is None else (out, vt)
 
 
 CONV_CBLOCK = int(os.environ.get("UR_CONV_CBLOCK", "320"))
