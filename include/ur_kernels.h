@@ -209,6 +209,10 @@ typedef struct ur_igemm_desc {
 
 int ur_igemm(const ur_igemm_desc* d, void* stream);
 
+/* 1 when the library was built with the experimental weight-streaming conv tiles (UR_TILE_WS320*: `make WSCONV=1`); the
+ * product build returns 0 and UR_E_UNSUPPORTED for those tile ids. */
+int ur_has_wsconv(void);
+
 /* Workspace (in floats) ur_igemm needs in `partial` for this descriptor (0 when splitk <= 1). */
 int64_t ur_igemm_partial_floats(const ur_igemm_desc* d);
 
@@ -440,8 +444,11 @@ typedef struct ur_adamw_tensor {
     float* v;
     int64_t n;
 } ur_adamw_tensor;
+/* hyper (ABI 8): NULL, or a device pointer to {lr, weight_decay} read by the kernel INSTEAD of the by-value arguments, so
+ * that a captured HIP graph of the update follows a learning-rate schedule (train.py --lr_scheduler) without re-capture. */
 int ur_adamw_multi(const ur_adamw_tensor* tensors, int n_tensors, float lr, float beta1, float beta2, float eps,
-                   float weight_decay, const float* step, const float* grad_scale, const float* found_inf, void* stream);
+                   float weight_decay, const float* step, const float* grad_scale, const float* found_inf,
+                   const float* hyper, void* stream);
 
 /* Flash backward of o = softmax(q k^T * scale) v (ur_attention_backward_supported: Tq % 64 == 0, d % 8 == 0, d <= 160).
  * Replaces the reference's autograd through F.scaled_dot_product_attention (diffusers AttnProcessor2_0 under

@@ -651,6 +651,48 @@ def test_graphed_train_step_single_gpu(dev):
         assert torch.equal(a, b)
 
 
+def test_graphed_train_step_follows_an_lr_schedule_without_recapture(dev):
+    """with a non-constant --lr_scheduler (train.py offers linear / cosine / *_with_warmup) the captured step
+    used to be re-captured on EVERY step (lr was a by-value kernel argument).  ``ur_adamw_multi`` now reads lr / weight
+    decay from a device pair that FusedAdamW.sync_hyper refreshes before the replay: a LambdaLR schedule over the graphed
+    step gives bit-identical parameters to the eager step, with ONE capture."""
+    from uni_renderer_amd.optim import FusedAdamW
+    from uni_renderer_amd.train_step import GraphedTrainStep, train_step
+
+    def setup():
+        oracle = O.build_triplet(O.TINY_CONFIG, seed=38)
+        nets = build_product_from_oracle(*oracle, torch.float32, dev)
+        for m in nets:
+            m.train()
+            m.requires_grad_(True)
+        opt = FusedAdamW([p for m in nets for p in m.parameters()], lr=4e-4, weight_decay=1e-2)
+        return nets, opt, torch.optim.lr_scheduler.LambdaLR(opt, lambda it: 1.0 / (1.0 + it))
+
+    def make_batch(it):
+        x, c, ehs, ti, ta = [t.to(dev) for t in O.make_inputs(2, 16, 64, seed=70 + it)]
+        g = torch.Generator().manual_seed(71 + it)
+        return dict(x_t=x, cond=c, ehs=ehs, t_img=ti, t_attr=ta, target_img=torch.randn(2, 4, 16, 16, generator=g).to(dev),
+                    target_attr=torch.randn(2, 28, 16, 16, generator=g).to(dev))
+
+    nets_e, opt_e, sch_e = setup()
+    eager = []
+    for it in range(4):
+        eager.append(train_step(nets_e, make_batch(it), optimizer=opt_e, dtype=torch.bfloat16)["loss"])
+        sch_e.step()
+    nets_g, opt_g, sch_g = setup()
+    step = GraphedTrainStep(nets_g, make_batch(0), opt_g, dtype=torch.bfloat16, warmup=0)
+    first_graph = step.g_fb
+    graphed = []
+    for it in range(4):
+        graphed.append(float(step.step(make_batch(it))["loss"]))
+        sch_g.step()
+    assert step.g_fb is first_graph, "the step was re-captured although only lr changed"
+    assert opt_g.param_groups[0]["lr"] == opt_e.param_groups[0]["lr"] != 4e-4
+    assert eager == graphed
+    for a, b in zip((p for m in nets_e for p in m.parameters()), (p for m in nets_g for p in m.parameters())):
+        assert torch.equal(a, b)
+
+
 def test_reference_fp16_amp_recipe_at_sd_size_and_an_overflow_step(dev):
     """VERDICT r3 'missing' 3: the reference's ACTUAL training precision is fp16 AMP with a GradScaler (train/train.sh:21
     ``--mixed_precision="fp16"``; train.py:882-887; accelerate: ``scaler.scale(loss).backward()``, ``unscale_`` inside

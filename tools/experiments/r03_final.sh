@@ -17,7 +17,7 @@ python tools/tchain_bench.py > gpurun_out/final_tchain_bench.json 2>/dev/null
 python tools/wsconv_bench.py --iters 20 > gpurun_out/final_wsconv_bench.txt 2>&1
 bash tools/pmc_conv_sq.sh gpurun_out/final_pmc_conv_sq.json > /dev/null 2>&1
 ./tools/ubench/mfma_rate > gpurun_out/final_mfma_rate.txt 2>&1
-bash tools/r03_run6.sh > gpurun_out/final_ring_depth_ab.txt 2>&1
+bash tools/experiments/r03_run6.sh > gpurun_out/final_ring_depth_ab.txt 2>&1
 python tools/train_bench.py --steps 3 --graph --torch-adamw > gpurun_out/final_train_graph_torch_adamw.json 2>/dev/null
 (cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && rocprofv3 --kernel-trace --stats -d gpurun_out/prof_train -o tr --output-format csv -- python tools/train_bench.py --steps 3 --graph > gpurun_out/final_train_under_rocprof.json 2>/dev/null; cp $(find gpurun_out/prof_train -name "*kernel_stats.csv" | head -1) gpurun_out/final_train_kernel_stats.csv; rm -rf gpurun_out/prof_train)
 tail -1 gpurun_out/prof_r03/bench_default.json | cut -c1-250

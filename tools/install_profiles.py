@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Copy the summaries of an end-of-round collection (tools/r02_final.sh -> gpurun_out/) into profiles/ under a round tag.
+"""Copy the summaries of an end-of-round collection (tools/experiments/r02_final.sh -> gpurun_out/) into profiles/ under a round tag.
 
     python tools/install_profiles.py r02
 

@@ -65,7 +65,7 @@ Round-3 additions: `{tag}_tchain_bench.json` (`tools/tchain_bench.py`: the three
 per-stage stamps of the kernels), `{tag}_pmc_conv_sq.json` / `{tag}_pmc_gemm320_sq.json` (`tools/pmc_conv_sq.sh`: three SQ-counter
 passes over the level-0 conv / a K = 320 GEMM replayed alone: parked, issue-stalled and active wave cycles, LDS activity,
 bank conflicts), `{tag}_mfma_rate.txt` (`tools/ubench/mfma_rate.hip`, the corrected MFMA issue-rate micro-benchmark: random
-operands, distinct A / B registers, 1 / 2 / 4 waves per SIMD), `{tag}_ring_depth_ab.txt` (`tools/r03_run6.sh`: a 3-deep LDS ring
+operands, distinct A / B registers, 1 / 2 / 4 waves per SIMD), `{tag}_ring_depth_ab.txt` (`tools/experiments/r03_run6.sh`: a 3-deep LDS ring
 on the 128x256 tile against the 2-deep one: no difference, the conv loop is not waiting for its copies).
 Second half of round 3: `{tag}_determinism.txt` (`tools/determinism_check.py`, `tools/tchain_determinism.py`: the grouped step
 and the three chain kernels repeated on fixed inputs, bitwise comparison -- after the LDS race of the first chain kernel was

@@ -1,7 +1,7 @@
 // Micro-benchmark (round 4): global -> LDS delivery rate of ONE CU, every CU streaming, as a function of the ADDRESS
 // PATTERN of the LDS-DMA pieces -- the conv / GEMM loaders copy row SEGMENTS (128 B or 64 B of a row whose neighbours
 // are a leading dimension apart), not contiguous KiB like tools/ubench/ldsdma_rate.hip.  The ablation builds of the
-// ping-pong kernel (tools/r04_run3.sh) deliver only ~45-55 GB/s per CU with no compute at all; which part of the pattern
+// ping-pong kernel (tools/experiments/r04_run3.sh) deliver only ~45-55 GB/s per CU with no compute at all; which part of the pattern
 // costs that?
 //   hipcc --offload-arch=gfx950 -O3 -o ldsdma_pattern ldsdma_pattern.hip && ./ldsdma_pattern
 // Patterns (8 waves per CU, 28 pieces of 1 KiB per stage, ring of NSLOT stages, counted vmcnt, one barrier per stage):

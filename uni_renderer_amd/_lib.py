@@ -136,7 +136,7 @@ SYMBOLS = {
     "ur_cast_multi": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp]),
     "ur_cast_multi_blocks": (C.c_int64, [vp, C.c_int]),
     "ur_cast_multi_sumsq": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp]),
-    "ur_adamw_multi": (C.c_int, [vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, vp, vp, vp, vp]),
+    "ur_adamw_multi": (C.c_int, [vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, vp, vp, vp, vp, vp]),
     "ur_silu_forward": (C.c_int, [vp, vp, C.c_int64, C.c_int, vp]),
     "ur_resample2x": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "ur_tchain": (C.c_int, [C.POINTER(TChainDesc), vp]),
@@ -147,6 +147,7 @@ SYMBOLS = {
     "ur_abi_version": (C.c_int, []),
     "ur_build_info": (C.c_char_p, []),
     "ur_sizeof_igemm_desc": (C.c_int, []),
+    "ur_has_wsconv": (C.c_int, []),
     "ur_sizeof_attn_desc": (C.c_int, []),
     "ur_sizeof_attn_bwd_desc": (C.c_int, []),
 }

@@ -51,10 +51,10 @@ class _TransposeDesc(C.Structure):
 
 # Bias gradients inside the transpose launch (ur_transpose_desc.colsum): correct and deterministic, removes ~650 launches per
 # step, but every transposing workgroup then pays a memory-side store + counter round trip: 84.7 vs 84.6 ms per graphed
-# step (tools/r03_run14.sh) -- no gain, so off by default.
+# step (tools/experiments/r03_run14.sh) -- no gain, so off by default.
 FUSED_COLSUM = os.environ.get("UR_FUSED_COLSUM", "0") != "0"
 # Column sums folded in the same launch by the last-arriving workgroup (ur_colsum_fused; identical bits, 476 launches fewer
-# per step): measured 81.4 vs 81.1 ms per step (tools/r03_run35.sh) -- the agent-scope hand-off costs what the fold launch
+# per step): measured 81.4 vs 81.1 ms per step (tools/experiments/r03_run35.sh) -- the agent-scope hand-off costs what the fold launch
 # did -- so off by default.
 COLSUM_ONE_LAUNCH = os.environ.get("UR_COLSUM_ONE_LAUNCH", "0") != "0"
 _colsum_counters: dict = {}

@@ -247,7 +247,7 @@ __global__ void __launch_bounds__(256) colsum_kernel(const T* __restrict__ x, in
     // one-launch form: the slice sums go to the workspace with agent-scope stores (they bypass the non-coherent L2s), the
     // last workgroup of a (group, column block) -- device-scope counter, left at zero -- adds them exactly as
     // colsum_fold_kernel would.  (The same hand-off cost every one of the thousands of small transposing workgroups a
-    // memory round trip, tools/r03_run14.sh; here there are <= 512 long-running workgroups and the fold launch goes away.)
+    // memory round trip, tools/experiments/r03_run14.sh; here there are <= 512 long-running workgroups and the fold launch goes away.)
     __shared__ int last;
     if (t < 64 && n0 + t < N) {
         float a = 0.f;
@@ -1142,6 +1142,7 @@ struct AdamwArgs {
     int n;
     float lr, beta1, beta2, eps, wd;
     const float *step, *grad_scale, *found_inf;
+    const float* hyper;  // NULL, or device {lr, weight_decay}: read at run time instead of the by-value arguments
 };
 constexpr int ADAMW_CHUNK = 16384;
 
@@ -1168,7 +1169,9 @@ __global__ void __launch_bounds__(256) adamw_multi_kernel(const AdamwArgs a) {
     // 1 - beta^step in double: beta2 = 0.999 at step 1 leaves 1e-3, which fp32 v_log / v_exp resolve to 1e-4 relative only
     const float bc1 = (float)(1.0 - pow((double)a.beta1, (double)step));
     const float bc2 = (float)(1.0 - pow((double)a.beta2, (double)step));
-    const float step_size = a.lr / bc1, rbc2 = 1.0f / sqrtf(bc2), decay = 1.0f - a.lr * a.wd;
+    // lr / weight decay from device memory when given: a captured graph then follows an lr scheduler without re-capture
+    const float lr = a.hyper ? a.hyper[0] : a.lr, wd = a.hyper ? a.hyper[1] : a.wd;
+    const float step_size = lr / bc1, rbc2 = 1.0f / sqrtf(bc2), decay = 1.0f - lr * wd;
     const float ginv = a.grad_scale ? *a.grad_scale : 1.0f;
     const bool vec = ((((uintptr_t)t.p) | ((uintptr_t)t.g) | ((uintptr_t)t.m) | ((uintptr_t)t.v)) & 15) == 0;
     if (vec) {
@@ -1200,7 +1203,7 @@ __global__ void __launch_bounds__(256) adamw_multi_kernel(const AdamwArgs a) {
 
 extern "C" int ur_adamw_multi(const ur_adamw_tensor* tensors, int n_tensors, float lr, float beta1, float beta2, float eps,
                               float weight_decay, const float* step, const float* grad_scale, const float* found_inf,
-                              void* stream) {
+                              const float* hyper, void* stream) {
     if (!tensors || n_tensors <= 0 || n_tensors > UR_ADAMW_MAX_TENSORS || !step || !(beta1 >= 0.f && beta1 < 1.f) ||
         !(beta2 >= 0.f && beta2 < 1.f))  // the same range torch.optim.AdamW (and optim.FusedAdamW) accept
         return UR_E_BADARG;
@@ -1216,7 +1219,7 @@ extern "C" int ur_adamw_multi(const ur_adamw_tensor* tensors, int n_tensors, flo
     a.chunk0[n_tensors] = (int)chunks;
     a.n = n_tensors;
     a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = weight_decay;
-    a.step = step; a.grad_scale = grad_scale; a.found_inf = found_inf;
+    a.step = step; a.grad_scale = grad_scale; a.found_inf = found_inf; a.hyper = hyper;
     hipLaunchKernelGGL(adamw_multi_kernel, dim3((unsigned)chunks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
     return last_error();
 }

@@ -588,7 +588,11 @@ static int launch_cfg(const ur_igemm_desc& d, hipStream_t s) {
     return 0;
 }
 
-int wsconv_launch(const ur_igemm_desc& d, hipStream_t s);  // wsconv.hip
+#ifdef UR_WITH_WSCONV
+int wsconv_launch(const ur_igemm_desc& d, hipStream_t s);  // wsconv.hip (make WSCONV=1)
+#else
+static int wsconv_launch(const ur_igemm_desc&, hipStream_t) { return UR_E_UNSUPPORTED; }  // not in the product build
+#endif
 int igemm_pp_launch(const ur_igemm_desc& d, hipStream_t s);  // igemm_pp.hip
 
 // ping-pong main pass + the shared split-K second pass
@@ -686,6 +690,14 @@ static int64_t padded_ldp(const ur_igemm_desc& d, int tile) {
 }
 
 }  // namespace ur
+
+extern "C" int ur_has_wsconv(void) {
+#ifdef UR_WITH_WSCONV
+    return 1;
+#else
+    return 0;
+#endif
+}
 
 extern "C" int64_t ur_igemm_partial_floats(const ur_igemm_desc* d) {
     if (!d || d->splitk <= 1) return 0;

@@ -33,12 +33,12 @@ namespace ur {
 
 constexpr int BKS = 32;  // K elements per stage (64 bytes per row)
 
-// -DUR_PP_ABLATE=<bits> builds measurement-only variants (tools/r04_pp_ablate.sh; never in the product build):
+// -DUR_PP_ABLATE=<bits> builds measurement-only variants (tools/experiments/r04_pp_ablate.sh; never in the product build):
 //   1 = no LDS-DMA copies (pointer bookkeeping kept), 2 = no MFMAs, 4 = no fragment reads, 8 = no barriers / waits
 #ifndef UR_PP_ABLATE
 #define UR_PP_ABLATE 0
 #endif
-// Schedule variants (compile-time, measured against each other in tools/r04_run5.sh):
+// Schedule variants (compile-time, measured against each other in tools/experiments/r04_run5.sh):
 //   bit 0: no s_setprio around the MFMA block
 //   bit 1: the LDS-DMA pieces are issued from INSIDE the MFMA block (one piece after every few MFMAs, in the shadow of
 //          the matrix pipe) instead of in the READ block, prefetch distance NS - 1 stages

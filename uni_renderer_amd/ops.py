@@ -352,7 +352,7 @@ def conv_cblock(cin: int) -> int:
 # Weight-streaming conv kernel (csrc/wsconv.hip) in the executors: OFF by default.  Isolated it matches or beats the tuned
 # LDS-tiled build by 2-6 % from K = 5760 up (tools/wsconv_bench.py), but inside the step -- weights cold in L2, one stage
 # of prefetch with one wave per SIMD -- the same launches are ~10 % slower: 11.88 -> 12.20 ms per step with it on for
-# K >= 5000 (tools/r03_run13.sh, two alternating repetitions on one box).  ``conv3x3(..., ws=...)`` still takes it
+# K >= 5000 (tools/experiments/r03_run13.sh, two alternating repetitions on one box).  ``conv3x3(..., ws=...)`` still takes it
 # explicitly (tests/test_wsconv_gpu.py).
 WSCONV = os.environ.get("UR_WSCONV", "0") != "0"
 WS_C = 320
@@ -371,6 +371,11 @@ def wsconv_images(w: torch.Tensor, n_out: Optional[int] = None) -> torch.Tensor:
     pos = torch.arange(8, device=w.device)[None, :] ^ ((r >> 1) & 7)[:, None]     # position c' holds chunk c' ^ key
     idx = pos[None, None, :, :, None].expand(v.shape[0], v.shape[1], WS_C, 8, 8)
     return torch.gather(v, 3, idx).reshape(-1).contiguous()
+
+
+def wsconv_built() -> bool:
+    """The weight-streaming conv tiles are an opt-in build of the library (``make WSCONV=1``, csrc/Makefile)."""
+    return bool(_lib.load().ur_has_wsconv())
 
 
 def wsconv_ok(x, N, *, x1=None, stride=1, ups=False, pad=1, tail=None, streams=1) -> bool:
@@ -392,7 +397,7 @@ WSCONV_MIN_K = int(os.environ.get("UR_WSCONV_MIN_K", "5000"))
 def wsconv_prefer(x, N, K, **kw) -> bool:
     """Policy: the weight-streaming kernel where it measured faster than the tuned LDS-tiled build (tools/wsconv_bench.py:
     +2 .. +6 % from K = 5760 up, -2 .. -20 % below: its per-workgroup prologue / epilogue is longer)."""
-    return WSCONV and K >= WSCONV_MIN_K and wsconv_ok(x, N, **kw)
+    return WSCONV and K >= WSCONV_MIN_K and wsconv_ok(x, N, **kw) and wsconv_built()
 
 
 def wsconv_splitk(M, N, K, zbatch) -> int:
@@ -449,7 +454,7 @@ def conv3x3(x, w, bias=None, *, x1=None, stride=1, ups=False, rowadd=None, res=N
                   zt0=(M * ca if streams > 1 else 0), zt1=(M * cb_ if streams > 1 else 0))
     Kt = 9 * (C0 + C1) + sum(tl.get(k, 0) for k in ("ct0", "ct1"))
     ldw = w.stride(-2)
-    if ws is not None and tile in (None, TILE_WS320, TILE_WS320_W8) and wsconv_ok(x, N, x1=x1, stride=stride, ups=ups, pad=pad, tail=tail, streams=streams):
+    if ws is not None and tile in (None, TILE_WS320, TILE_WS320_W8) and wsconv_built() and wsconv_ok(x, N, x1=x1, stride=stride, ups=ups, pad=pad, tail=tail, streams=streams):
         if C0 > WS_C and cblock != WS_C:
             raise RuntimeError("conv3x3: the weight-streaming kernel walks K in the cblock = 320 order")
         w, tile, ldw = ws, (WSCONV_TILE if tile is None else tile), 8
@@ -460,7 +465,6 @@ def conv3x3(x, w, bias=None, *, x1=None, stride=1, ups=False, rowadd=None, res=N
     igemm(x0=x, x1=x1, w=w, out=out, M=M, N=N, K=Kt, c0=C0, c1=C1, ldx0=C0, ldx1=C1,
           ldw=ldw, ldc=N, taps=9, conv=(B, H, W, Ho, Wo), stride=stride, ups=int(ups), bias=bias,
           rowadd=rowadd, rows_per_b=Ho * Wo, res=res, ldres=(N if res is not None else 0), out_scale=out_scale,
-          act=(int(os.environ.get("UR_WS_DEBUG_ACT", "0")) if tile in (TILE_WS320, TILE_WS320_W8) else ACT_NONE),
           tile=tile, splitk=splitk, res_lo=lo_of(res), out_lo=lo_of(out), cblock=cblock, pad=pad, **tl, **z)
     return out
 

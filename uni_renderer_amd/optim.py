@@ -43,6 +43,26 @@ class FusedAdamW(torch.optim.Optimizer):
                         amsgrad=False, maximize=False, foreach=None, differentiable=False)
         super().__init__(params, defaults)
 
+    def sync_hyper(self):
+        """Copy every group's lr / weight_decay into its device scalar pair (created on first use).  The kernel reads them
+        from there, so an ``lr_scheduler`` (train.py --lr_scheduler / --lr_warmup_steps) changes what a CAPTURED update
+        does without a re-capture: ``step()`` calls this itself when it runs eagerly; around a graph replay the owner of
+        the graph calls it before ``replay()`` (train_step.GraphedTrainStep.step)."""
+        for group in self.param_groups:
+            lr = group["lr"]
+            if isinstance(lr, torch.Tensor):
+                raise NotImplementedError("FusedAdamW: tensor learning rates are not supported")
+            want = (float(lr), float(group["weight_decay"]))
+            hy = group.get("_ur_hyper")
+            if hy is None:
+                dev = next((p.device for p in group["params"]), None)
+                if dev is None or dev.type != "cuda":
+                    continue
+                hy = group["_ur_hyper"] = [torch.empty(2, dtype=torch.float32, device=dev), None]
+            if hy[1] != want:
+                hy[0].copy_(torch.tensor(want, dtype=torch.float32), non_blocking=False)
+                hy[1] = want
+
     def _init_state(self, p):
         st = self.state[p]
         if not st:
@@ -60,6 +80,8 @@ class FusedAdamW(torch.optim.Optimizer):
         lib = _lib.load()
         grad_scale = getattr(self, "grad_scale", None)
         found_inf = getattr(self, "found_inf", None)
+        if not torch.cuda.is_current_stream_capturing():
+            self.sync_hyper()  # inside a capture the device pair must already exist (and is refreshed outside the graph)
         for group in self.param_groups:
             if group.get("amsgrad") or group.get("maximize"):
                 raise NotImplementedError("FusedAdamW: amsgrad / maximize are not used by the reference (train.py:1093-1100)")
@@ -109,11 +131,14 @@ class FusedAdamW(torch.optim.Optimizer):
         if isinstance(lr, torch.Tensor):
             raise NotImplementedError("FusedAdamW: tensor learning rates are not supported")
         s_ = _stream()
+        hy = group.get("_ur_hyper")
+        if hy is None:
+            raise RuntimeError("FusedAdamW.step() inside a graph capture before any eager step: call sync_hyper() first")
         for arr in arrays:
             check(lib.ur_adamw_multi(arr, len(arr), float(lr), float(beta1), float(beta2), float(group["eps"]),
                                      float(group["weight_decay"]), step_t.data_ptr(),
                                      grad_scale.data_ptr() if grad_scale is not None else None,
-                                     found_inf.data_ptr() if found_inf is not None else None, s_), "ur_adamw_multi")
+                                     found_inf.data_ptr() if found_inf is not None else None, hy[0].data_ptr(), s_), "ur_adamw_multi")
         if found_inf is not None:
             # the kernel leaves parameters and moments alone when found_inf != 0; like torch's fused AdamW, a skipped
             # step must not advance the bias correction either (a device op: no host synchronisation, capturable)
@@ -121,7 +146,7 @@ class FusedAdamW(torch.optim.Optimizer):
 
     def __getstate__(self):
         state = super().__getstate__()
-        state["param_groups"] = [{k: v for k, v in g.items() if k != "_ur_launches"} for g in state["param_groups"]]
+        state["param_groups"] = [{k: v for k, v in g.items() if k not in ("_ur_launches", "_ur_hyper")} for g in state["param_groups"]]
         return state  # the launch cache holds raw device addresses in ctypes arrays: never pickled, rebuilt on the next step
 
     def state_dict(self):
@@ -130,6 +155,7 @@ class FusedAdamW(torch.optim.Optimizer):
         sd = super().state_dict()
         for grp in sd["param_groups"]:
             grp.pop("_ur_launches", None)  # host-side launch cache, not optimizer state
+            grp.pop("_ur_hyper", None)     # device copy of (lr, weight_decay), rebuilt from the group's values
         # torch hands out the LIVE per-parameter dicts: build copies, never assign into them (replacing the live
         # ``step`` entry would cut its alias to the device counter the cached launches keep incrementing)
         sd["state"] = {k: ({**st, "step": st["step"].clone()} if "step" in st else dict(st)) for k, st in sd["state"].items()}
@@ -139,6 +165,7 @@ class FusedAdamW(torch.optim.Optimizer):
         super().load_state_dict(state_dict)
         for group in self.param_groups:
             group.pop("_ur_launches", None)  # the state tensors were replaced
+            group.pop("_ur_hyper", None)
         for group in self.param_groups:  # private fp32 device scalars (torch may hand back the caller's tensors uncopied)
             for p in group["params"]:
                 st = self.state.get(p)

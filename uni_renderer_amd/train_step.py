@@ -553,12 +553,17 @@ class GraphedTrainStep:
         self._capture()
 
     def _hyper(self):
-        """The optimizer hyper-parameters the captured update holds BY VALUE (kernel arguments of ``ur_adamw_multi``)."""
-        return tuple((float(g["lr"]), tuple(float(b) for b in g["betas"]), float(g["eps"]), float(g["weight_decay"]))
-                     for g in self.optimizer.param_groups)
+        """The optimizer hyper-parameters the captured update holds BY VALUE (kernel arguments of ``ur_adamw_multi``).
+        lr and weight_decay are NOT among them when the optimizer keeps them in device memory (optim.FusedAdamW.sync_hyper):
+        a scheduler step then only needs that copy refreshed before the replay."""
+        dev_lr = hasattr(self.optimizer, "sync_hyper")
+        return tuple(((None if dev_lr else float(g["lr"])), tuple(float(b) for b in g["betas"]), float(g["eps"]),
+                      (None if dev_lr else float(g["weight_decay"]))) for g in self.optimizer.param_groups)
 
     def _capture(self):
         nets, optimizer, buckets, kw, max_grad_norm = self.nets, self.optimizer, self.buckets, self._kw, self.max_grad_norm
+        if hasattr(optimizer, "sync_hyper"):
+            optimizer.sync_hyper()
         self._captured_hyper = self._hyper()
         self.g_fb = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.g_fb):
@@ -584,10 +589,11 @@ class GraphedTrainStep:
         if batch is not None:
             for k, v in batch.items():
                 self.batch[k].copy_(v)
+        if hasattr(self.optimizer, "sync_hyper"):
+            self.optimizer.sync_hyper()  # lr / weight_decay of an lr_scheduler step -> the device pair the kernel reads
         if self._hyper() != self._captured_hyper:
-            # an lr_scheduler step (train.py --lr_scheduler / --lr_warmup_steps) or resume_from_checkpoint changed lr /
-            # betas / eps / weight_decay: the captured update holds the old values as kernel arguments.  Capture again
-            # (tens of ms, once per change -- a per-step schedule should run the eager train_step instead)
+            # betas / eps changed (resume_from_checkpoint with other settings), or an optimizer that holds lr by value:
+            # the captured update has the old values as kernel arguments.  Capture again (tens of ms, once per change)
             torch.cuda.synchronize()
             self._capture()
         self.g_fb.replay()
