@@ -185,8 +185,27 @@ def load() -> C.CDLL:
     if (lib.ur_sizeof_igemm_desc() != C.sizeof(IGemmDesc) or lib.ur_sizeof_attn_desc() != C.sizeof(AttnDesc)
             or lib.ur_sizeof_attn_bwd_desc() != C.sizeof(AttnBwdDesc) or lib.ur_sizeof_tchain_desc() != C.sizeof(TChainDesc)):
         raise UrLibraryError("descriptor layout mismatch between include/ur_kernels.h and _lib.py")
+    for fn_name, ctype in LAYOUT_CHECKS:  # mirrors declared next to their users (backward.py: ur_transpose_desc)
+        _check_layout(lib, fn_name, ctype)
     _lib = lib
     return lib
+
+
+LAYOUT_CHECKS: list = []
+
+
+def _check_layout(lib, fn_name: str, ctype) -> None:
+    if getattr(lib, fn_name)() != C.sizeof(ctype):
+        raise UrLibraryError(f"descriptor layout mismatch: {fn_name}() = {getattr(lib, fn_name)()} vs sizeof({ctype.__name__}) = "
+                             f"{C.sizeof(ctype)} (include/ur_kernels.h vs the ctypes mirror)")
+
+
+def register_layout(fn_name: str, ctype) -> None:
+    """A ctypes mirror of a descriptor struct that lives outside this module: checked against the library's sizeof when
+    the library is loaded (immediately if it already is) -- the same loud failure as for the descriptors above."""
+    LAYOUT_CHECKS.append((fn_name, ctype))
+    if _lib is not None:
+        _check_layout(_lib, fn_name, ctype)
 
 
 def check(rc: int, what: str) -> None:

@@ -49,6 +49,8 @@ class _TransposeDesc(C.Structure):
                 ("rows_out", C.c_int32), ("colsum", C.c_void_p), ("colsum_ws", C.c_void_p), ("colsum_cnt", C.c_void_p)]
 
 
+_lib.register_layout("ur_sizeof_transpose_desc", _TransposeDesc)  # checked in _lib.load(), not only in a test
+
 # Bias gradients inside the transpose launch (ur_transpose_desc.colsum): correct and deterministic, removes ~650 launches per
 # step, but every transposing workgroup then pays a memory-side store + counter round trip: 84.7 vs 84.6 ms per graphed
 # step (tools/experiments/r03_run14.sh) -- no gain, so off by default.

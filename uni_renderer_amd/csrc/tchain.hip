@@ -584,14 +584,16 @@ extern "C" int ur_tchain(const ur_tchain_desc* din, void* stream) {
     if (d.zbatch < 1) d.zbatch = 1;
     if (d.mode == UR_TCHAIN_Q) {
         if (!d.y_out) return UR_E_BADARG;
-        if (d.z_consts < TCC_Q_END || d.z_wstream < 10 * (int64_t)TC_STAGE) return UR_E_BADARG;
+        if (d.z_consts < TCC_Q_END || d.z_wstream != 10 * (int64_t)TC_STAGE) return UR_E_BADARG;  // exactly this chain's stream
     } else if (d.mode == UR_TCHAIN_PRE) {
         if (!d.y_out || !d.out2 || !d.out3) return UR_E_BADARG;
         if (d.rows_per_b <= 0 || (d.rows_per_b % 32) || (d.M % d.rows_per_b) || d.ld_vt < d.rows_per_b || (d.ld_vt % 8)) return UR_E_BADARG;
-        if (d.z_consts < TCC_Q_END || d.z_wstream < 20 * (int64_t)TC_STAGE) return UR_E_BADARG;
+        if (d.z_consts < TCC_Q_END || d.z_wstream != 20 * (int64_t)TC_STAGE) return UR_E_BADARG;
     } else if (d.mode == UR_TCHAIN_FF) {
         if (!d.blk) return UR_E_BADARG;
-        if (d.z_consts < TCC_FF_END || d.z_wstream < (10 + 3 * (TC_FF / 64)) * (int64_t)TC_STAGE) return UR_E_BADARG;
+        // a feed-forward of another hidden size would pack a stream of another length: refuse it instead of streaming
+        // the wrong stage images
+        if (d.z_consts < TCC_FF_END || d.z_wstream != (10 + 3 * (TC_FF / 64)) * (int64_t)TC_STAGE) return UR_E_BADARG;
     } else {
         return UR_E_BADARG;
     }

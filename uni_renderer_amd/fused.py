@@ -262,7 +262,9 @@ class GroupedDualStreamStep:
         (tchain.py) -- proj_in + LayerNorm1 + q / k / V^T projections; attn1 out-projection + residual + LayerNorm2 +
         cross-attention query projection; attn2 out-projection + residual + LayerNorm3 + GEGLU feed-forward + residual +
         proj_out + block input -- instead of ten GEMM and three LayerNorm launches.  ``x`` = the GroupNorm output, ``blk_in``
-        the transformer's input.  Same arithmetic and the same rounding points as ``_tblock`` + proj_in / proj_out."""
+        the transformer's input.  Same arithmetic as ``_tblock`` + proj_in / proj_out; the activations round at the same points,
+        with one difference on the weight side: the chain folds the q / k scale sqrt(d^-1/2 log2 e) into the projection WEIGHTS
+        before their fp16 / bf16 cast (tchain.pack_*), where ``_attn`` applies ``out_scale`` to the fp32 accumulator."""
         S, pk, dt = len(bs), self.pk, x.dtype
         a1, a2 = [b.attn1 for b in bs], [b.attn2 for b in bs]
         a0 = a1[0]
@@ -317,8 +319,13 @@ class GroupedDualStreamStep:
         wo = pk.get("x.wo", ts, [t.proj_out.weight for t in ts], dt, lambda: _stk(pack_matrix(t.proj_out.weight, dt) for t in ts))
         bo = pk.get("x.bo", ts, [t.proj_out.bias for t in ts], dt, lambda: _stk(f32(t.proj_out.bias) for t in ts))
         h = ops.groupnorm(x, g, b_, ts[0].norm.eps, groups=ts[0].groups, silu=False, streams=S)
+        b0 = ts[0].transformer_blocks[0]
+        # the chain kernels hard-code C = 320 (tchain.supported), 8 heads of 40, bias-free q / k / v and a feed-forward of
+        # 2 x 1280 -> 320; anything else takes the GEMM-by-GEMM path
         if (self.use_tchain and len(ts[0].transformer_blocks) == 1 and tchain.supported(h) and self.hilo
-                and (H * W) % 32 == 0 and ts[0].transformer_blocks[0].attn1.dim_head == 40):
+                and (H * W) % 32 == 0 and b0.attn1.dim_head == 40 and b0.attn1.heads * 40 == Cc
+                and b0.ff.net[2].weight.shape[1] == tchain.FF_HIDDEN and b0.ff.net[0].proj.weight.shape[0] == 2 * tchain.FF_HIDDEN
+                and all(getattr(a, nm).bias is None for a in (b0.attn1, b0.attn2) for nm in ("to_q", "to_k", "to_v"))):
             return ops.view_hilo(self._tblock_chain([t.transformer_blocks[0] for t in ts], ts, h.view(Bt, H * W, Cc),
                                                     ops.view_hilo(x, Bt, H * W, Cc), kc, vtc, kv_slices[0]), Bt, H, W, Cc)
         ops.set_site("pi")

@@ -32,6 +32,7 @@ from ._lib import TChainDesc, check
 
 MODE_Q, MODE_FF, MODE_PRE = 0, 1, 2
 CH = 320           # the level the kernel is built for
+FF_HIDDEN = 4 * CH  # GEGLU hidden width the feed-forward chain is built for (TC_FF in csrc/tchain.hip)
 STAGE = 40960      # bytes per stage image
 KPERM16 = (0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15)
 
