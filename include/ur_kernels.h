@@ -209,6 +209,15 @@ typedef struct ur_igemm_desc {
 
 int ur_igemm(const ur_igemm_desc* d, void* stream);
 
+/* A split-K 3x3 conv whose ONLY consumer is a GroupNorm (+ SiLU): main pass of `d` (splitk > 1, no residual / activation /
+ * low part; bias and rowadd allowed), then ONE second pass per (z, sample, group) that sums the fp32 slabs, adds bias and the
+ * per-sample row, rounds to the storage dtype, normalises over the group (eps, gamma / beta [N] fp32, + z * zgn for problem
+ * z) and writes only the normalised tensor to d->out -- the conv output is never materialised.  The conv1 -> norm2 -> SiLU
+ * hand-off of a ResnetBlock2D (models/unet_2d_blocks.py:1100-1111) at the 16x16 / 8x8 levels; replaces the split-K reduce
+ * launch + ur_groupnorm_fused.  Needs (N / groups) % 4 == 0 and Hout * Wout * (N / groups) <= 16384, else UR_E_UNSUPPORTED. */
+int ur_igemm_splitk_gn(const ur_igemm_desc* d, const float* gamma, const float* beta, int64_t zgn, float eps, int groups,
+                       int silu, void* stream);
+
 /* 1 when the library was built with the experimental weight-streaming conv tiles (UR_TILE_WS320*: `make WSCONV=1`); the
  * product build returns 0 and UR_E_UNSUPPORTED for those tile ids. */
 int ur_has_wsconv(void);

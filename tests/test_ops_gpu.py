@@ -514,3 +514,42 @@ def test_qkv_projection_with_transposed_value_output(dev, dtype, tile, splitk, S
         assert torch.equal(qk2, qk)
     vt2 = ops.vt_proj(x, (w[:, 2 * C:].contiguous() if S > 1 else w[0, 2 * C:].contiguous()), streams=S)
     assert rel_l2(vt, vt2.float().cpu()) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", [(16, 640, 1280, 4, 2, True), (8, 1280, 1280, 8, 2, True), (16, 320, 640, 2, 1, False),
+                                 (8, 640, 1280, 16, 1, True), (32, 320, 640, 2, 2, True)])
+def test_conv_groupnorm_as_the_splitk_second_pass(dev, dtype, cfg):
+    """ur_igemm_splitk_gn: split-K conv3x3 (+bias, + per-sample time-embedding row) whose second pass IS the GroupNorm
+    (+ SiLU) of its output -- against fp32 conv2d -> storage rounding -> group_norm -> silu, and against the unfused
+    product path (split-K reduce, then the one-launch GroupNorm), which rounds at the same point: both streams of a grouped
+    launch, split-K 2 .. 16; the last case (32x32 map: 1024 rows) is outside the kernel's strip limit and must fall back
+    to conv + groupnorm with the same result."""
+    from uni_renderer_amd import ops
+    from uni_renderer_amd.layers import pack_conv3x3
+    L, Ci, Co, sk, S, silu = cfg
+    B = 2
+    x = _rand((S * B, L, L, Ci), dtype, dev, seed=1)
+    wt = [_rand((Co, Ci, 3, 3), torch.float32, dev, seed=2 + s_) * (9 * Ci) ** -0.5 for s_ in range(S)]
+    w = torch.stack([pack_conv3x3(t, dtype) for t in wt])
+    bias = torch.stack([_rand((Co,), torch.float32, dev, seed=5 + s_) for s_ in range(S)])
+    gam = torch.stack([1.0 + 0.3 * _rand((Co,), torch.float32, dev, seed=7 + s_) for s_ in range(S)])
+    bet = torch.stack([0.2 * _rand((Co,), torch.float32, dev, seed=9 + s_) for s_ in range(S)])
+    temb = _rand((S * B, 2 * Co), dtype, dev, seed=11)
+    if S == 1:
+        w, bias, gam, bet = w[0], bias[0], gam[0], bet[0]
+    kw = dict(rowadd=temb[:, Co // 2: Co // 2 + Co], streams=S, splitk=sk, tile=2)
+    fused = ops.conv3x3(x, w, bias, gn=(gam, bet, 1e-5, 32, silu), **kw)
+    h = ops.conv3x3(x, w, bias, **kw)
+    unfused = ops.groupnorm(h, gam, bet, 1e-5, groups=32, silu=silu, streams=S)
+    assert ops.splitk_gn_ok(L * L, Co, 32) == (L * L * (Co // 32) <= 16384)
+    for s_ in range(S):
+        sl = slice(s_ * B, (s_ + 1) * B)
+        ref = F.conv2d(x[sl].float().cpu().permute(0, 3, 1, 2), wt[s_].to(dtype).float().cpu(),
+                       (bias[s_] if S > 1 else bias).cpu(), padding=1)
+        ref = ref + temb[sl, Co // 2: Co // 2 + Co].float().cpu()[:, :, None, None]
+        ref = ref.to(dtype).float()  # the storage rounding of the conv output
+        ref = F.group_norm(ref, 32, (gam[s_] if S > 1 else gam).cpu(), (bet[s_] if S > 1 else bet).cpu(), 1e-5)
+        ref = (F.silu(ref) if silu else ref).permute(0, 2, 3, 1)
+        assert rel_l2(fused[sl], ref) < TOL[dtype], cfg
+    assert rel_l2(fused, unfused.float().cpu()) < 0.3 * TOL[dtype]  # same rounding points, different summation order

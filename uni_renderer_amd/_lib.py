@@ -148,6 +148,7 @@ SYMBOLS = {
     "ur_build_info": (C.c_char_p, []),
     "ur_sizeof_igemm_desc": (C.c_int, []),
     "ur_has_wsconv": (C.c_int, []),
+    "ur_igemm_splitk_gn": (C.c_int, [vp, vp, vp, i64, C.c_float, C.c_int, C.c_int, vp]),
     "ur_sizeof_attn_desc": (C.c_int, []),
     "ur_sizeof_attn_bwd_desc": (C.c_int, []),
 }

@@ -515,6 +515,81 @@ __global__ void __launch_bounds__(256) igemm_splitk_reduce(const ur_igemm_desc p
     }
 }
 
+
+// Second pass of split-K FUSED with the GroupNorm (+ SiLU) that follows the conv: one workgroup per (problem z, sample,
+// group) sums the fp32 slabs of its [rows][cpg] strip, adds bias and the per-sample time-embedding row, rounds to the
+// storage dtype (the value the two-kernel path would have stored and re-read), takes the group statistics in fp32 (fixed
+// order), normalises and writes ONLY the normalised tensor: the conv output itself is never materialised.  This is the
+// conv1 -> norm2 -> SiLU hand-off inside a ResnetBlock2D at the 16x16 / 8x8 levels (models/unet_2d_blocks.py:1100-1111),
+// where conv1 runs split-K and its output has no other consumer.  Replaces igemm_splitk_reduce + gn_fused_kernel.
+constexpr int RGN_THREADS = 1024, RGN_MAXQ = 4;  // <= 4 channel quads per thread: rows * cpg <= 16384
+template <typename T>
+__global__ void __launch_bounds__(RGN_THREADS) igemm_splitk_reduce_gn(const ur_igemm_desc p, const float* __restrict__ gamma,
+                                                                       const float* __restrict__ beta, int64_t zgn, float eps,
+                                                                       int groups, int silu, int rows) {
+    __shared__ float red[2][RGN_THREADS / 64];
+    const int g = blockIdx.x, b = blockIdx.y, zb = blockIdx.z;
+    const int cpg = p.N / groups, qpr = cpg >> 2;  // channel quads per row of the strip
+    const int nq = rows * qpr;
+    const int c0 = g * cpg;
+    const float* biasz = p.bias ? p.bias + (int64_t)zb * p.zbias : nullptr;
+    const T* rowz = p.rowadd ? reinterpret_cast<const T*>(p.rowadd) + (int64_t)zb * p.zrow + (int64_t)b * p.ld_rowadd : nullptr;
+    float v[RGN_MAXQ][4];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < RGN_MAXQ; ++i) {
+        const int e = threadIdx.x + i * RGN_THREADS;
+        if (e < nq) {
+            const int r = e / qpr, c = c0 + (e - r * qpr) * 4;
+            const int m = b * rows + r;
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int ks = 0; ks < p.splitk; ++ks) {
+                const float4 t = *reinterpret_cast<const float4*>(p.partial + (((int64_t)zb * p.splitk + ks) * p.M + m) * p.ldp + c);
+                a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+            }
+            float x[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (biasz) x[k] += biasz[c + k];
+                if (rowz) x[k] += to_f(rowz[c + k]);
+                x[k] = to_f(from_f<T>(x[k] * p.out_scale));  // what the unfused path stores and GroupNorm re-reads
+                v[i][k] = x[k];
+                s1 += x[k];
+                s2 = fmaf(x[k], x[k], s2);
+            }
+        }
+    }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s1; red[1][threadIdx.x >> 6] = s2; }
+    __syncthreads();
+    float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+    for (int w = 0; w < RGN_THREADS / 64; ++w) { t1 += red[0][w]; t2 += red[1][w]; }
+    const float n = (float)rows * (float)cpg;
+    const float mean = t1 / n;
+    const float rstd = rsqrtf(fmaxf(t2 / n - mean * mean, 0.f) + eps);
+    const float* gz = gamma + (int64_t)zb * zgn;
+    const float* bz = beta + (int64_t)zb * zgn;
+    T* outz = reinterpret_cast<T*>(p.out) + (int64_t)zb * p.zout;
+#pragma unroll
+    for (int i = 0; i < RGN_MAXQ; ++i) {
+        const int e = threadIdx.x + i * RGN_THREADS;
+        if (e < nq) {
+            const int r = e / qpr, c = c0 + (e - r * qpr) * 4;
+            const int m = b * rows + r;
+            T y[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float a = rstd * gz[c + k];
+                const float t = (v[i][k] - mean) * a + bz[c + k];
+                y[k] = from_f<T>(silu ? silu_f(t) : t);
+            }
+            *reinterpret_cast<uint2*>(outz + (int64_t)m * p.ldc + c) = *reinterpret_cast<const uint2*>(y);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
@@ -563,7 +638,7 @@ static void ensure_lds_limit(int lds) {
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int NSTAGE, int MF = 16, int NL = 0>
-static int launch_cfg(const ur_igemm_desc& d, hipStream_t s) {
+static int launch_cfg(const ur_igemm_desc& d, hipStream_t s, bool reduce) {
     const int tiles_m = (d.M + BM - 1) / BM, tiles_n = (d.N + BN - 1) / BN;
     dim3 grid(tiles_m * tiles_n, 1, d.zbatch * d.splitk);
     const size_t lds = (NSTAGE > 0 ? NSTAGE : 2) * (BM + BN) * 128;
@@ -597,10 +672,10 @@ int igemm_pp_launch(const ur_igemm_desc& d, hipStream_t s);  // igemm_pp.hip
 
 // ping-pong main pass + the shared split-K second pass
 template <typename T>
-static int launch_pp(const ur_igemm_desc& d, hipStream_t s) {
+static int launch_pp(const ur_igemm_desc& d, hipStream_t s, bool reduce) {
     const int rc = igemm_pp_launch(d, s);
     if (rc) return rc;
-    if (d.splitk > 1) {
+    if (d.splitk > 1 && reduce) {
         const int64_t total = (int64_t)d.M * (d.ldp / 16);
         int blocks = (int)((total + 255) / 256);
         if (blocks > 4096) blocks = 4096;
@@ -613,10 +688,10 @@ static int launch_pp(const ur_igemm_desc& d, hipStream_t s) {
 
 // weight-streaming conv main pass + the shared split-K second pass
 template <typename T>
-static int launch_ws(const ur_igemm_desc& d, hipStream_t s) {
+static int launch_ws(const ur_igemm_desc& d, hipStream_t s, bool reduce) {
     const int rc = wsconv_launch(d, s);
     if (rc) return rc;
-    if (d.splitk > 1) {
+    if (d.splitk > 1 && reduce) {
         const int64_t total = (int64_t)d.M * (d.ldp / 16);
         int blocks = (int)((total + 255) / 256);
         if (blocks > 4096) blocks = 4096;
@@ -628,58 +703,59 @@ static int launch_ws(const ur_igemm_desc& d, hipStream_t s) {
 }
 
 template <typename T>
-static int launch_dtype(ur_igemm_desc& d, hipStream_t s) {
+// reduce = false: main pass only (the caller runs its own second pass over the fp32 slabs: ur_igemm_splitk_gn)
+static int launch_dtype(ur_igemm_desc& d, hipStream_t s, bool reduce) {
     switch (d.tile) {
-        case UR_TILE_128x128: return launch_cfg<T, 128, 128, 2, 2, 2>(d, s);
-        case UR_TILE_128x64: return launch_cfg<T, 128, 64, 4, 1, 3>(d, s);
-        case UR_TILE_64x64: return launch_cfg<T, 64, 64, 4, 1, 3>(d, s);
-        case UR_TILE_128x128_S3: return launch_cfg<T, 128, 128, 2, 2, 3>(d, s);
-        case UR_TILE_128x64_S2: return launch_cfg<T, 128, 64, 4, 1, 2>(d, s);
-        case UR_TILE_64x64_S4: return launch_cfg<T, 64, 64, 4, 1, 4>(d, s);
-        case UR_TILE_64x64_S2: return launch_cfg<T, 64, 64, 4, 1, 2>(d, s);
-        case UR_TILE_256x128: return launch_cfg<T, 256, 128, 4, 2, 2>(d, s);
-        case UR_TILE_128x320: return launch_cfg<T, 128, 320, 2, 5, 2>(d, s);
-        case UR_TILE_128x256: return launch_cfg<T, 128, 256, 2, 4, 2>(d, s);
-        case UR_TILE_256x256: return launch_cfg<T, 256, 256, 4, 4, 2>(d, s);
-        case UR_TILE_64x64_R: return launch_cfg<T, 64, 64, 4, 1, -2>(d, s);
-        case UR_TILE_128x64_R: return launch_cfg<T, 128, 64, 4, 1, -2>(d, s);
-        case UR_TILE_128x128_R: return launch_cfg<T, 128, 128, 2, 2, -2>(d, s);
-        case UR_TILE_128x320_R: return launch_cfg<T, 128, 320, 2, 5, -2>(d, s);
-        case UR_TILE_256x128_R: return launch_cfg<T, 256, 128, 4, 2, -2>(d, s);
-        case UR_TILE_64x64_W1: return launch_cfg<T, 64, 64, 1, 1, 2>(d, s);
-        case UR_TILE_128x64_W2: return launch_cfg<T, 128, 64, 2, 1, 2>(d, s);
-        case UR_TILE_64x64_W1_S3: return launch_cfg<T, 64, 64, 1, 1, 3>(d, s);
-        case UR_TILE_64x128_W2: return launch_cfg<T, 64, 128, 1, 2, 2>(d, s);
-        case UR_TILE_64x64_W1_S4: return launch_cfg<T, 64, 64, 1, 1, 4>(d, s);
-        case UR_TILE_128x320_M32: return launch_cfg<T, 128, 320, 2, 5, 2, 32>(d, s);
-        case UR_TILE_128x128_M32: return launch_cfg<T, 128, 128, 2, 2, 2, 32>(d, s);
-        case UR_TILE_128x64_M32: return launch_cfg<T, 128, 64, 4, 1, 2, 32>(d, s);
-        case UR_TILE_128x64_S3_M32: return launch_cfg<T, 128, 64, 4, 1, 3, 32>(d, s);
-        case UR_TILE_64x64_M32: return launch_cfg<T, 64, 64, 2, 2, 2, 32>(d, s);
-        case UR_TILE_64x64_S3_M32: return launch_cfg<T, 64, 64, 2, 2, 3, 32>(d, s);
-        case UR_TILE_256x256_M32: return launch_cfg<T, 256, 256, 4, 4, 2, 32>(d, s);
-        case UR_TILE_256x128_M32: return launch_cfg<T, 256, 128, 4, 2, 2, 32>(d, s);
-        case UR_TILE_128x256_M32: return launch_cfg<T, 128, 256, 2, 4, 2, 32>(d, s);
-        case UR_TILE_128x320_L2: return launch_cfg<T, 128, 320, 2, 5, 2, 16, 2>(d, s);
-        case UR_TILE_128x320_L4: return launch_cfg<T, 128, 320, 2, 5, 2, 16, 4>(d, s);
-        case UR_TILE_128x128_L2: return launch_cfg<T, 128, 128, 2, 2, 2, 16, 2>(d, s);
-        case UR_TILE_128x128_S3_L2: return launch_cfg<T, 128, 128, 2, 2, 3, 16, 2>(d, s);
-        case UR_TILE_128x64_L1: return launch_cfg<T, 128, 64, 4, 1, 2, 16, 1>(d, s);
-        case UR_TILE_128x64_S3_L2: return launch_cfg<T, 128, 64, 4, 1, 3, 16, 2>(d, s);
-        case UR_TILE_64x64_S3_L1: return launch_cfg<T, 64, 64, 4, 1, 3, 16, 1>(d, s);
-        case UR_TILE_256x128_L2: return launch_cfg<T, 256, 128, 4, 2, 2, 16, 2>(d, s);
+        case UR_TILE_128x128: return launch_cfg<T, 128, 128, 2, 2, 2>(d, s, reduce);
+        case UR_TILE_128x64: return launch_cfg<T, 128, 64, 4, 1, 3>(d, s, reduce);
+        case UR_TILE_64x64: return launch_cfg<T, 64, 64, 4, 1, 3>(d, s, reduce);
+        case UR_TILE_128x128_S3: return launch_cfg<T, 128, 128, 2, 2, 3>(d, s, reduce);
+        case UR_TILE_128x64_S2: return launch_cfg<T, 128, 64, 4, 1, 2>(d, s, reduce);
+        case UR_TILE_64x64_S4: return launch_cfg<T, 64, 64, 4, 1, 4>(d, s, reduce);
+        case UR_TILE_64x64_S2: return launch_cfg<T, 64, 64, 4, 1, 2>(d, s, reduce);
+        case UR_TILE_256x128: return launch_cfg<T, 256, 128, 4, 2, 2>(d, s, reduce);
+        case UR_TILE_128x320: return launch_cfg<T, 128, 320, 2, 5, 2>(d, s, reduce);
+        case UR_TILE_128x256: return launch_cfg<T, 128, 256, 2, 4, 2>(d, s, reduce);
+        case UR_TILE_256x256: return launch_cfg<T, 256, 256, 4, 4, 2>(d, s, reduce);
+        case UR_TILE_64x64_R: return launch_cfg<T, 64, 64, 4, 1, -2>(d, s, reduce);
+        case UR_TILE_128x64_R: return launch_cfg<T, 128, 64, 4, 1, -2>(d, s, reduce);
+        case UR_TILE_128x128_R: return launch_cfg<T, 128, 128, 2, 2, -2>(d, s, reduce);
+        case UR_TILE_128x320_R: return launch_cfg<T, 128, 320, 2, 5, -2>(d, s, reduce);
+        case UR_TILE_256x128_R: return launch_cfg<T, 256, 128, 4, 2, -2>(d, s, reduce);
+        case UR_TILE_64x64_W1: return launch_cfg<T, 64, 64, 1, 1, 2>(d, s, reduce);
+        case UR_TILE_128x64_W2: return launch_cfg<T, 128, 64, 2, 1, 2>(d, s, reduce);
+        case UR_TILE_64x64_W1_S3: return launch_cfg<T, 64, 64, 1, 1, 3>(d, s, reduce);
+        case UR_TILE_64x128_W2: return launch_cfg<T, 64, 128, 1, 2, 2>(d, s, reduce);
+        case UR_TILE_64x64_W1_S4: return launch_cfg<T, 64, 64, 1, 1, 4>(d, s, reduce);
+        case UR_TILE_128x320_M32: return launch_cfg<T, 128, 320, 2, 5, 2, 32>(d, s, reduce);
+        case UR_TILE_128x128_M32: return launch_cfg<T, 128, 128, 2, 2, 2, 32>(d, s, reduce);
+        case UR_TILE_128x64_M32: return launch_cfg<T, 128, 64, 4, 1, 2, 32>(d, s, reduce);
+        case UR_TILE_128x64_S3_M32: return launch_cfg<T, 128, 64, 4, 1, 3, 32>(d, s, reduce);
+        case UR_TILE_64x64_M32: return launch_cfg<T, 64, 64, 2, 2, 2, 32>(d, s, reduce);
+        case UR_TILE_64x64_S3_M32: return launch_cfg<T, 64, 64, 2, 2, 3, 32>(d, s, reduce);
+        case UR_TILE_256x256_M32: return launch_cfg<T, 256, 256, 4, 4, 2, 32>(d, s, reduce);
+        case UR_TILE_256x128_M32: return launch_cfg<T, 256, 128, 4, 2, 2, 32>(d, s, reduce);
+        case UR_TILE_128x256_M32: return launch_cfg<T, 128, 256, 2, 4, 2, 32>(d, s, reduce);
+        case UR_TILE_128x320_L2: return launch_cfg<T, 128, 320, 2, 5, 2, 16, 2>(d, s, reduce);
+        case UR_TILE_128x320_L4: return launch_cfg<T, 128, 320, 2, 5, 2, 16, 4>(d, s, reduce);
+        case UR_TILE_128x128_L2: return launch_cfg<T, 128, 128, 2, 2, 2, 16, 2>(d, s, reduce);
+        case UR_TILE_128x128_S3_L2: return launch_cfg<T, 128, 128, 2, 2, 3, 16, 2>(d, s, reduce);
+        case UR_TILE_128x64_L1: return launch_cfg<T, 128, 64, 4, 1, 2, 16, 1>(d, s, reduce);
+        case UR_TILE_128x64_S3_L2: return launch_cfg<T, 128, 64, 4, 1, 3, 16, 2>(d, s, reduce);
+        case UR_TILE_64x64_S3_L1: return launch_cfg<T, 64, 64, 4, 1, 3, 16, 1>(d, s, reduce);
+        case UR_TILE_256x128_L2: return launch_cfg<T, 256, 128, 4, 2, 2, 16, 2>(d, s, reduce);
         case UR_TILE_256x256_L0: return UR_E_UNSUPPORTED;  /* 16 consumer waves already fill the 1024-thread limit */
-        case UR_TILE_128x256_L2: return launch_cfg<T, 128, 256, 2, 4, 2, 16, 2>(d, s);
-        case UR_TILE_128x256_S3: return launch_cfg<T, 128, 256, 2, 4, 3>(d, s);
-        case UR_TILE_128x320_W8_M32: return launch_cfg<T, 128, 320, 4, 2, 2, 32>(d, s);
-        case UR_TILE_256x320_W16_M32: return launch_cfg<T, 256, 320, 8, 2, 2, 32>(d, s);
-        case UR_TILE_128x160_M32: return launch_cfg<T, 128, 160, 4, 1, 2, 32>(d, s);
-        case UR_TILE_128x160_S3_M32: return launch_cfg<T, 128, 160, 4, 1, 3, 32>(d, s);
-        case UR_TILE_64x320_M32: return launch_cfg<T, 64, 320, 2, 2, 2, 32>(d, s);
-        case UR_TILE_WS320: return launch_ws<T>(d, s);
-        case UR_TILE_WS320_W8: return launch_ws<T>(d, s);
+        case UR_TILE_128x256_L2: return launch_cfg<T, 128, 256, 2, 4, 2, 16, 2>(d, s, reduce);
+        case UR_TILE_128x256_S3: return launch_cfg<T, 128, 256, 2, 4, 3>(d, s, reduce);
+        case UR_TILE_128x320_W8_M32: return launch_cfg<T, 128, 320, 4, 2, 2, 32>(d, s, reduce);
+        case UR_TILE_256x320_W16_M32: return launch_cfg<T, 256, 320, 8, 2, 2, 32>(d, s, reduce);
+        case UR_TILE_128x160_M32: return launch_cfg<T, 128, 160, 4, 1, 2, 32>(d, s, reduce);
+        case UR_TILE_128x160_S3_M32: return launch_cfg<T, 128, 160, 4, 1, 3, 32>(d, s, reduce);
+        case UR_TILE_64x320_M32: return launch_cfg<T, 64, 320, 2, 2, 2, 32>(d, s, reduce);
+        case UR_TILE_WS320: return launch_ws<T>(d, s, reduce);
+        case UR_TILE_WS320_W8: return launch_ws<T>(d, s, reduce);
         case UR_TILE_PP_128x320: case UR_TILE_PP_128x320_S4: case UR_TILE_PP_256x128: case UR_TILE_PP_128x256:
-        case UR_TILE_PP_256x256: case UR_TILE_PP_128x128: case UR_TILE_PP_256x320: return launch_pp<T>(d, s);
+        case UR_TILE_PP_256x256: case UR_TILE_PP_128x128: case UR_TILE_PP_256x320: return launch_pp<T>(d, s, reduce);
     }
     return UR_E_BADARG;
 }
@@ -711,10 +787,9 @@ extern "C" int64_t ur_igemm_partial_floats(const ur_igemm_desc* d) {
     return (int64_t)d->splitk * (d->zbatch > 1 ? d->zbatch : 1) * d->M * ldp;
 }
 
-extern "C" int ur_igemm(const ur_igemm_desc* din, void* stream) {
+// validates and completes the descriptor, then launches (main pass + the standard split-K second pass if `reduce`)
+static int igemm_run(ur_igemm_desc& d, void* stream, bool reduce = true) {
     using namespace ur;
-    if (!din) return UR_E_BADARG;
-    ur_igemm_desc d = *din;
     if (!d.x0 || !d.w || !d.out || !d.zero_page) return UR_E_BADARG;
     if (d.M <= 0 || d.N <= 0 || d.K <= 0) return UR_E_BADARG;
     if (d.taps != 1 && d.taps != 9) return UR_E_BADARG;
@@ -751,7 +826,37 @@ extern "C" int ur_igemm(const ur_igemm_desc* din, void* stream) {
     if (d.tile < 1 || d.tile >= UR_TILE_COUNT) return UR_E_BADARG;
     d.ldp = padded_ldp(d, d.tile);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (d.dtype == UR_DT_F16) return launch_dtype<f16>(d, s);
-    if (d.dtype == UR_DT_BF16) return launch_dtype<bf16>(d, s);
+    if (d.dtype == UR_DT_F16) return launch_dtype<f16>(d, s, reduce);
+    if (d.dtype == UR_DT_BF16) return launch_dtype<bf16>(d, s, reduce);
     return UR_E_BADARG;
+}
+
+extern "C" int ur_igemm(const ur_igemm_desc* din, void* stream) {
+    if (!din) return UR_E_BADARG;
+    ur_igemm_desc d = *din;
+    return igemm_run(d, stream);
+}
+
+extern "C" int ur_igemm_splitk_gn(const ur_igemm_desc* din, const float* gamma, const float* beta, int64_t zgn, float eps,
+                                  int groups, int silu, void* stream) {
+    using namespace ur;
+    if (!din || !gamma || !beta || groups <= 0) return UR_E_BADARG;
+    ur_igemm_desc d = *din;
+    if (d.taps != 9 || d.splitk <= 1 || d.res || d.out_lo || d.out_vt || d.act != UR_ACT_NONE) return UR_E_BADARG;
+    const int rows = d.Hout * d.Wout;
+    if (d.N % groups || ((d.N / groups) & 3) || (d.ldc & 3) || (int64_t)rows * (d.N / groups) > (int64_t)RGN_THREADS * RGN_MAXQ * 4)
+        return UR_E_UNSUPPORTED;
+    if (d.rowadd && d.rows_per_b != rows) return UR_E_BADARG;
+    if (d.n_store > 0 && d.n_store != d.N) return UR_E_BADARG;
+    const int rc = igemm_run(d, stream, /*reduce=*/false);
+    if (rc) return rc;
+    if (d.splitk <= 1) return UR_E_BADARG;  // (clamped away: K too short for a split)
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const dim3 grid(groups, d.B, d.zbatch);
+    if (d.dtype == UR_DT_F16)
+        hipLaunchKernelGGL((igemm_splitk_reduce_gn<f16>), grid, dim3(RGN_THREADS), 0, s, d, gamma, beta, zgn, eps, groups, silu, rows);
+    else
+        hipLaunchKernelGGL((igemm_splitk_reduce_gn<bf16>), grid, dim3(RGN_THREADS), 0, s, d, gamma, beta, zgn, eps, groups, silu, rows);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : -(int)e;
 }

@@ -145,9 +145,11 @@ class GroupedDualStreamStep:
         c2 = pk.get("r.c2", rs, [r.conv2.bias for r in rs], dt, lambda: _stk(f32(r.conv2.bias) for r in rs))
         lo, hi = slice_
         h = ops.groupnorm(x, g1, b1, r0.eps, x1=x1, groups=r0.groups, silu=True, streams=S)
+        # conv1 -> norm2 -> SiLU: conv1's output has no other consumer, so where conv1 runs split-K on a small map (the
+        # 16x16 / 8x8 levels) the GroupNorm is the split-K second pass and the conv output is never written (ops.conv3x3 gn=)
         h = ops.conv3x3(h, w1, c1, rowadd=temb[:, lo:hi], streams=S, cblock=ops.conv_cblock(h.shape[-1]),
-                        ws=self._ws("r.w1ws", rs, [r.conv1.weight for r in rs], w1, h, streams=S))
-        h = ops.groupnorm(h, g2, b2, r0.eps, groups=r0.groups, silu=True, streams=S)
+                        ws=self._ws("r.w1ws", rs, [r.conv1.weight for r in rs], w1, h, streams=S),
+                        gn=(g2, b2, r0.eps, r0.groups, True))
         if r0.conv_shortcut is not None and ops.FOLD_SHORTCUT:
             # the 1x1 conv_shortcut over (x | x1) rides in conv2's K loop (ur_igemm_desc.t0 / t1): one launch less and no
             # round trip of its output through memory

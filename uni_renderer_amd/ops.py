@@ -180,7 +180,9 @@ def igemm(*, x0, w, out, M, N, K, c0, c1=0, x1=None, ldx0, ldx1=0, ldw, ldc, tap
           bias=None, rowadd=None, rows_per_b=0, res=None, ldres=0, n_store=0, act=ACT_NONE, out_scale=1.0,
           zbatch=1, zx=0, zw=0, zout=0, zx1=0, zbias=0, zrow=0, zres=0, zx_div=1, tile=None, splitk=None,
           res_lo=None, out_lo=None, cblock=0, t0=None, t1=None, ldt0=0, ldt1=0, zt0=0, zt1=0, ct0=0, ct1=0, pad=1,
-          out_vt=None, vt_n0=0, vt_rows=0, zvt=0):
+          out_vt=None, vt_n0=0, vt_rows=0, zvt=0, gn=None):
+    """``gn`` = (gamma, beta, per-z stride, eps, groups, silu): split-K launches only -- the second pass normalises
+    (ur_igemm_splitk_gn) and ``out`` receives GroupNorm(conv) instead of the conv."""
     _require_gpu(x0)
     lib = _lib.load()
     if tile is None or splitk is None:
@@ -228,12 +230,19 @@ def igemm(*, x0, w, out, M, N, K, c0, c1=0, x1=None, ldx0, ldx1=0, ldw, ldc, tap
     if bias is not None and bias.dtype != torch.float32:
         raise RuntimeError("bias must be fp32")
     e0 = _prof_begin()
-    check(lib.ur_igemm(C.byref(d), _stream()), "ur_igemm")
+    if gn is not None:
+        if splitk <= 1:
+            raise RuntimeError("igemm(gn=...) is the fused second pass of a split-K launch")
+        gam, bet, zgn, eps, groups, silu = gn
+        check(lib.ur_igemm_splitk_gn(C.byref(d), gam.data_ptr(), bet.data_ptr(), int(zgn), float(eps), int(groups), int(silu),
+                                     _stream()), "ur_igemm_splitk_gn")
+    else:
+        check(lib.ur_igemm(C.byref(d), _stream()), "ur_igemm")
     if e0 is not None:
         el = x0.element_size()
         z = max(zbatch, 1)
         key = (f"igemm_{_TILES[tile][0]}x{_TILES[tile][1]}s{_TILES[tile][3]}_{'conv3x3' if taps == 9 else 'gemm'}"
-               + ("_splitk" if splitk > 1 else ""))
+               + ("_splitk" if splitk > 1 else "") + ("_gn" if gn is not None else ""))
         if _prof_by_shape:
             key += f"|M{M}_N{N}_K{K}_z{z}_sk{splitk}"
         # algorithmic bytes: every operand once -- activations (the conv reads each input pixel once: M*stride^2/4^ups
@@ -418,7 +427,7 @@ _ws_table: dict = {}
 
 
 def conv3x3(x, w, bias=None, *, x1=None, stride=1, ups=False, rowadd=None, res=None, out_scale=1.0, n_out=None,
-            tile=None, splitk=None, streams=1, hilo=False, cblock=0, tail=None, pad=1, ws=None):
+            tile=None, splitk=None, streams=1, hilo=False, cblock=0, tail=None, pad=1, ws=None, gn=None):
     """3x3 conv, pad 1, over NHWC ``x`` (optionally cat(x, x1) on channels, optionally after a nearest-2x
     upsample).  ``w`` is [Npad >= n_out, 9*Cin] with k = (ky*3+kx)*Cin + c, or, with ``cblock`` > 0, in the
     block-outer order k = (c // cblock)*9*cblock + (ky*3+kx)*cblock + c % cblock.  Output [B, Ho, Wo, n_out].
@@ -426,7 +435,10 @@ def conv3x3(x, w, bias=None, *, x1=None, stride=1, ups=False, rowadd=None, res=N
     its [N, Ct0 + Ct1] weight matrix is appended to ``w`` along K (stride 1, no upsampling only).
     ``streams=S``: x is [S*B, H, W, C] (stream-major), ``w`` [S, N, 9*Cin], ``bias`` [S, N]: one grouped launch.
     ``ws``: the same weights as stage images (``wsconv_images``; [S, N*K] with streams): when given and the shape fits
-    (``wsconv_ok``) the weight-streaming kernel runs instead of the LDS-tiled one."""
+    (``wsconv_ok``) the weight-streaming kernel runs instead of the LDS-tiled one.
+    ``gn`` = (gamma, beta, eps, groups, silu): the result is GroupNorm(conv(x)) (-> SiLU): where the conv runs split-K and
+    the map is small (``splitk_gn_ok``) the normalisation IS the split-K second pass (ur_igemm_splitk_gn) and the conv
+    output is never written; otherwise conv, then ``groupnorm``."""
     Bt, H, W, C0 = x.shape
     B = Bt // streams
     C1 = x1.shape[-1] if x1 is not None else 0
@@ -462,11 +474,31 @@ def conv3x3(x, w, bias=None, *, x1=None, stride=1, ups=False, rowadd=None, res=N
             z["zw"] = ws.stride(0)
         if splitk is None:
             splitk = wsconv_splitk(M, N, Kt, streams)
+    gkw = {}
+    if gn is not None:
+        gam, bet, eps, groups, silu = gn
+        if tile is None or splitk is None:
+            pt, ps = plan_igemm(M, N, Kt, 9, streams)
+            tile, splitk = (pt if tile is None else tile), (ps if splitk is None else splitk)
+        if SPLITK_GN and splitk > 1 and res is None and not hilo and splitk_gn_ok(Ho * Wo, N, groups) and min(splitk, Kt // 64) > 1:
+            gkw = dict(gn=(gam, bet, (gam.stride(0) if streams > 1 else 0), eps, groups, silu))
     igemm(x0=x, x1=x1, w=w, out=out, M=M, N=N, K=Kt, c0=C0, c1=C1, ldx0=C0, ldx1=C1,
           ldw=ldw, ldc=N, taps=9, conv=(B, H, W, Ho, Wo), stride=stride, ups=int(ups), bias=bias,
           rowadd=rowadd, rows_per_b=Ho * Wo, res=res, ldres=(N if res is not None else 0), out_scale=out_scale,
-          tile=tile, splitk=splitk, res_lo=lo_of(res), out_lo=lo_of(out), cblock=cblock, pad=pad, **tl, **z)
+          tile=tile, splitk=splitk, res_lo=lo_of(res), out_lo=lo_of(out), cblock=cblock, pad=pad, **tl, **z, **gkw)
+    if gn is not None and not gkw:
+        return groupnorm(out, gam, bet, eps, groups=groups, silu=silu, streams=streams)
     return out
+
+
+# conv -> GroupNorm (+ SiLU) with the normalisation as the split-K second pass (ur_igemm_splitk_gn); UR_SPLITK_GN=0 restores
+# split-K reduce + one-launch GroupNorm (same-box A/B)
+SPLITK_GN = os.environ.get("UR_SPLITK_GN", "1") != "0"
+
+
+def splitk_gn_ok(rows: int, N: int, groups: int) -> bool:
+    """Shapes ur_igemm_splitk_gn takes: a (sample, group) strip of at most 16384 values, groups of a multiple of 4 channels."""
+    return N % groups == 0 and (N // groups) % 4 == 0 and rows * (N // groups) <= 16384
 
 
 def vt_proj(x, wv, streams=1, shared_x=False):
