@@ -35,6 +35,8 @@ from .layers import (LOG2E, Attention, BasicTransformerBlock, ResnetBlock2D, Tra
 # q | k | v of a self-attention as ONE grouped GEMM with a transposed side output for V (ur_igemm_desc.out_vt, ABI 8);
 # UR_QKV_ONE_LAUNCH=0 restores the q | k GEMM + transposed V projection pair (same-box A/B runs)
 QKV_ONE_LAUNCH = os.environ.get("UR_QKV_ONE_LAUNCH", "1") != "0"
+# the same for the prompt's K / V^T projections of a phase (one GEMM over [Wk; Wv] instead of a K GEMM + a V^T GEMM per stream)
+CTXKV_ONE_LAUNCH = os.environ.get("UR_CTXKV_ONE_LAUNCH", "1") != "0"
 
 
 class _Packs:
@@ -372,9 +374,21 @@ class GroupedDualStreamStep:
             B, Tk, Cc = ehs.shape
             n = wk.shape[1]
             kc = torch.empty(S * B, Tk, n, dtype=dt, device=ehs.device)
-            ops.igemm(x0=ehs, w=wk, out=kc, M=B * Tk, N=n, K=Cc, c0=Cc, ldx0=Cc, ldw=Cc, ldc=n, zbatch=S, zx=0,
-                      zw=wk.stride(0), zout=B * Tk * n)  # the prompt is shared by the streams (zx = 0)
-            vtc = ops.vt_proj(ehs, wv, streams=S, shared_x=True)
+            if CTXKV_ONE_LAUNCH and n % 16 == 0:
+                # prompt K and V^T of every cross-attention of the phase from ONE grouped GEMM over [Wk; Wv]: the value
+                # columns leave the epilogue transposed (ur_igemm_desc.out_vt) into a zero-filled [S*B, n, Tpad] tensor
+                # (77 keys: the pad columns must be zero for the attention kernel) -- instead of a K GEMM plus one
+                # transposed V projection per stream
+                wkv = pk.get(("p.wkv", ckey), nets, [t for al in cross_lists for a in al for t in (a.to_k.weight, a.to_v.weight)], dt,
+                             lambda: torch.cat([wk, wv], 1).contiguous())
+                Tpad = (Tk + 63) // 64 * 64
+                vtc = torch.zeros(S * B, n, Tpad, dtype=dt, device=ehs.device)
+                ops.igemm(x0=ehs, w=wkv, out=kc, M=B * Tk, N=2 * n, K=Cc, c0=Cc, ldx0=Cc, ldw=Cc, ldc=n, n_store=n, zbatch=S, zx=0,
+                          zw=wkv.stride(0), zout=B * Tk * n, out_vt=vtc, vt_n0=n, vt_rows=Tk, zvt=B * n * Tpad)
+            else:
+                ops.igemm(x0=ehs, w=wk, out=kc, M=B * Tk, N=n, K=Cc, c0=Cc, ldx0=Cc, ldw=Cc, ldc=n, zbatch=S, zx=0,
+                          zw=wk.stride(0), zout=B * Tk * n)  # the prompt is shared by the streams (zx = 0)
+                vtc = ops.vt_proj(ehs, wv, streams=S, shared_x=True)
             off = 0
             for a in cross_lists[0]:
                 kslices[id(a)] = (off, off + a.inner)
