@@ -491,9 +491,12 @@ def conv3x3(x, w, bias=None, *, x1=None, stride=1, ups=False, rowadd=None, res=N
     return out
 
 
-# conv -> GroupNorm (+ SiLU) with the normalisation as the split-K second pass (ur_igemm_splitk_gn); UR_SPLITK_GN=0 restores
-# split-K reduce + one-launch GroupNorm (same-box A/B)
-SPLITK_GN = os.environ.get("UR_SPLITK_GN", "1") != "0"
+# conv -> GroupNorm (+ SiLU) with the normalisation as the split-K second pass (ur_igemm_splitk_gn).  OFF by default: parity is
+# green (tests/test_ops_gpu.py), but the step is 0.07 ms SLOWER with it (85.42 / 85.65 -> 85.01 / 84.92 steps/s alternating
+# on one box, profiles/r04_splitk_gn_ab.txt): one workgroup per (sample, group) reads its strip of the fp32 slabs in
+# 160-byte runs from 256 workgroups, where the plain reduce pass streams them fully coalesced from 4096 -- the slab traffic
+# (42 MB at the 16x16 level), not the launch, is what the second pass costs.  UR_SPLITK_GN=1 enables it.
+SPLITK_GN = os.environ.get("UR_SPLITK_GN", "0") != "0"
 
 
 def splitk_gn_ok(rows: int, N: int, groups: int) -> bool:
