@@ -519,7 +519,7 @@ def test_qkv_projection_with_transposed_value_output(dev, dtype, tile, splitk, S
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("cfg", [(16, 640, 1280, 4, 2, True), (8, 1280, 1280, 8, 2, True), (16, 320, 640, 2, 1, False),
                                  (8, 640, 1280, 16, 1, True), (32, 320, 640, 2, 2, True)])
-def test_conv_groupnorm_as_the_splitk_second_pass(dev, dtype, cfg):
+def test_conv_groupnorm_as_the_splitk_second_pass(dev, dtype, cfg, monkeypatch):
     """ur_igemm_splitk_gn: split-K conv3x3 (+bias, + per-sample time-embedding row) whose second pass IS the GroupNorm
     (+ SiLU) of its output -- against fp32 conv2d -> storage rounding -> group_norm -> silu, and against the unfused
     product path (split-K reduce, then the one-launch GroupNorm), which rounds at the same point: both streams of a grouped
@@ -527,6 +527,7 @@ def test_conv_groupnorm_as_the_splitk_second_pass(dev, dtype, cfg):
     to conv + groupnorm with the same result."""
     from uni_renderer_amd import ops
     from uni_renderer_amd.layers import pack_conv3x3
+    monkeypatch.setattr(ops, "SPLITK_GN", True)  # off by default (measured slower in the step): exercised here
     L, Ci, Co, sk, S, silu = cfg
     B = 2
     x = _rand((S * B, L, L, Ci), dtype, dev, seed=1)
