@@ -60,20 +60,34 @@ commands below and keeps the summaries; this file is `python tools/make_profiles
 round 1 (first complete collection / end of round), kept for the history of the numbers; `{tag}_*` = the state at the
 end of round {tag[1:3].lstrip("0")}.
 
-Round-3 additions: `{tag}_tchain_bench.json` (`tools/tchain_bench.py`: the three row-local chain launches of the
+Round-3 additions: `r03_tchain_bench.json` (`tools/tchain_bench.py`: the three row-local chain launches of the
 320-channel transformer blocks against the GEMM / LayerNorm launches they replace, graph-timed, plus s_memtime phase and
-per-stage stamps of the kernels), `{tag}_pmc_conv_sq.json` / `{tag}_pmc_gemm320_sq.json` (`tools/pmc_conv_sq.sh`: three SQ-counter
+per-stage stamps of the kernels), `r03_pmc_conv_sq.json` / `r03_pmc_gemm320_sq.json` (`tools/pmc_conv_sq.sh`: three SQ-counter
 passes over the level-0 conv / a K = 320 GEMM replayed alone: parked, issue-stalled and active wave cycles, LDS activity,
-bank conflicts), `{tag}_mfma_rate.txt` (`tools/ubench/mfma_rate.hip`, the corrected MFMA issue-rate micro-benchmark: random
-operands, distinct A / B registers, 1 / 2 / 4 waves per SIMD), `{tag}_ring_depth_ab.txt` (`tools/experiments/r03_run6.sh`: a 3-deep LDS ring
+bank conflicts), `r03_mfma_rate.txt` (`tools/ubench/mfma_rate.hip`, the corrected MFMA issue-rate micro-benchmark: random
+operands, distinct A / B registers, 1 / 2 / 4 waves per SIMD), `r03_ring_depth_ab.txt` (`tools/experiments/r03_run6.sh`: a 3-deep LDS ring
 on the 128x256 tile against the 2-deep one: no difference, the conv loop is not waiting for its copies).
-Second half of round 3: `{tag}_determinism.txt` (`tools/determinism_check.py`, `tools/tchain_determinism.py`: the grouped step
+Second half of round 3: `r03_determinism.txt` (`tools/determinism_check.py`, `tools/tchain_determinism.py`: the grouped step
 and the three chain kernels repeated on fixed inputs, bitwise comparison -- after the LDS race of the first chain kernel was
-fixed, DESIGN.md section 5), `{tag}_gap_analysis.txt` (`tools/gap_analysis.py` over a `rocprofv3 --kernel-trace` of the graph
-replay: 393 kernels per step, 0.1 % idle between them), `{tag}_wsconv_bench.txt` (`tools/wsconv_bench.py`: the weight-streaming
-conv kernel against the tuned LDS-tiled one on the 18 resnet conv shapes of the step), `{tag}_pmc_attn_slot.txt`
-(`tools/pmc_attn.sh`: SQ counters of the d = 40 self-attention on the pre-scaled path), `{tag}_ab_collections.txt` (same-box
+fixed, DESIGN.md section 5), `r03_gap_analysis.txt` (`tools/gap_analysis.py` over a `rocprofv3 --kernel-trace` of the graph
+replay: 393 kernels per step, 0.1 % idle between them), `r03_wsconv_bench.txt` (`tools/wsconv_bench.py`: the weight-streaming
+conv kernel against the tuned LDS-tiled one on the 18 resnet conv shapes of the step), `r03_pmc_attn_slot.txt`
+(`tools/pmc_attn.sh`: SQ counters of the d = 40 self-attention on the pre-scaled path), `r03_ab_collections.txt` (same-box
 A/B of the commits of the round's two collections: the 11.67 vs 12.01 ms of their bench lines is the box, not the code).
+Round-4 additions (each is the output of one `tools/experiments/r04_run*.sh` call): `r04_pp_ab.txt` (`tools/pp_ab.py`: the
+8-wave ping-pong tiles of `csrc/igemm_pp.hip` against the shipped table on the 41 heaviest problems of the step, isolated
+graph replay, with the rel-L2 between the two outputs), `r04_pp_ablate.txt` (ablation builds of the ping-pong kernel on the
+level-0 conv and three more problems: no copies / no MFMAs / no fragment reads / pairs / no barriers; first block =
+unablated tiles 9, 49, 50, 55), `r04_pp_variants.txt` (four schedule variants: `s_setprio` on / off x copies issued in the
+READ block or between the MFMAs), `r04_pp_cblock.txt` (K order of the conv: channel blocks of 64 / 320, lock-step, loader-wave
+and ping-pong tiles, and the copies-only build), `r04_insitu_pp.txt` (in-situ tuning pass with the ping-pong tiles as
+candidates: 244 captured steps), `r04_ldsdma_pattern.txt` (`tools/ubench/ldsdma_pattern.hip`: global -> LDS delivery rate of
+a CU by address pattern: contiguous / 128-byte / 64-byte row segments, shared / private / mixed regions, buffer vs flat
+addressing, ring depth 2 / 3 / 5), `r04_qkv_ab.txt` and `r04_splitk_gn_ab.txt` (same-box alternations of `UR_QKV_ONE_LAUNCH`,
+`UR_SPLITK_GN`, `UR_CTXKV_ONE_LAUNCH`), `r04_loop_parity.json` (`tools/loop_parity.py`: the full 50-step DDIM loop of cfg 3 at SD
+size against the oracle loop, per-step trajectory), `r04_weight_sensitivity.json` (`tools/weight_sensitivity.py`: fp16 rounding
+of the checkpoint by parameter subset kept in fp32, oracle arithmetic), `r04_smoke.txt` (`__graft_entry__.smoke()`),
+`r04_gap_analysis.txt`, `r04_determinism.txt`.  The cfg 2 / cfg 5 lines of round 4 carry `roofline` with live traffic.
 Other summaries: `{tag}_parity_numbers.json` (every rel-L2 the `-m gpu` suite printed: the chain kernels, cfg 3 at batch 2 and 4
 and as a 5-step DDIM loop, cfg 5 vs the oracle, the 16384-token attention, UpRes, the module-surface and cfg-4 training steps
 incl. the inverse branch at SD size, the VAE, the RCCL world-size-1 collectives),

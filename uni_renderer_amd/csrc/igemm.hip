@@ -528,7 +528,10 @@ __global__ void __launch_bounds__(RGN_THREADS) igemm_splitk_reduce_gn(const ur_i
                                                                        const float* __restrict__ beta, int64_t zgn, float eps,
                                                                        int groups, int silu, int rows) {
     __shared__ float red[2][RGN_THREADS / 64];
-    const int g = blockIdx.x, b = blockIdx.y, zb = blockIdx.z;
+    // the groups of one sample on ONE XCD: neighbouring groups share the 128-byte lines of the slabs (a strip is a 4 * cpg-byte
+    // run of every row), which would otherwise be fetched into two or three L2s
+    const int lid_ = xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x * gridDim.y * gridDim.z);
+    const int g = lid_ % gridDim.x, b = (lid_ / gridDim.x) % gridDim.y, zb = lid_ / (gridDim.x * gridDim.y);
     const int cpg = p.N / groups, qpr = cpg >> 2;  // channel quads per row of the strip
     const int nq = rows * qpr;
     const int c0 = g * cpg;

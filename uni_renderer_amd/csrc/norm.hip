@@ -7,6 +7,13 @@
 #include <cstdlib>
 
 // UR_NORM_XCD=0 switches the XCD row-ownership remap of the norm kernels off (A/B runs); read once.
+// UR_GNF_XCD=0: the one-launch GroupNorm keeps the dispatcher's placement (group g of a sample on XCD g % 8) instead of
+// putting the groups of one sample on ONE XCD (A/B runs); read once.
+static int gnf_xcd() {
+    static const int v = [] { const char* e = std::getenv("UR_GNF_XCD"); return (e && e[0] == '0') ? 0 : 1; }();
+    return v;
+}
+
 static int norm_xcd() {
     static const int v = [] { const char* e = std::getenv("UR_NORM_XCD"); return (e && e[0] == '0') ? 0 : 1; }();
     return v;
@@ -452,10 +459,13 @@ __global__ void __launch_bounds__(GNF_THREADS) gn_fused_kernel(const T* __restri
                                                        const lo_t<T>* __restrict__ x0_lo, const lo_t<T>* __restrict__ x1_lo, int c0,
                                                        int c1, int rows, int groups, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float eps, int silu, int bper,
-                                                       int pstride, T* __restrict__ out) {
+                                                       int pstride, T* __restrict__ out, int xcd) {
     __shared__ float2 red[GNF_THREADS / 64];
     __shared__ __attribute__((aligned(16))) float2 aff[128];  // per channel of the group: (gamma * rstd, beta - mean * gamma * rstd)
-    const int t = threadIdx.x, g = blockIdx.x, b = blockIdx.y;
+    // a group's strip is cpg * 2 bytes of every 128-byte line it touches: neighbouring groups share lines.  xcd: consecutive
+    // logical ids (groups of one sample) on ONE XCD, so a line is fetched into one L2 instead of two or three
+    const int lid_ = xcd ? xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y) : blockIdx.x + gridDim.x * blockIdx.y;
+    const int t = threadIdx.x, g = lid_ % gridDim.x, b = lid_ / gridDim.x;
     const int C = c0 + c1, cpg = C / groups, ppr = cpg / P;  // pieces per row
     const int total = rows * ppr;
     const int dr = GNF_THREADS / ppr, dp = GNF_THREADS - dr * ppr;  // (row, piece) step of i += GNF_THREADS
@@ -609,7 +619,7 @@ static int launch_gn_fused(const void* x0, const void* x1, const void* x0_lo, co
     dim3 grid(groups, B);
 #define UR_GNF(PP)                                                                                                     \
     hipLaunchKernelGGL((gn_fused_kernel<T, PP>), grid, dim3(GNF_THREADS), 0, s, (const T*)x0, (const T*)x1, (const lo_t<T>*)x0_lo, \
-                       (const lo_t<T>*)x1_lo, c0, c1, rows, groups, gamma, beta, eps, silu, bper, pstride, (T*)out)
+                       (const lo_t<T>*)x1_lo, c0, c1, rows, groups, gamma, beta, eps, silu, bper, pstride, (T*)out, gnf_xcd())
     if (cpg > 128) return UR_E_UNSUPPORTED;  // the group's affine pairs are staged in a 128-entry LDS table
     if (cpg % 8 == 0) UR_GNF(8);
     else if (cpg % 4 == 0) UR_GNF(4);
