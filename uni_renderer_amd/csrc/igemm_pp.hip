@@ -33,7 +33,7 @@ namespace ur {
 
 constexpr int BKS = 32;  // K elements per stage (64 bytes per row)
 
-// -DUR_PP_ABLATE=<bits> builds measurement-only variants (tools/experiments/r04_pp_ablate.sh; never in the product build):
+// -DUR_PP_ABLATE=<bits> builds measurement-only variants (tools/experiments/r04_run3.sh; never in the product build):
 //   1 = no LDS-DMA copies (pointer bookkeeping kept), 2 = no MFMAs, 4 = no fragment reads, 8 = no barriers / waits
 #ifndef UR_PP_ABLATE
 #define UR_PP_ABLATE 0
