@@ -262,7 +262,13 @@ __global__ void __launch_bounds__((WM * WN + NL) * 64) igemm_kernel(const ur_ige
         char* ws = xs + XT_BYTES;
 #pragma unroll
         for (int it = 0; it < XI; ++it) {
+#if defined(UR_ABLATE) && UR_ABLATE == 3
+            // timing-only upper bound of "the three dx taps share one staged pixel block" (DESIGN.md section 4, round 4): the
+            // pixel tile is copied for one tap in three, the other two multiply stale LDS contents (results are garbage)
+            if (it * NW + wave < BM / 8 && !(CONV && seg_src < 2 && (seg_tap % 3) != 0)) glds16(xptr[it], xs + (it * NW + wave) * 1024);
+#else
             if (it * NW + wave < BM / 8) glds16(xptr[it], xs + (it * NW + wave) * 1024);
+#endif
             xptr[it] += xinc[it];
         }
 #pragma unroll
