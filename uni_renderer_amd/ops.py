@@ -553,9 +553,11 @@ def resize_nearest(x, size):
     return out
 
 
-# maps of at most this many pixels per sample (16x16 and 8x8 levels) take the one-launch GroupNorm: measured 6-12 us
-# against 12-21 us for stats + apply; at 32x32 and above the two-launch path wins (tools/gn_bench.py)
-GN_FUSED_MAX_ROWS = int(os.environ.get("UR_GN_FUSED_MAX_ROWS", "256"))
+# maps of at most this many pixels per sample take the one-launch GroupNorm.  Round 4: with the groups of one sample placed on
+# ONE XCD (UR_GNF_XCD, csrc/norm.hip: neighbouring groups share cache lines) the one-launch kernel also wins at the 32x32
+# level (12-15 us against 14-16 for stats + apply; at 64x64 31 against 26: tools/gn_bench.py, profiles/r04_gnf_xcd_ab.txt);
+# in the step 256 -> 1024 rows is +0.45 % steps/s (tools/experiments/r04_run11.sh)
+GN_FUSED_MAX_ROWS = int(os.environ.get("UR_GN_FUSED_MAX_ROWS", "1024"))
 
 
 def groupnorm(x, gamma, beta, eps, *, x1=None, groups=32, silu=False, nstat=None, napply=None, streams=1, fused=None,
