@@ -205,9 +205,19 @@ typedef struct ur_igemm_desc {
     void* out_vt;
     int64_t ldvt, vt_bstride, zvt;
     int32_t vt_n0, vt_rows;
+    /* size of the zero region behind zero_page in bytes (a power of two >= 256; 0 = 256).  Padding rows are read from it; with
+     * a large region every (workgroup, wave) reads its own 128-byte line instead of all 256 CUs hammering one line of one L2
+     * channel (round 4: the conv kernels read 2 - 8 padding rows per K step). */
+    int32_t zero_page_bytes;
 } ur_igemm_desc;
 
 int ur_igemm(const ur_igemm_desc* d, void* stream);
+
+/* 1 when ur_igemm runs this 3x3 conv (tile resolved, not UR_TILE_AUTO) on the kernel whose three dx taps share one staged
+ * pixel block (csrc/igemm_dxs.hip: stride 1, pad 1, one source, W_out a power of two >= 8 dividing the tile height) -- only
+ * in a library built with `make DXS=1` AND with UR_DXS=1 in the environment (measured slower in the step: an experiment,
+ * not the product path); 0 when it stays on the lock-step kernel (always, in the product build). */
+int ur_igemm_uses_dxs(const ur_igemm_desc* d);
 
 /* A split-K 3x3 conv whose ONLY consumer is a GroupNorm (+ SiLU): main pass of `d` (splitk > 1, no residual / activation /
  * low part; bias and rowadd allowed), then ONE second pass per (z, sample, group) that sums the fp32 slabs, adds bias and the

@@ -554,3 +554,68 @@ def test_conv_groupnorm_as_the_splitk_second_pass(dev, dtype, cfg, monkeypatch):
         ref = (F.silu(ref) if silu else ref).permute(0, 2, 3, 1)
         assert rel_l2(fused[sl], ref) < TOL[dtype], cfg
     assert rel_l2(fused, unfused.float().cpu()) < 0.3 * TOL[dtype]  # same rounding points, different summation order
+
+
+DXS_TILES = [9, 5, 2, 7, 3, 1, 8]  # tiles csrc/igemm_dxs.hip instantiates (128x320, 128x64, 64x64, 128x128, 256x128)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("tile", DXS_TILES)
+def test_conv3x3_with_shared_dx_taps(dev, dtype, tile, monkeypatch):
+    """csrc/igemm_dxs.hip: the three dx taps of a (channel block, dy, chunk) multiply out of ONE staged pixel block with a
+    zero halo per image row.  Every shape class the step has -- all four latent widths (64 .. 8: 2 .. 16 image rows per
+    128-pixel tile, tiles that span two samples), the nearest-2x fused upsample, the channel-block-outer K order, the 1x1
+    tail over one and two sources, split-K slices of uneven length incl. slices that start inside the tail, grouped
+    launches, ragged N, bias + time-embedding row + (hi, lo) residual -- against fp32 conv2d; the launch must really have
+    taken the kernel (ur_igemm_uses_dxs)."""
+    from uni_renderer_amd import ops
+    from uni_renderer_amd.layers import pack_conv3x3
+    if not ops.dxs_active():
+        pytest.skip("the dx-tap-sharing conv kernel is an opt-in build (make DXS=1, UR_DXS=1): measured 4-8 % slower in the "
+                    "step than the lock-step kernels (DESIGN.md section 4, round 4), not part of the product library")
+    trace = []
+    monkeypatch.setattr(ops, "DXS_TRACE", trace)
+    cases = [  # (B, H=W, Cin, Cout, ups, cblock, tail channels (a, b), splitk, streams)
+        (1, 64, 64, 96, False, 0, (0, 0), 1, 1), (2, 32, 128, 320, False, 0, (0, 0), 1, 2), (3, 16, 640, 200, False, 320, (0, 0), 3, 1),
+        (4, 8, 640, 320, False, 320, (0, 0), 4, 2), (2, 8, 128, 64, True, 0, (0, 0), 1, 1), (1, 16, 320, 128, True, 0, (0, 0), 2, 2),
+        (2, 16, 128, 192, False, 0, (64, 0), 1, 1), (2, 32, 640, 320, False, 320, (128, 64), 7, 2), (5, 8, 192, 64, False, 64, (64, 64), 10, 1)]
+    for (B, L, Ci, Co, ups, cb, (ca, cbt), sk, S) in cases:
+        Lo = 2 * L if ups else L
+        x = _rand((S * B, L, L, Ci), dtype, dev, seed=1)
+        wt = [_rand((Co, Ci, 3, 3), torch.float32, dev, seed=2 + s_) * (9 * Ci) ** -0.5 for s_ in range(S)]
+        ta = _rand((S * B, Lo, Lo, ca), dtype, dev, seed=20) if ca else None
+        tb = _rand((S * B, Lo, Lo, cbt), dtype, dev, seed=21) if cbt else None
+        w1 = [_rand((Co, ca + cbt), torch.float32, dev, seed=30 + s_) * max(ca + cbt, 1) ** -0.5 for s_ in range(S)] if ca else None
+        w = torch.stack([torch.cat([pack_conv3x3(wt[s_], dtype, cblock=cb)] + ([w1[s_].to(dtype)] if ca else []), 1) for s_ in range(S)])
+        bias = torch.stack([_rand((Co,), torch.float32, dev, seed=40 + s_) for s_ in range(S)])
+        temb = _rand((S * B, Co), dtype, dev, seed=50)
+        res = _rand((S * B, Lo, Lo, Co), dtype, dev, seed=51)
+        if S == 1:
+            w, bias = w[0], bias[0]
+        del trace[:]
+        y = ops.conv3x3(x, w, bias, ups=ups, rowadd=temb, res=res, out_scale=0.5, tile=tile, splitk=sk, streams=S, hilo=True,
+                        cblock=cb, tail=((ta, tb) if ca else None))
+        assert trace == [1], (B, L, Ci, Co, ups, cb, ca, cbt, sk, S, trace)
+        for s_ in range(S):
+            sl = slice(s_ * B, (s_ + 1) * B)
+            ref = _conv_ref(x[sl], wt[s_].to(dtype), (bias[s_] if S > 1 else bias), 1, ups)
+            if ca:
+                tcat = torch.cat([ta[sl], tb[sl]], -1) if cbt else ta[sl]
+                ref = ref + (tcat.float().cpu() @ w1[s_].to(dtype).float().cpu().t())
+            ref = (ref + temb[sl].float().cpu()[:, None, None, :] + res[sl].float().cpu()) * 0.5
+            full = y[sl].float() + ops.lo_float(y.lo[sl])
+            assert rel_l2(y[sl], ref) < TOL[dtype], (B, L, Ci, Co, ups, cb, ca, cbt, sk, S, s_)
+            assert rel_l2(full, ref) < TOL[dtype]
+    # ineligible shapes stay on the lock-step kernel: odd widths, stride 2, two sources
+    del trace[:]
+    x = _rand((2, 12, 10, 128), dtype, dev, seed=1)
+    wt_ = _rand((64, 128, 3, 3), dtype, dev, 1 / math.sqrt(9 * 128), seed=2)
+    ops.conv3x3(x, pack_conv3x3(wt_, dtype), None, tile=tile, splitk=1)
+    x = _rand((2, 16, 16, 128), dtype, dev, seed=1)
+    ops.conv3x3(x, pack_conv3x3(wt_, dtype), None, stride=2, tile=tile, splitk=1)
+    assert trace == [0, 0]
+    # 200 launches of the level-0 shape are bit-identical (the ring protocol of the pixel / weight buffers)
+    x = _rand((2, 64, 64, 320), dtype, dev, seed=8)
+    w = pack_conv3x3(_rand((320, 320, 3, 3), dtype, dev, 1 / math.sqrt(2880), seed=9), dtype)
+    first = ops.conv3x3(x, w, None, tile=tile, splitk=1).clone()
+    assert sum(int(not torch.equal(ops.conv3x3(x, w, None, tile=tile, splitk=1), first)) for _ in range(200)) == 0

@@ -40,6 +40,7 @@ class IGemmDesc(C.Structure):
         ("t0", vp), ("t1", vp), ("ldt0", i64), ("ldt1", i64), ("zt0", i64), ("zt1", i64), ("ct0", i32), ("ct1", i32),
         ("pad", i32),
         ("out_vt", vp), ("ldvt", i64), ("vt_bstride", i64), ("zvt", i64), ("vt_n0", i32), ("vt_rows", i32),
+        ("zero_page_bytes", i32),
     ]
 
 
@@ -148,6 +149,7 @@ SYMBOLS = {
     "ur_build_info": (C.c_char_p, []),
     "ur_sizeof_igemm_desc": (C.c_int, []),
     "ur_has_wsconv": (C.c_int, []),
+    "ur_igemm_uses_dxs": (C.c_int, [vp]),
     "ur_igemm_splitk_gn": (C.c_int, [vp, vp, vp, i64, C.c_float, C.c_int, C.c_int, vp]),
     "ur_sizeof_attn_desc": (C.c_int, []),
     "ur_sizeof_attn_bwd_desc": (C.c_int, []),

@@ -17,6 +17,8 @@
 //     operand B, so a lane ends up with consecutive output channels of ONE pixel; the weight rows are
 //     permuted while loading so that those channels are 16 consecutive ones -> 32-byte vector
 //     stores/loads per lane and full 128-byte lines per pixel row in the epilogue.
+#include <cstdlib>
+
 #include "igemm_epi.h"
 
 namespace ur {
@@ -96,7 +98,10 @@ __global__ void __launch_bounds__((WM * WN + NL) * 64) igemm_kernel(const ur_ige
     auto jsw = [&](int piece) __attribute__((always_inline)) {
         return MF == 16 ? ((lane & 7) ^ (lane >> 3)) : ((lane & 7) ^ ((4 * piece + (lane >> 4)) & 7));
     };
-    const char* zp = reinterpret_cast<const char*>(p.zero_page) + (lane & 7) * 16;
+    // padding rows: this (workgroup, wave)'s own 128-byte line of the zero region (one hot line would be served to all CUs
+    // by one L2 channel)
+    const unsigned zbytes = p.zero_page_bytes >= 256 ? (unsigned)p.zero_page_bytes : 256u;
+    const char* zp = reinterpret_cast<const char*>(p.zero_page) + ((((unsigned)lid * 16u + (unsigned)wave_id) * 128u) & (zbytes - 128u)) + (lane & 7) * 16;
 
     // ---- per-lane row bookkeeping (fixed over the K loop) ----
     // The K axis is walked as segments (tap, source) of c_src/64 chunks.  Per segment every lane
@@ -678,6 +683,22 @@ int wsconv_launch(const ur_igemm_desc& d, hipStream_t s);  // wsconv.hip (make W
 static int wsconv_launch(const ur_igemm_desc&, hipStream_t) { return UR_E_UNSUPPORTED; }  // not in the product build
 #endif
 int igemm_pp_launch(const ur_igemm_desc& d, hipStream_t s);  // igemm_pp.hip
+// igemm_dxs.hip: the 3x3 conv with the three dx taps sharing one staged pixel block.  Parity-green and 4-8 % SLOWER in the step
+// than the lock-step kernels, so an opt-in build like wsconv.hip: `make DXS=1`, then UR_DXS=1.
+#ifdef UR_WITH_DXS
+int igemm_dxs_launch(const ur_igemm_desc& d, hipStream_t s);
+bool igemm_dxs_ok(const ur_igemm_desc& d, int bm);
+int igemm_dxs_tile_bm(int tile);
+static int dxs_enabled() {
+    static const int v = [] { const char* e = std::getenv("UR_DXS"); return (e && e[0] == '1') ? 1 : 0; }();
+    return v;
+}
+#else
+static int igemm_dxs_launch(const ur_igemm_desc&, hipStream_t) { return UR_E_UNSUPPORTED; }
+static bool igemm_dxs_ok(const ur_igemm_desc&, int) { return false; }
+static int igemm_dxs_tile_bm(int) { return 0; }
+static int dxs_enabled() { return 0; }
+#endif
 
 // ping-pong main pass + the shared split-K second pass
 template <typename T>
@@ -714,6 +735,22 @@ static int launch_ws(const ur_igemm_desc& d, hipStream_t s, bool reduce) {
 template <typename T>
 // reduce = false: main pass only (the caller runs its own second pass over the fp32 slabs: ur_igemm_splitk_gn)
 static int launch_dtype(ur_igemm_desc& d, hipStream_t s, bool reduce) {
+    if (d.taps == 9 && dxs_enabled()) {
+        const int bm = igemm_dxs_tile_bm(d.tile);
+        if (bm && igemm_dxs_ok(d, bm)) {
+            const int rc = igemm_dxs_launch(d, s);
+            if (rc) return rc;
+            if (d.splitk > 1 && reduce) {
+                const int64_t total = (int64_t)d.M * (d.ldp / 16);
+                int blocks = (int)((total + 255) / 256);
+                if (blocks > 4096) blocks = 4096;
+                hipLaunchKernelGGL((igemm_splitk_reduce<T>), dim3(blocks, d.zbatch), dim3(256), 0, s, d);
+                const hipError_t e = hipGetLastError();
+                if (e != hipSuccess) return -(int)e;
+            }
+            return 0;
+        }
+    }
     switch (d.tile) {
         case UR_TILE_128x128: return launch_cfg<T, 128, 128, 2, 2, 2>(d, s, reduce);
         case UR_TILE_128x64: return launch_cfg<T, 128, 64, 4, 1, 3>(d, s, reduce);
@@ -831,6 +868,7 @@ static int igemm_run(ur_igemm_desc& d, void* stream, bool reduce = true) {
         if (d.n_store > d.vt_n0) return UR_E_BADARG;
     }
     if (d.n_store <= 0) d.n_store = (d.act == UR_ACT_GEGLU) ? d.N / 2 : d.N;
+    if (d.zero_page_bytes != 0 && (d.zero_page_bytes < 256 || (d.zero_page_bytes & (d.zero_page_bytes - 1)))) return UR_E_BADARG;
     if (d.tile == UR_TILE_AUTO) d.tile = pick_tile(d);
     if (d.tile < 1 || d.tile >= UR_TILE_COUNT) return UR_E_BADARG;
     d.ldp = padded_ldp(d, d.tile);
@@ -838,6 +876,14 @@ static int igemm_run(ur_igemm_desc& d, void* stream, bool reduce = true) {
     if (d.dtype == UR_DT_F16) return launch_dtype<f16>(d, s, reduce);
     if (d.dtype == UR_DT_BF16) return launch_dtype<bf16>(d, s, reduce);
     return UR_E_BADARG;
+}
+
+// 1 when ur_igemm would run this conv on the dx-tap-sharing kernel (igemm_dxs.hip), 0 otherwise -- for tests and tools
+extern "C" int ur_igemm_uses_dxs(const ur_igemm_desc* d) {
+    using namespace ur;
+    if (!d || d->taps != 9 || !dxs_enabled()) return 0;
+    const int bm = igemm_dxs_tile_bm(d->tile);
+    return bm && igemm_dxs_ok(*d, bm) ? 1 : 0;
 }
 
 extern "C" int ur_igemm(const ur_igemm_desc* din, void* stream) {

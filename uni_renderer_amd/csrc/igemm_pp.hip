@@ -97,7 +97,10 @@ __global__ void __launch_bounds__(512) igemm_pp_kernel(const ur_igemm_desc p) {
     // lane l of a piece copies LDS position (row 16 * piece + l / 4, chunk l & 3) <- source chunk (l & 3) ^ key(row),
     // key(row) = (row >> 2) & 3 = (l >> 4) & 3 (piece bases are multiples of 16 rows)
     const int jsrc = (lane & 3) ^ ((lane >> 4) & 3);
-    const char* zp = reinterpret_cast<const char*>(p.zero_page) + (lane & 3) * 16;
+    // padding rows: this (workgroup, wave)'s own 128-byte line of the zero region (one hot line would be served to all CUs
+    // by one L2 channel)
+    const unsigned zbytes = p.zero_page_bytes >= 256 ? (unsigned)p.zero_page_bytes : 256u;
+    const char* zp = reinterpret_cast<const char*>(p.zero_page) + ((((unsigned)lid * 16u + (unsigned)wave) * 128u) & (zbytes - 128u)) + (lane & 3) * 16;
 
     // ---- per-lane row bookkeeping (fixed over the K loop): igemm.hip's, with 16-row pieces ----
     int xa[XI], xy[XI], xx[XI];

@@ -97,11 +97,16 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+# zero region the implicit-GEMM loaders read padding rows from: 1 MiB so that every (workgroup, wave) has its own line
+# (ur_igemm_desc.zero_page_bytes); UR_ZERO_PAGE_BYTES=4096 restores the single hot page (A/B)
+ZERO_PAGE_BYTES = int(os.environ.get("UR_ZERO_PAGE_BYTES", str(1 << 20)))
+
+
 def zero_page(device) -> torch.Tensor:
     key = (device.type, device.index)
     z = _zero_pages.get(key)
     if z is None:
-        z = torch.zeros(4096, dtype=torch.uint8, device=device)
+        z = torch.zeros(ZERO_PAGE_BYTES, dtype=torch.uint8, device=device)
         _zero_pages[key] = z
     return z
 
@@ -176,6 +181,18 @@ def plan_igemm(M: int, N: int, K: int, taps: int = 1, zbatch: int = 1) -> Tuple[
 # ---------------------------------------------------------------------------------------------
 # implicit GEMM
 # ---------------------------------------------------------------------------------------------
+DXS_TRACE = None  # a list to collect ur_igemm_uses_dxs() of every launch (tests)
+
+
+def dxs_active() -> bool:
+    """The dx-tap-sharing conv kernel (csrc/igemm_dxs.hip) is built in (`make DXS=1`) and switched on (UR_DXS=1)."""
+    d = IGemmDesc()
+    d.taps, d.stride, d.pad, d.tile = 9, 1, 1, 9
+    d.Hin = d.Win = d.Hout = d.Wout = 64
+    d.M = 64 * 64
+    return bool(_lib.load().ur_igemm_uses_dxs(C.byref(d)))
+
+
 def igemm(*, x0, w, out, M, N, K, c0, c1=0, x1=None, ldx0, ldx1=0, ldw, ldc, taps=1, conv=None, stride=1, ups=0,
           bias=None, rowadd=None, rows_per_b=0, res=None, ldres=0, n_store=0, act=ACT_NONE, out_scale=1.0,
           zbatch=1, zx=0, zw=0, zout=0, zx1=0, zbias=0, zrow=0, zres=0, zx_div=1, tile=None, splitk=None,
@@ -211,6 +228,7 @@ def igemm(*, x0, w, out, M, N, K, c0, c1=0, x1=None, ldx0, ldx1=0, ldw, ldc, tap
     if t0 is not None or t1 is not None:
         d.t0, d.t1, d.ldt0, d.ldt1, d.zt0, d.zt1, d.ct0, d.ct1 = _ptr(t0), _ptr(t1), ldt0, ldt1, zt0, zt1, ct0, ct1
     d.zero_page = zero_page(x0.device).data_ptr()
+    d.zero_page_bytes = ZERO_PAGE_BYTES
     d.ldx0, d.ldw, d.ldc, d.c0 = ldx0, ldw, ldc, c0
     if zbatch > 1 or zx or zw or zout:
         d.zx, d.zw, d.zout = zx, zw, zout
@@ -229,6 +247,8 @@ def igemm(*, x0, w, out, M, N, K, c0, c1=0, x1=None, ldx0, ldx1=0, ldw, ldc, tap
         d.partial = part.data_ptr()
     if bias is not None and bias.dtype != torch.float32:
         raise RuntimeError("bias must be fp32")
+    if DXS_TRACE is not None:  # tests: which launches take the dx-tap-sharing conv kernel (csrc/igemm_dxs.hip)
+        DXS_TRACE.append(int(lib.ur_igemm_uses_dxs(C.byref(d))))
     e0 = _prof_begin()
     if gn is not None:
         if splitk <= 1:
