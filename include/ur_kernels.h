@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define UR_ABI_VERSION 8
+#define UR_ABI_VERSION 9
 
 #define UR_E_BADARG (-1001)   /* inconsistent descriptor (shape / alignment / null pointer)   */
 #define UR_E_UNSUPPORTED (-1002) /* shape outside what the kernels are instantiated for       */
@@ -431,6 +431,43 @@ typedef struct ur_transpose_desc {
 } ur_transpose_desc;
 int ur_transpose2d_multi(const ur_transpose_desc* descs, int n, int dtype, void* stream);
 
+/*
+ * Weight gradient of a linear layer or of a 3x3 conv WITHOUT transposed copies of its operands (ABI 9):
+ *     dw[n][k] = sum over p < P of dy[p][n] * xcol[p][k],      db[n] = sum over p of dy[p][n]
+ * where xcol[p][k] = x[p][k] (taps == 1) or, for taps == 9, the im2col row of output pixel p = (b, oy, ox):
+ * k = tap * C + c -> x[b][oy * stride - pad + tap / 3][ox * stride - pad + tap % 3][c], zero outside the image -- the
+ * packed weight layout [N][(ky, kx, c)] of ur_igemm.  Both operands are read as they lie in memory (rows = pixels / tokens,
+ * the contraction index p is the SLOW dimension of both): the kernel stages [p][n] / [p][k] tiles with LDS-DMA and feeds the
+ * MFMAs through the LDS transpose read (ds_read_b64_tr_b16).  Replaces ur_transpose2d_multi of dy and x (+ their zero
+ * padding to 64), ur_im2col3x3_t and the ur_colsum of dy in the backward of train/train.py:1416 (autograd of F.linear /
+ * F.conv2d, the weight / bias gradients).
+ *   N % 8 == 0, K % 8 == 0 (taps == 9: C % 64 == 0, K = 9 * C, Hout and Wout powers of two); P arbitrary.
+ *   splits > 1: the P range is cut into `splits` slices (each a multiple of 32 rows), fp32 slabs in `partial`
+ *   (ur_wgrad_plan gives the slice count the library would choose and the floats needed), summed in slice order by a
+ *   second launch -- deterministic.  db may be NULL.  dw is written in `dtype`.
+ */
+typedef struct ur_wgrad_desc {
+    const void* dy;       /* [P][lddy]                                                              */
+    const void* x;        /* taps == 1: [P][ldx]; taps == 9: NHWC [B][Hin][Win] pixels of ldx elements */
+    void* dw;             /* [N][lddw] dtype                                                        */
+    float* db;            /* [N] fp32 or NULL                                                       */
+    float* partial;       /* splits > 1: ur_wgrad_plan's float count                                */
+    const void* zero_page; /* zero region (rows >= P, taps outside the image), 16-byte aligned       */
+    int64_t lddy, ldx, lddw;
+    int32_t P, N, K;
+    int32_t C, B, Hin, Win, Hout, Wout; /* taps == 9 only                                           */
+    int32_t taps, stride, pad;
+    int32_t splits;       /* >= 1                                                                   */
+    int32_t tile;         /* 0: library's choice; (k) x (n) = 1: 128 x 128; 2: 128 x 64; 3: 64 x 64; 4: 256 x 256; 5: 256 x 128; 6: 128 x 256 */
+    int32_t zero_page_bytes; /* as ur_igemm_desc.zero_page_bytes                                    */
+    int32_t dtype;
+} ur_wgrad_desc;
+int ur_wgrad(const ur_wgrad_desc* d, void* stream);
+/* the slice count the library would use for this problem (d->splits ignored) and the floats `partial` needs for it */
+int ur_wgrad_plan(const ur_wgrad_desc* d, int32_t* splits, int64_t* partial_floats);
+/* floats `partial` needs for d->splits as given (0 when splits <= 1) */
+int64_t ur_wgrad_partial_floats(const ur_wgrad_desc* d);
+
 /* dst[i] = (dst type) src[i] for up to UR_CAST_MAX_TENSORS contiguous tensors in one launch: fp32 -> dtype (to_f32 = 0: the
  * master parameters into the compute dtype) or dtype -> fp32 (to_f32 = 1: their gradients back).  dtype: UR_DT_F16 / BF16. */
 #define UR_CAST_MAX_TENSORS 128
@@ -592,6 +629,7 @@ int ur_sizeof_attn_desc(void);
 int ur_sizeof_attn_bwd_desc(void);
 int ur_sizeof_tchain_desc(void);
 int ur_sizeof_transpose_desc(void);
+int ur_sizeof_wgrad_desc(void);
 
 #ifdef __cplusplus
 }

@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must be imported first, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("UR_LIB_PATH", os.path.join(_HERE, "liburhip.so"))  # override = kernel experiments only
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
@@ -145,6 +145,10 @@ SYMBOLS = {
     "ur_tchain_const_floats": (C.c_int, [C.c_int]),
     "ur_sizeof_tchain_desc": (C.c_int, []),
     "ur_sizeof_transpose_desc": (C.c_int, []),
+    "ur_sizeof_wgrad_desc": (C.c_int, []),
+    "ur_wgrad": (C.c_int, [vp, vp]),
+    "ur_wgrad_plan": (C.c_int, [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
+    "ur_wgrad_partial_floats": (C.c_int64, [vp]),
     "ur_abi_version": (C.c_int, []),
     "ur_build_info": (C.c_char_p, []),
     "ur_sizeof_igemm_desc": (C.c_int, []),

@@ -226,6 +226,99 @@ def colsum(x: torch.Tensor, rows_per_group: int = 0) -> torch.Tensor:
     return out if rows_per_group > 0 else out[0]
 
 
+class _WgradDesc(C.Structure):
+    _fields_ = [("dy", C.c_void_p), ("x", C.c_void_p), ("dw", C.c_void_p), ("db", C.c_void_p), ("partial", C.c_void_p),
+                ("zero_page", C.c_void_p), ("lddy", C.c_int64), ("ldx", C.c_int64), ("lddw", C.c_int64),
+                ("P", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+                ("C", C.c_int32), ("B", C.c_int32), ("Hin", C.c_int32), ("Win", C.c_int32), ("Hout", C.c_int32),
+                ("Wout", C.c_int32), ("taps", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
+                ("splits", C.c_int32), ("tile", C.c_int32), ("zero_page_bytes", C.c_int32), ("dtype", C.c_int32)]
+
+
+_lib.register_layout("ur_sizeof_wgrad_desc", _WgradDesc)
+
+# dW (+ db) straight from dy and x as they lie in memory (ur_wgrad: LDS transpose reads) instead of transposed copies +
+# the forward GEMM kernel.  UR_WGRAD=0 restores the round-3 path (the A/B of tools/experiments/r04_run24.sh).
+WGRAD = os.environ.get("UR_WGRAD", "1") != "0"
+WGRAD_TILE = int(os.environ.get("UR_WGRAD_TILE", "0"))
+WGRAD_SPLITS = int(os.environ.get("UR_WGRAD_SPLITS", "0"))
+# measured (tile, slices) per problem "P,N,K,taps,stride" (tools/tune_wgrad.py); anything else takes the library's choice
+WGRAD_TABLE_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "wgrad_tuning.json")
+_wgrad_table: Optional[dict] = None
+WGRAD_TRACE: Optional[dict] = None  # set to a dict to count the problems that pass through wgrad() (the tuner's input)
+
+
+def wgrad_table() -> dict:
+    global _wgrad_table
+    if _wgrad_table is None:
+        _wgrad_table = {}
+        if os.environ.get("UR_WGRAD_TABLE", "1") != "0" and os.path.exists(WGRAD_TABLE_PATH):
+            import json
+            with open(WGRAD_TABLE_PATH) as f:
+                _wgrad_table = {k: tuple(v) for k, v in json.load(f).items() if not k.startswith("_")}
+    return _wgrad_table
+
+
+def _pow2(v: int) -> bool:
+    return v > 0 and (v & (v - 1)) == 0
+
+
+def wgrad_ok(dy2: torch.Tensor, x: torch.Tensor, conv: Optional[Tuple[int, int]] = None) -> bool:
+    """Shapes ``wgrad`` takes (include/ur_kernels.h: ur_wgrad): 16-byte aligned rows, N and K multiples of 8; a conv
+    needs C % 64 == 0 and power-of-two output sizes."""
+    if dy2.dtype not in DT or x.dtype != dy2.dtype or dy2.dim() != 2 or dy2.stride(1) != 1 or dy2.stride(0) % 8:
+        return False
+    if dy2.shape[1] % 8 or dy2.data_ptr() % 16 or x.data_ptr() % 16 or x.stride(-1) != 1:
+        return False
+    if conv is None:
+        return x.dim() == 2 and x.shape[1] % 8 == 0 and x.stride(0) % 8 == 0 and x.shape[0] == dy2.shape[0]
+    Ho, Wo = conv
+    return x.dim() == 4 and x.is_contiguous() and x.shape[3] % 64 == 0 and _pow2(Ho) and _pow2(Wo)
+
+
+def wgrad(dy2: torch.Tensor, x: torch.Tensor, need_bias: bool = True, conv: Optional[Tuple[int, int, int]] = None,
+          tile: int = 0, splits: int = 0) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """dw[n][k] = sum_p dy2[p][n] * xcol[p][k], db[n] = sum_p dy2[p][n] (fp32) -- ``ur_wgrad``.
+    dy2 [P, N] (row stride free); x [P, K] for a linear layer, or NHWC [B, H, W, C] with ``conv = (Ho, Wo, stride)``:
+    xcol is then the implicit im2col of the 3x3 / pad 1 conv and dw comes out in the packed layout [N][(ky, kx, c)]."""
+    _require_gpu(dy2)
+    lib = _lib.load()
+    P, N = dy2.shape
+    d = _WgradDesc()
+    if conv is None:
+        K = x.shape[1]
+        d.taps, d.ldx = 1, x.stride(0)
+    else:
+        Ho, Wo, stride = conv
+        B, H, W, Cc = x.shape
+        K = 9 * Cc
+        d.taps, d.ldx, d.C, d.B, d.Hin, d.Win, d.Hout, d.Wout, d.stride, d.pad = 9, Cc, Cc, B, H, W, Ho, Wo, stride, 1
+    dw = torch.empty(N, K, dtype=dy2.dtype, device=dy2.device)
+    db = torch.empty(N, dtype=torch.float32, device=dy2.device) if need_bias else None
+    zp = ops.zero_page(dy2.device)
+    d.dy, d.x, d.dw, d.db = dy2.data_ptr(), x.data_ptr(), dw.data_ptr(), (db.data_ptr() if need_bias else None)
+    d.zero_page, d.zero_page_bytes = zp.data_ptr(), ops.ZERO_PAGE_BYTES
+    d.lddy, d.lddw, d.P, d.N, d.K = dy2.stride(0), K, P, N, K
+    key = f"{P},{N},{K},{d.taps},{d.stride}"
+    if WGRAD_TRACE is not None:
+        WGRAD_TRACE[key] = WGRAD_TRACE.get(key, 0) + 1
+    tuned = wgrad_table().get(key) if not (tile or splits or WGRAD_TILE or WGRAD_SPLITS) else None
+    d.tile, d.dtype, d.splits = (tuned[0] if tuned else (tile or WGRAD_TILE)), DT[dy2.dtype], 1
+    want = tuned[1] if tuned else (splits or WGRAD_SPLITS)
+    if want:
+        d.splits = max(1, min(want, (P + 31) // 32))
+    else:
+        ns, nf = C.c_int32(0), C.c_int64(0)
+        check(lib.ur_wgrad_plan(C.byref(d), C.byref(ns), C.byref(nf)), "ur_wgrad_plan")
+        d.splits = ns.value
+    part = None
+    if d.splits > 1:
+        part = torch.empty(int(lib.ur_wgrad_partial_floats(C.byref(d))), dtype=torch.float32, device=dy2.device)
+        d.partial = part.data_ptr()
+    check(lib.ur_wgrad(C.byref(d), _stream()), "ur_wgrad")
+    return dw, db
+
+
 def _pad_rows64(t: torch.Tensor) -> torch.Tensor:
     """zero-pad the last (contraction) dim of a [R, M] matrix to a multiple of 64 (ur_igemm's K granularity)."""
     M = t.shape[-1]
@@ -242,6 +335,10 @@ def linear_backward(x: torch.Tensor, w: torch.Tensor, dy: torch.Tensor, need_bia
     dx = dy @ w, dw = dy^T @ x (both through ``ur_igemm``), db = column sums of dy (fp32)."""
     K, N = x.shape[-1], w.shape[0]
     x2, dy2 = x.reshape(-1, K), dy.reshape(-1, N)
+    if WGRAD and wgrad_ok(dy2, x2):
+        dw, db = wgrad(dy2, x2, need_bias)
+        dx = ops.linear(dy2, transpose2d(w)).view(x.shape)   # [M, N] @ [K, N]^T
+        return dx, dw, db
     dy2p = dy2  # transpose2d zero-pads the row count (M = batch rows in the time-embedding GEMMs) to a multiple of 8
     # [K, N], [N, Mp], [K, Mp]: one launch; the last two zero-padded to the 64-granularity of the dW contraction
     if need_bias:
@@ -313,6 +410,10 @@ def conv3x3_backward(x: torch.Tensor, w_packed: torch.Tensor, dy: torch.Tensor, 
         if dx.shape[1] != H or dx.shape[2] != W:
             raise RuntimeError("conv3x3_backward: odd input sizes are not supported with stride 2")
     P = B * Ho * Wo
+    xc = x.contiguous()
+    if WGRAD and wgrad_ok(dyp.reshape(P, Np), xc, (Ho, Wo)):
+        dw, db = wgrad(dyp.reshape(P, Np), xc, need_bias, conv=(Ho, Wo, stride))
+        return dx, dw[:N], (db[:N].contiguous() if need_bias else None)
     Pp = (P + 63) // 64 * 64
     xcol_t = torch.empty(9 * Cc, Pp, dtype=x.dtype, device=x.device)
     check(lib.ur_im2col3x3_t(x.contiguous().data_ptr(), B, H, W, Cc, stride, xcol_t.data_ptr(), Pp, DT[x.dtype], _stream()),
