@@ -463,6 +463,20 @@ typedef struct ur_wgrad_desc {
     int32_t dtype;
 } ur_wgrad_desc;
 int ur_wgrad(const ur_wgrad_desc* d, void* stream);
+/* n <= UR_WGRAD_GROUP_MAX problems of ONE shape (everything in `d` except dy / x / dw / db, which come from g[i]) in one launch
+ * (+ one reduce launch when d->splits > 1): the weight gradients of equally shaped layers -- q | k | v, out and feed-forward
+ * projections of the transformer blocks of a UNet level -- fill the chip together instead of one small GEMM after the other,
+ * and need fewer (or no) slices.  `partial`: n times the floats of one problem (ur_wgrad_group_plan).  g[i].db may be NULL
+ * per problem. */
+#define UR_WGRAD_GROUP_MAX 64
+typedef struct ur_wgrad_ptrs {
+    const void* dy;
+    const void* x;
+    void* dw;
+    float* db;
+} ur_wgrad_ptrs;
+int ur_wgrad_group(const ur_wgrad_desc* d, const ur_wgrad_ptrs* g, int n, void* stream);
+int ur_wgrad_group_plan(const ur_wgrad_desc* d, const ur_wgrad_ptrs* g, int n, int32_t* splits, int64_t* partial_floats);
 /* the slice count the library would use for this problem (d->splits ignored) and the floats `partial` needs for it */
 int ur_wgrad_plan(const ur_wgrad_desc* d, int32_t* splits, int64_t* partial_floats);
 /* floats `partial` needs for d->splits as given (0 when splits <= 1) */

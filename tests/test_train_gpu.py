@@ -278,6 +278,41 @@ def _reference_step_losses(controlnet, unet, controldec, b, inverse, F=torch.nn.
     return loss
 
 
+def test_deferred_grouped_weight_gradients_are_the_immediate_ones(dev, monkeypatch):
+    """Linear weight / bias gradients deferred to the CastParams / ParamBarrier nodes and computed in grouped launches
+    (backward.WgradQueue) against the same step with every Linear computing its own at once: every parameter gradient of the
+    three networks, both objectives of the step (the inverse branch runs enc + unet twice: two CastParams nodes per network)."""
+    from uni_renderer_amd import backward as B_
+    from uni_renderer_amd.train_step import train_step
+
+    oracle = O.build_triplet(O.TINY_CONFIG, seed=41)
+    x, c, ehs, ti, ta = [t.to(dev) for t in O.make_inputs(2, 16, 64, seed=17)]
+    g = torch.Generator().manual_seed(18)
+    batch = dict(x_t=x, cond=c, ehs=ehs, t_img=ti, t_attr=ta, target_img=torch.randn(2, 4, 16, 16, generator=g).to(dev),
+                 target_attr=torch.randn(2, 28, 16, 16, generator=g).to(dev))
+    grads = {}
+    for flag in (True, False):
+        monkeypatch.setattr(B_, "WGRAD_DEFER", flag)
+        nets = build_product_from_oracle(*oracle, torch.float32, dev)
+        for m in nets:
+            m.train()
+            m.requires_grad_(True)
+        B_.wgrad_queue.trace = {} if flag else None
+        stats = train_step(nets, batch, optimizer=None, dtype=torch.bfloat16, max_grad_norm=None)
+        grads[flag] = ([p.grad.clone() for m in nets for p in m.parameters()], stats["loss"])
+        if flag:
+            groups, B_.wgrad_queue.trace = B_.wgrad_queue.trace, None
+            assert groups and max(int(k.split("@")[1]) for k in groups) > 1, groups   # something was actually grouped
+            assert not B_.wgrad_queue.items
+    assert grads[True][1] == grads[False][1]
+    worst = 0.0
+    for a, b in zip(grads[True][0], grads[False][0]):
+        # same kernels on the same operands; only the slice count (and so the fp32 summation order) may differ
+        worst = max(worst, (a - b).abs().max().item() / max(b.abs().max().item(), 1e-6))
+    print({"deferred_vs_immediate_max_rel": worst})
+    assert worst <= 1e-2
+
+
 def _train_batch(B, L, cross, seed):
     x, c, ehs, ti, ta = O.make_inputs(B, L, cross, seed=seed)
     g = torch.Generator().manual_seed(seed + 1)

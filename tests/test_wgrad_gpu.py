@@ -107,3 +107,40 @@ def test_descriptor_validation():
     assert not B_.wgrad_ok(_mk((144, 64), torch.float16), xc, (12, 12))   # output size not a power of two
     with pytest.raises(RuntimeError):
         B_.wgrad(_mk((144, 64), torch.float16), xc, conv=(12, 12, 1))
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("P,N,K,n,tile,splits", [(4096, 320, 320, 7, 1, 1), (1024, 640, 640, 64, 3, 2), (308, 320, 768, 5, 0, 0),
+                                                 (16384, 320, 320, 12, 1, 4), (50, 8, 2560, 3, 2, 1), (2048, 1280, 320, 9, 5, 0)])
+def test_grouped_problems_are_the_single_launches(dt, P, N, K, n, tile, splits):
+    """ur_wgrad_group: n equally shaped problems in one launch give the bits of n single launches with the same tile / slices;
+    a problem without a bias gradient in the middle of the group."""
+    torch.manual_seed(P + N + n)
+    probs = [(_mk((P, N), dt), _mk((P, K), dt)) for _ in range(n)]
+    items = [(dy, x, torch.empty(N, K, dtype=dt, device="cuda"),
+              None if i == 1 else torch.empty(N, dtype=torch.float32, device="cuda")) for i, (dy, x) in enumerate(probs)]
+    trace = {}
+    B_.wgrad_group(items, tile=tile, splits=splits, trace=trace)
+    assert trace == {f"{P},{N},{K},1,0@{n}": 1}
+    for i, (dy, x, dw, db) in enumerate(items):
+        _close(dw, dy.float().t() @ x.float(), dt, f"dw[{i}]")
+        if tile and splits:
+            dw1, db1 = B_.wgrad(dy, x, db is not None, tile=tile, splits=splits)
+            assert torch.equal(dw, dw1) and (db is None or torch.equal(db, db1))
+        elif db is not None:
+            assert (db - dy.float().sum(0)).abs().max().item() <= 2e-4 * max(1.0, dy.float().abs().sum(0).max().item())
+
+
+def test_queue_groups_by_shape_and_flushes_on_a_repeated_weight():
+    dt = torch.bfloat16
+    q = B_.WgradQueue()
+    q.trace = {}
+    a = [(_mk((256, 64), dt), _mk((256, 128), dt)) for _ in range(3)]
+    b = [(_mk((512, 64), dt), _mk((512, 128), dt)) for _ in range(2)]
+    outs = [q.add(dy, x, 1000 + i, True) for i, (dy, x) in enumerate(a + b)]
+    assert all(o is not None for o in outs) and len(q.items) == 5
+    assert q.add(a[0][0], a[0][1], 1000, True) is None and not q.items       # same weight again: flushed, caller computes at once
+    assert q.trace == {"256,64,128,1,0@3": 1, "512,64,128,1,0@2": 1}
+    for (dy, x), (dw, db) in zip(a + b, outs):
+        _close(dw, dy.float().t() @ x.float(), dt, "queued dw")
+        assert (db - dy.float().sum(0)).abs().max().item() <= 1e-2

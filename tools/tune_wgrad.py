@@ -32,10 +32,12 @@ def collect(batch_size, latent, dt):
     batch = dict(x_t=mk(B, 4, L, L), cond=mk(B, 28, L, L), ehs=mk(B, 77, 768) * 0.5,
                  t_img=torch.randint(0, 1000, (B,), device=dev, generator=g), t_attr=torch.randint(0, 1000, (B,), device=dev, generator=g),
                  target_img=mk(B, 4, L, L), target_attr=mk(B, 28, L, L))
-    B_.WGRAD_TRACE = {}
+    B_.WGRAD_TRACE, B_.wgrad_queue.trace = {}, {}
     train_step(nets, batch, optimizer=None, buckets=None, dtype=dt)
     torch.cuda.synchronize()
     seen, B_.WGRAD_TRACE = B_.WGRAD_TRACE, None
+    seen.update(B_.wgrad_queue.trace)   # "P,N,K,1,0@G": G equally shaped Linear problems of one flush (backward.WgradQueue)
+    B_.wgrad_queue.trace = None
     del nets
     torch.cuda.empty_cache()
     return seen
@@ -74,8 +76,9 @@ def main():
     mk = lambda *s: torch.randn(*s, device="cuda").to(dt)
     total_best = total_auto = 0.0
     for key, calls in sorted(seen.items(), key=lambda kv: -kv[1]):
-        P, N, K, taps, stride = (int(v) for v in key.split(","))
-        dy = mk(P, N)
+        shape, _, grp = key.partition("@")
+        G = int(grp) if grp else 1
+        P, N, K, taps, stride = (int(v) for v in shape.split(","))
         if taps == 9:
             Cc = K // 9
             # the tuner does not know the image shape: a square power-of-two map of P / 4 ... P pixels per sample reproduces it
@@ -83,26 +86,34 @@ def main():
             Bn = next(b for b in (1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20) if P % b == 0 and int(round((P // b) ** 0.5)) ** 2 == P // b
                       and ((P // b) & (P // b - 1)) == 0)
             Ho = int(round((P // Bn) ** 0.5))
-            x, conv = mk(Bn, Ho * stride, Ho * stride, Cc), (Ho, Ho, stride)
+            dy, x, conv = mk(P, N), mk(Bn, Ho * stride, Ho * stride, Cc), (Ho, Ho, stride)
+            run = lambda tile, sp: B_.wgrad(dy, x, True, conv=conv, tile=tile, splits=sp)
+        elif G == 1:
+            dy, x = mk(P, N), mk(P, K)
+            run = lambda tile, sp: B_.wgrad(dy, x, True, tile=tile, splits=sp)
         else:
-            x, conv = mk(P, K), None
+            items = [(mk(P, N), mk(P, K), torch.empty(N, K, dtype=dt, device="cuda"), torch.empty(N, dtype=torch.float32, device="cuda"))
+                     for _ in range(G)]
+            run = lambda tile, sp: B_.wgrad_group(items, tile=tile, splits=sp)
         best = None
         for tile in (1, 2, 3, 4, 5, 6):
             for sp in (1, 2, 4, 8, 16, 32, 64):
-                if sp > 1 and sp * 4 > (P + 31) // 32:
+                if sp > 1 and (sp * 4 > (P + 31) // 32 or G * sp > 256):
                     continue
-                t = timeit(lambda: B_.wgrad(dy, x, True, conv=conv, tile=tile, splits=sp), args.iters)
+                t = timeit(lambda: run(tile, sp), args.iters)
                 if best is None or t < best[0]:
                     best = (t, tile, sp)
         B_._wgrad_table = {}
-        t_auto = timeit(lambda: B_.wgrad(dy, x, True, conv=conv), args.iters)
+        t_auto = timeit(lambda: run(0, 0), args.iters)
         table[key] = [best[1], best[2]]
         total_best += best[0] * calls
         total_auto += t_auto * calls
-        print(f"  {key:28s} x{calls:3d}  best tile {best[1]} slices {best[2]:2d}: {best[0]:7.1f} us   (library's choice {t_auto:7.1f} us)", flush=True)
+        print(f"  {key:32s} x{calls:3d}  best tile {best[1]} slices {best[2]:2d}: {best[0]:7.1f} us   (library's choice {t_auto:7.1f} us)", flush=True)
+        del run
     print(f"[tune_wgrad] per step: {total_best / 1e3:.2f} ms tuned, {total_auto / 1e3:.2f} ms with the library's choice")
     table = dict(sorted(table.items()))
-    table["_comment"] = "ur_wgrad (tile, slices) per problem P,N,K,taps,stride -- tools/tune_wgrad.py, isolated timings on an MI355X"
+    table["_comment"] = ("ur_wgrad (tile, slices) per problem P,N,K,taps,stride (@G: a group of G problems in one launch) -- "
+                         "tools/tune_wgrad.py, isolated timings on an MI355X")
     with open(args.out, "w") as f:
         json.dump(table, f, indent=0, sort_keys=True)
         f.write("\n")

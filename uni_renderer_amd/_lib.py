@@ -149,6 +149,8 @@ SYMBOLS = {
     "ur_wgrad": (C.c_int, [vp, vp]),
     "ur_wgrad_plan": (C.c_int, [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "ur_wgrad_partial_floats": (C.c_int64, [vp]),
+    "ur_wgrad_group": (C.c_int, [vp, vp, C.c_int, vp]),
+    "ur_wgrad_group_plan": (C.c_int, [vp, vp, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "ur_abi_version": (C.c_int, []),
     "ur_build_info": (C.c_char_p, []),
     "ur_sizeof_igemm_desc": (C.c_int, []),

@@ -14,6 +14,31 @@ from ._lib import check
 from .ops import DT, _stream
 
 
+# Deferred weight gradients (backward.WgradQueue): a Linear may hand autograd UNINITIALISED dw / db tensors only if their first
+# reader flushes the queue first.  That is the case for weights that are (views of) a CastParams output and biases that are a
+# ParamBarrier output; both register here, by storage / data pointer, with a weak reference that dies with the autograd graph.
+_deferred_w: dict = {}   # storage data_ptr of a CastParams buffer -> weakref(buffer)
+_deferred_b: dict = {}   # data_ptr of a ParamBarrier output      -> weakref(output)
+deferred_bias: dict = {}  # id(fp32 bias parameter) -> its ParamBarrier output for the current network forward (train_step)
+
+
+def _alive(table: dict, ptr: int) -> bool:
+    ref = table.get(ptr)
+    if ref is None:
+        return False
+    t = ref()
+    if t is None:
+        del table[ptr]
+        return False
+    return True
+
+
+def _can_defer(w, b) -> bool:
+    if not bw.WGRAD_DEFER or not bw.WGRAD or not _alive(_deferred_w, w.untyped_storage().data_ptr()):
+        return False
+    return b is None or _alive(_deferred_b, b.data_ptr())
+
+
 class Linear(Function):
     """y = x @ w^T (+ b) (+ rowadd[m // rows_per_b]) (+ res).  x [..., K], w [N, K], b fp32 [N], rowadd [B, N]."""
 
@@ -21,6 +46,7 @@ class Linear(Function):
     def forward(ctx, x, w, b, res, rowadd, rows_per_b):
         ctx.save_for_backward(x, w)
         ctx.flags = (b is not None, res is not None, rowadd is not None, int(rows_per_b))
+        ctx.defer = _can_defer(w, b)
         return ops.linear(x, w, b, res=res, rowadd=rowadd, rows_per_b=rows_per_b)
 
     @staticmethod
@@ -28,9 +54,30 @@ class Linear(Function):
         x, w = ctx.saved_tensors
         has_b, has_res, has_row, rpb = ctx.flags
         dy = dy.contiguous()
-        dx, dw, db = bw.linear_backward(x, w, dy, need_bias=has_b)
+        dx, dw, db = bw.linear_backward(x, w, dy, need_bias=has_b, defer=ctx.defer)
         drow = bw.colsum(dy, rows_per_group=rpb).to(dy.dtype) if has_row else None
         return dx, dw, db, (dy if has_res else None), drow, None
+
+
+class ParamBarrier(Function):
+    """Identity over many fp32 parameters (the Linear biases of a network): the outputs are new tensor objects over the
+    parameters' own storage; the backward runs when the LAST of their gradients has arrived, flushes the deferred weight
+    gradient queue (which fills the bias gradients handed out uninitialised) and passes them on."""
+
+    @staticmethod
+    def forward(ctx, *params):
+        import weakref
+        ctx.set_materialize_grads(False)
+        outs = tuple(torch.empty(0, dtype=p.dtype, device=p.device).set_(p.untyped_storage(), p.storage_offset(), p.shape, p.stride())
+                     for p in params)
+        for o in outs:
+            _deferred_b[o.data_ptr()] = weakref.ref(o)
+        return outs
+
+    @staticmethod
+    def backward(ctx, *grads):
+        bw.wgrad_queue.flush()
+        return grads
 
 
 class Conv3x3(Function):
@@ -214,6 +261,8 @@ class Add(Function):
 
 
 def linear(x, w, b=None, res=None, rowadd=None, rows_per_b=0):
+    if b is not None and deferred_bias:
+        b = deferred_bias.get(id(b), b)
     return Linear.apply(x, w, b, res, rowadd, rows_per_b)
 
 
@@ -306,12 +355,18 @@ class CastParams(Function):
 
     @staticmethod
     def forward(ctx, dtype, *params):
+        import weakref
         ctx.set_materialize_grads(False)
         ctx.pids = [id(p) for p in params]
-        return tuple(bw.cast_many([p.detach() for p in params], dtype, packed=True))
+        outs = tuple(bw.cast_many([p.detach() for p in params], dtype, packed=True))
+        if outs and outs[0].is_cuda:
+            flat = outs[0]._base if outs[0]._base is not None else outs[0]
+            _deferred_w[flat.untyped_storage().data_ptr()] = weakref.ref(flat)
+        return outs
 
     @staticmethod
     def backward(ctx, *grads):
+        bw.wgrad_queue.flush()  # the weight gradients below may have been handed out uninitialised (Linear.backward)
         idx = [i for i, g in enumerate(grads) if g is not None]
         res = [None] * len(grads)
         if idx:

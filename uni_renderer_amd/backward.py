@@ -319,6 +319,89 @@ def wgrad(dy2: torch.Tensor, x: torch.Tensor, need_bias: bool = True, conv: Opti
     return dw, db
 
 
+class _WgradPtrs(C.Structure):
+    _fields_ = [("dy", C.c_void_p), ("x", C.c_void_p), ("dw", C.c_void_p), ("db", C.c_void_p)]
+
+
+WGRAD_GROUP_MAX = 64
+
+
+class WgradQueue:
+    """Weight gradients of Linear layers, DEFERRED: ``add`` hands out uninitialised dw / db tensors and remembers (dy, x);
+    ``flush`` computes everything pending, equally shaped problems together in one ``ur_wgrad_group`` launch.  The 16384 x 320 x
+    320 projections of a UNet level are 30 us launches of 25 tiles x 16 slices each when run one by one
+    (profiles/r04_tune_wgrad.txt); 56 of them in one launch fill the chip without slices, slabs or reduce passes.
+
+    Safe only where nothing reads the tensors before the flush: autograd_ops.Linear uses it for weights that come from
+    ``CastParams`` (whose backward -- the first reader -- flushes first) and biases that come from ``ParamBarrier``; a weight that
+    appears a second time before a flush (autograd would ADD the two gradients right away) forces the flush."""
+
+    def __init__(self):
+        self.items, self.seen = [], set()
+        self.trace: Optional[dict] = None   # set to a dict to count (problem, group size) per flush (tools/tune_wgrad.py)
+
+    def add(self, dy2: torch.Tensor, x2: torch.Tensor, w_key: int, need_bias: bool):
+        if w_key in self.seen:
+            self.flush()
+            return None
+        self.seen.add(w_key)
+        dw = torch.empty(dy2.shape[1], x2.shape[1], dtype=dy2.dtype, device=dy2.device)
+        db = torch.empty(dy2.shape[1], dtype=torch.float32, device=dy2.device) if need_bias else None
+        self.items.append((dy2, x2, dw, db))
+        return dw, db
+
+    def flush(self):
+        items, self.items, self.seen = self.items, [], set()
+        groups: dict = {}
+        for it in items:
+            dy2, x2 = it[0], it[1]
+            groups.setdefault((dy2.shape, x2.shape[1], dy2.stride(0), x2.stride(0), dy2.dtype, dy2.device), []).append(it)
+        for (shape, K, lddy, ldx, dt, dev), its in groups.items():
+            for i in range(0, len(its), WGRAD_GROUP_MAX):
+                wgrad_group(its[i:i + WGRAD_GROUP_MAX], trace=self.trace)
+
+
+wgrad_queue = WgradQueue()
+# Deferred + grouped Linear weight gradients (WgradQueue).  UR_WGRAD_DEFER=0: every Linear computes its own at once.
+WGRAD_DEFER = os.environ.get("UR_WGRAD_DEFER", "1") != "0"
+
+
+def wgrad_group(items, tile: int = 0, splits: int = 0, trace: Optional[dict] = None):
+    """``ur_wgrad_group`` over ``items`` = [(dy2 [P, N], x2 [P, K], dw [N, K] out, db [N] fp32 out or None)], all of one shape and
+    one pair of row strides."""
+    lib = _lib.load()
+    dy0, x0 = items[0][0], items[0][1]
+    _require_gpu(dy0)
+    P, N = dy0.shape
+    K = x0.shape[1]
+    n = len(items)
+    d = _WgradDesc()
+    zp = ops.zero_page(dy0.device)
+    d.zero_page, d.zero_page_bytes = zp.data_ptr(), ops.ZERO_PAGE_BYTES
+    d.taps, d.lddy, d.ldx, d.lddw, d.P, d.N, d.K, d.dtype = 1, dy0.stride(0), x0.stride(0), K, P, N, K, DT[dy0.dtype]
+    g = (_WgradPtrs * n)()
+    for i, (dy2, x2, dw, db) in enumerate(items):
+        g[i].dy, g[i].x, g[i].dw, g[i].db = dy2.data_ptr(), x2.data_ptr(), dw.data_ptr(), (db.data_ptr() if db is not None else None)
+    d.dy, d.x, d.dw = g[0].dy, g[0].x, g[0].dw
+    key = f"{P},{N},{K},1,0@{n}"
+    if trace is not None:
+        trace[key] = trace.get(key, 0) + 1
+    tuned = wgrad_table().get(key) if not (tile or splits or WGRAD_TILE or WGRAD_SPLITS) else None
+    d.tile, d.splits = (tuned[0] if tuned else (tile or WGRAD_TILE)), 1
+    want = tuned[1] if tuned else (splits or WGRAD_SPLITS)
+    if want:
+        d.splits = max(1, min(want, (P + 31) // 32))
+    else:
+        ns, nf = C.c_int32(0), C.c_int64(0)
+        check(lib.ur_wgrad_group_plan(C.byref(d), g, n, C.byref(ns), C.byref(nf)), "ur_wgrad_group_plan")
+        d.splits = ns.value
+    part = None
+    if d.splits > 1:
+        part = torch.empty(int(lib.ur_wgrad_partial_floats(C.byref(d))) * n, dtype=torch.float32, device=dy0.device)
+        d.partial = part.data_ptr()
+    check(lib.ur_wgrad_group(C.byref(d), g, n, _stream()), "ur_wgrad_group")
+
+
 def _pad_rows64(t: torch.Tensor) -> torch.Tensor:
     """zero-pad the last (contraction) dim of a [R, M] matrix to a multiple of 64 (ur_igemm's K granularity)."""
     M = t.shape[-1]
@@ -329,15 +412,16 @@ def _pad_rows64(t: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def linear_backward(x: torch.Tensor, w: torch.Tensor, dy: torch.Tensor, need_bias: bool = True
+def linear_backward(x: torch.Tensor, w: torch.Tensor, dy: torch.Tensor, need_bias: bool = True, defer: bool = False
                     ) -> Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]:
     """y = x @ w^T + b  (x [..., K], w [N, K] in the compute dtype, dy [..., N])  ->  (dx, dw, db).
     dx = dy @ w, dw = dy^T @ x (both through ``ur_igemm``), db = column sums of dy (fp32)."""
     K, N = x.shape[-1], w.shape[0]
     x2, dy2 = x.reshape(-1, K), dy.reshape(-1, N)
     if WGRAD and wgrad_ok(dy2, x2):
-        dw, db = wgrad(dy2, x2, need_bias)
         dx = ops.linear(dy2, transpose2d(w)).view(x.shape)   # [M, N] @ [K, N]^T
+        later = wgrad_queue.add(dy2, x2, w.data_ptr(), need_bias) if (defer and WGRAD_DEFER) else None
+        dw, db = later if later is not None else wgrad(dy2, x2, need_bias)
         return dx, dw, db
     dy2p = dy2  # transpose2d zero-pads the row count (M = batch rows in the time-embedding GEMMs) to a multiple of 8
     # [K, N], [N, Mp], [K, Mp]: one launch; the last two zero-padded to the 64-granularity of the dW contraction

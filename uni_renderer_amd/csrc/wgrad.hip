@@ -39,6 +39,14 @@ __device__ __forceinline__ int wg_key(int r) {
 
 constexpr int WG_BKP = 32;  // contraction rows per stage
 
+// kernel arguments: the shared description + the operand pointers of up to UR_WGRAD_GROUP_MAX equally shaped problems
+// (ur_wgrad_group: the q / k / v / out / feed-forward weight gradients of all transformer blocks of a level in ONE launch)
+struct WgradArgs {
+    ur_wgrad_desc d;
+    int n;
+    ur_wgrad_ptrs g[UR_WGRAD_GROUP_MAX];
+};
+
 template <int TK, int TN, int NS>
 constexpr int wgrad_lds_bytes() { return NS * WG_BKP * (TK + TN) * 2; }
 
@@ -48,7 +56,8 @@ constexpr int wgrad_lds_bytes() { return NS * WG_BKP * (TK + TN) * 2; }
 // ABL (experiment builds only, `make WGRAD_ABL=1`; results are garbage): 1 no LDS-DMA copies, 2 no MFMAs, 3 no fragment reads,
 // 4 plain ds_read_b64 at the same addresses instead of the transpose read
 template <typename T, int TK, int TN, int WK, int WN, int NS, bool CONV, int ABL = 0>
-__global__ void __launch_bounds__(WK * WN * 64, 4) wgrad_kernel(const ur_wgrad_desc p) {
+__global__ void __launch_bounds__(WK * WN * 64, 4) wgrad_kernel(const WgradArgs a) {
+    const ur_wgrad_desc& p = a.d;
     typedef typename Vec8<T>::type vec8;
     constexpr int BKP = WG_BKP;
     constexpr int NW = WK * WN;
@@ -68,9 +77,13 @@ __global__ void __launch_bounds__(WK * WN * 64, 4) wgrad_kernel(const ur_wgrad_d
     const int tiles = tiles_k * tiles_n;
     // slice-major logical ids: an XCD owns a contiguous run of them, i.e. a few P slices whose dy / x rows stay in its L2
     // while every (k, n) tile of the slice passes over them
+    // problem-major, then slice-major
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
-    const int split = lid / tiles;
-    const int t_ = lid - split * tiles;
+    const int prob = lid / (tiles * p.splits);
+    const int lip = lid - prob * tiles * p.splits;
+    const int split = lip / tiles;
+    const int t_ = lip - split * tiles;
+    const ur_wgrad_ptrs gp = a.g[prob];
     // the dimension with fewer tiles runs fastest: the run of tiles an XCD works on at a time then spans a near-square patch
     // (few distinct dy AND few distinct x tiles in its L2) instead of one x tile against every dy tile
     const bool k_inner = tiles_k <= tiles_n;
@@ -91,8 +104,8 @@ __global__ void __launch_bounds__(WK * WN * 64, 4) wgrad_kernel(const ur_wgrad_d
     // one packed word (registers are what bounds the number of workgroups per CU): byte offset of the column in bits 0..23,
     // tile row in bits 24..28, valid column in bit 31; a conv adds (ky, kx) of the slot's tap in a second word ----
     const int PP = p.P;
-    const char* const dyb = reinterpret_cast<const char*>(p.dy);
-    const char* const xb = reinterpret_cast<const char*>(p.x);
+    const char* const dyb = reinterpret_cast<const char*>(gp.dy);
+    const char* const xb = reinterpret_cast<const char*>(gp.x);
     unsigned ymeta[YI], xmeta[XI];
     int xtap[XI];
     const unsigned ystep = (unsigned)p.lddy * (unsigned)sizeof(T);  // byte offsets fit 32 bits (wgrad_check)
@@ -170,7 +183,7 @@ __global__ void __launch_bounds__(WK * WN * 64, 4) wgrad_kernel(const ur_wgrad_d
     float dbacc[NREP];
 #pragma unroll
     for (int b = 0; b < NREP; ++b) dbacc[b] = 0.f;
-    const bool want_db = p.db != nullptr && tile_k == 0 && wk == 0;  // wave-uniform
+    const bool want_db = gp.db != nullptr && tile_k == 0 && wk == 0;  // wave-uniform
 
     auto frag = [&](const char* base, int off, int row_bytes) __attribute__((always_inline)) {
         if constexpr (ABL == 3) {
@@ -247,7 +260,7 @@ __global__ void __launch_bounds__(WK * WN * 64, 4) wgrad_kernel(const ur_wgrad_d
     // ---- epilogue: lane (g, i16) of block (a, b) holds dw[n = .. + i16][k = .. + 4 g + 0..3] ----
     const int ldp = (p.K + 4 + 3) & ~3;  // slab row: K gradient columns, then the bias-gradient column
     const int Np = (p.N + 7) & ~7;
-    float* slab = p.splits > 1 ? p.partial + (int64_t)split * Np * ldp : nullptr;
+    float* slab = p.splits > 1 ? p.partial + ((int64_t)prob * p.splits + split) * Np * ldp : nullptr;
 #pragma unroll
     for (int b = 0; b < NREP; ++b) {
         const int n = n0 + (wn * NREP + b) * 16 + i16;
@@ -264,7 +277,7 @@ __global__ void __launch_bounds__(WK * WN * 64, 4) wgrad_kernel(const ur_wgrad_d
                     for (int r = 0; r < 4; ++r) o[r] = from_f<T>(acc[a][b][r]);
                     uint2 bits;
                     __builtin_memcpy(&bits, o, 8);
-                    *reinterpret_cast<uint2*>(reinterpret_cast<T*>(p.dw) + (int64_t)n * p.lddw + k) = bits;
+                    *reinterpret_cast<uint2*>(reinterpret_cast<T*>(gp.dw) + (int64_t)n * p.lddw + k) = bits;
                 }
             }
         }
@@ -274,27 +287,30 @@ __global__ void __launch_bounds__(WK * WN * 64, 4) wgrad_kernel(const ur_wgrad_d
             v += __shfl_xor(v, 32, 64);
             if (g == 0 && n < p.N) {
                 if (slab) slab[(int64_t)n * ldp + p.K] = v;
-                else p.db[n] = v;
+                else gp.db[n] = v;
             }
         }
     }
 }
 
-// second pass: sum the slabs in slice order; columns < K -> dw (dtype), column K -> db
+// second pass: sum the slabs in slice order; columns < K -> dw (dtype), column K -> db.  blockIdx.y = problem.
 template <typename T>
-__global__ void __launch_bounds__(256) wgrad_reduce(const ur_wgrad_desc p) {
+__global__ void __launch_bounds__(256) wgrad_reduce(const WgradArgs a) {
+    const ur_wgrad_desc& p = a.d;
+    const ur_wgrad_ptrs gp = a.g[blockIdx.y];
     const int ldp = (p.K + 4 + 3) & ~3;
     const int Np = (p.N + 7) & ~7;
-    const int groups = p.K / 4 + (p.db ? 1 : 0);
+    const int groups = p.K / 4 + (gp.db ? 1 : 0);
     const int64_t total = (int64_t)p.N * groups;
     const int64_t slab = (int64_t)Np * ldp;
+    const float* part = p.partial + (int64_t)blockIdx.y * p.splits * slab;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
         const int n = (int)(idx / groups), gq = (int)(idx - (int64_t)n * groups);
-        const float* src = p.partial + (int64_t)n * ldp + gq * 4;
+        const float* src = part + (int64_t)n * ldp + gq * 4;
         if (gq * 4 >= p.K) {
             float s = 0.f;
             for (int z = 0; z < p.splits; ++z) s += src[z * slab];
-            p.db[n] = s;
+            gp.db[n] = s;
             continue;
         }
         float4 s = *reinterpret_cast<const float4*>(src);
@@ -305,7 +321,7 @@ __global__ void __launch_bounds__(256) wgrad_reduce(const ur_wgrad_desc p) {
         T o[4] = {from_f<T>(s.x), from_f<T>(s.y), from_f<T>(s.z), from_f<T>(s.w)};
         uint2 bits;
         __builtin_memcpy(&bits, o, 8);
-        *reinterpret_cast<uint2*>(reinterpret_cast<T*>(p.dw) + (int64_t)n * p.lddw + gq * 4) = bits;
+        *reinterpret_cast<uint2*>(reinterpret_cast<T*>(gp.dw) + (int64_t)n * p.lddw + gq * 4) = bits;
     }
 }
 
@@ -355,10 +371,10 @@ static void tile_dims(int tile, int& tk, int& tn) {
 
 // Slices: a power of two (the slices then map onto whole XCDs) that brings the launch closest to ~4 workgroups of 4 waves
 // per CU, with at least 8 stages per slice (every slice costs a tile of fp32 slab traffic).
-static int wgrad_auto_splits(const ur_wgrad_desc& d) {
+static int wgrad_auto_splits(const ur_wgrad_desc& d, int nprob) {
     int tk, tn;
     tile_dims(wgrad_tile(d), tk, tn);
-    const int tiles = ((d.K + tk - 1) / tk) * ((d.N + tn - 1) / tn);
+    const int tiles = ((d.K + tk - 1) / tk) * ((d.N + tn - 1) / tn) * nprob;
     const int steps = (d.P + WG_BKP - 1) / WG_BKP;
     const int waves = (tk / 64) * (tn / 64) < 4 ? 4 : (tk / 64) * (tn / 64);
     const int target = 1024 * 4 / waves;
@@ -380,55 +396,56 @@ static int64_t wgrad_floats(const ur_wgrad_desc& d, int splits) {
 
 #ifdef UR_WGRAD_ABL
 template <typename T, int TK, int TN, int WK, int WN, int NS, int ABL>
-static void wgrad_launch_abl(const ur_wgrad_desc& d, hipStream_t s, dim3 grid, int lds) {
-    if (d.taps == 9) {
+static void wgrad_launch_abl(const WgradArgs& a, hipStream_t s, dim3 grid, int lds) {
+    if (a.d.taps == 9) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, TK, TN, WK, WN, NS, true, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        hipLaunchKernelGGL((wgrad_kernel<T, TK, TN, WK, WN, NS, true, ABL>), grid, dim3(WK * WN * 64), lds, s, d);
+        hipLaunchKernelGGL((wgrad_kernel<T, TK, TN, WK, WN, NS, true, ABL>), grid, dim3(WK * WN * 64), lds, s, a);
     } else {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, TK, TN, WK, WN, NS, false, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        hipLaunchKernelGGL((wgrad_kernel<T, TK, TN, WK, WN, NS, false, ABL>), grid, dim3(WK * WN * 64), lds, s, d);
+        hipLaunchKernelGGL((wgrad_kernel<T, TK, TN, WK, WN, NS, false, ABL>), grid, dim3(WK * WN * 64), lds, s, a);
     }
 }
 #endif
 
 template <typename T, int TK, int TN, int WK, int WN, int NS>
-static int wgrad_launch_cfg(const ur_wgrad_desc& d, hipStream_t s) {
+static int wgrad_launch_cfg(const WgradArgs& a, hipStream_t s) {
     static std::atomic<uint64_t> done_c{0}, done_l{0};
+    const ur_wgrad_desc& d = a.d;
     constexpr int lds = wgrad_lds_bytes<TK, TN, NS>();
     const int tiles = ((d.K + TK - 1) / TK) * ((d.N + TN - 1) / TN);
-    const dim3 grid(tiles * d.splits);
+    const dim3 grid(tiles * d.splits * a.n);
 #ifdef UR_WGRAD_ABL
     if (const char* e = getenv("UR_WGRAD_ABLATE")) {
         switch (atoi(e)) {
-            case 1: wgrad_launch_abl<T, TK, TN, WK, WN, NS, 1>(d, s, grid, lds); return 0;
-            case 2: wgrad_launch_abl<T, TK, TN, WK, WN, NS, 2>(d, s, grid, lds); return 0;
-            case 3: wgrad_launch_abl<T, TK, TN, WK, WN, NS, 3>(d, s, grid, lds); return 0;
-            case 4: wgrad_launch_abl<T, TK, TN, WK, WN, NS, 4>(d, s, grid, lds); return 0;
+            case 1: wgrad_launch_abl<T, TK, TN, WK, WN, NS, 1>(a, s, grid, lds); return 0;
+            case 2: wgrad_launch_abl<T, TK, TN, WK, WN, NS, 2>(a, s, grid, lds); return 0;
+            case 3: wgrad_launch_abl<T, TK, TN, WK, WN, NS, 3>(a, s, grid, lds); return 0;
+            case 4: wgrad_launch_abl<T, TK, TN, WK, WN, NS, 4>(a, s, grid, lds); return 0;
             default: break;
         }
     }
 #endif
     if (d.taps == 9) {
         set_lds_limit_once(done_c, reinterpret_cast<const void*>(&wgrad_kernel<T, TK, TN, WK, WN, NS, true>), lds);
-        hipLaunchKernelGGL((wgrad_kernel<T, TK, TN, WK, WN, NS, true>), grid, dim3(WK * WN * 64), lds, s, d);
+        hipLaunchKernelGGL((wgrad_kernel<T, TK, TN, WK, WN, NS, true>), grid, dim3(WK * WN * 64), lds, s, a);
     } else {
         set_lds_limit_once(done_l, reinterpret_cast<const void*>(&wgrad_kernel<T, TK, TN, WK, WN, NS, false>), lds);
-        hipLaunchKernelGGL((wgrad_kernel<T, TK, TN, WK, WN, NS, false>), grid, dim3(WK * WN * 64), lds, s, d);
+        hipLaunchKernelGGL((wgrad_kernel<T, TK, TN, WK, WN, NS, false>), grid, dim3(WK * WN * 64), lds, s, a);
     }
     if (d.splits > 1) {
-        const int64_t total = (int64_t)d.N * (d.K / 4 + (d.db ? 1 : 0));
-        const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-        hipLaunchKernelGGL((wgrad_reduce<T>), dim3(blocks), dim3(256), 0, s, d);
+        const int64_t total = (int64_t)d.N * (d.K / 4 + 1);
+        const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+        hipLaunchKernelGGL((wgrad_reduce<T>), dim3(blocks, a.n), dim3(256), 0, s, a);
     }
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : -(int)e;
 }
 
 template <typename T>
-static int wgrad_launch(const ur_wgrad_desc& d, hipStream_t s) {
+static int wgrad_launch(const WgradArgs& d, hipStream_t s) {
     // tile id = dims (1..6) + 8 * depth code; depth code 0 = the product's 2-stage ring (more workgroups per CU hide the
     // delivery latency better than a deeper ring does: profiles/r04_wgrad_ring.txt), 1 / 2 = 3 / 4 stages (experiment builds)
-    switch (wgrad_tile(d)) {
+    switch (wgrad_tile(d.d)) {
         case 1: return wgrad_launch_cfg<T, 128, 128, 2, 2, 2>(d, s);
         case 2: return wgrad_launch_cfg<T, 128, 64, 2, 2, 2>(d, s);
         case 3: return wgrad_launch_cfg<T, 64, 64, 2, 2, 2>(d, s);
@@ -454,25 +471,52 @@ static int wgrad_launch(const ur_wgrad_desc& d, hipStream_t s) {
 
 extern "C" int ur_sizeof_wgrad_desc(void) { return (int)sizeof(ur_wgrad_desc); }
 
-extern "C" int ur_wgrad_plan(const ur_wgrad_desc* d, int32_t* splits, int64_t* partial_floats) {
+static int wgrad_group_check(const ur_wgrad_desc& c, const ur_wgrad_ptrs* g, int n) {
+    if (!g || n < 1 || n > UR_WGRAD_GROUP_MAX) return UR_E_BADARG;
+    for (int i = 0; i < n; ++i) {
+        ur_wgrad_desc d = c;
+        d.dy = g[i].dy; d.x = g[i].x; d.dw = g[i].dw; d.db = g[i].db;
+        const int rc = ur::wgrad_check(d);
+        if (rc) return rc;
+    }
+    if (c.splits < 1 || (c.splits > 1 && !c.partial)) return UR_E_BADARG;
+    if (c.splits > (c.P + ur::WG_BKP - 1) / ur::WG_BKP) return UR_E_BADARG;
+    return 0;
+}
+
+extern "C" int ur_wgrad_group_plan(const ur_wgrad_desc* d, const ur_wgrad_ptrs* g, int n, int32_t* splits, int64_t* partial_floats) {
     if (!d || !splits || !partial_floats) return UR_E_BADARG;
     ur_wgrad_desc c = *d;
-    if (c.splits < 1) c.splits = 1;
-    const int rc = ur::wgrad_check(c);
+    c.splits = 1;
+    const int rc = wgrad_group_check(c, g, n);
     if (rc) return rc;
-    *splits = ur::wgrad_auto_splits(c);
-    *partial_floats = ur::wgrad_floats(c, *splits);
+    *splits = ur::wgrad_auto_splits(c, n);
+    *partial_floats = ur::wgrad_floats(c, *splits) * n;
     return 0;
+}
+
+extern "C" int ur_wgrad_group(const ur_wgrad_desc* d, const ur_wgrad_ptrs* g, int n, void* stream) {
+    if (!d) return UR_E_BADARG;
+    const int rc = wgrad_group_check(*d, g, n);
+    if (rc) return rc;
+    ur::WgradArgs a;
+    a.d = *d;
+    a.n = n;
+    for (int i = 0; i < n; ++i) a.g[i] = g[i];
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    return d->dtype == UR_DT_F16 ? ur::wgrad_launch<ur::f16>(a, s) : ur::wgrad_launch<ur::bf16>(a, s);
+}
+
+extern "C" int ur_wgrad_plan(const ur_wgrad_desc* d, int32_t* splits, int64_t* partial_floats) {
+    if (!d) return UR_E_BADARG;
+    const ur_wgrad_ptrs g = {d->dy, d->x, d->dw, d->db};
+    return ur_wgrad_group_plan(d, &g, 1, splits, partial_floats);
 }
 
 extern "C" int64_t ur_wgrad_partial_floats(const ur_wgrad_desc* d) { return d ? ur::wgrad_floats(*d, d->splits) : 0; }
 
 extern "C" int ur_wgrad(const ur_wgrad_desc* d, void* stream) {
     if (!d) return UR_E_BADARG;
-    const int rc = ur::wgrad_check(*d);
-    if (rc) return rc;
-    if (d->splits < 1 || (d->splits > 1 && !d->partial)) return UR_E_BADARG;
-    if (d->splits > (d->P + ur::WG_BKP - 1) / ur::WG_BKP) return UR_E_BADARG;
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    return d->dtype == UR_DT_F16 ? ur::wgrad_launch<ur::f16>(*d, s) : ur::wgrad_launch<ur::bf16>(*d, s);
+    const ur_wgrad_ptrs g = {d->dy, d->x, d->dw, d->db};
+    return ur_wgrad_group(d, &g, 1, stream);
 }

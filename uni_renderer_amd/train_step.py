@@ -55,17 +55,29 @@ class _batched_casts:
                     for w in (m.attn2.to_k.weight, m.attn2.to_v.weight)]
             first = {id(w) for w in temb + ctxw}
             ws = temb + ctxw + [w for w in ws if id(w) not in first]
-            hit = _castable[id(self.net)] = (self.net, [w for w in ws if w.dtype == torch.float32])
+            bs = [m.bias for m in self.net.modules()
+                  if (isinstance(m, torch.nn.Linear) or (isinstance(m, torch.nn.Conv2d) and m.kernel_size == (1, 1)))
+                  and m.bias is not None and m.bias.dtype == torch.float32]
+            hit = _castable[id(self.net)] = (self.net, [w for w in ws if w.dtype == torch.float32], bs)
         ws = [w for w in hit[1] if w.requires_grad]
         if ws:
             for w, c in zip(ws, A.CastParams.apply(self.dt, *ws)):
                 _cast[id(w)] = c
         self.keys = [id(w) for w in ws]
+        # the biases of the same layers behind one barrier node: their gradients may then be deferred with the weights'
+        # (autograd_ops.ParamBarrier; A.linear looks them up in A.deferred_bias)
+        bs = [b for b in hit[2] if b.requires_grad] if (ws and B.WGRAD_DEFER and B.WGRAD) else []
+        if bs:
+            for b, o in zip(bs, A.ParamBarrier.apply(*bs)):
+                A.deferred_bias[id(b)] = o
+        self.bkeys = [id(b) for b in bs]
         return self
 
     def __exit__(self, *exc):
         for k in getattr(self, "keys", ()):
             _cast.pop(k, None)
+        for k in getattr(self, "bkeys", ()):
+            A.deferred_bias.pop(k, None)
         return False
 
 
@@ -398,6 +410,7 @@ def _forward_backward(nets, batch, optimizer, buckets, dtype, inverse, grad_accu
             loss.backward()
     else:
         loss.backward()  # with ``buckets``: complete buckets are all-reduced (async) while the backward is still running
+    B.wgrad_queue.flush()  # nothing pending after a complete backward (CastParams / ParamBarrier flush); a partial graph may leave some
     return report
 
 
