@@ -144,3 +144,19 @@ def test_queue_groups_by_shape_and_flushes_on_a_repeated_weight():
     for (dy, x), (dw, db) in zip(a + b, outs):
         _close(dw, dy.float().t() @ x.float(), dt, "queued dw")
         assert (db - dy.float().sum(0)).abs().max().item() <= 1e-2
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("Bn,H,Cc,N,stride,n,tile,splits", [(2, 16, 64, 64, 1, 5, 3, 1), (1, 32, 320, 320, 1, 3, 2, 2), (2, 16, 128, 320, 2, 4, 1, 1),
+                                                            (4, 8, 1280, 1280, 1, 2, 5, 1)])
+def test_grouped_conv_problems_are_the_single_launches(dt, Bn, H, Cc, N, stride, n, tile, splits):
+    torch.manual_seed(Bn + H + Cc + n)
+    Ho = H // stride
+    probs = [(_mk((Bn, Ho, Ho, N), dt, 0.5), _mk((Bn, H, H, Cc), dt)) for _ in range(n)]
+    items = [(dy.reshape(-1, N), x, torch.empty(N, 9 * Cc, dtype=dt, device="cuda"), torch.empty(N, dtype=torch.float32, device="cuda"))
+             for dy, x in probs]
+    B_.wgrad_group(items, tile=tile, splits=splits, conv=(Ho, Ho, stride))
+    for (dy, x), (_, _, dw, db) in zip(probs, items):
+        _close(dw, _conv_ref(x, dy, stride), dt, "grouped conv dw")
+        dw1, db1 = B_.wgrad(dy.reshape(-1, N), x, True, conv=(Ho, Ho, stride), tile=tile, splits=splits)
+        assert torch.equal(dw, dw1) and torch.equal(db, db1)

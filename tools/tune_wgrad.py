@@ -79,6 +79,7 @@ def main():
         shape, _, grp = key.partition("@")
         G = int(grp) if grp else 1
         P, N, K, taps, stride = (int(v) for v in shape.split(","))
+        conv = None
         if taps == 9:
             Cc = K // 9
             # the tuner does not know the image shape: a square power-of-two map of P / 4 ... P pixels per sample reproduces it
@@ -86,15 +87,17 @@ def main():
             Bn = next(b for b in (1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20) if P % b == 0 and int(round((P // b) ** 0.5)) ** 2 == P // b
                       and ((P // b) & (P // b - 1)) == 0)
             Ho = int(round((P // Bn) ** 0.5))
-            dy, x, conv = mk(P, N), mk(Bn, Ho * stride, Ho * stride, Cc), (Ho, Ho, stride)
-            run = lambda tile, sp: B_.wgrad(dy, x, True, conv=conv, tile=tile, splits=sp)
-        elif G == 1:
-            dy, x = mk(P, N), mk(P, K)
-            run = lambda tile, sp: B_.wgrad(dy, x, True, tile=tile, splits=sp)
+            conv = (Ho, Ho, stride)
+            mkx = lambda: mk(Bn, Ho * stride, Ho * stride, Cc)
         else:
-            items = [(mk(P, N), mk(P, K), torch.empty(N, K, dtype=dt, device="cuda"), torch.empty(N, dtype=torch.float32, device="cuda"))
+            mkx = lambda: mk(P, K)
+        if G == 1:
+            dy, x = mk(P, N), mkx()
+            run = lambda tile, sp: B_.wgrad(dy, x, True, conv=conv, tile=tile, splits=sp)
+        else:
+            items = [(mk(P, N), mkx(), torch.empty(N, K, dtype=dt, device="cuda"), torch.empty(N, dtype=torch.float32, device="cuda"))
                      for _ in range(G)]
-            run = lambda tile, sp: B_.wgrad_group(items, tile=tile, splits=sp)
+            run = lambda tile, sp: B_.wgrad_group(items, tile=tile, splits=sp, conv=conv)
         best = None
         for tile in (1, 2, 3, 4, 5, 6):
             for sp in (1, 2, 4, 8, 16, 32, 64):

@@ -87,6 +87,7 @@ class Conv3x3(Function):
     def forward(ctx, x, wp, b, res, rowadd, stride):
         ctx.save_for_backward(x, wp)
         ctx.flags = (b is not None, res is not None, rowadd is not None, int(stride))
+        ctx.defer = _can_defer(wp, b)
         return ops.conv3x3(x, wp, b, stride=stride, rowadd=rowadd, res=res)
 
     @staticmethod
@@ -94,7 +95,8 @@ class Conv3x3(Function):
         x, wp = ctx.saved_tensors
         has_b, has_res, has_row, stride = ctx.flags
         dy = dy.contiguous()
-        dx, dw, db = bw.conv3x3_backward(x, wp, dy, need_bias=has_b, stride=stride, need_dx=ctx.needs_input_grad[0])
+        dx, dw, db = bw.conv3x3_backward(x, wp, dy, need_bias=has_b, stride=stride, need_dx=ctx.needs_input_grad[0],
+                                         defer=ctx.defer)
         drow = None
         if has_row:
             drow = bw.colsum(bw._pad_cols64(dy), rows_per_group=dy.shape[1] * dy.shape[2])[:, : dy.shape[-1]].to(dy.dtype)
@@ -267,6 +269,8 @@ def linear(x, w, b=None, res=None, rowadd=None, rows_per_b=0):
 
 
 def conv3x3(x, wp, b=None, res=None, rowadd=None, stride=1):
+    if b is not None and deferred_bias:
+        b = deferred_bias.get(id(b), b)
     return Conv3x3.apply(x, wp, b, res, rowadd, stride)
 
 
@@ -337,8 +341,61 @@ class PackConvWeight(Function):
         return g, None, None
 
 
+class PackConvWeights(Function):
+    """PackConvWeight for ALL 3x3 conv weights of a network as one autograd node: the packed copies are made up front, and the
+    backward runs when the last packed gradient has arrived -- it flushes the deferred weight-gradient queue first
+    (backward.WgradQueue: Conv3x3.backward hands out uninitialised dw for these weights), then unpacks every gradient."""
+
+    @staticmethod
+    def forward(ctx, dtype, cin_pads, *weights):
+        import weakref
+        lib = _lib.load()
+        ctx.set_materialize_grads(False)
+        ctx.geoms, ctx.pids, outs = [], [id(w) for w in weights], []
+        for w_, cpad in zip(weights, cin_pads):
+            co, ci = w_.shape[:2]
+            cp = ci if cpad is None else cpad
+            ctx.geoms.append((co, ci, cp))
+            out = torch.empty(co, 9 * cp, dtype=dtype, device=w_.device)
+            check(lib.ur_pack_conv_weight(w_.detach().contiguous().data_ptr(), out.data_ptr(), co, ci, cp, DT[dtype], _stream()),
+                  "ur_pack_conv_weight")
+            _deferred_w[out.untyped_storage().data_ptr()] = weakref.ref(out)
+            outs.append(out)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        lib = _lib.load()
+        bw.wgrad_queue.flush()
+        res = []
+        for dwp, (co, ci, cp), pid in zip(grads, ctx.geoms, ctx.pids):
+            if dwp is None:
+                res.append(None)
+                continue
+            if dwp.stride(-1) != 1:
+                dwp = dwp.contiguous()
+            g = torch.empty(co, ci, 3, 3, dtype=torch.float32, device=dwp.device)
+            if bw.FUSED_GRADNORM:
+                part = torch.empty(int(lib.ur_unpack_conv_weight_grad_blocks(co, ci)), dtype=torch.float32, device=dwp.device)
+                check(lib.ur_unpack_conv_weight_grad_sumsq(dwp.data_ptr(), dwp.stride(0), g.data_ptr(), co, ci, cp, part.data_ptr(),
+                                                           DT[dwp.dtype], _stream()), "ur_unpack_conv_weight_grad_sumsq")
+                bw.grad_squares.add(part, [pid])
+            else:
+                check(lib.ur_unpack_conv_weight_grad(dwp.data_ptr(), dwp.stride(0), g.data_ptr(), co, ci, cp, DT[dwp.dtype], _stream()),
+                      "ur_unpack_conv_weight_grad")
+            res.append(g)
+        return (None, None, *res)
+
+
+packed_conv: dict = {}  # (id(fp32 conv weight), cin_pad) -> its PackConvWeights output for the current network forward (train_step)
+
+
 def pack_conv_weight(weight: torch.Tensor, dtype, cin_pad=None) -> torch.Tensor:
     """differentiable version of layers.pack_conv3x3: [Co, Ci, 3, 3] fp32 master -> [Co][(ky,kx,ci_pad)] compute dtype."""
+    if packed_conv:
+        hit = packed_conv.get((id(weight), cin_pad))
+        if hit is not None and hit.dtype == dtype:
+            return hit
     if weight.is_cuda and weight.dtype == torch.float32 and dtype in DT and weight.dim() == 4 and tuple(weight.shape[2:]) == (3, 3):
         return PackConvWeight.apply(weight, dtype, cin_pad)
     co, ci = weight.shape[:2]

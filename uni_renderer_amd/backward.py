@@ -340,25 +340,27 @@ class WgradQueue:
         self.items, self.seen = [], set()
         self.trace: Optional[dict] = None   # set to a dict to count (problem, group size) per flush (tools/tune_wgrad.py)
 
-    def add(self, dy2: torch.Tensor, x2: torch.Tensor, w_key: int, need_bias: bool):
+    def add(self, dy2: torch.Tensor, x2: torch.Tensor, w_key: int, need_bias: bool, conv: Optional[Tuple[int, int, int]] = None):
+        """``conv`` = (Ho, Wo, stride) with x2 the NHWC input of a 3x3 conv (dw then in the packed layout), else x2 [P, K]."""
         if w_key in self.seen:
             self.flush()
             return None
         self.seen.add(w_key)
-        dw = torch.empty(dy2.shape[1], x2.shape[1], dtype=dy2.dtype, device=dy2.device)
+        K = x2.shape[1] if conv is None else 9 * x2.shape[3]
+        dw = torch.empty(dy2.shape[1], K, dtype=dy2.dtype, device=dy2.device)
         db = torch.empty(dy2.shape[1], dtype=torch.float32, device=dy2.device) if need_bias else None
-        self.items.append((dy2, x2, dw, db))
+        self.items.append((dy2, x2, dw, db, conv))
         return dw, db
 
     def flush(self):
         items, self.items, self.seen = self.items, [], set()
         groups: dict = {}
         for it in items:
-            dy2, x2 = it[0], it[1]
-            groups.setdefault((dy2.shape, x2.shape[1], dy2.stride(0), x2.stride(0), dy2.dtype, dy2.device), []).append(it)
-        for (shape, K, lddy, ldx, dt, dev), its in groups.items():
+            dy2, x2, conv = it[0], it[1], it[4]
+            groups.setdefault((dy2.shape, x2.shape, dy2.stride(0), x2.stride(0), conv, dy2.dtype, dy2.device), []).append(it[:4])
+        for key, its in groups.items():
             for i in range(0, len(its), WGRAD_GROUP_MAX):
-                wgrad_group(its[i:i + WGRAD_GROUP_MAX], trace=self.trace)
+                wgrad_group(its[i:i + WGRAD_GROUP_MAX], conv=key[4], trace=self.trace)
 
 
 wgrad_queue = WgradQueue()
@@ -366,24 +368,31 @@ wgrad_queue = WgradQueue()
 WGRAD_DEFER = os.environ.get("UR_WGRAD_DEFER", "1") != "0"
 
 
-def wgrad_group(items, tile: int = 0, splits: int = 0, trace: Optional[dict] = None):
-    """``ur_wgrad_group`` over ``items`` = [(dy2 [P, N], x2 [P, K], dw [N, K] out, db [N] fp32 out or None)], all of one shape and
-    one pair of row strides."""
+def wgrad_group(items, tile: int = 0, splits: int = 0, trace: Optional[dict] = None, conv: Optional[Tuple[int, int, int]] = None):
+    """``ur_wgrad_group`` over ``items`` = [(dy2 [P, N], x, dw [N, K] out, db [N] fp32 out or None)], all of one shape and one
+    pair of row strides; x [P, K], or NHWC [B, H, W, C] with ``conv`` = (Ho, Wo, stride) (K = 9 C, packed layout)."""
     lib = _lib.load()
     dy0, x0 = items[0][0], items[0][1]
     _require_gpu(dy0)
     P, N = dy0.shape
-    K = x0.shape[1]
     n = len(items)
     d = _WgradDesc()
     zp = ops.zero_page(dy0.device)
     d.zero_page, d.zero_page_bytes = zp.data_ptr(), ops.ZERO_PAGE_BYTES
-    d.taps, d.lddy, d.ldx, d.lddw, d.P, d.N, d.K, d.dtype = 1, dy0.stride(0), x0.stride(0), K, P, N, K, DT[dy0.dtype]
+    if conv is None:
+        K = x0.shape[1]
+        d.taps, d.ldx = 1, x0.stride(0)
+    else:
+        Ho, Wo, stride = conv
+        Bn, H, W, Cc = x0.shape
+        K = 9 * Cc
+        d.taps, d.ldx, d.C, d.B, d.Hin, d.Win, d.Hout, d.Wout, d.stride, d.pad = 9, Cc, Cc, Bn, H, W, Ho, Wo, stride, 1
+    d.lddy, d.lddw, d.P, d.N, d.K, d.dtype = dy0.stride(0), K, P, N, K, DT[dy0.dtype]
     g = (_WgradPtrs * n)()
     for i, (dy2, x2, dw, db) in enumerate(items):
         g[i].dy, g[i].x, g[i].dw, g[i].db = dy2.data_ptr(), x2.data_ptr(), dw.data_ptr(), (db.data_ptr() if db is not None else None)
     d.dy, d.x, d.dw = g[0].dy, g[0].x, g[0].dw
-    key = f"{P},{N},{K},1,0@{n}"
+    key = f"{P},{N},{K},{d.taps},{d.stride}@{n}"
     if trace is not None:
         trace[key] = trace.get(key, 0) + 1
     tuned = wgrad_table().get(key) if not (tile or splits or WGRAD_TILE or WGRAD_SPLITS) else None
@@ -472,7 +481,7 @@ def _pad_cols64(t: torch.Tensor) -> torch.Tensor:
 
 
 def conv3x3_backward(x: torch.Tensor, w_packed: torch.Tensor, dy: torch.Tensor, need_bias: bool = True, stride: int = 1,
-                     need_dx: bool = True) -> Tuple[Optional[torch.Tensor], torch.Tensor, Optional[torch.Tensor]]:
+                     need_dx: bool = True, defer: bool = False) -> Tuple[Optional[torch.Tensor], torch.Tensor, Optional[torch.Tensor]]:
     """3x3 / pad 1 / stride 1|2 conv over NHWC x [B,H,W,C] (C % 64 == 0) with packed weights [N][(ky,kx,c)],
     dy [B,Ho,Wo,N]  ->  (dx [B,H,W,C], dw [N][(ky,kx,c)], db [N] fp32).
     dx is the same implicit-GEMM conv applied to dy (zero-inserted for stride 2) with the rotated / channel-transposed
@@ -496,6 +505,11 @@ def conv3x3_backward(x: torch.Tensor, w_packed: torch.Tensor, dy: torch.Tensor, 
     P = B * Ho * Wo
     xc = x.contiguous()
     if WGRAD and wgrad_ok(dyp.reshape(P, Np), xc, (Ho, Wo)):
+        later = None
+        if defer and WGRAD_DEFER and Np == N:
+            later = wgrad_queue.add(dyp.reshape(P, Np), xc, w_packed.data_ptr(), need_bias, conv=(Ho, Wo, stride))
+        if later is not None:
+            return dx, later[0], later[1]
         dw, db = wgrad(dyp.reshape(P, Np), xc, need_bias, conv=(Ho, Wo, stride))
         return dx, dw[:N], (db[:N].contiguous() if need_bias else None)
     Pp = (P + 63) // 64 * 64

@@ -56,9 +56,12 @@ class _batched_casts:
             first = {id(w) for w in temb + ctxw}
             ws = temb + ctxw + [w for w in ws if id(w) not in first]
             bs = [m.bias for m in self.net.modules()
-                  if (isinstance(m, torch.nn.Linear) or (isinstance(m, torch.nn.Conv2d) and m.kernel_size == (1, 1)))
+                  if (isinstance(m, torch.nn.Linear) or (isinstance(m, torch.nn.Conv2d) and m.kernel_size in ((1, 1), (3, 3))))
                   and m.bias is not None and m.bias.dtype == torch.float32]
-            hit = _castable[id(self.net)] = (self.net, [w for w in ws if w.dtype == torch.float32], bs)
+            conv_in = getattr(self.net, "conv_in", None)
+            c3 = [(m.weight, CIN_PAD if m is conv_in else None) for m in self.net.modules()
+                  if isinstance(m, torch.nn.Conv2d) and m.kernel_size == (3, 3) and m.weight.dtype == torch.float32]
+            hit = _castable[id(self.net)] = (self.net, [w for w in ws if w.dtype == torch.float32], bs, c3)
         ws = [w for w in hit[1] if w.requires_grad]
         if ws:
             for w, c in zip(ws, A.CastParams.apply(self.dt, *ws)):
@@ -71,6 +74,13 @@ class _batched_casts:
             for b, o in zip(bs, A.ParamBarrier.apply(*bs)):
                 A.deferred_bias[id(b)] = o
         self.bkeys = [id(b) for b in bs]
+        # ... and the 3x3 conv weights packed up front by one node (autograd_ops.PackConvWeights), same reason
+        c3 = [(w, cp) for w, cp in hit[3] if w.requires_grad and w.is_cuda] if (B.WGRAD_DEFER and B.WGRAD) else []
+        if c3:
+            outs = A.PackConvWeights.apply(self.dt, tuple(cp for _, cp in c3), *[w for w, _ in c3])
+            for (w, cp), o in zip(c3, outs):
+                A.packed_conv[(id(w), cp)] = o
+        self.ckeys = [(id(w), cp) for w, cp in c3]
         return self
 
     def __exit__(self, *exc):
@@ -78,6 +88,8 @@ class _batched_casts:
             _cast.pop(k, None)
         for k in getattr(self, "bkeys", ()):
             A.deferred_bias.pop(k, None)
+        for k in getattr(self, "ckeys", ()):
+            A.packed_conv.pop(k, None)
         return False
 
 
