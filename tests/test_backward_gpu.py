@@ -302,6 +302,20 @@ def test_conv_weight_pack_unpack_and_rotation_kernels(dev, dtype, shape):
         w4 = ref.view(co, 3, 3, cp)
         assert torch.equal(rot, w4.flip(1, 2).permute(3, 1, 2, 0).reshape(cp, 9 * co).contiguous())
 
+def test_rotated_conv_weights_and_linear_transposes_in_multi_tensor_launches(dev):
+    """backward.rot_weights_many (all dgrad conv weights of a network, 32 per ur_transpose2d_multi launch) against
+    _rot_weights, and 40 matrices through transpose2d_many (two launches) against the single-tensor kernel."""
+    from uni_renderer_amd import backward as bw
+    g = torch.Generator().manual_seed(9)
+    shapes = [(64, 64), (128, 320), (320, 64), (64, 8)] * 9
+    ws = [(torch.randn(co, 9 * ci, generator=g).to(torch.bfloat16).to(dev), ci) for co, ci in shapes]
+    for (w, ci), r in zip(ws, bw.rot_weights_many(ws)):
+        assert torch.equal(r, bw._rot_weights(w, ci))
+    ms = [torch.randn(8 * (1 + i % 7), 16 * (1 + i % 5), generator=g).to(torch.bfloat16).to(dev) for i in range(40)]
+    for m, t in zip(ms, bw.transpose2d_many(ms)):
+        assert torch.equal(t, m.t().contiguous())
+
+
 def test_transpose2d_many(dev):
     """ur_transpose2d_multi: several (batched, strided, ragged) transposes in one launch == the single-tensor kernel."""
     from uni_renderer_amd import backward as bw

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--latent", type=int, default=64)
     ap.add_argument("--min-us", type=float, default=25.0, help="skip problems whose table plan runs faster than this")
     ap.add_argument("--tiles", default="49,50,51,52,53,54,55")
+    ap.add_argument("--max-wgs", type=int, default=1024, help="skip candidates with more workgroups than this (512 with split-K)")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r04", "pp_ab.json"))
     a = ap.parse_args()
     import bench
@@ -52,7 +53,7 @@ def main():
                 if sk > 1 and K // 64 < 4 * sk:
                     continue
                 wgs = -(-M // bm) * -(-N // bn) * zb * sk
-                if wgs > 1024 or (sk > 1 and wgs > 512):
+                if wgs > a.max_wgs or (sk > 1 and wgs > a.max_wgs // 2):
                     continue
                 t = T.time_cfg(kw, tile, sk)
                 if t is None:

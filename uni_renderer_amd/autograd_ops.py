@@ -361,12 +361,22 @@ class PackConvWeights(Function):
                   "ur_pack_conv_weight")
             _deferred_w[out.untyped_storage().data_ptr()] = weakref.ref(out)
             outs.append(out)
+        # the dgrad form of every weight (taps rotated, channels transposed), 32 per launch (bw.weight_rot; dropped in the backward)
+        ctx.rot_keys = []
+        if bw.BATCH_WT:
+            elig = [(o, g[2]) for o, g in zip(outs, ctx.geoms) if g[0] % 64 == 0 and g[2] % 8 == 0]
+            for (o, _), r in zip(elig, bw.rot_weights_many(elig) if elig else []):
+                key = (o.data_ptr(), tuple(o.shape))
+                bw.weight_rot[key] = r
+                ctx.rot_keys.append(key)
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, *grads):
         lib = _lib.load()
         bw.wgrad_queue.flush()
+        for key in ctx.rot_keys:
+            bw.weight_rot.pop(key, None)
         res = []
         for dwp, (co, ci, cp), pid in zip(grads, ctx.geoms, ctx.pids):
             if dwp is None:
@@ -416,14 +426,25 @@ class CastParams(Function):
         ctx.set_materialize_grads(False)
         ctx.pids = [id(p) for p in params]
         outs = tuple(bw.cast_many([p.detach() for p in params], dtype, packed=True))
+        ctx.wt_keys = []
         if outs and outs[0].is_cuda:
             flat = outs[0]._base if outs[0]._base is not None else outs[0]
             _deferred_w[flat.untyped_storage().data_ptr()] = weakref.ref(flat)
+            if bw.BATCH_WT and bw.WGRAD:
+                # W^T for the dx GEMMs of the backward, 32 matrices per launch (bw.weight_t; dropped in the backward below)
+                w2 = [o.reshape(o.shape[0], -1) for o in outs if o.dim() >= 2]
+                w2 = [o for o in w2 if o.shape[0] % 8 == 0 and o.shape[1] % 8 == 0 and o.numel()]
+                for o, t in zip(w2, bw.transpose2d_many(w2) if w2 else []):
+                    key = (o.data_ptr(), tuple(o.shape))
+                    bw.weight_t[key] = t
+                    ctx.wt_keys.append(key)
         return outs
 
     @staticmethod
     def backward(ctx, *grads):
         bw.wgrad_queue.flush()  # the weight gradients below may have been handed out uninitialised (Linear.backward)
+        for key in ctx.wt_keys:
+            bw.weight_t.pop(key, None)
         idx = [i for i, g in enumerate(grads) if g is not None]
         res = [None] * len(grads)
         if idx:

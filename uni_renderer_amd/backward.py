@@ -72,6 +72,12 @@ def _colsum_counter(device) -> torch.Tensor:
 
 
 MULTI_TRANSPOSE = os.environ.get("UR_MULTI_TRANSPOSE", "1") != "0"
+TRANSPOSE_MAX = 32  # UR_TRANSPOSE_MAX
+# W^T of the Linear weights for dx = dy . W, made in a few multi-tensor launches right after the batched cast of the weights
+# (autograd_ops.CastParams) instead of one transpose launch per layer in the backward (426 launches, 3.1 ms per step):
+# (data_ptr, shape) of the compute-dtype weight -> its transpose.  UR_BATCH_WT=0: every linear_backward transposes its own.
+BATCH_WT = os.environ.get("UR_BATCH_WT", "1") != "0"
+weight_t: dict = {}
 
 
 def transpose2d_many(xs, colsum_of: Optional[int] = None, pad64=()):
@@ -107,7 +113,7 @@ def transpose2d_many(xs, colsum_of: Optional[int] = None, pad64=()):
         descs.append((x, out, ld, bs, Rp, Rp * Cc, R, Cc, batch))
     if len({x.dtype for x in xs}) != 1:
         raise ValueError("transpose2d_many: one dtype per call")
-    nmax = 4
+    nmax = TRANSPOSE_MAX
     sums = ws = None
     for i in range(0, len(descs), nmax):
         part = descs[i:i + nmax]
@@ -428,7 +434,8 @@ def linear_backward(x: torch.Tensor, w: torch.Tensor, dy: torch.Tensor, need_bia
     K, N = x.shape[-1], w.shape[0]
     x2, dy2 = x.reshape(-1, K), dy.reshape(-1, N)
     if WGRAD and wgrad_ok(dy2, x2):
-        dx = ops.linear(dy2, transpose2d(w)).view(x.shape)   # [M, N] @ [K, N]^T
+        wt = weight_t.get((w.data_ptr(), tuple(w.shape)))
+        dx = ops.linear(dy2, wt if wt is not None else transpose2d(w)).view(x.shape)   # [M, N] @ [K, N]^T
         later = wgrad_queue.add(dy2, x2, w.data_ptr(), need_bias) if (defer and WGRAD_DEFER) else None
         dw, db = later if later is not None else wgrad(dy2, x2, need_bias)
         return dx, dw, db
@@ -457,6 +464,29 @@ def _rot_weights(w_packed: torch.Tensor, cin: int) -> torch.Tensor:
     check(lib.ur_transpose2d(w_packed.data_ptr() + 8 * cin * esz, 9 * cin, -cin, out.data_ptr(), 9 * N, N, N, cin, 9,
                              DT[w_packed.dtype], _stream()), "ur_transpose2d")
     return out
+
+
+weight_rot: dict = {}  # (data_ptr, shape) of a packed conv weight -> its rotated / channel-transposed form (rot_weights_many)
+
+
+def rot_weights_many(ws) -> list:
+    """``[_rot_weights(w, cin) for w, cin in ws]`` with 32 weights per launch (``ur_transpose2d_multi``; every weight [N, 9 cin]
+    contiguous with N and cin multiples of 8): the dgrad weights of all 3x3 convs of a network right after they are packed
+    (autograd_ops.PackConvWeights) instead of one launch per conv in the backward."""
+    lib = _lib.load()
+    outs = [torch.empty(cin, 9 * w.shape[0], dtype=w.dtype, device=w.device) for w, cin in ws]
+    for i in range(0, len(ws), TRANSPOSE_MAX):
+        part = list(zip(ws[i:i + TRANSPOSE_MAX], outs[i:i + TRANSPOSE_MAX]))
+        arr = (_TransposeDesc * len(part))()
+        for k, ((w, cin), out) in enumerate(part):
+            N = w.shape[0]
+            if N % 8 or cin % 8 or not w.is_contiguous() or w.shape[1] != 9 * cin or w.dtype != ws[0][0].dtype:
+                raise ValueError("rot_weights_many: packed [N, 9 cin] weights of one dtype with N, cin multiples of 8")
+            arr[k].src, arr[k].dst = w.data_ptr() + 8 * cin * w.element_size(), out.data_ptr()
+            arr[k].ld_src, arr[k].bs_src, arr[k].ld_dst, arr[k].bs_dst = 9 * cin, -cin, 9 * N, N
+            arr[k].R, arr[k].C, arr[k].batch, arr[k].rows_out = N, cin, 9, 0
+        check(lib.ur_transpose2d_multi(arr, len(part), DT[ws[0][0].dtype], _stream()), "ur_transpose2d_multi")
+    return outs
 
 
 def resample2x(x: torch.Tensor, mode: int) -> torch.Tensor:
@@ -499,7 +529,8 @@ def conv3x3_backward(x: torch.Tensor, w_packed: torch.Tensor, dy: torch.Tensor, 
     if need_dx:
         wpad = w_packed if Np == N else torch.cat([w_packed, w_packed.new_zeros(Np - N, w_packed.shape[1])], 0)
         src = dyp if stride == 1 else resample2x(dyp, 2)      # stride 2: zero insertion, then a stride-1 conv
-        dx = ops.conv3x3(src, _rot_weights(wpad, Cc))
+        rot = weight_rot.get((w_packed.data_ptr(), tuple(w_packed.shape))) if Np == N else None
+        dx = ops.conv3x3(src, rot if rot is not None else _rot_weights(wpad, Cc))
         if dx.shape[1] != H or dx.shape[2] != W:
             raise RuntimeError("conv3x3_backward: odd input sizes are not supported with stride 2")
     P = B * Ho * Wo

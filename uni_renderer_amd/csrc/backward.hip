@@ -87,10 +87,11 @@ struct TransposeMultiArgs {
 template <typename T>
 __global__ void __launch_bounds__(256) transpose2d_multi_kernel(const TransposeMultiArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t tile[64 * 32];
-    int k = 0;
-#pragma unroll
-    for (int i = 1; i < UR_TRANSPOSE_MAX; ++i)
-        if (i < a.n && (int)blockIdx.x >= a.tile0[i]) k = i;
+    int k = 0, hi = a.n;  // last descriptor with tile0 <= blockIdx.x
+    while (hi - k > 1) {
+        const int mid = (k + hi) >> 1;
+        if (a.tile0[mid] <= (int)blockIdx.x) k = mid; else hi = mid;
+    }
     const ur_transpose_desc d = a.d[k];
     const int tc = (d.C + 63) / 64, tr = (d.R + 63) / 64;
     int id = (int)blockIdx.x - a.tile0[k];
