@@ -119,18 +119,7 @@ extern "C" {
 #define UR_TILE_PP_256x256 53     /* 4 x 2 waves of 64 x 128, 4 slots (128 KB) */
 #define UR_TILE_PP_128x128 54     /* 4 x 2 waves of 32 x 64, 5 slots (80 KB) */
 #define UR_TILE_PP_256x320 55     /* 4 x 2 waves of 64 x 160, 4 slots (144 KB) */
-/* 32-DEEP K chunks (csrc/igemm.hip, igemm_k32_kernel): 64-byte LDS rows, half the LDS per stage, registers capped at 128 --
-   four 4-wave workgroups per CU instead of two (round 4: resident workgroups per CU were the strongest lever on the
-   delivery-bound weight-gradient loop).  Same descriptor, operand layouts, split-K slabs and epilogue as the lock-step tiles.
-   Parity-green, but 10-20 % SLOWER than the 64-deep tiles on 39 of the step's 40 heavy problems (profiles/r04_k32_ab.txt):
-   only in a library built with `make K32=1` (ur_has_k32()); the product build answers UR_E_UNSUPPORTED. */
-#define UR_TILE_K32_128x128 56    /* 2 x 2 waves, 2 stages (32 KB) */
-#define UR_TILE_K32_128x64 57     /* 4 x 1 waves, 2 stages (24 KB) */
-#define UR_TILE_K32_128x128_S3 58 /* 2 x 2 waves, 3 stages (48 KB) */
-#define UR_TILE_K32_256x128 59    /* 4 x 2 waves, 2 stages (48 KB) */
-#define UR_TILE_K32_64x64 60      /* 4 x 1 waves, 2 stages (16 KB) */
-#define UR_TILE_K32_128x256 61    /* 2 x 4 waves, 2 stages (48 KB) */
-#define UR_TILE_COUNT 62
+#define UR_TILE_COUNT 56
 
 /*
  * Implicit GEMM:  out[m][n] = epilogue( sum_k X[m][k] * W[n][k] )
@@ -242,9 +231,6 @@ int ur_igemm_splitk_gn(const ur_igemm_desc* d, const float* gamma, const float* 
 /* 1 when the library was built with the experimental weight-streaming conv tiles (UR_TILE_WS320*: `make WSCONV=1`); the
  * product build returns 0 and UR_E_UNSUPPORTED for those tile ids. */
 int ur_has_wsconv(void);
-/* 1 when the library was built with the 32-deep-chunk tiles (UR_TILE_K32_*: `make K32=1`); the product build returns 0 and
- * UR_E_UNSUPPORTED for those tile ids (they measured slower than the 64-deep tiles on the step's problems). */
-int ur_has_k32(void);
 
 /* Workspace (in floats) ur_igemm needs in `partial` for this descriptor (0 when splitk <= 1). */
 int64_t ur_igemm_partial_floats(const ur_igemm_desc* d);

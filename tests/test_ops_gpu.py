@@ -14,14 +14,8 @@ pytestmark = pytest.mark.gpu
 TOL = {torch.float16: 2e-3, torch.bfloat16: 1.2e-2}
 DTYPES = [torch.float16, torch.bfloat16]
 PP_TILES = list(range(49, 56))  # 8-wave ping-pong builds (csrc/igemm_pp.hip)
-K32_TILES = list(range(56, 62))  # 32-deep K chunks, four workgroups per CU (igemm_k32_kernel)
-ALL_TILES = [t for t in range(1, 47) if t != 39] + PP_TILES + K32_TILES
+ALL_TILES = [t for t in range(1, 47) if t != 39] + PP_TILES
 
-
-def _skip_unbuilt(tile):
-    from uni_renderer_amd import ops
-    if tile in K32_TILES and not ops.k32_built():
-        pytest.skip("32-deep-chunk tiles are an opt-in build (make K32=1): slower than the 64-deep tiles on the step's problems")
 
 
 def _rand(shape, dtype, dev, scale=1.0, seed=0):
@@ -33,7 +27,6 @@ def _rand(shape, dtype, dev, scale=1.0, seed=0):
 @pytest.mark.parametrize("tile", ALL_TILES)
 @pytest.mark.parametrize("shape", [(256, 320, 320), (300, 64, 128), (1000, 448, 640), (4, 1280, 320)])
 def test_linear_bias_res(dev, dtype, tile, shape):
-    _skip_unbuilt(tile)
     from uni_renderer_amd import ops
     M, N, K = shape
     x = _rand((M, K), dtype, dev, seed=1)
@@ -73,7 +66,6 @@ def test_linear_two_sources(dev, dtype):
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("tile", ALL_TILES)
 def test_geglu(dev, dtype, tile):
-    _skip_unbuilt(tile)
     from uni_renderer_amd import ops
     from uni_renderer_amd.layers import geglu_perm
     M, K, NH = 300, 128, 512
@@ -100,7 +92,6 @@ def _conv_ref(x_nhwc, w_oihw, b, stride=1, ups=False):
 @pytest.mark.parametrize("tile", ALL_TILES)
 @pytest.mark.parametrize("mode", ["s1", "s2", "ups"])
 def test_conv3x3(dev, dtype, tile, mode):
-    _skip_unbuilt(tile)
     from uni_renderer_amd import ops
     from uni_renderer_amd.layers import pack_conv3x3
     B, H, W, Ci, Co = 2, 12, 10, 128, 192
@@ -463,13 +454,12 @@ def test_conv3x3_with_1x1_tail(dev, dtype, cfg):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("tile", PP_TILES + K32_TILES)
+@pytest.mark.parametrize("tile", PP_TILES)
 def test_pingpong_tiles_long_k_splitk_concat_and_repeatability(dev, dtype, tile):
     """The ping-pong main loop (csrc/igemm_pp.hip) where its ring protocol matters: K long enough to wrap the 4- / 5-slot
     ring many times, split-K slices of uneven length (slices that END early exercise the tail of the counted waits), a
     two-source concat, a ragged M and N tile, stride 2 -- against fp32 conv2d; then 200 launches of one problem must be
     BIT-identical (a ring race shows as a rare differing launch, not as a tolerance failure: DESIGN.md section 5)."""
-    _skip_unbuilt(tile)
     from uni_renderer_amd import ops
     from uni_renderer_amd.layers import pack_conv3x3
     for (B, H, W, C0, C1, Co, stride, sk) in [(2, 20, 18, 640, 0, 320, 1, 1), (2, 20, 18, 320, 320, 200, 1, 3),

@@ -11,7 +11,9 @@ bash tools/collect_profiles.sh r04 > gpurun_out/final_collect.log 2>&1
 python bench.py --batch 1 --latent 128 --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/final_bench_cfg5.json 2>/dev/null
 python bench.py --batch 2 --latent 32 --dtype bf16 --direction render --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/final_bench_cfg2.json 2>/dev/null
 for b in 5 8 10 20; do python bench.py --batch $b --steps 10 --warmup 3 --no-cpu-baseline --no-roofline > gpurun_out/final_bench_b$b.json 2>/dev/null; done
-python tools/train_bench.py --steps 3 --graph > gpurun_out/final_train_graph.json 2>/dev/null
+python tools/train_bench.py --steps 5 --graph > gpurun_out/final_train_graph.json 2>/dev/null
+UR_WGRAD=0 python tools/train_bench.py --steps 5 --graph > gpurun_out/final_train_graph_transposed_path.json 2>/dev/null
+python tools/wgrad_bench.py > gpurun_out/final_wgrad_bench.txt 2>&1
 python tools/train_bench.py --steps 3 > gpurun_out/final_train_eager.json 2>/dev/null
 python tools/loop_bench.py > gpurun_out/final_loop_bench.json 2>/dev/null
 python tools/vae_bench.py > gpurun_out/final_vae_bench.json 2>/dev/null

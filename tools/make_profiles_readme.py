@@ -88,6 +88,18 @@ addressing, ring depth 2 / 3 / 5), `r04_qkv_ab.txt` and `r04_splitk_gn_ab.txt` (
 size against the oracle loop, per-step trajectory), `r04_weight_sensitivity.json` (`tools/weight_sensitivity.py`: fp16 rounding
 of the checkpoint by parameter subset kept in fp32, oracle arithmetic), `r04_smoke.txt` (`__graft_entry__.smoke()`),
 `r04_gap_analysis.txt`, `r04_determinism.txt`.  The cfg 2 / cfg 5 lines of round 4 carry `roofline` with live traffic.
+Round 4, second half (the weight-gradient kernel `csrc/wgrad.hip`): `r04_tr_probe.txt` (`tools/ubench/tr_probe.hip`: what
+`ds_read_b64_tr_b16` returns lane by lane), `r04_wgrad_bench.txt` (`tools/wgrad_bench.py --sweep`: `ur_wgrad` per tile / ring
+depth / slice count against transposes + im2col + GEMM + column sums on 29 problems of the training step),
+`r04_wgrad_ablate.txt` (`tools/wgrad_ablate.py` on a `make WGRAD_ABL=1` library: no copies / no MFMAs / no fragment reads /
+plain 8-byte reads, with the LDS conflict counters of the full kernel), `r04_wgrad_l2.txt` (TCC hit / miss of the kernel),
+`r04_wgrad_ring.txt` (ring depth 2 / 4 / 8 at equal tiles: workgroups per CU, not bytes in flight, is the lever),
+`r04_tune_wgrad.txt` / `r04_tune_wgrad_groups.txt` (`tools/tune_wgrad.py`: the (tile, slices) table, single problems and the
+grouped launches of the deferred queue), `r04_wgrad_step_ab.txt` (graphed training step alternating `UR_WGRAD_DEFER=1`,
+`UR_WGRAD_DEFER=0`, `UR_WGRAD=0` on one box), `r04_insitu_final.txt` / `r04_insitu_train.txt` (in-situ tile tuning of the inference
+step and of the captured training step on the final tree), `r04_k32_ab.txt` (`tools/pp_ab.py --tiles 56..61`: the 32-deep-chunk
+tiles of `ur_igemm`, four workgroups per CU, against the table: slower on 39 of 40 problems; the tiles are not in the tree,
+`tools/experiments/r04_k32_tiles.patch`).
 Other summaries: `{tag}_parity_numbers.json` (every rel-L2 the `-m gpu` suite printed: the chain kernels, cfg 3 at batch 2 and 4
 and as a 5-step DDIM loop, cfg 5 vs the oracle, the 16384-token attention, UpRes, the module-surface and cfg-4 training steps
 incl. the inverse branch at SD size, the VAE, the RCCL world-size-1 collectives),

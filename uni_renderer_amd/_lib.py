@@ -146,7 +146,6 @@ SYMBOLS = {
     "ur_sizeof_tchain_desc": (C.c_int, []),
     "ur_sizeof_transpose_desc": (C.c_int, []),
     "ur_sizeof_wgrad_desc": (C.c_int, []),
-    "ur_has_k32": (C.c_int, []),
     "ur_wgrad": (C.c_int, [vp, vp]),
     "ur_wgrad_plan": (C.c_int, [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "ur_wgrad_partial_floats": (C.c_int64, [vp]),

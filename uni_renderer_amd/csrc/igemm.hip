@@ -39,18 +39,9 @@ namespace ur {
 // Here NL extra waves do NOTHING but the loader's bookkeeping and DMA issue for the whole tile, while the WM x WN
 // consumer waves run an uninterrupted MFMA stream; the barrier protocol is unchanged (one s_barrier per chunk: the
 // loader has waited for chunk t, the consumers have left the buffer chunk t+1 goes into).
-// KB = 64: a K chunk is one 128-byte line per tile row (the original formulation).  KB = 32 (round 4): 64-byte rows, half the
-// LDS per stage -- a 128 x 128 tile with a 2-stage ring is 32 KB, so FOUR workgroups (16 waves) share a CU instead of two: the
-// weight-gradient kernel (wgrad.hip) measured resident workgroups per CU as the strongest lever on these delivery-bound loops.
-// MF 16, symmetric waves, LDS-DMA ring only.  LDS image: 16-byte chunk c of row r at c ^ (((r >> 3) & 1) << 1): the four
-// 16-lane service groups of a ds_read_b128 (MI355X_MICROARCH.md) then hit 16 distinct 16-byte slots of the 256-byte window.
-template <typename T, int BM, int BN, int WM, int WN, int NSTAGE, bool CONV, int MF, int NL, int KB>
-__device__ __forceinline__ void igemm_body(const ur_igemm_desc& p) {
+template <typename T, int BM, int BN, int WM, int WN, int NSTAGE, bool CONV, int MF, int NL>
+__global__ void __launch_bounds__((WM * WN + NL) * 64) igemm_kernel(const ur_igemm_desc p) {
     typedef typename Vec8<T>::type vec8;
-    static_assert(KB == 64 || (KB == 32 && MF == 16 && NL == 0 && NSTAGE > 0), "32-deep chunks: MF 16, symmetric waves, LDS-DMA ring");
-    constexpr int RB = KB * 2;          // bytes per tile row
-    constexpr int RPP = 1024 / RB;      // tile rows per 1-KiB LDS-DMA piece
-    constexpr int RSH = KB == 64 ? 3 : 2;  // lane >> RSH = row within the piece
     constexpr int NWC = WM * WN;              // consumer waves (own the output tile)
     constexpr int NW = NL > 0 ? NL : NWC;     // waves that copy: the NL loader waves, or everybody
     static_assert(NL == 0 || NSTAGE > 0, "loader waves use the LDS-DMA ring");
@@ -60,13 +51,13 @@ __device__ __forceinline__ void igemm_body(const ur_igemm_desc& p) {
     static_assert(MF == 32 || NREP == 4, "a wave spans 64 output columns (epilogue layout)");
     static_assert(MF == 16 || ((BM / WM) % 32 == 0 && (BN / WN) % 32 == 0), "32x32 MFMA: wave tile in multiples of 32");
     constexpr int MI = BM / WM / 32, NI = BN / WN / 32;  // 32x32 blocks of a wave tile (MF == 32)
-    constexpr int XT_BYTES = BM * RB;
-    constexpr int WT_BYTES = BN * RB;
+    constexpr int XT_BYTES = BM * 128;
+    constexpr int WT_BYTES = BN * 128;
     constexpr int STAGE = XT_BYTES + WT_BYTES;
     constexpr bool REGSTAGE = NSTAGE < 0;  // register-staged loader with 2 LDS buffers
-    constexpr int XI = (BM / RPP + NW - 1) / NW;  // LDS-DMA instructions per wave per X tile (RPP rows each)
-    constexpr int WI = (BN / RPP + NW - 1) / NW;
-    static_assert(NSTAGE <= 2 || ((BM / RPP) % NW == 0 && (BN / RPP) % NW == 0), "counted vmcnt needs uniform loads per wave");
+    constexpr int XI = (BM / 8 + NW - 1) / NW;  // LDS-DMA instructions per wave per X tile (8 rows each)
+    constexpr int WI = (BN / 8 + NW - 1) / NW;
+    static_assert(NSTAGE <= 2 || ((BM / 8) % NW == 0 && (BN / 8) % NW == 0), "counted vmcnt needs uniform loads per wave");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -88,7 +79,7 @@ __device__ __forceinline__ void igemm_body(const ur_igemm_desc& p) {
     const int tile_m = tid_xy / tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-    const int kt_total = p.K / KB;
+    const int kt_total = p.K / BK;
     int kbeg = 0, kend = kt_total, zb = zidx;  // grid.z = zbatch * splitk, split index fastest
     if (p.splitk > 1) {
         zb = zidx / p.splitk;
@@ -105,7 +96,6 @@ __device__ __forceinline__ void igemm_body(const ur_igemm_desc& p) {
     // swizzled source chunk of this lane's 16 bytes in LDS-DMA piece `piece` (8 tile rows, row = 8 * piece + lane / 8):
     // key = row & 7 (MF 16) or (row >> 1) & 7 (MF 32)
     auto jsw = [&](int piece) __attribute__((always_inline)) {
-        if constexpr (KB == 32) return (lane & 3) ^ (((lane >> 5) & 1) << 1);  // row within the piece = lane >> 2; key = bit 3 of it
         return MF == 16 ? ((lane & 7) ^ (lane >> 3)) : ((lane & 7) ^ ((4 * piece + (lane >> 4)) & 7));
     };
     // padding rows: this (workgroup, wave)'s own 128-byte line of the zero region (one hot line would be served to all CUs
@@ -121,7 +111,7 @@ __device__ __forceinline__ void igemm_body(const ur_igemm_desc& p) {
     int xa[XI], xy[XI], xx[XI];
 #pragma unroll
     for (int it = 0; it < XI; ++it) {
-        const int r = (it * NW + wave) * RPP + (lane >> RSH);
+        const int r = (it * NW + wave) * 8 + (lane >> 3);
         const int m = m0 + r;
         if (CONV) {
             const int hw = p.Hout * p.Wout;
@@ -144,7 +134,7 @@ __device__ __forceinline__ void igemm_body(const ur_igemm_desc& p) {
     int winc[WI];
 #pragma unroll
     for (int it = 0; it < WI; ++it) {
-        const int r = (it * NW + wave) * RPP + (lane >> RSH);  // LDS row of the tile
+        const int r = (it * NW + wave) * 8 + (lane >> 3);  // LDS row of the tile
         int sem;
         if (MF == 16) {
             const int rho = r & 63;
@@ -157,9 +147,9 @@ __device__ __forceinline__ void igemm_body(const ur_igemm_desc& p) {
         }
         const int n = n0 + sem;
         const bool ok = n < p.N;
-        const int64_t off = ((int64_t)n * p.ldw + (int64_t)kbeg * KB + jsw(it * NW + wave) * 8) * (int64_t)sizeof(T);
+        const int64_t off = ((int64_t)n * p.ldw + (int64_t)kbeg * BK + jsw(it * NW + wave) * 8) * (int64_t)sizeof(T);
         wptr[it] = ok ? wp + off : zp;
-        winc[it] = ok ? RB : 0;
+        winc[it] = ok ? 128 : 0;
     }
 
     // segment state of the loader (all wave-uniform).  Tap-outer order (cblock == 0): segments (tap, source) of
@@ -203,18 +193,18 @@ __device__ __forceinline__ void igemm_body(const ur_igemm_desc& p) {
             }
             const int64_t off = ((int64_t)pix * ld + seg_coff + cc + jsw(it * NW + wave) * 8) * (int64_t)sizeof(T);
             xptr[it] = ok ? sb + off : zp;
-            xinc[it] = ok ? RB : 0;
+            xinc[it] = ok ? 128 : 0;
         }
     };
     {
         const int Cin = pc0 + pc1;
-        const int kglob = kbeg * KB;
+        const int kglob = kbeg * BK;
         int cc;
         if (CONV && kglob >= 9 * Cin) {  // a split-K slice that starts inside the tail
             cc = kglob - 9 * Cin;
             seg_src = 2; seg_base = t0; seg_ld = pldt0;
-            seg_left = (pct0 - cc) / KB;
-            if (cc >= pct0) { seg_src = 3; cc -= pct0; seg_base = t1; seg_ld = pldt1; seg_left = (pct1 - cc) / KB; }
+            seg_left = (pct0 - cc) / BK;
+            if (cc >= pct0) { seg_src = 3; cc -= pct0; seg_base = t1; seg_ld = pldt1; seg_left = (pct1 - cc) / BK; }
             seg_tap = 4;
         } else if (cblk > 0) {
             const int blk = kglob / (9 * cblk);
@@ -223,13 +213,13 @@ __device__ __forceinline__ void igemm_body(const ur_igemm_desc& p) {
             cc = rem - seg_tap * cblk;
             seg_src = 0;
             seg_coff = blk * cblk;
-            seg_left = (cblk - cc) / KB;
+            seg_left = (cblk - cc) / BK;
         } else {
             seg_tap = kglob / Cin;
             cc = kglob - seg_tap * Cin;
             seg_src = (cc >= pc0) ? 1 : 0;
             if (seg_src) { cc -= pc0; seg_base = x1; seg_ld = pldx1; }
-            seg_left = ((seg_src ? pc1 : pc0) - cc) / KB;
+            seg_left = ((seg_src ? pc1 : pc0) - cc) / BK;
         }
         set_pointers(cc);
     }
@@ -238,22 +228,22 @@ __device__ __forceinline__ void igemm_body(const ur_igemm_desc& p) {
         bool to_tail = false;
         if (seg_src >= 2) {
             seg_src = 3;  // tail source 0 -> 1 (or past the end of K: never loaded)
-            seg_base = t1; seg_ld = pldt1; seg_left = pct1 / KB;
+            seg_base = t1; seg_ld = pldt1; seg_left = pct1 / BK;
         } else if (cblk > 0) {
             seg_tap += 1;
             if (seg_tap == 9) { seg_tap = 0; seg_coff += cblk; }
-            seg_left = cblk / KB;
+            seg_left = cblk / BK;
             to_tail = CONV && seg_coff >= pc0;
         } else {
             seg_src += 1;
             if (seg_src >= segs_per_tap) { seg_src = 0; seg_tap += 1; }
             seg_base = seg_src ? x1 : x0;
             seg_ld = seg_src ? pldx1 : pldx0;
-            seg_left = (seg_src ? pc1 : pc0) / KB;
+            seg_left = (seg_src ? pc1 : pc0) / BK;
             to_tail = CONV && seg_tap == 9;
         }
         if (to_tail) {  // centre tap of the tail sources (stride 1, no upsampling: output pixel = input pixel)
-            seg_src = 2; seg_base = t0; seg_ld = pldt0; seg_left = pct0 / KB;
+            seg_src = 2; seg_base = t0; seg_ld = pldt0; seg_left = pct0 / BK;
             seg_tap = 4; seg_coff = 0;
         }
         // the segment state is wave-uniform by construction; say so, or it lives in VGPRs (and spills)
@@ -280,15 +270,15 @@ __device__ __forceinline__ void igemm_body(const ur_igemm_desc& p) {
 #if defined(UR_ABLATE) && UR_ABLATE == 3
             // timing-only upper bound of "the three dx taps share one staged pixel block" (DESIGN.md section 4, round 4): the
             // pixel tile is copied for one tap in three, the other two multiply stale LDS contents (results are garbage)
-            if (it * NW + wave < BM / RPP && !(CONV && seg_src < 2 && (seg_tap % 3) != 0)) glds16(xptr[it], xs + (it * NW + wave) * 1024);
+            if (it * NW + wave < BM / 8 && !(CONV && seg_src < 2 && (seg_tap % 3) != 0)) glds16(xptr[it], xs + (it * NW + wave) * 1024);
 #else
-            if (it * NW + wave < BM / RPP) glds16(xptr[it], xs + (it * NW + wave) * 1024);
+            if (it * NW + wave < BM / 8) glds16(xptr[it], xs + (it * NW + wave) * 1024);
 #endif
             xptr[it] += xinc[it];
         }
 #pragma unroll
         for (int it = 0; it < WI; ++it) {
-            if (it * NW + wave < BN / RPP) glds16(wptr[it], ws + (it * NW + wave) * 1024);
+            if (it * NW + wave < BN / 8) glds16(wptr[it], ws + (it * NW + wave) * 1024);
             wptr[it] += winc[it];
         }
         seg_left -= 1;
@@ -303,12 +293,12 @@ __device__ __forceinline__ void igemm_body(const ur_igemm_desc& p) {
     auto gload = [&]() {
 #pragma unroll
         for (int it = 0; it < XI; ++it) {
-            if (it * NW + wave < BM / RPP) xr[it] = *reinterpret_cast<const u32x4*>(xptr[it]);
+            if (it * NW + wave < BM / 8) xr[it] = *reinterpret_cast<const u32x4*>(xptr[it]);
             xptr[it] += xinc[it];
         }
 #pragma unroll
         for (int it = 0; it < WI; ++it) {
-            if (it * NW + wave < BN / RPP) wr[it] = *reinterpret_cast<const u32x4*>(wptr[it]);
+            if (it * NW + wave < BN / 8) wr[it] = *reinterpret_cast<const u32x4*>(wptr[it]);
             wptr[it] += winc[it];
         }
         seg_left -= 1;
@@ -319,10 +309,10 @@ __device__ __forceinline__ void igemm_body(const ur_igemm_desc& p) {
         char* ws = xs + XT_BYTES;
 #pragma unroll
         for (int it = 0; it < XI; ++it)
-            if (it * NW + wave < BM / RPP) *reinterpret_cast<u32x4*>(xs + (it * NW + wave) * 1024) = xr[it];
+            if (it * NW + wave < BM / 8) *reinterpret_cast<u32x4*>(xs + (it * NW + wave) * 1024) = xr[it];
 #pragma unroll
         for (int it = 0; it < WI; ++it)
-            if (it * NW + wave < BN / RPP) *reinterpret_cast<u32x4*>(ws + (it * NW + wave) * 1024) = wr[it];
+            if (it * NW + wave < BN / 8) *reinterpret_cast<u32x4*>(ws + (it * NW + wave) * 1024) = wr[it];
     };
 
     f32x4 acc[MF == 16 ? MREP : 1][MF == 16 ? NREP : 1];
@@ -368,19 +358,6 @@ __device__ __forceinline__ void igemm_body(const ur_igemm_desc& p) {
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni) acc32[mi][ni] = mfma32(wf[ni], xf[mi], acc32[mi][ni]);
             }
-        } else if constexpr (KB == 32) {
-            const int c = (q ^ (((l15 >> 3) & 1) << 1)) << 4;  // one 32-deep step: chunk q of the lane's 64-byte row, swizzled
-            vec8 wf[NREP], xf[MREP];
-#pragma unroll
-            for (int f = 0; f < NREP; ++f)
-                wf[f] = *reinterpret_cast<const vec8*>(ws + (wn * 64 + f * 16 + l15) * RB + c);
-#pragma unroll
-            for (int mf = 0; mf < MREP; ++mf)
-                xf[mf] = *reinterpret_cast<const vec8*>(xs + (wm * (16 * MREP) + mf * 16 + l15) * RB + c);
-#pragma unroll
-            for (int mf = 0; mf < MREP; ++mf)
-#pragma unroll
-                for (int f = 0; f < NREP; ++f) acc[mf][f] = mfma16(wf[f], xf[mf], acc[mf][f]);
         } else {
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
@@ -514,17 +491,6 @@ __device__ __forceinline__ void igemm_body(const ur_igemm_desc& p) {
             finish(m, nc, v);
         }
     }
-}
-
-template <typename T, int BM, int BN, int WM, int WN, int NSTAGE, bool CONV, int MF, int NL>
-__global__ void __launch_bounds__((WM * WN + NL) * 64) igemm_kernel(const ur_igemm_desc p) {
-    igemm_body<T, BM, BN, WM, WN, NSTAGE, CONV, MF, NL, 64>(p);
-}
-
-// 32-deep chunks: registers capped at 128 so that four waves per SIMD are resident (4-wave workgroups: four per CU)
-template <typename T, int BM, int BN, int WM, int WN, int NSTAGE, bool CONV>
-__global__ void __launch_bounds__(WM * WN * 64, 4) igemm_k32_kernel(const ur_igemm_desc p) {
-    igemm_body<T, BM, BN, WM, WN, NSTAGE, CONV, 16, 0, 32>(p);
 }
 
 // Second pass of split-K: sum the fp32 slabs and run the epilogue.  One thread per (row, 16 columns).
@@ -661,9 +627,7 @@ static const TileCfg kTiles[UR_TILE_COUNT] = {{0, 0, 0},      {128, 128, 2}, {12
                                               {128, 320, 2}, {128, 320, 2},
                                               // 8-wave ping-pong builds (igemm_pp.hip)
                                               {128, 320, 5}, {128, 320, 4}, {256, 128, 5}, {128, 256, 5}, {256, 256, 4},
-                                              {128, 128, 5}, {256, 320, 4},
-                                              // 32-deep K chunks (igemm_k32_kernel)
-                                              {128, 128, 2}, {128, 64, 2}, {128, 128, 3}, {256, 128, 2}, {64, 64, 2}, {128, 256, 2}};
+                                              {128, 128, 5}, {256, 320, 4}};
 
 static int pick_tile(const ur_igemm_desc& d) {
     // Cost model: the busiest CU runs ceil(workgroups / 256) tiles; bigger tiles have a better
@@ -703,32 +667,6 @@ static int launch_cfg(const ur_igemm_desc& d, hipStream_t s, bool reduce) {
     e = hipGetLastError();
     if (e != hipSuccess) return -(int)e;
     if (d.splitk > 1) {
-        const int64_t total = (int64_t)d.M * (d.ldp / 16);
-        int blocks = (int)((total + 255) / 256);
-        if (blocks > 4096) blocks = 4096;
-        hipLaunchKernelGGL((igemm_splitk_reduce<T>), dim3(blocks, d.zbatch), dim3(256), 0, s, d);
-        e = hipGetLastError();
-        if (e != hipSuccess) return -(int)e;
-    }
-    return 0;
-}
-
-template <typename T, int BM, int BN, int WM, int WN, int NSTAGE>
-static int launch_k32(const ur_igemm_desc& d, hipStream_t s, bool reduce) {
-    static std::atomic<uint64_t> done_c{0}, done_l{0};
-    const int tiles_m = (d.M + BM - 1) / BM, tiles_n = (d.N + BN - 1) / BN;
-    dim3 grid(tiles_m * tiles_n, 1, d.zbatch * d.splitk);
-    constexpr int lds = NSTAGE * (BM + BN) * 64;
-    if (d.taps == 9) {
-        set_lds_limit_once(done_c, reinterpret_cast<const void*>(&igemm_k32_kernel<T, BM, BN, WM, WN, NSTAGE, true>), lds);
-        hipLaunchKernelGGL((igemm_k32_kernel<T, BM, BN, WM, WN, NSTAGE, true>), grid, dim3(WM * WN * 64), lds, s, d);
-    } else {
-        set_lds_limit_once(done_l, reinterpret_cast<const void*>(&igemm_k32_kernel<T, BM, BN, WM, WN, NSTAGE, false>), lds);
-        hipLaunchKernelGGL((igemm_k32_kernel<T, BM, BN, WM, WN, NSTAGE, false>), grid, dim3(WM * WN * 64), lds, s, d);
-    }
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return -(int)e;
-    if (d.splitk > 1 && reduce) {
         const int64_t total = (int64_t)d.M * (d.ldp / 16);
         int blocks = (int)((total + 255) / 256);
         if (blocks > 4096) blocks = 4096;
@@ -864,14 +802,6 @@ static int launch_dtype(ur_igemm_desc& d, hipStream_t s, bool reduce) {
         case UR_TILE_WS320_W8: return launch_ws<T>(d, s, reduce);
         case UR_TILE_PP_128x320: case UR_TILE_PP_128x320_S4: case UR_TILE_PP_256x128: case UR_TILE_PP_128x256:
         case UR_TILE_PP_256x256: case UR_TILE_PP_128x128: case UR_TILE_PP_256x320: return launch_pp<T>(d, s, reduce);
-#ifdef UR_WITH_K32  // measured 10-20 % slower than the table on 39 of the step's 40 heavy problems: an opt-in build (make K32=1)
-        case UR_TILE_K32_128x128: return launch_k32<T, 128, 128, 2, 2, 2>(d, s, reduce);
-        case UR_TILE_K32_128x64: return launch_k32<T, 128, 64, 4, 1, 2>(d, s, reduce);
-        case UR_TILE_K32_128x128_S3: return launch_k32<T, 128, 128, 2, 2, 3>(d, s, reduce);
-        case UR_TILE_K32_256x128: return launch_k32<T, 256, 128, 4, 2, 2>(d, s, reduce);
-        case UR_TILE_K32_64x64: return launch_k32<T, 64, 64, 4, 1, 2>(d, s, reduce);
-        case UR_TILE_K32_128x256: return launch_k32<T, 128, 256, 2, 4, 2>(d, s, reduce);
-#endif
     }
     return UR_E_BADARG;
 }
@@ -882,14 +812,6 @@ static int64_t padded_ldp(const ur_igemm_desc& d, int tile) {
 }
 
 }  // namespace ur
-
-extern "C" int ur_has_k32(void) {
-#ifdef UR_WITH_K32
-    return 1;
-#else
-    return 0;
-#endif
-}
 
 extern "C" int ur_has_wsconv(void) {
 #ifdef UR_WITH_WSCONV

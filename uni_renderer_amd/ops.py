@@ -44,16 +44,7 @@ _TILES = {TILE_128x128: (128, 128, 1.0, 2), TILE_128x64: (128, 64, 0.85, 3), TIL
           47: (128, 320, 1.4, "ws"), 48: (128, 320, 1.4, "ws8"),
           # 8-wave ping-pong builds (csrc/igemm_pp.hip): "pp<ring slots>"
           49: (128, 320, 1.5, "pp5"), 50: (128, 320, 1.5, "pp4"), 51: (256, 128, 1.4, "pp5"), 52: (128, 256, 1.4, "pp5"),
-          53: (256, 256, 1.5, "pp4"), 54: (128, 128, 1.2, "pp5"), 55: (256, 320, 1.5, "pp4"),
-          # 32-deep K chunks, <= 128 registers: four 4-wave workgroups per CU (igemm_k32_kernel): "k32s<stages>"
-          56: (128, 128, 1.2, "k32s2"), 57: (128, 64, 1.0, "k32s2"), 58: (128, 128, 1.2, "k32s3"), 59: (256, 128, 1.3, "k32s2"),
-          60: (64, 64, 0.8, "k32s2"), 61: (128, 256, 1.3, "k32s2")}
-K32_TILES = tuple(range(56, 62))
-
-
-def k32_built() -> bool:
-    """True when liburhip.so carries the 32-deep-chunk tiles (``make K32=1``; not in the product build)."""
-    return bool(_lib.load().ur_has_k32())
+          53: (256, 256, 1.5, "pp4"), 54: (128, 128, 1.2, "pp5"), 55: (256, 320, 1.5, "pp4")}
 TILE_PP_128x320, TILE_PP_128x320_S4, TILE_PP_256x128, TILE_PP_128x256, TILE_PP_256x256, TILE_PP_128x128, TILE_PP_256x320 = range(49, 56)
 TILE_WS320, TILE_WS320_W8 = 47, 48
 # which build ``conv3x3(ws=...)`` launches: 8 waves per workgroup (two instruction streams per SIMD) or 4 (one)
