@@ -36,7 +36,10 @@ def _alive(table: dict, ptr: int) -> bool:
 def _can_defer(w, b) -> bool:
     if not bw.WGRAD_DEFER or not bw.WGRAD or not _alive(_deferred_w, w.untyped_storage().data_ptr()):
         return False
-    return b is None or _alive(_deferred_b, b.data_ptr())
+    if b is None:
+        return True
+    ref = _deferred_b.get(b.data_ptr())
+    return ref is not None and ref() is b   # the barrier's output OBJECT, not merely a tensor at the parameter's address
 
 
 class Linear(Function):

@@ -358,6 +358,10 @@ class WgradQueue:
         self.items.append((dy2, x2, dw, db, conv))
         return dw, db
 
+    def reset(self):
+        """Drop whatever is pending (a backward that raised half-way leaves entries whose gradients nobody will read)."""
+        self.items, self.seen = [], set()
+
     def flush(self):
         items, self.items, self.seen = self.items, [], set()
         groups: dict = {}

@@ -410,6 +410,7 @@ def _forward_backward(nets, batch, optimizer, buckets, dtype, inverse, grad_accu
     fresh = (n == 1 and loss_scale is None and scaler is None and buckets is None
              and all(p.grad is None for p in _parameters(nets)))
     B.grad_squares.begin(token=_nets_token(nets), trusted=fresh)
+    B.wgrad_queue.reset()
     report = loss.detach()
     if n > 1:
         loss = loss / n
