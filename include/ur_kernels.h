@@ -407,6 +407,11 @@ int ur_geglu_backward(const void* h, const void* dy, void* dh, int64_t M, int D,
 int ur_groupnorm_backward(const void* x, const void* dy, int C, int B, int rows, int groups, int nstat,
                           const float* partial, const float* gamma, const float* beta, float eps, int silu, int nred,
                           float* chan_part, float* chan_sum, int nchunks, void* dx, int dtype, void* stream);
+/* The same gradient in ONE launch for small maps (one 1024-thread workgroup per (sample, group); no forward statistics, no
+ * workspace): dx and chan_sum[b][C][2] as ur_groupnorm_backward leaves them.  Group width C / groups even and <= 128
+ * (UR_E_UNSUPPORTED otherwise); meant for <= ~1024 pixels per sample (the 32x32 / 16x16 / 8x8 levels). */
+int ur_groupnorm_backward_fused(const void* x, const void* dy, int C, int B, int rows, int groups, const float* gamma,
+                                const float* beta, float eps, int silu, float* chan_sum, void* dx, int dtype, void* stream);
 /* ... with `skip` (NULL or [rows][C] dtype): dx += skip -- the gradient of a residual connection around the norm (ABI 7) */
 int ur_layernorm_backward_skip(const void* x, const void* dy, const float* gamma, float eps, int rows, int C,
                                int rows_per_wave, void* dx, float* part, const void* skip, int dtype, void* stream);

@@ -103,6 +103,35 @@ def test_groupnorm_backward(dev, dtype, silu, C):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("silu", [False, True])
+@pytest.mark.parametrize("shape", [(4, 32, 32, 640), (1, 16, 16, 960), (2, 8, 8, 2560), (3, 16, 8, 1920), (2, 32, 32, 320)])
+def test_groupnorm_backward_one_launch_against_the_chunked_path(dev, dtype, silu, shape, monkeypatch):
+    """ur_groupnorm_backward_fused (one workgroup per (sample, group): the 32x32 / 16x16 / 8x8 maps of the training step, group
+    widths 10 .. 80 = pieces of 2 / 4 / 8 channels) against fp32 autograd and against the four-launch path on the same inputs."""
+    from uni_renderer_amd import backward as bw
+    B, H, W, C = shape
+    x = _rand((B, H, W, C), dtype, dev, 1, 1.5) + 0.3
+    dy = _rand((B, H, W, C), dtype, dev, 2)
+    gam = torch.randn(C, generator=torch.Generator().manual_seed(3)).to(dev)
+    bet = torch.randn(C, generator=torch.Generator().manual_seed(4)).to(dev)
+    assert H * W <= bw.GN_BWD_FUSED_MAX_ROWS
+    dx, dg, db = bw.groupnorm_backward(x, dy, gam, bet, 1e-5, groups=32, silu=silu)
+    monkeypatch.setattr(bw, "GN_BWD_FUSED_MAX_ROWS", 0)
+    dx2, dg2, db2 = bw.groupnorm_backward(x, dy, gam, bet, 1e-5, groups=32, silu=silu)
+    xr = x.float().cpu().permute(0, 3, 1, 2).contiguous().requires_grad_()
+    gr, br = gam.cpu().clone().requires_grad_(), bet.cpu().clone().requires_grad_()
+    y = F.group_norm(xr, 32, gr, br, 1e-5)
+    if silu:
+        y = F.silu(y)
+    (y * dy.float().cpu().permute(0, 3, 1, 2)).sum().backward()
+    for got, ref, tol in ((dx, xr.grad.permute(0, 2, 3, 1), 2.0), (dg, gr.grad, 1.0), (db, br.grad, 1.0)):
+        assert rel_l2(got, ref) < TOL[dtype] * tol
+    assert rel_l2(dx, dx2.float().cpu()) < TOL[dtype] and rel_l2(dg, dg2.cpu()) < 1e-4 and rel_l2(db, db2.cpu()) < 1e-4
+    dx3, dg3, db3 = (lambda: (monkeypatch.setattr(bw, "GN_BWD_FUSED_MAX_ROWS", 1024), bw.groupnorm_backward(x, dy, gam, bet, 1e-5, groups=32, silu=silu))[1])()
+    assert torch.equal(dx, dx3) and torch.equal(dg, dg3) and torch.equal(db, db3)   # fixed-order sums
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("C", [320, 640, 1280])
 def test_layernorm_backward(dev, dtype, C):
     from uni_renderer_amd import backward as bw

@@ -124,6 +124,8 @@ SYMBOLS = {
     "ur_geglu_backward": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int, C.c_int, vp]),
     "ur_groupnorm_backward": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_float,
                                         C.c_int, C.c_int, vp, vp, C.c_int, vp, C.c_int, vp]),
+    "ur_groupnorm_backward_fused": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_float, C.c_int, vp, vp,
+                                              C.c_int, vp]),
     "ur_layernorm_backward": (C.c_int, [vp, vp, vp, C.c_float, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp]),
     "ur_layernorm_backward_skip": (C.c_int, [vp, vp, vp, C.c_float, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp]),
     "ur_split_heads": (C.c_int, [vp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp]),

@@ -589,6 +589,11 @@ def geglu_backward(h: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
     return dh
 
 
+# GroupNorm backward of maps up to this many pixels per sample in ONE launch (ur_groupnorm_backward_fused) instead of
+# statistics + channel partials + fold + dx; 0 disables (the A/B of tools/experiments/r04_run35.sh)
+GN_BWD_FUSED_MAX_ROWS = int(os.environ.get("UR_GN_BWD_FUSED_MAX_ROWS", "1024"))
+
+
 def groupnorm_backward(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float,
                        groups: int = 32, silu: bool = False, stats: Optional[torch.Tensor] = None
                        ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
@@ -599,8 +604,20 @@ def groupnorm_backward(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, b
     lib = _lib.load()
     B, Cc = x.shape[0], x.shape[-1]
     rows = x.numel() // (B * Cc)
-    nstat, nchunks = ops._gn_chunks_bytes(B, rows, Cc, x.element_size())
+    cpg = Cc // groups
     s = _stream()
+    if (rows <= GN_BWD_FUSED_MAX_ROWS and cpg % 2 == 0 and cpg <= 128 and Cc % 8 == 0 and x.is_contiguous() and dy.is_contiguous()
+            and x.data_ptr() % 16 == 0 and dy.data_ptr() % 16 == 0):
+        # small maps: one workgroup per (sample, group) does statistics, channel sums and dx in one launch
+        chan_sum = torch.empty(B, Cc, 2, dtype=torch.float32, device=x.device)
+        dx = torch.empty_like(x)
+        check(lib.ur_groupnorm_backward_fused(x.data_ptr(), dy.data_ptr(), Cc, B, rows, groups, gamma.data_ptr(), beta.data_ptr(),
+                                              float(eps), int(silu), chan_sum.data_ptr(), dx.data_ptr(), DT[x.dtype], s),
+              "ur_groupnorm_backward_fused")
+        sums = torch.empty(2, Cc, dtype=torch.float32, device=x.device)
+        check(lib.ur_pairsum_rows(chan_sum.data_ptr(), B, Cc, sums.data_ptr(), s), "ur_pairsum_rows")
+        return dx, sums[1], sums[0]
+    nstat, nchunks = ops._gn_chunks_bytes(B, rows, Cc, x.element_size())
     if stats is not None and stats.numel() == B * nstat * groups * 2:
         part = stats  # the forward's partial statistics (ops.groupnorm(return_stats=True)): same chunking, x not re-read
     else:

@@ -448,6 +448,148 @@ __global__ void __launch_bounds__(256) gn_bwd_reduce_kernel(const T* __restrict_
     }
 }
 
+// GroupNorm backward in ONE launch for the small maps (<= 1024 pixels per sample: the 32x32 / 16x16 / 8x8 levels): one
+// 1024-thread workgroup per (sample, group) owns the group's [rows][cpg] strip -- statistics, the per-channel sums
+// (sum dz, sum dz * xhat) and dx need no other workgroup.  Three sweeps over x and two over dy, all but the first from the
+// XCD's L2 (workgroups of one sample sit on one XCD: neighbouring groups share the 128-byte lines of the strip, as in
+// gn_fused_kernel).  Replaces ur_groupnorm_stats + gn_bwd_reduce + gn_bwd_fold + gn_bwd_apply (the forward of these maps is
+// the one-launch GroupNorm, which keeps no statistics).  A thread keeps ONE piece of P channels for all its rows, so the
+// per-channel sums stay in registers until one fixed-order fold through LDS.
+constexpr int GNB_THREADS = 1024;
+
+template <typename T, int P>
+__device__ __forceinline__ void gnb_load(const T* p, float (&v)[P]) {
+    if constexpr (P == 8) {
+        load8(p, v);
+    } else if constexpr (P == 4) {
+        const uint2 raw = *reinterpret_cast<const uint2*>(p);
+        T h[4];
+        __builtin_memcpy(h, &raw, 8);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = to_f(h[i]);
+    } else {
+        const unsigned raw = *reinterpret_cast<const unsigned*>(p);
+        T h[2];
+        __builtin_memcpy(h, &raw, 4);
+        v[0] = to_f(h[0]);
+        v[1] = to_f(h[1]);
+    }
+}
+template <typename T, int P>
+__device__ __forceinline__ void gnb_store(T* p, const float (&v)[P]) {
+    if constexpr (P == 8) {
+        store8(p, v);
+    } else {
+        T h[P];
+#pragma unroll
+        for (int i = 0; i < P; ++i) h[i] = from_f<T>(v[i]);
+        if constexpr (P == 4) { uint2 raw; __builtin_memcpy(&raw, h, 8); *reinterpret_cast<uint2*>(p) = raw; }
+        else { unsigned raw; __builtin_memcpy(&raw, h, 4); *reinterpret_cast<unsigned*>(p) = raw; }
+    }
+}
+
+template <typename T, int P>
+__global__ void __launch_bounds__(GNB_THREADS) gn_bwd_fused_kernel(const T* __restrict__ x, const T* __restrict__ dy, int C, int rows,
+                                                                   int groups, const float* __restrict__ gamma,
+                                                                   const float* __restrict__ beta, float eps, int silu,
+                                                                   float* __restrict__ chan_sum, T* __restrict__ dx) {
+    __shared__ float2 red[GNB_THREADS / 64];
+    __shared__ float2 csum[128];                 // per channel of the group: (sum dz, sum dz * xhat)
+    __shared__ float2 part[GNB_THREADS];         // one (sum dz, sum dz * xhat) per thread, one channel of the piece at a time
+    __shared__ float2 gab;                       // (A, Bg) of the group
+    const int lid = xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
+    const int t = threadIdx.x, g = lid % gridDim.x, b = lid / gridDim.x;
+    const int cpg = C / groups, ppr = cpg / P;   // pieces per row
+    const int R = GNB_THREADS / ppr;             // rows per sweep step; threads >= R * ppr idle
+    const int pc = t % ppr, r0 = t / ppr;
+    const bool active = r0 < R;
+    const int c0 = g * cpg + pc * P;
+    const T* xb = x + (int64_t)b * rows * C + c0;
+    const T* db = dy + (int64_t)b * rows * C + c0;
+    T* ob = dx + (int64_t)b * rows * C + c0;
+
+    // ---- sweep 1: statistics of the strip ----
+    float s1 = 0.f, s2 = 0.f;
+    if (active) {
+        for (int r = r0; r < rows; r += R) {
+            float v[P];
+            gnb_load<T, P>(xb + (int64_t)r * C, v);
+#pragma unroll
+            for (int k = 0; k < P; ++k) { s1 += v[k]; s2 += v[k] * v[k]; }
+        }
+    }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if ((t & 63) == 0) red[t >> 6] = make_float2(s1, s2);
+    __syncthreads();
+    const float n = (float)rows * (float)cpg;
+    float sum = 0.f, sq = 0.f;
+#pragma unroll
+    for (int w = 0; w < GNB_THREADS / 64; ++w) { sum += red[w].x; sq += red[w].y; }  // fixed order
+    const float mean = sum / n;
+    const float rstd = rsqrtf(fmaxf(sq / n - mean * mean, 0.f) + eps);
+
+    float gm[P], bt[P];
+#pragma unroll
+    for (int k = 0; k < P; ++k) { gm[k] = gamma[c0 + k]; bt[k] = beta[c0 + k]; }
+
+    // ---- sweep 2: per-channel sums of dz and dz * xhat ----
+    float sd[P], sx[P];
+#pragma unroll
+    for (int k = 0; k < P; ++k) { sd[k] = 0.f; sx[k] = 0.f; }
+    if (active) {
+        for (int r = r0; r < rows; r += R) {
+            float xv[P], dv[P];
+            gnb_load<T, P>(xb + (int64_t)r * C, xv);
+            gnb_load<T, P>(db + (int64_t)r * C, dv);
+#pragma unroll
+            for (int k = 0; k < P; ++k) {
+                const float xh = (xv[k] - mean) * rstd;
+                const float dz = silu ? dv[k] * silu_grad_f(xh * gm[k] + bt[k]) : dv[k];
+                sd[k] += dz;
+                sx[k] += dz * xh;
+            }
+        }
+    }
+    // fold the R row lanes of every channel in a fixed order: channel k of piece pc is summed by thread (pc, row lane 0)
+#pragma unroll
+    for (int k = 0; k < P; ++k) {
+        __syncthreads();
+        part[t] = make_float2(sd[k], sx[k]);
+        __syncthreads();
+        if (t < ppr) {
+            float a = 0.f, a2 = 0.f;
+            for (int j = 0; j < R; ++j) { const float2 v = part[j * ppr + t]; a += v.x; a2 += v.y; }
+            csum[t * P + k] = make_float2(a, a2);
+        }
+    }
+    __syncthreads();
+    if (t < cpg) reinterpret_cast<float2*>(chan_sum)[(int64_t)b * C + g * cpg + t] = csum[t];
+    if (t == 0) {
+        float a = 0.f, a2 = 0.f;
+        for (int c = 0; c < cpg; ++c) { a += gamma[g * cpg + c] * csum[c].x; a2 += gamma[g * cpg + c] * csum[c].y; }
+        gab = make_float2(a / n, a2 / n);
+    }
+    __syncthreads();
+    const float A = gab.x, Bg = gab.y;
+
+    // ---- sweep 3: dx ----
+    if (active) {
+        for (int r = r0; r < rows; r += R) {
+            float xv[P], dv[P];
+            gnb_load<T, P>(xb + (int64_t)r * C, xv);
+            gnb_load<T, P>(db + (int64_t)r * C, dv);
+#pragma unroll
+            for (int k = 0; k < P; ++k) {
+                const float xh = (xv[k] - mean) * rstd;
+                const float dz = silu ? dv[k] * silu_grad_f(xh * gm[k] + bt[k]) : dv[k];
+                xv[k] = rstd * (dz * gm[k] - A - xh * Bg);
+            }
+            gnb_store<T, P>(ob + (int64_t)r * C, xv);
+        }
+    }
+}
+
 // chan_sum[b][c] = sum over the nred chunks of chan_part[b][chunk][c] (fixed order); one thread per (channel, component)
 // A workgroup folds 32 columns: eight 32-lane groups each sum a contiguous eighth of the chunks (up to 512 dependent adds
 // in one thread made this 16 us on a dozen workgroups), then the eight partial sums are added in group order.
@@ -1019,6 +1161,25 @@ extern "C" int ur_groupnorm_backward(const void* x, const void* dy, int C, int B
         hipLaunchKernelGGL((gn_bwd_apply_kernel<T>), dim3(nchunks, B), dim3(256), 0, s, (const T*)x, (const T*)dy, C, rows,
                            groups, nstat, 1, nchunks, partial, chan_sum, gamma, beta, eps, silu, (T*)dx);
     });
+    return last_error();
+}
+
+extern "C" int ur_groupnorm_backward_fused(const void* x, const void* dy, int C, int B, int rows, int groups, const float* gamma,
+                                           const float* beta, float eps, int silu, float* chan_sum, void* dx, int dtype,
+                                           void* stream) {
+    if (!x || !dy || !gamma || !beta || !chan_sum || !dx || C <= 0 || B <= 0 || rows <= 0 || groups <= 0 || C % groups)
+        return UR_E_BADARG;
+    const int cpg = C / groups;
+    if (cpg > 128 || (cpg & 1) || (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15) || (C & 7)) return UR_E_UNSUPPORTED;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    dim3 grid(groups, B);
+#define UR_GNB(PP)                                                                                                        \
+    UR_DISPATCH(dtype, hipLaunchKernelGGL((gn_bwd_fused_kernel<T, PP>), grid, dim3(GNB_THREADS), 0, s, (const T*)x, (const T*)dy, C, \
+                                          rows, groups, gamma, beta, eps, silu, chan_sum, (T*)dx))
+    if (cpg % 8 == 0) { UR_GNB(8); }
+    else if (cpg % 4 == 0) { UR_GNB(4); }
+    else { UR_GNB(2); }
+#undef UR_GNB
     return last_error();
 }
 
