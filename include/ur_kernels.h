@@ -532,8 +532,9 @@ int ur_adamw_multi(const ur_adamw_tensor* tensors, int n_tensors, float lr, floa
  * there are few keys), every sum in a fixed order.  All matrices are the reference's token matrices [B][T][ld] with head
  * h at columns h*d .. h*d+d-1 of the pointer handed in (q | k | v parts of a fused projection = column offsets):
  *   q, o, dout  [B][Tq][ld*]     k, v  [B][Tk][ld*]          dq | dk, dv: same layouts as q | k, v
- *   qt, dot     [B][H*d][ldqt | lddot]  transposes of q, dout (ur_transpose2d), row stride >= Tq
- *   kt          [B][H*d][ldkt]          transpose of k, row stride >= Tk rounded up to 64, columns >= Tk ZERO
+ *   qt, dot, kt ABI <= 8: transposes of q, dout, k ([B][H*d][ld]).  ABI 9: NOT READ any more (may be NULL, ld* ignored): the
+ *               kernels gather the transposed MFMA fragments from the row-major tiles with the LDS transpose read;
+ *               ur_attention_backward_needs_transposes() is 0 (1 only in a library built with -DUR_ATTN_BWD_TRN=1)
  *   stats       [2][B*H][Tq] fp32 workspace (row log-sum-exp in log2 units | rowsum(dout * o)), written here;
  *               has_lse = 1: the first half already holds the forward's ur_attn_desc.lse
  * Per-head copies are the same interface with B = batch * heads, H = 1, d = the padded head dim (what the host side
@@ -556,6 +557,7 @@ typedef struct ur_attn_bwd_desc {
 int ur_attention_backward(const ur_attn_bwd_desc* d, void* stream);
 int ur_attention_backward_supported(int Tq, int Tk, int d);
 int ur_attention_backward_splits(int S, int Tq, int Tk64, int dp);
+int ur_attention_backward_needs_transposes(void);
 
 /* Attention backward helpers: P = softmax(Q K^T * scale) is recomputed and materialised per (batch, head); the five
  * GEMMs of the gradient (S, dV = P^T dO, dP = dO V^T, dQ = dS K, dK = dS^T Q) run z-batched on ur_igemm.

@@ -135,6 +135,7 @@ SYMBOLS = {
     "ur_attention_backward": (C.c_int, [C.POINTER(AttnBwdDesc), vp]),
     "ur_attention_backward_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "ur_attention_backward_splits": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "ur_attention_backward_needs_transposes": (C.c_int, []),
     "ur_transpose2d_multi": (C.c_int, [vp, C.c_int, C.c_int, vp]),
     "ur_cast_multi": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp]),
     "ur_cast_multi_blocks": (C.c_int64, [vp, C.c_int]),

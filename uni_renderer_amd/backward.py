@@ -704,6 +704,9 @@ def _flash_attention_backward(q, k, v, o, do, H, scale, fused_qkv, oq, ok, ov, C
     S, dp = B * H, (d + 31) // 32 * 32
     esz = q.element_size()
     direct = d >= FLASH_DIRECT_MIN_D
+    # the transposed copies q^T, k^T, dO^T: only a library built with -DUR_ATTN_BWD_TRN=1 still reads them (ABI 9: the kernels
+    # gather the transposed fragments from the row-major tiles with the LDS transpose read)
+    need_t = bool(lib.ur_attention_backward_needs_transposes())
     has_lse = stats is not None and tuple(stats.shape) == (2, S, Tq)
     if not has_lse:
         stats = torch.empty(2, S, Tq, dtype=torch.float32, device=q.device)
@@ -714,10 +717,11 @@ def _flash_attention_backward(q, k, v, o, do, H, scale, fused_qkv, oq, ok, ov, C
         for t in (q, k, v, o, do):
             if t.stride(2) != 1 or t.stride(0) != t.shape[1] * t.stride(1):
                 raise RuntimeError("flash attention backward: [B, T, ld] operands with contiguous batches")
-        # [B, C, T], one launch; the key side zero-padded to the 64-key tiles by the launch itself
-        qt, kt, dot_ = transpose2d_many([q[..., oq:oq + Cc], k[..., ok:ok + Cc], do], pad64=((1,) if Tk % 64 else ()))
-        if kt.shape[-1] != Tkp:
-            kt = _pad_rows64(kt)
+        qt = kt = dot_ = None
+        if need_t:  # ABI <= 8 libraries: [B, C, T], one launch; the key side zero-padded to the 64-key tiles by the launch itself
+            qt, kt, dot_ = transpose2d_many([q[..., oq:oq + Cc], k[..., ok:ok + Cc], do], pad64=((1,) if Tk % 64 else ()))
+            if kt.shape[-1] != Tkp:
+                kt = _pad_rows64(kt)
         if fused_qkv:
             g = torch.empty(B, Tq, 3 * Cc, dtype=q.dtype, device=q.device)
             outs, ldg, offs = (g, g, g), 3 * Cc, (oq, ok, ov)
@@ -734,14 +738,15 @@ def _flash_attention_backward(q, k, v, o, do, H, scale, fused_qkv, oq, ok, ov, C
     else:
         qp, kp, vp = _split_heads(q, H, d, Tq, dp, oq), _split_heads(k, H, d, Tkp, dp, ok), _split_heads(v, H, d, Tkp, dp, ov)
         op, dop = _split_heads(o, H, d, Tq, dp), _split_heads(do, H, d, Tq, dp)       # [S, T, dp]
-        qt, kt, dot_ = transpose2d_many([qp, kp, dop])                                # [S, dp, T], one launch
+        qt, kt, dot_ = transpose2d_many([qp, kp, dop]) if need_t else (None, None, None)  # [S, dp, T], one launch
         dQ, dK, dV = torch.empty_like(qp), torch.empty_like(kp), torch.empty_like(kp)
         a.q, a.k, a.v, a.o, a.dout = qp.data_ptr(), kp.data_ptr(), vp.data_ptr(), op.data_ptr(), dop.data_ptr()
         a.ldq = a.ldk = a.ldv = a.ldo = a.lddo = a.lddq = a.lddk = a.lddv = dp
         a.dq, a.dk, a.dv = dQ.data_ptr(), dK.data_ptr(), dV.data_ptr()
         a.B, a.H, a.d, a.Tk_rows = S, 1, dp, Tkp
-    a.qt, a.kt, a.dot = qt.data_ptr(), kt.data_ptr(), dot_.data_ptr()
-    a.ldqt, a.ldkt, a.lddot = qt.shape[-1], kt.shape[-1], dot_.shape[-1]
+    if need_t:
+        a.qt, a.kt, a.dot = qt.data_ptr(), kt.data_ptr(), dot_.data_ptr()
+        a.ldqt, a.ldkt, a.lddot = qt.shape[-1], kt.shape[-1], dot_.shape[-1]
     a.stats = stats.data_ptr()
     a.part = part.data_ptr() if part is not None else None
     a.Tq, a.Tk, a.has_lse = Tq, Tk, int(has_lse)

@@ -126,6 +126,35 @@ __device__ __forceinline__ typename Vec8<T>::type frag_trn(const char* lds, int 
     const uint4 u = make_uint4(a.x, a.y, b.x, b.y);
     return __builtin_bit_cast(typename Vec8<T>::type, u);
 }
+// Round 4: the same fragments WITHOUT a transposed tile (and without the transposed copies q^T, k^T, dO^T in memory): the LDS
+// transpose read gathers them from the row-major tile that is staged for the other GEMMs anyway.  Within a 16-lane group, lane
+// 4 rr + q4 supplies the address of tile row (k index) rr, columns 4 q4 .. 4 q4 + 3, and lane i receives column i of that
+// 4 x 16 block (ds_read_b64_tr_b16; tools/ubench/tr_probe.hip): two reads = the 8 permuted k values.  -DUR_ATTN_BWD_TRN=1
+// builds the former transposed-tile form (the A/B of tools/experiments/r04_run36.sh).
+#ifndef UR_ATTN_BWD_TRN
+#define UR_ATTN_BWD_TRN 0
+#endif
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef short s16x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ s16x4_t lds_tr16(const char* q) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)q);
+}
+// MFMA 16x16x32 A operand: row = tile column 16 blk + (lane & 15), k = tile rows 32 ks + 4 g + (0..3) and + 16
+template <typename T, int DP>
+__device__ __forceinline__ typename Vec8<T>::type frag_tr(const char* lds, int blk, int ks, int lane) {
+    const int i16 = lane & 15, g = lane >> 4;
+    const char* r = lds + (32 * ks + 4 * g + (i16 >> 2)) * BwdLds<DP>::RS + (16 * blk + 4 * (i16 & 3)) * 2;
+    const s16x4_t a = lds_tr16(r), b = lds_tr16(r + 16 * BwdLds<DP>::RS);
+    return __builtin_bit_cast(typename Vec8<T>::type, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+// MFMA 32x32x16 A operand: row = tile column 32 blk + (lane & 31), k = tile rows row0 + 4 hh + (0..3) and + 8 (hh = lane >> 5)
+template <typename T>
+__device__ __forceinline__ typename Vec8<T>::type frag_tr32(const char* lds, int blk, int row0, int lane) {
+    const int i16 = lane & 15, gi = lane >> 4;
+    const char* r = lds + (row0 + 4 * (gi >> 1) + (i16 >> 2)) * BwdLds<64>::RS + (32 * blk + 16 * (gi & 1) + 4 * (i16 & 3)) * 2;
+    const s16x4_t a = lds_tr16(r), b = lds_tr16(r + 8 * BwdLds<64>::RS);
+    return __builtin_bit_cast(typename Vec8<T>::type, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
+}
 template <typename T>
 __device__ __forceinline__ typename Vec8<T>::type pack2(const f32x4& a, const f32x4& b) {
     typename Vec8<T>::type v;
@@ -272,7 +301,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const AttnBwdArgs p) {
     do {                                                          \
         gload_rows<T, DP, GEN>(K + (int64_t)(kt_) * p.ldk, p.ldk, p.Tk_valid - (kt_), d, rk, tid); \
         gload_rows<T, DP, GEN>(V + (int64_t)(kt_) * p.ldv, p.ldv, p.Tk_valid - (kt_), d, rv, tid); \
-        gload_trn<T, DP, GEN>(Kt + (kt_), p.ldkt, d, rkt, tid);        \
+        if (UR_ATTN_BWD_TRN) gload_trn<T, DP, GEN>(Kt + (kt_), p.ldkt, d, rkt, tid); \
     } while (0)
     if (PF) UR_GLOAD_KV(0);
     for (int kt = 0; kt < Tn; kt += 64) {
@@ -280,7 +309,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const AttnBwdArgs p) {
         __syncthreads();
         lstore_rows<DP>(Ks, rk, tid);
         lstore_rows<DP>(Vs, rv, tid);
-        lstore_trn<DP>(Kts, rkt, tid);
+        if (UR_ATTN_BWD_TRN) lstore_trn<DP>(Kts, rkt, tid);
         __syncthreads();
         if (PF && kt + 64 < Tn) UR_GLOAD_KV(kt + 64);
 #pragma unroll
@@ -317,7 +346,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const AttnBwdArgs p) {
             }
 #pragma unroll
             for (int db = 0; db < DB; ++db) {
-                const vec8 a = frag_trn<T, DP>(Kts, db, h, j, g);
+                const vec8 a = UR_ATTN_BWD_TRN ? frag_trn<T, DP>(Kts, db, h, j, g) : frag_tr<T, DP>(Ks, db, h, lane);
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) acc[db][nb] = mfma16(a, dsf[nb], acc[db][nb]);
             }
@@ -345,7 +374,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dkdv_kernel(const AttnBwdArgs p)
     char* dOs = smem + L::ROWS;
     char* Qts = smem + 2 * L::ROWS;
     char* dOts = Qts + L::TRN;
-    float* st = reinterpret_cast<float*>(dOts + L::TRN);  // [0..63] lse, [64..127] D of the query tile
+    float* st = reinterpret_cast<float*>(UR_ATTN_BWD_TRN ? dOts + L::TRN : smem + 2 * L::ROWS);  // [0..63] lse, [64..127] D of the query tile
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
     const int s = blockIdx.y, Tn = p.Tq, Tk = p.Tk;  // Tn: the streamed (query) side
     const int b = s / p.H, hd = (s - b * p.H) * p.d, d = p.d, C = p.H * p.d;
@@ -389,8 +418,8 @@ __global__ void __launch_bounds__(256) attn_bwd_dkdv_kernel(const AttnBwdArgs p)
     do {                                                          \
         gload_rows<T, DP, GEN>(Q + (int64_t)(qt_) * p.ldq, p.ldq, 64, d, rq, tid);     \
         gload_rows<T, DP, GEN>(dO + (int64_t)(qt_) * p.lddo, p.lddo, 64, d, rdo, tid); \
-        gload_trn<T, DP, GEN>(Qt + (qt_), p.ldqt, d, rqt, tid);        \
-        gload_trn<T, DP, GEN>(dOt + (qt_), p.lddot, d, rdot, tid);     \
+        if (UR_ATTN_BWD_TRN) gload_trn<T, DP, GEN>(Qt + (qt_), p.ldqt, d, rqt, tid); \
+        if (UR_ATTN_BWD_TRN) gload_trn<T, DP, GEN>(dOt + (qt_), p.lddot, d, rdot, tid); \
         if (tid < 128) rst = st_g[qt_];                           \
     } while (0)
     if (PF && q_beg < q_end) UR_GLOAD_Q(q_beg);
@@ -399,8 +428,8 @@ __global__ void __launch_bounds__(256) attn_bwd_dkdv_kernel(const AttnBwdArgs p)
         __syncthreads();
         lstore_rows<DP>(Qs, rq, tid);
         lstore_rows<DP>(dOs, rdo, tid);
-        lstore_trn<DP>(Qts, rqt, tid);
-        lstore_trn<DP>(dOts, rdot, tid);
+        if (UR_ATTN_BWD_TRN) lstore_trn<DP>(Qts, rqt, tid);
+        if (UR_ATTN_BWD_TRN) lstore_trn<DP>(dOts, rdot, tid);
         if (tid < 128) st[tid] = rst;
         __syncthreads();
         if (PF && qt + 64 < q_end) UR_GLOAD_Q(qt + 64);
@@ -443,8 +472,8 @@ __global__ void __launch_bounds__(256) attn_bwd_dkdv_kernel(const AttnBwdArgs p)
             }
 #pragma unroll
             for (int db = 0; db < DB; ++db) {
-                const vec8 da = frag_trn<T, DP>(dOts, db, h, j, g);
-                const vec8 qa = frag_trn<T, DP>(Qts, db, h, j, g);
+                const vec8 da = UR_ATTN_BWD_TRN ? frag_trn<T, DP>(dOts, db, h, j, g) : frag_tr<T, DP>(dOs, db, h, lane);
+                const vec8 qa = UR_ATTN_BWD_TRN ? frag_trn<T, DP>(Qts, db, h, j, g) : frag_tr<T, DP>(Qs, db, h, lane);
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
                     dv[db][nb] = mfma16(da, pf[nb], dv[db][nb]);
@@ -585,14 +614,14 @@ __global__ void __launch_bounds__(256) attn_bwd_dq32_kernel(const AttnBwdArgs p)
     do {                                                          \
         gload_rows<T, DP, GEN>(K + (int64_t)(kt_) * p.ldk, p.ldk, p.Tk_valid - (kt_), d, rk, tid); \
         gload_rows<T, DP, GEN>(V + (int64_t)(kt_) * p.ldv, p.ldv, p.Tk_valid - (kt_), d, rv, tid); \
-        gload_trn<T, DP, GEN>(Kt + (kt_), p.ldkt, d, rkt, tid);        \
+        if (UR_ATTN_BWD_TRN) gload_trn<T, DP, GEN>(Kt + (kt_), p.ldkt, d, rkt, tid); \
     } while (0)
     UR_GLOAD_KV32(0);
     for (int kt = 0; kt < Tn; kt += 64) {
         __syncthreads();
         lstore_rows<DP>(Ks, rk, tid);
         lstore_rows<DP>(Vs, rv, tid);
-        lstore_trn<DP>(Kts, rkt, tid);
+        if (UR_ATTN_BWD_TRN) lstore_trn<DP>(Kts, rkt, tid);
         __syncthreads();
         if (kt + 64 < Tn) UR_GLOAD_KV32(kt + 64);
 #pragma unroll
@@ -614,7 +643,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dq32_kernel(const AttnBwdArgs p)
                 const vec8 dsf = pack8<T>(sc, t);
 #pragma unroll
                 for (int db = 0; db < 2; ++db)
-                    acc[db] = mfma32(frag_trn32<T>(Kts, db, 32 * kb + 16 * t, j, hh), dsf, acc[db]);
+                    acc[db] = mfma32(UR_ATTN_BWD_TRN ? frag_trn32<T>(Kts, db, 32 * kb + 16 * t, j, hh) : frag_tr32<T>(Ks, db, 32 * kb + 16 * t, lane), dsf, acc[db]);
             }
         }
     }
@@ -638,7 +667,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dkdv32_kernel(const AttnBwdArgs 
     char* dOs = smem + L::ROWS;
     char* Qts = smem + 2 * L::ROWS;
     char* dOts = Qts + L::TRN;
-    float* st = reinterpret_cast<float*>(dOts + L::TRN);
+    float* st = reinterpret_cast<float*>(UR_ATTN_BWD_TRN ? dOts + L::TRN : smem + 2 * L::ROWS);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, hh = lane >> 5;
     const int s = blockIdx.y, Tn = p.Tq, Tk = p.Tk;
     const int b = s / p.H, hd = (s - b * p.H) * p.d, d = p.d, C = p.H * p.d;
@@ -671,8 +700,8 @@ __global__ void __launch_bounds__(256) attn_bwd_dkdv32_kernel(const AttnBwdArgs 
     do {                                                          \
         gload_rows<T, DP, GEN>(Q + (int64_t)(qt_) * p.ldq, p.ldq, 64, d, rq, tid);     \
         gload_rows<T, DP, GEN>(dO + (int64_t)(qt_) * p.lddo, p.lddo, 64, d, rdo, tid); \
-        gload_trn<T, DP, GEN>(Qt + (qt_), p.ldqt, d, rqt, tid);        \
-        gload_trn<T, DP, GEN>(dOt + (qt_), p.lddot, d, rdot, tid);     \
+        if (UR_ATTN_BWD_TRN) gload_trn<T, DP, GEN>(Qt + (qt_), p.ldqt, d, rqt, tid); \
+        if (UR_ATTN_BWD_TRN) gload_trn<T, DP, GEN>(dOt + (qt_), p.lddot, d, rdot, tid); \
         if (tid < 128) rst = st_g[qt_];                           \
     } while (0)
     if (q_beg < q_end) UR_GLOAD_Q32(q_beg);
@@ -680,8 +709,8 @@ __global__ void __launch_bounds__(256) attn_bwd_dkdv32_kernel(const AttnBwdArgs 
         __syncthreads();
         lstore_rows<DP>(Qs, rq, tid);
         lstore_rows<DP>(dOs, rdo, tid);
-        lstore_trn<DP>(Qts, rqt, tid);
-        lstore_trn<DP>(dOts, rdot, tid);
+        if (UR_ATTN_BWD_TRN) lstore_trn<DP>(Qts, rqt, tid);
+        if (UR_ATTN_BWD_TRN) lstore_trn<DP>(dOts, rdot, tid);
         if (tid < 128) st[tid] = rst;
         __syncthreads();
         if (qt + 64 < q_end) UR_GLOAD_Q32(qt + 64);
@@ -710,8 +739,8 @@ __global__ void __launch_bounds__(256) attn_bwd_dkdv32_kernel(const AttnBwdArgs 
                 const vec8 pf = pack8<T>(sc, t), dsf = pack8<T>(dp, t);
 #pragma unroll
                 for (int db = 0; db < 2; ++db) {
-                    dv[db] = mfma32(frag_trn32<T>(dOts, db, 32 * qb + 16 * t, j, hh), pf, dv[db]);
-                    dk[db] = mfma32(frag_trn32<T>(Qts, db, 32 * qb + 16 * t, j, hh), dsf, dk[db]);
+                    dv[db] = mfma32(UR_ATTN_BWD_TRN ? frag_trn32<T>(dOts, db, 32 * qb + 16 * t, j, hh) : frag_tr32<T>(dOs, db, 32 * qb + 16 * t, lane), pf, dv[db]);
+                    dk[db] = mfma32(UR_ATTN_BWD_TRN ? frag_trn32<T>(Qts, db, 32 * qb + 16 * t, j, hh) : frag_tr32<T>(Qs, db, 32 * qb + 16 * t, lane), dsf, dk[db]);
                 }
             }
         }
@@ -747,7 +776,7 @@ template <typename T, int DP, int NB, bool HAS_LSE, bool MASK, bool GEN>
 static void launch_dq(const AttnBwdArgs& a, hipStream_t st) {
     typedef BwdLds<DP> L;
     constexpr bool PF = DP <= 64;  // register prefetch of the next tile: 32 VGPRs at DP = 64, too many above
-    constexpr int lds_dq = 2 * L::ROWS + L::TRN;
+    constexpr int lds_dq = 2 * L::ROWS + (UR_ATTN_BWD_TRN ? L::TRN : 0);
     static std::atomic<uint64_t> done{0};
     set_lds_limit_once(done, reinterpret_cast<const void*>(&attn_bwd_dq_kernel<T, DP, NB, PF, HAS_LSE, MASK, GEN>), lds_dq);
     hipLaunchKernelGGL((attn_bwd_dq_kernel<T, DP, NB, PF, HAS_LSE, MASK, GEN>), dim3(a.Tq / (64 * NB), a.S), dim3(256), lds_dq, st, a);
@@ -756,7 +785,7 @@ template <typename T, int DP, int NB, bool SPLIT, bool GEN>
 static void launch_dkdv(const AttnBwdArgs& a, hipStream_t st) {
     typedef BwdLds<DP> L;
     constexpr bool PF = DP <= 64;
-    constexpr int lds_kv = 2 * L::ROWS + 2 * L::TRN + 512;
+    constexpr int lds_kv = 2 * L::ROWS + (UR_ATTN_BWD_TRN ? 2 * L::TRN : 0) + 512;
     static std::atomic<uint64_t> done{0};
     set_lds_limit_once(done, reinterpret_cast<const void*>(&attn_bwd_dkdv_kernel<T, DP, NB, PF, SPLIT, GEN>), lds_kv);
     hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, DP, NB, PF, SPLIT, GEN>), dim3(a.Tk / (64 * NB), a.S, SPLIT ? a.G : 1), dim3(256),
@@ -778,7 +807,7 @@ static bool full_tiles(const AttnBwdArgs& a, int dp) { return a.d == dp && a.Tk_
 template <typename T, bool GEN>
 static int launch_bwd32(const AttnBwdArgs& a, hipStream_t st) {
     typedef BwdLds<64> L;
-    constexpr int lds_dq = 2 * L::ROWS + L::TRN, lds_kv = 2 * L::ROWS + 2 * L::TRN + 512;
+    constexpr int lds_dq = 2 * L::ROWS + (UR_ATTN_BWD_TRN ? L::TRN : 0), lds_kv = 2 * L::ROWS + (UR_ATTN_BWD_TRN ? 2 * L::TRN : 0) + 512;
     const dim3 gq(a.Tq / 128, a.S), gk(a.Tk / 128, a.S, a.G);
     if (a.Tk_valid < a.Tk) hipLaunchKernelGGL((attn_bwd_dq32_kernel<T, true, GEN>), gq, dim3(256), lds_dq, st, a);
     else hipLaunchKernelGGL((attn_bwd_dq32_kernel<T, false, GEN>), gq, dim3(256), lds_dq, st, a);
@@ -828,6 +857,8 @@ static int dispatch_bwd(const AttnBwdArgs& a, int dp, hipStream_t st) {
 
 }  // namespace ur
 
+extern "C" int ur_attention_backward_needs_transposes(void) { return UR_ATTN_BWD_TRN; }
+
 extern "C" int ur_attention_backward_splits(int S, int Tq, int Tk, int dp) {
     // query splits of the dk / dv kernel: enough workgroups to fill the chip when there are few keys
     const int nbk = (dp == 64 && (Tk % 128) == 0) ? 2 : 1;
@@ -840,14 +871,21 @@ extern "C" int ur_attention_backward_splits(int S, int Tq, int Tk, int dp) {
 extern "C" int ur_attention_backward(const ur_attn_bwd_desc* dsc, void* stream) {
     if (!dsc) return UR_E_BADARG;
     const ur_attn_bwd_desc& x = *dsc;
-    if (!x.q || !x.k || !x.v || !x.o || !x.dout || !x.qt || !x.kt || !x.dot || !x.stats || !x.dq || !x.dk || !x.dv || x.B <= 0 ||
+    if (UR_ATTN_BWD_TRN && (!x.qt || !x.kt || !x.dot)) return UR_E_BADARG;  // the transposed copies: not read any more (ABI 9)
+    if (!x.q || !x.k || !x.v || !x.o || !x.dout || !x.stats || !x.dq || !x.dk || !x.dv || x.B <= 0 ||
         x.H <= 0 || x.d <= 0 || (x.d & 7) || x.Tq <= 0 || (x.Tq & 63) || x.Tk <= 0 || (x.Tk_rows != 0 && x.Tk_rows < x.Tk))
         return UR_E_BADARG;
-    const int64_t lds[] = {x.ldq, x.ldk, x.ldv, x.ldo, x.lddo, x.ldqt, x.ldkt, x.lddot, x.lddq, x.lddk, x.lddv};
+    const int64_t lds[] = {x.ldq, x.ldk, x.ldv, x.ldo, x.lddo, x.lddq, x.lddk, x.lddv};
     for (int64_t ld : lds)
         if (ld <= 0 || (ld & 7)) return UR_E_BADARG;
     const int S = x.B * x.H, Tkp = (x.Tk + 63) / 64 * 64, dp = (x.d + 31) / 32 * 32;
-    if (S > 65535 || x.ldqt < x.Tq || x.lddot < x.Tq || x.ldkt < Tkp) return UR_E_BADARG;
+    if (S > 65535) return UR_E_BADARG;
+    if (UR_ATTN_BWD_TRN) {
+        const int64_t ldt[] = {x.ldqt, x.ldkt, x.lddot};
+        for (int64_t ld : ldt)
+            if (ld <= 0 || (ld & 7)) return UR_E_BADARG;
+        if (x.ldqt < x.Tq || x.lddot < x.Tq || x.ldkt < Tkp) return UR_E_BADARG;
+    }
     const int G = ur_attention_backward_splits(S, x.Tq, Tkp, dp);
     if (G > 1 && !x.part) return UR_E_BADARG;
     ur::AttnBwdArgs a{x.q, x.k, x.v, x.o, x.dout, x.qt, x.kt, x.dot, x.ldq, x.ldk, x.ldv, x.ldo, x.lddo, x.ldqt, x.ldkt, x.lddot,
