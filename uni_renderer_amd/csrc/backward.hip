@@ -946,19 +946,40 @@ using namespace ur;
 template <typename T>
 __global__ void __launch_bounds__(256) pack_conv_weight_kernel(const float* __restrict__ w, T* __restrict__ out, int Co,
                                                                int Ci, int Cpad) {
+    // runs of 256 (co, c) pairs: the 2304 consecutive master floats of the real channels come in with coalesced 4-byte loads
+    // into LDS ([pair][tap]); every thread then writes the nine taps of its pair (lanes along c: coalesced 2-byte stores)
+    __shared__ float tile[256 * 9];
     const int64_t total = (int64_t)Co * Cpad;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int c = (int)(i % Cpad);
-        const int64_t co = i / Cpad;
-        T* o = out + co * 9 * Cpad + c;
-        if (c < Ci) {
-            const float* src = w + (co * Ci + c) * 9;
+    if (Cpad != Ci) {  // padded input channels (conv_in): the simple form, a thread reads its own nine floats
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+            const int c = (int)(i % Cpad);
+            const int64_t co = i / Cpad;
+            T* o = out + co * 9 * Cpad + c;
+            if (c < Ci) {
+                const float* src = w + (co * Ci + c) * 9;
 #pragma unroll
-            for (int t = 0; t < 9; ++t) o[(int64_t)t * Cpad] = (T)src[t];
-        } else {
+                for (int t = 0; t < 9; ++t) o[(int64_t)t * Cpad] = (T)src[t];
+            } else {
 #pragma unroll
-            for (int t = 0; t < 9; ++t) o[(int64_t)t * Cpad] = (T)0.0f;
+                for (int t = 0; t < 9; ++t) o[(int64_t)t * Cpad] = (T)0.0f;
+            }
         }
+        return;
+    }
+    for (int64_t i0 = (int64_t)blockIdx.x * 256; i0 < total; i0 += (int64_t)gridDim.x * 256) {
+        const int64_t n = (total - i0 < 256 ? total - i0 : 256) * 9;
+        const float* src = w + i0 * 9;
+        for (int e = threadIdx.x; e < n; e += 256) tile[e] = src[e];
+        __syncthreads();
+        const int64_t i = i0 + threadIdx.x;
+        if (i < total) {
+            const int c = (int)(i % Ci);
+            const int64_t co = i / Ci;
+            T* o = out + co * 9 * Cpad + c;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) o[(int64_t)t * Cpad] = (T)tile[threadIdx.x * 9 + t];
+        }
+        __syncthreads();
     }
 }
 
@@ -972,22 +993,33 @@ __device__ __forceinline__ void block_partial_store(float v, float* dst) {
     if (threadIdx.x == 0) dst[blockIdx.x] = ((wsum[0] + wsum[1]) + wsum[2]) + wsum[3];
 }
 
+// A workgroup moves runs of 256 (co, ci) pairs = 2304 consecutive output floats: the nine taps of a pair are read with
+// coalesced 2-byte loads (lanes along ci), staged in LDS as [pair][tap], and leave as fully coalesced 4-byte stores over the
+// contiguous run (a thread writing its own nine floats is a 36-byte lane stride: 18 partial lines per store instruction).
 template <typename T>
 __global__ void __launch_bounds__(256) unpack_conv_weight_kernel(const T* __restrict__ dwp, int64_t ld, float* __restrict__ out,
                                                                  int Co, int Ci, int Cpad, float* __restrict__ sumsq) {
+    __shared__ float tile[256 * 9];
     const int64_t total = (int64_t)Co * Ci;
     float sq = 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int c = (int)(i % Ci);
-        const int64_t co = i / Ci;
-        const T* src = dwp + co * ld + c;
-        float* o = out + i * 9;
+    for (int64_t i0 = (int64_t)blockIdx.x * 256; i0 < total; i0 += (int64_t)gridDim.x * 256) {
+        const int64_t i = i0 + threadIdx.x;
+        if (i < total) {
+            const int c = (int)(i % Ci);
+            const int64_t co = i / Ci;
+            const T* src = dwp + co * ld + c;
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const float g = (float)src[(int64_t)t * Cpad];
-            o[t] = g;
-            sq = fmaf(g, g, sq);
+            for (int t = 0; t < 9; ++t) {
+                const float g = (float)src[(int64_t)t * Cpad];
+                tile[threadIdx.x * 9 + t] = g;   // lane stride 9 words: odd, conflict-free
+                sq = fmaf(g, g, sq);
+            }
         }
+        __syncthreads();
+        const int64_t n = (total - i0 < 256 ? total - i0 : 256) * 9;
+        float* o = out + i0 * 9;
+        for (int e = threadIdx.x; e < n; e += 256) o[e] = tile[e];
+        __syncthreads();
     }
     if (sumsq) block_partial_store(sq, sumsq);
 }
