@@ -37,7 +37,8 @@ def main():
         def __torch_dispatch__(self, func, types, args=(), kwargs=None):
             name = str(func)
             if any(k in name for k in ("fill", "zero", "aten.add", "aten.copy", "aten.cat", "aten.mul", "aten.sum", "aten.clone", "_to_copy", "aten.div")):
-                frames = [f for f in traceback.extract_stack() if "/uni_renderer_amd/" in f.filename or "/tools/" in f.filename]
+                frames = [f for f in traceback.extract_stack()
+                          if ("/uni_renderer_amd/" in f.filename or "/tools/" in f.filename) and not f.filename.endswith("find_fills.py")]
                 fr = frames[-1] if frames else None
                 by[(name, f"{os.path.basename(fr.filename)}:{fr.lineno} {fr.line}"[:120] if fr else "?")] += 1
             return func(*args, **(kwargs or {}))
