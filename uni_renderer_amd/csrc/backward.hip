@@ -552,14 +552,24 @@ __global__ void __launch_bounds__(GNB_THREADS) gn_bwd_fused_kernel(const T* __re
         }
     }
     // fold the R row lanes of every channel in a fixed order: channel k of piece pc is summed by thread (pc, row lane 0)
+    // (two levels: 16 threads per piece each add every 16th row lane, then one thread adds the 16 partial sums in order)
+    __shared__ float2 part2[16 * 64];
+    const int fq = t / ppr, fp = t - fq * ppr;   // t < 16 * ppr: second-level lane fq of piece fp (ppr <= 64)
 #pragma unroll
     for (int k = 0; k < P; ++k) {
         __syncthreads();
         part[t] = make_float2(sd[k], sx[k]);
         __syncthreads();
+        if (fq < 16) {
+            float a = 0.f, a2 = 0.f;
+            for (int j = fq; j < R; j += 16) { const float2 v = part[j * ppr + fp]; a += v.x; a2 += v.y; }
+            part2[fq * 64 + fp] = make_float2(a, a2);
+        }
+        __syncthreads();
         if (t < ppr) {
             float a = 0.f, a2 = 0.f;
-            for (int j = 0; j < R; ++j) { const float2 v = part[j * ppr + t]; a += v.x; a2 += v.y; }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) { const float2 v = part2[j * 64 + t]; a += v.x; a2 += v.y; }
             csum[t * P + k] = make_float2(a, a2);
         }
     }
@@ -946,40 +956,22 @@ using namespace ur;
 template <typename T>
 __global__ void __launch_bounds__(256) pack_conv_weight_kernel(const float* __restrict__ w, T* __restrict__ out, int Co,
                                                                int Ci, int Cpad) {
-    // runs of 256 (co, c) pairs: the 2304 consecutive master floats of the real channels come in with coalesced 4-byte loads
-    // into LDS ([pair][tap]); every thread then writes the nine taps of its pair (lanes along c: coalesced 2-byte stores)
-    __shared__ float tile[256 * 9];
+    // (an LDS-staged form with coalesced 4-byte loads of the master measured SLOWER, 16.1 vs 12.7 us per launch: the nine
+    // loads of a thread already use every byte of the lines they touch, and the staging adds two barriers per 256 pairs;
+    // the reverse direction, unpack_conv_weight_kernel below, does gain from it)
     const int64_t total = (int64_t)Co * Cpad;
-    if (Cpad != Ci) {  // padded input channels (conv_in): the simple form, a thread reads its own nine floats
-        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-            const int c = (int)(i % Cpad);
-            const int64_t co = i / Cpad;
-            T* o = out + co * 9 * Cpad + c;
-            if (c < Ci) {
-                const float* src = w + (co * Ci + c) * 9;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % Cpad);
+        const int64_t co = i / Cpad;
+        T* o = out + co * 9 * Cpad + c;
+        if (c < Ci) {
+            const float* src = w + (co * Ci + c) * 9;
 #pragma unroll
-                for (int t = 0; t < 9; ++t) o[(int64_t)t * Cpad] = (T)src[t];
-            } else {
+            for (int t = 0; t < 9; ++t) o[(int64_t)t * Cpad] = (T)src[t];
+        } else {
 #pragma unroll
-                for (int t = 0; t < 9; ++t) o[(int64_t)t * Cpad] = (T)0.0f;
-            }
+            for (int t = 0; t < 9; ++t) o[(int64_t)t * Cpad] = (T)0.0f;
         }
-        return;
-    }
-    for (int64_t i0 = (int64_t)blockIdx.x * 256; i0 < total; i0 += (int64_t)gridDim.x * 256) {
-        const int64_t n = (total - i0 < 256 ? total - i0 : 256) * 9;
-        const float* src = w + i0 * 9;
-        for (int e = threadIdx.x; e < n; e += 256) tile[e] = src[e];
-        __syncthreads();
-        const int64_t i = i0 + threadIdx.x;
-        if (i < total) {
-            const int c = (int)(i % Ci);
-            const int64_t co = i / Ci;
-            T* o = out + co * 9 * Cpad + c;
-#pragma unroll
-            for (int t = 0; t < 9; ++t) o[(int64_t)t * Cpad] = (T)tile[threadIdx.x * 9 + t];
-        }
-        __syncthreads();
     }
 }
 
