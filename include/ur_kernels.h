@@ -568,6 +568,19 @@ int ur_split_heads(const void* x, int64_t ld, int off, int B, int T, int H, int 
                    void* stream);
 int ur_merge_heads(const void* g, int Tp, int dp, int B, int T, int H, int d, void* out, int64_t ld, int off, int dtype,
                    void* stream);
+/* ur_split_heads / ur_merge_heads for up to UR_HEADS_MAX tensors of one (B, H, d, dp) in ONE launch (ABI 9): `tok` is the token
+ * matrix [B][T][ld] (head h at columns off + h * d), `heads` the per-head copy [B * H][Tp][dp]; split reads tok and writes
+ * heads (rows T .. Tp and columns d .. dp zero), merge the reverse. */
+#define UR_HEADS_MAX 8
+typedef struct ur_heads_desc {
+    void* tok;
+    void* heads;
+    int64_t ld;
+    int32_t off, T, Tp, reserved;
+} ur_heads_desc;
+int ur_split_heads_multi(const ur_heads_desc* descs, int n, int B, int H, int d, int dp, int dtype, void* stream);
+int ur_merge_heads_multi(const ur_heads_desc* descs, int n, int B, int H, int d, int dp, int dtype, void* stream);
+int ur_sizeof_heads_desc(void);
 int ur_softmax_rows(void* s, int64_t ld, int64_t rows, int ncols, int dtype, void* stream);
 int ur_softmax_backward_rows(const void* p, void* dp, int64_t ld, int64_t rows, int ncols, float scale, int dtype,
                              void* stream);

@@ -345,6 +345,25 @@ def test_rotated_conv_weights_and_linear_transposes_in_multi_tensor_launches(dev
         assert torch.equal(t, m.t().contiguous())
 
 
+def test_split_and_merge_heads_of_several_tensors_in_one_launch(dev):
+    """ur_split_heads_multi / ur_merge_heads_multi against the single-tensor entry points: the five per-head copies and the
+    three gradients of a d = 40 attention backward, column offsets of a fused q | k | v, key rows padded to 128."""
+    from uni_renderer_amd import backward as bw
+    g = torch.Generator().manual_seed(21)
+    B, H, d, dp, Tq, Tk, Tkp = 2, 8, 40, 64, 192, 77, 128
+    qkv = torch.randn(B, Tq, 3 * H * d, generator=g).to(torch.bfloat16).to(dev)
+    kv = torch.randn(B, Tk, 2 * H * d, generator=g).to(torch.bfloat16).to(dev)
+    o = torch.randn(B, Tq, H * d, generator=g).to(torch.bfloat16).to(dev)
+    items = [(qkv, Tq, 0), (kv, Tkp, 0), (kv, Tkp, H * d), (o, Tq, 0), (qkv, Tq, 2 * H * d)]
+    many = bw.split_heads_many(items, H, d, dp)
+    for (x, Tp, off), got in zip(items, many):
+        assert torch.equal(got, bw._split_heads(x, H, d, Tp, dp, off))
+    outs = [torch.zeros(B, Tq, 3 * H * d, dtype=torch.bfloat16, device=dev), torch.zeros(B, Tk, H * d, dtype=torch.bfloat16, device=dev)]
+    bw.merge_heads_many([(many[0], outs[0], 0), (many[4], outs[0], 2 * H * d), (many[1], outs[1], 0)], B, H, d)
+    assert torch.equal(outs[0][..., :H * d], qkv[..., :H * d]) and torch.equal(outs[0][..., 2 * H * d:], qkv[..., 2 * H * d:])
+    assert torch.equal(outs[1], kv[..., :H * d]) and not outs[0][..., H * d:2 * H * d].any()
+
+
 def test_transpose2d_many(dev):
     """ur_transpose2d_multi: several (batched, strided, ragged) transposes in one launch == the single-tensor kernel."""
     from uni_renderer_amd import backward as bw

@@ -675,6 +675,39 @@ def _merge_heads(g: torch.Tensor, B: int, T: int, H: int, d: int, out: Optional[
     return out
 
 
+class _HeadsDesc(C.Structure):
+    _fields_ = [("tok", C.c_void_p), ("heads", C.c_void_p), ("ld", C.c_int64), ("off", C.c_int32), ("T", C.c_int32),
+                ("Tp", C.c_int32), ("reserved", C.c_int32)]
+
+
+_lib.register_layout("ur_sizeof_heads_desc", _HeadsDesc)
+# the per-head copies of the d = 40 flash backward (q, k, v, o, dO in; dq, dk, dv out) in one launch each way instead of 5 + 3
+HEADS_MULTI = os.environ.get("UR_HEADS_MULTI", "1") != "0"
+
+
+def split_heads_many(items, H: int, d: int, dp: int):
+    """``[_split_heads(x, H, d, Tp, dp, off) for (x, Tp, off) in items]`` in one launch (``ur_split_heads_multi``)."""
+    lib = _lib.load()
+    B = items[0][0].shape[0]
+    outs = [torch.empty(B * H, Tp, dp, dtype=x.dtype, device=x.device) for x, Tp, _ in items]
+    arr = (_HeadsDesc * len(items))()
+    for i, ((x, Tp, off), o) in enumerate(zip(items, outs)):
+        if x.shape[0] != B or x.stride(2) != 1 or x.stride(0) != x.shape[1] * x.stride(1):
+            raise RuntimeError("split_heads_many: [B, T, ld] operands with contiguous batches")
+        arr[i].tok, arr[i].heads, arr[i].ld, arr[i].off, arr[i].T, arr[i].Tp = x.data_ptr(), o.data_ptr(), x.stride(1), off, x.shape[1], Tp
+    check(lib.ur_split_heads_multi(arr, len(items), B, H, d, dp, DT[items[0][0].dtype], _stream()), "ur_split_heads_multi")
+    return outs
+
+
+def merge_heads_many(items, B: int, H: int, d: int):
+    """items = [(g [B*H, Tp, dp], out [B, T, ld], off)]: columns off .. off + H*d of every ``out`` in one launch."""
+    lib = _lib.load()
+    arr = (_HeadsDesc * len(items))()
+    for i, (g, out, off) in enumerate(items):
+        arr[i].tok, arr[i].heads, arr[i].ld, arr[i].off, arr[i].T, arr[i].Tp = out.data_ptr(), g.data_ptr(), out.stride(1), off, out.shape[1], g.shape[1]
+    check(lib.ur_merge_heads_multi(arr, len(items), B, H, d, items[0][0].shape[2], DT[items[0][0].dtype], _stream()), "ur_merge_heads_multi")
+
+
 FLASH_BACKWARD = os.environ.get("UR_FLASH_BACKWARD", "1") != "0"  # 0: always the materialised-P path below
 FORWARD_LSE = os.environ.get("UR_FORWARD_LSE", "1") != "0"        # 0: the dq kernel recomputes the row log-sum-exp
 
@@ -736,8 +769,11 @@ def _flash_attention_backward(q, k, v, o, do, H, scale, fused_qkv, oq, ok, ov, C
         a.lddq = a.lddk = a.lddv = ldg
         a.B, a.H, a.d, a.Tk_rows = B, H, d, Tk
     else:
-        qp, kp, vp = _split_heads(q, H, d, Tq, dp, oq), _split_heads(k, H, d, Tkp, dp, ok), _split_heads(v, H, d, Tkp, dp, ov)
-        op, dop = _split_heads(o, H, d, Tq, dp), _split_heads(do, H, d, Tq, dp)       # [S, T, dp]
+        if HEADS_MULTI and all(t.stride(2) == 1 and t.stride(0) == t.shape[1] * t.stride(1) for t in (q, k, v, o, do)):
+            qp, kp, vp, op, dop = split_heads_many([(q, Tq, oq), (k, Tkp, ok), (v, Tkp, ov), (o, Tq, 0), (do, Tq, 0)], H, d, dp)
+        else:
+            qp, kp, vp = _split_heads(q, H, d, Tq, dp, oq), _split_heads(k, H, d, Tkp, dp, ok), _split_heads(v, H, d, Tkp, dp, ov)
+            op, dop = _split_heads(o, H, d, Tq, dp), _split_heads(do, H, d, Tq, dp)       # [S, T, dp]
         qt, kt, dot_ = transpose2d_many([qp, kp, dop]) if need_t else (None, None, None)  # [S, dp, T], one launch
         dQ, dK, dV = torch.empty_like(qp), torch.empty_like(kp), torch.empty_like(kp)
         a.q, a.k, a.v, a.o, a.dout = qp.data_ptr(), kp.data_ptr(), vp.data_ptr(), op.data_ptr(), dop.data_ptr()
@@ -756,9 +792,17 @@ def _flash_attention_backward(q, k, v, o, do, H, scale, fused_qkv, oq, ok, ov, C
         return outs[0] if fused_qkv else outs
     if fused_qkv:
         g = torch.empty(B, Tq, 3 * Cc, dtype=q.dtype, device=q.device)
+        if HEADS_MULTI:
+            merge_heads_many([(dQ, g, oq), (dK, g, ok), (dV, g, ov)], B, H, d)
+            return g
         for part_, off in ((dQ, oq), (dK, ok), (dV, ov)):
             _merge_heads(part_, B, Tq, H, d, out=g, off=off)
         return g
+    if HEADS_MULTI:
+        outs = (torch.empty(B, Tq, H * d, dtype=q.dtype, device=q.device), torch.empty(B, Tk, H * d, dtype=q.dtype, device=q.device),
+                torch.empty(B, Tk, H * d, dtype=q.dtype, device=q.device))
+        merge_heads_many([(dQ, outs[0], 0), (dK, outs[1], 0), (dV, outs[2], 0)], B, H, d)
+        return outs
     return _merge_heads(dQ, B, Tq, H, d), _merge_heads(dK, B, Tk, H, d), _merge_heads(dV, B, Tk, H, d)
 
 

@@ -830,6 +830,49 @@ __global__ void __launch_bounds__(256) merge_heads_kernel(const T* __restrict__ 
     }
 }
 
+// The same copies for up to UR_HEADS_MAX tensors in ONE launch (blockIdx.y = tensor): q, k, v, o, dO -> per-head padded copies
+// before the d = 40 flash backward, dq, dk, dv back afterwards (five + three launches per attention otherwise).
+struct HeadsMultiArgs {
+    ur_heads_desc t[UR_HEADS_MAX];
+    int n, B, H, d, dp;
+};
+template <typename T>
+__global__ void __launch_bounds__(256) split_heads_multi_kernel(const HeadsMultiArgs a) {
+    const ur_heads_desc e = a.t[blockIdx.y];
+    const T* x = reinterpret_cast<const T*>(e.tok);
+    T* out = reinterpret_cast<T*>(e.heads);
+    const int dv = a.dp >> 3;
+    const int64_t total = (int64_t)a.B * a.H * e.Tp * dv;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % dv) * 8;
+        const int64_t r = i / dv;
+        const int t = (int)(r % e.Tp);
+        const int bh = (int)(r / e.Tp), b = bh / a.H, h = bh - b * a.H;
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = 0.f;
+        if (t < e.T && c < a.d) load8(x + ((int64_t)b * e.T + t) * e.ld + e.off + h * a.d + c, v);
+        store8(out + i * 8, v);
+    }
+}
+template <typename T>
+__global__ void __launch_bounds__(256) merge_heads_multi_kernel(const HeadsMultiArgs a) {
+    const ur_heads_desc e = a.t[blockIdx.y];
+    const T* g = reinterpret_cast<const T*>(e.heads);
+    T* out = reinterpret_cast<T*>(e.tok);
+    const int dv = a.d >> 3;
+    const int64_t total = (int64_t)a.B * a.H * e.T * dv;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % dv) * 8;
+        const int64_t r = i / dv;
+        const int t = (int)(r % e.T);
+        const int bh = (int)(r / e.T), b = bh / a.H, h = bh - b * a.H;
+        float v[8];
+        load8(g + ((int64_t)bh * e.Tp + t) * a.dp + c, v);
+        store8(out + ((int64_t)b * e.T + t) * e.ld + e.off + h * a.d + c, v);
+    }
+}
+
 // one wave per row; columns in 16-byte vectors; three passes over the row (max, sum, write) out of L2
 template <typename T>
 __global__ void __launch_bounds__(256) softmax_rows_kernel(T* __restrict__ s, int64_t ld, int64_t rows, int ncols) {
@@ -1253,6 +1296,32 @@ extern "C" int ur_merge_heads(const void* g, int Tp, int dp, int B, int T_, int 
                                           T_, H, d, (T*)out, ld, off));
     return last_error();
 }
+
+static int heads_multi(const ur_heads_desc* descs, int n, int B, int H, int d, int dp, int dtype, void* stream, bool split) {
+    if (!descs || n <= 0 || n > UR_HEADS_MAX || B <= 0 || H <= 0 || d <= 0 || (d & 7) || (dp & 7) || dp < d) return UR_E_BADARG;
+    HeadsMultiArgs a;
+    int64_t most = 0;
+    for (int i = 0; i < n; ++i) {
+        const ur_heads_desc& e = descs[i];
+        if (!e.tok || !e.heads || e.T <= 0 || e.Tp < e.T || (e.ld & 7) || (e.off & 7)) return UR_E_BADARG;
+        a.t[i] = e;
+        const int64_t total = (int64_t)B * H * (split ? (int64_t)e.Tp * (dp / 8) : (int64_t)e.T * (d / 8));
+        if (total > most) most = total;
+    }
+    a.n = n; a.B = B; a.H = H; a.d = d; a.dp = dp;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const dim3 grid(grid_for(most), n);
+    if (split) { UR_DISPATCH(dtype, hipLaunchKernelGGL((split_heads_multi_kernel<T>), grid, dim3(256), 0, s, a)); }
+    else { UR_DISPATCH(dtype, hipLaunchKernelGGL((merge_heads_multi_kernel<T>), grid, dim3(256), 0, s, a)); }
+    return last_error();
+}
+extern "C" int ur_split_heads_multi(const ur_heads_desc* descs, int n, int B, int H, int d, int dp, int dtype, void* stream) {
+    return heads_multi(descs, n, B, H, d, dp, dtype, stream, true);
+}
+extern "C" int ur_merge_heads_multi(const ur_heads_desc* descs, int n, int B, int H, int d, int dp, int dtype, void* stream) {
+    return heads_multi(descs, n, B, H, d, dp, dtype, stream, false);
+}
+extern "C" int ur_sizeof_heads_desc(void) { return (int)sizeof(ur_heads_desc); }
 
 extern "C" int ur_softmax_rows(void* s_, int64_t ld, int64_t rows, int ncols, int dtype, void* stream) {
     if (!s_ || rows <= 0 || ncols <= 0 || (ld & 7) || ld < ncols) return UR_E_BADARG;
