@@ -581,6 +581,19 @@ typedef struct ur_heads_desc {
 int ur_split_heads_multi(const ur_heads_desc* descs, int n, int B, int H, int d, int dp, int dtype, void* stream);
 int ur_merge_heads_multi(const ur_heads_desc* descs, int n, int B, int H, int d, int dp, int dtype, void* stream);
 int ur_sizeof_heads_desc(void);
+/* out[c] = sum over the M rows of in[r][c] for up to UR_COLSUM_MULTI_MAX fp32 matrices [M][N] in ONE launch, fixed-order sums
+ * (ABI 9).  pair != 0: the columns are (channel, component) pairs [N / 2][2] and the result is planar, out[k * N / 2 + c] --
+ * ur_pairsum_rows.  What the training step uses for the gamma / beta gradients of all LayerNorms and GroupNorms of a network
+ * at the end of its backward (their per-wave / per-sample partial sums are summed in one launch instead of one or two per layer). */
+#define UR_COLSUM_MULTI_MAX 96
+typedef struct ur_colsum_item {
+    const float* in;
+    float* out;
+    int32_t M, N;
+    int32_t pair, reserved;
+} ur_colsum_item;
+int ur_colsum_multi(const ur_colsum_item* items, int n, void* stream);
+int ur_sizeof_colsum_item(void);
 int ur_softmax_rows(void* s, int64_t ld, int64_t rows, int ncols, int dtype, void* stream);
 int ur_softmax_backward_rows(const void* p, void* dp, int64_t ld, int64_t rows, int ncols, float scale, int dtype,
                              void* stream);

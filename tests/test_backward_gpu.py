@@ -364,6 +364,31 @@ def test_split_and_merge_heads_of_several_tensors_in_one_launch(dev):
     assert torch.equal(outs[1], kv[..., :H * d]) and not outs[0][..., H * d:2 * H * d].any()
 
 
+def test_column_sums_of_many_matrices_in_one_launch(dev):
+    """backward.NormSums / ur_colsum_multi: the deferred gamma / beta gradients of the norm layers -- plain column sums
+    (LayerNorm: per-wave rows [waves, 2 C]) and the (channel, component) pair form (GroupNorm: [B, C, 2] -> [2, C]), 100 items
+    = two launches, against torch sums; two flushes give identical bits."""
+    from uni_renderer_amd import backward as bw
+    g = torch.Generator().manual_seed(33)
+    q = bw.NormSums()
+    items = []
+    for i in range(100):
+        M, N = (1 + 37 * i) % 2050 + 1, 2 * (8 + (13 * i) % 700)
+        part = torch.randn(M, N, generator=g).to(dev)
+        items.append((part, bool(i % 2), q.add(part, bool(i % 2))))
+    q.flush()
+    assert not q.items
+    q2 = bw.NormSums()
+    again = [q2.add(part, pair) for part, pair, _ in items]
+    q2.flush()
+    for (part, pair, out), out2 in zip(items, again):
+        ref = part.double().sum(0)
+        if pair:
+            ref = ref.view(-1, 2).t().reshape(-1)
+        assert (out.double() - ref).abs().max().item() <= 1e-4 * max(1.0, part.abs().sum(0).max().item())
+        assert torch.equal(out, out2)
+
+
 def test_transpose2d_many(dev):
     """ur_transpose2d_multi: several (batched, strided, ragged) transposes in one launch == the single-tensor kernel."""
     from uni_renderer_amd import backward as bw

@@ -133,6 +133,8 @@ SYMBOLS = {
     "ur_split_heads_multi": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "ur_merge_heads_multi": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "ur_sizeof_heads_desc": (C.c_int, []),
+    "ur_colsum_multi": (C.c_int, [vp, C.c_int, vp]),
+    "ur_sizeof_colsum_item": (C.c_int, []),
     "ur_softmax_rows": (C.c_int, [vp, C.c_int64, C.c_int64, C.c_int, C.c_int, vp]),
     "ur_softmax_backward_rows": (C.c_int, [vp, vp, C.c_int64, C.c_int64, C.c_int, C.c_float, C.c_int, vp]),
     "ur_attention_backward": (C.c_int, [C.POINTER(AttnBwdDesc), vp]),

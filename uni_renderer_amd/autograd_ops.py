@@ -118,10 +118,34 @@ class Up2x(Function):
         return bw.resample2x(dy.contiguous(), 1)
 
 
+def _is_barrier(t) -> bool:
+    """``t`` is the very output object of a live ParamBarrier (its gradient may be handed out uninitialised)."""
+    ref = _deferred_b.get(t.data_ptr())
+    return ref is not None and ref() is t
+
+
+def _norm_params(gamma, beta):
+    """the ParamBarrier outputs of a norm layer's parameters inside a batched-cast context (train_step), else themselves"""
+    if deferred_bias:
+        return deferred_bias.get(id(gamma), gamma), deferred_bias.get(id(beta), beta)
+    return gamma, beta
+
+
+def group_norm(x, gamma, beta, eps, groups, silu):
+    gamma, beta = _norm_params(gamma, beta)
+    return GroupNorm.apply(x, gamma, beta, eps, groups, silu)
+
+
+def layer_norm_skip(x, gamma, beta, eps):
+    gamma, beta = _norm_params(gamma, beta)
+    return LayerNormSkip.apply(x, gamma, beta, eps)
+
+
 class GroupNorm(Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, eps, groups, silu):
         ctx.save_for_backward(x, gamma, beta)
+        ctx.defer = bw.NORM_DEFER and bw.WGRAD_DEFER and _is_barrier(gamma) and _is_barrier(beta)
         ctx.cfg = (float(eps), int(groups), bool(silu))
         y, ctx.stats = ops.groupnorm(x, gamma, beta, eps, groups=groups, silu=silu, return_stats=True)
         return y
@@ -130,7 +154,8 @@ class GroupNorm(Function):
     def backward(ctx, dy):
         x, gamma, beta = ctx.saved_tensors
         eps, groups, silu = ctx.cfg
-        dx, dg, db = bw.groupnorm_backward(x, dy.contiguous(), gamma, beta, eps, groups=groups, silu=silu, stats=ctx.stats)
+        dx, dg, db = bw.groupnorm_backward(x, dy.contiguous(), gamma, beta, eps, groups=groups, silu=silu, stats=ctx.stats,
+                                            defer=ctx.defer)
         return dx, dg, db, None, None, None
 
 
@@ -157,6 +182,7 @@ class LayerNormSkip(Function):
     def forward(ctx, x, gamma, beta, eps):
         ctx.save_for_backward(x, gamma)
         ctx.eps = float(eps)
+        ctx.defer = bw.NORM_DEFER and bw.WGRAD_DEFER and _is_barrier(gamma) and _is_barrier(beta)
         ctx.set_materialize_grads(False)
         return x.view_as(x), ops.layernorm(x, gamma, beta, eps)
 
@@ -166,7 +192,7 @@ class LayerNormSkip(Function):
         if dy is None:
             return dskip, None, None, None
         skip = dskip.contiguous() if dskip is not None else None
-        dx, dg, db = bw.layernorm_backward(x, dy.contiguous(), gamma, ctx.eps, skip=skip)
+        dx, dg, db = bw.layernorm_backward(x, dy.contiguous(), gamma, ctx.eps, skip=skip, defer=ctx.defer)
         return dx, dg, db, None
 
 

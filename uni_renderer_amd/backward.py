@@ -361,8 +361,10 @@ class WgradQueue:
     def reset(self):
         """Drop whatever is pending (a backward that raised half-way leaves entries whose gradients nobody will read)."""
         self.items, self.seen = [], set()
+        norm_sums.reset()
 
     def flush(self):
+        norm_sums.flush()  # the deferred gamma / beta gradients ride on the same barriers
         items, self.items, self.seen = self.items, [], set()
         groups: dict = {}
         for it in items:
@@ -373,6 +375,47 @@ class WgradQueue:
                 wgrad_group(its[i:i + WGRAD_GROUP_MAX], conv=key[4], trace=self.trace)
 
 
+class _ColsumItem(C.Structure):
+    _fields_ = [("inp", C.c_void_p), ("out", C.c_void_p), ("M", C.c_int32), ("N", C.c_int32), ("pair", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+_lib.register_layout("ur_sizeof_colsum_item", _ColsumItem)
+COLSUM_MULTI_MAX = 96
+
+
+class NormSums:
+    """gamma / beta gradients of LayerNorm / GroupNorm layers, DEFERRED like the weight gradients: ``add`` keeps the layer's
+    partial sums ([M, N] fp32: per-wave rows of the LayerNorm backward, per-sample (channel, component) pairs of the GroupNorm
+    backward) and hands out an uninitialised [N] result; ``flush`` sums up to 96 of them per ``ur_colsum_multi`` launch (one or
+    two launches per layer otherwise: ~310 per training step).  Only for parameters behind ``autograd_ops.ParamBarrier``."""
+
+    def __init__(self):
+        self.items = []
+
+    def add(self, part: torch.Tensor, pair: bool) -> torch.Tensor:
+        out = torch.empty(part.shape[1], dtype=torch.float32, device=part.device)
+        self.items.append((part, out, pair))
+        return out
+
+    def reset(self):
+        self.items = []
+
+    def flush(self):
+        items, self.items = self.items, []
+        if not items:
+            return
+        lib = _lib.load()
+        for i in range(0, len(items), COLSUM_MULTI_MAX):
+            chunk = items[i:i + COLSUM_MULTI_MAX]
+            arr = (_ColsumItem * len(chunk))()
+            for k, (part, out, pair) in enumerate(chunk):
+                arr[k].inp, arr[k].out, arr[k].M, arr[k].N, arr[k].pair = part.data_ptr(), out.data_ptr(), part.shape[0], part.shape[1], int(pair)
+            check(lib.ur_colsum_multi(arr, len(chunk), _stream()), "ur_colsum_multi")
+
+
+norm_sums = NormSums()
+NORM_DEFER = os.environ.get("UR_NORM_DEFER", "1") != "0"
 wgrad_queue = WgradQueue()
 # Deferred + grouped Linear weight gradients (WgradQueue).  UR_WGRAD_DEFER=0: every Linear computes its own at once.
 WGRAD_DEFER = os.environ.get("UR_WGRAD_DEFER", "1") != "0"
@@ -595,7 +638,7 @@ GN_BWD_FUSED_MAX_ROWS = int(os.environ.get("UR_GN_BWD_FUSED_MAX_ROWS", "1024"))
 
 
 def groupnorm_backward(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float,
-                       groups: int = 32, silu: bool = False, stats: Optional[torch.Tensor] = None
+                       groups: int = 32, silu: bool = False, stats: Optional[torch.Tensor] = None, defer: bool = False
                        ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """x, dy NHWC [B,H,W,C]; y = act(GN(x)*gamma + beta).  -> (dx, dgamma, dbeta) (the last two fp32).
     ``stats``: the forward pass's partial statistics when it kept them; otherwise they are recomputed with
@@ -614,6 +657,9 @@ def groupnorm_backward(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, b
         check(lib.ur_groupnorm_backward_fused(x.data_ptr(), dy.data_ptr(), Cc, B, rows, groups, gamma.data_ptr(), beta.data_ptr(),
                                               float(eps), int(silu), chan_sum.data_ptr(), dx.data_ptr(), DT[x.dtype], s),
               "ur_groupnorm_backward_fused")
+        if defer and NORM_DEFER:
+            sums = norm_sums.add(chan_sum.view(B, 2 * Cc), True).view(2, Cc)
+            return dx, sums[1], sums[0]
         sums = torch.empty(2, Cc, dtype=torch.float32, device=x.device)
         check(lib.ur_pairsum_rows(chan_sum.data_ptr(), B, Cc, sums.data_ptr(), s), "ur_pairsum_rows")
         return dx, sums[1], sums[0]
@@ -631,13 +677,16 @@ def groupnorm_backward(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, b
     check(lib.ur_groupnorm_backward(x.data_ptr(), dy.data_ptr(), Cc, B, rows, groups, nstat, part.data_ptr(),
                                     gamma.data_ptr(), beta.data_ptr(), float(eps), int(silu), nred, chan_part.data_ptr(),
                                     chan_sum.data_ptr(), nchunks, dx.data_ptr(), DT[x.dtype], s), "ur_groupnorm_backward")
+    if defer and NORM_DEFER:
+        sums = norm_sums.add(chan_sum.view(B, 2 * Cc), True).view(2, Cc)
+        return dx, sums[1], sums[0]
     sums = torch.empty(2, Cc, dtype=torch.float32, device=x.device)  # rows: sum dz (= dbeta), sum dz * xhat (= dgamma)
     check(lib.ur_pairsum_rows(chan_sum.data_ptr(), B, Cc, sums.data_ptr(), s), "ur_pairsum_rows")
     return dx, sums[1], sums[0]
 
 
 def layernorm_backward(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, eps: float = 1e-5,
-                       skip: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+                       skip: Optional[torch.Tensor] = None, defer: bool = False) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """x, dy [..., C] -> (dx, dgamma, dbeta) (fp32 parameter gradients).  ``skip``: a gradient reaching x around the norm
     (same shape), added to dx by the kernel."""
     _require_gpu(x)
@@ -651,6 +700,9 @@ def layernorm_backward(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, e
     check(lib.ur_layernorm_backward_skip(x.data_ptr(), dy.data_ptr(), gamma.data_ptr(), float(eps), rows, Cc, rpw, dx.data_ptr(),
                                          part.data_ptr(), skip.data_ptr() if skip is not None else None, DT[x.dtype], _stream()),
           "ur_layernorm_backward_skip")
+    if defer and NORM_DEFER:
+        sums = norm_sums.add(part.view(waves, 2 * Cc), False).view(2, Cc)
+        return dx, sums[0], sums[1]
     sums = colsum(part.view(waves, 2 * Cc)).view(2, Cc)
     return dx, sums[0].contiguous(), sums[1].contiguous()
 

@@ -1297,6 +1297,57 @@ extern "C" int ur_merge_heads(const void* g, int Tp, int dp, int B, int T_, int 
     return last_error();
 }
 
+// Column sums of up to UR_COLSUM_MULTI_MAX fp32 matrices [M][N] in ONE launch (the parameter gradients of every LayerNorm /
+// GroupNorm of a network, deferred to the end of its backward: backward.NormSums): a workgroup owns 32 columns of one matrix,
+// eight row lanes per column, folded in a fixed order.  pair: the columns are (channel, component) pairs [C][2] and the
+// result is planar, out[k * C + c] (ur_pairsum_rows).
+struct ColsumMultiArgs {
+    ur_colsum_item t[UR_COLSUM_MULTI_MAX];
+    int blk0[UR_COLSUM_MULTI_MAX + 1];
+    int n;
+};
+__global__ void __launch_bounds__(256) colsum_multi_kernel(const ColsumMultiArgs a) {
+    __shared__ float red[8][32];
+    int lo = 0, hi = a.n;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (a.blk0[mid] <= (int)blockIdx.x) lo = mid; else hi = mid;
+    }
+    const ur_colsum_item e = a.t[lo];
+    const int cl = threadIdx.x & 31, q = threadIdx.x >> 5;   // 32 columns x 8 row lanes: 128-byte row segments
+    const int col = ((int)blockIdx.x - a.blk0[lo]) * 32 + cl;
+    float s0 = 0.f, s1 = 0.f;
+    if (col < e.N) {
+        int r = q;
+        for (; r + 8 < e.M; r += 16) { s0 += e.in[(int64_t)r * e.N + col]; s1 += e.in[(int64_t)(r + 8) * e.N + col]; }
+        if (r < e.M) s0 += e.in[(int64_t)r * e.N + col];
+    }
+    red[q][cl] = s0 + s1;
+    __syncthreads();
+    if (q == 0 && col < e.N) {
+        float v = red[0][cl];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) v += red[i][cl];
+        e.out[e.pair ? (col & 1) * (e.N >> 1) + (col >> 1) : col] = v;
+    }
+}
+extern "C" int ur_colsum_multi(const ur_colsum_item* items, int n, void* stream) {
+    if (!items || n <= 0 || n > UR_COLSUM_MULTI_MAX) return UR_E_BADARG;
+    ColsumMultiArgs a;
+    int blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!items[i].in || !items[i].out || items[i].M <= 0 || items[i].N <= 0 || (items[i].pair && (items[i].N & 1))) return UR_E_BADARG;
+        a.t[i] = items[i];
+        a.blk0[i] = blocks;
+        blocks += (items[i].N + 31) / 32;
+    }
+    a.blk0[n] = blocks;
+    a.n = n;
+    hipLaunchKernelGGL(colsum_multi_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+    return last_error();
+}
+extern "C" int ur_sizeof_colsum_item(void) { return (int)sizeof(ur_colsum_item); }
+
 static int heads_multi(const ur_heads_desc* descs, int n, int B, int H, int d, int dp, int dtype, void* stream, bool split) {
     if (!descs || n <= 0 || n > UR_HEADS_MAX || B <= 0 || H <= 0 || d <= 0 || (d & 7) || (dp & 7) || dp < d) return UR_E_BADARG;
     HeadsMultiArgs a;

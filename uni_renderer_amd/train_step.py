@@ -58,6 +58,9 @@ class _batched_casts:
             bs = [m.bias for m in self.net.modules()
                   if (isinstance(m, torch.nn.Linear) or (isinstance(m, torch.nn.Conv2d) and m.kernel_size in ((1, 1), (3, 3))))
                   and m.bias is not None and m.bias.dtype == torch.float32]
+            # gamma / beta of the norm layers too: their gradients are summed in one launch at the barrier (backward.NormSums)
+            bs += [p_ for m in self.net.modules() if isinstance(m, (torch.nn.GroupNorm, torch.nn.LayerNorm)) and m.weight is not None
+                   for p_ in (m.weight, m.bias) if p_ is not None and p_.dtype == torch.float32]
             conv_in = getattr(self.net, "conv_in", None)
             c3 = [(m.weight, CIN_PAD if m is conv_in else None) for m in self.net.modules()
                   if isinstance(m, torch.nn.Conv2d) and m.kernel_size == (3, 3) and m.weight.dtype == torch.float32]
@@ -127,10 +130,10 @@ def _resnet(r, x, temb, dt, x1=None):
     """models/unet_2d_blocks.py:1100-1111 (ResnetBlock2D, time_embedding_norm='default'); ``temb``: the dict of
     _temb_projections."""
     xin = torch.cat([x, x1], -1) if x1 is not None else x
-    h = A.GroupNorm.apply(xin, r.norm1.weight, r.norm1.bias, r.eps, r.groups, True)
+    h = A.group_norm(xin, r.norm1.weight, r.norm1.bias, r.eps, r.groups, True)
     t = temb[id(r)]
     h = A.conv3x3(h, A.pack_conv_weight(r.conv1.weight, dt), r.conv1.bias, rowadd=t)
-    h = A.GroupNorm.apply(h, r.norm2.weight, r.norm2.bias, r.eps, r.groups, True)
+    h = A.group_norm(h, r.norm2.weight, r.norm2.bias, r.eps, r.groups, True)
     sc = xin if r.conv_shortcut is None else A.linear(xin, _w2(r.conv_shortcut, dt), r.conv_shortcut.bias)
     if r.output_scale_factor != 1.0:
         raise NotImplementedError("output_scale_factor != 1 in the training path")
@@ -168,19 +171,19 @@ def _context_projections(blocks, ehs, dt):
 
 def _tblock(b, x, kvs, dt):
     # (x, LN(x)) as one autograd node: the residual's gradient is added inside the LayerNorm backward kernel
-    xs, xn = A.LayerNormSkip.apply(x, b.norm1.weight, b.norm1.bias, b.norm1.eps)
+    xs, xn = A.layer_norm_skip(x, b.norm1.weight, b.norm1.bias, b.norm1.eps)
     x = _self_attn(b.attn1, xn, xs, dt)
-    xs, xn = A.LayerNormSkip.apply(x, b.norm2.weight, b.norm2.bias, b.norm2.eps)
+    xs, xn = A.layer_norm_skip(x, b.norm2.weight, b.norm2.bias, b.norm2.eps)
     x = _cross_attn(b.attn2, xn, kvs[id(b)], xs, dt)
     proj, out = b.ff.net[0].proj, b.ff.net[2]
-    xs, xn = A.LayerNormSkip.apply(x, b.norm3.weight, b.norm3.bias, b.norm3.eps)
+    xs, xn = A.layer_norm_skip(x, b.norm3.weight, b.norm3.bias, b.norm3.eps)
     h = A.linear(xn, _w2(proj, dt), proj.bias)
     return A.linear(A.GEGLU.apply(h), _w2(out, dt), out.bias, res=xs)
 
 
 def _transformer(t, x, ehs, dt):
     B, H, W, Cc = x.shape
-    h = A.GroupNorm.apply(x, t.norm.weight, t.norm.bias, t.norm.eps, t.groups, False)
+    h = A.group_norm(x, t.norm.weight, t.norm.bias, t.norm.eps, t.groups, False)
     h = A.linear(h.view(B, H * W, Cc), _w2(t.proj_in, dt), t.proj_in.bias)
     for blk in t.transformer_blocks:
         h = _tblock(blk, h, ehs, dt)
@@ -246,7 +249,7 @@ def _up_out(net, x, skips: List[torch.Tensor], temb_act, ehs, dt, extras=None, c
                 raise NotImplementedError("training path: latent sides must be multiples of 2**num_upsamplers")
             x = _conv(blk.upsamplers[0].conv, A.Up2x.apply(x), dt)
     n = net.conv_norm_out
-    h = A.GroupNorm.apply(x, n.weight, n.bias, n.eps, n.num_groups, True)
+    h = A.group_norm(x, n.weight, n.bias, n.eps, n.num_groups, True)
     return _conv(net.conv_out, h, dt)
 
 
