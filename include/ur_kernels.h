@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define UR_ABI_VERSION 9
+#define UR_ABI_VERSION 10
 
 #define UR_E_BADARG (-1001)   /* inconsistent descriptor (shape / alignment / null pointer)   */
 #define UR_E_UNSUPPORTED (-1002) /* shape outside what the kernels are instantiated for       */
@@ -231,6 +231,7 @@ int ur_igemm_splitk_gn(const ur_igemm_desc* d, const float* gamma, const float* 
 /* 1 when the library was built with the experimental weight-streaming conv tiles (UR_TILE_WS320*: `make WSCONV=1`); the
  * product build returns 0 and UR_E_UNSUPPORTED for those tile ids. */
 int ur_has_wsconv(void);
+int ur_has_pp(void);     /* 1: the ping-pong tiles (UR_TILE_PP_*) are built in (`make PP=1`); else they return UR_E_UNSUPPORTED */
 
 /* Workspace (in floats) ur_igemm needs in `partial` for this descriptor (0 when splitk <= 1). */
 int64_t ur_igemm_partial_floats(const ur_igemm_desc* d);
@@ -300,6 +301,25 @@ int ur_add(const void* a, const void* b, float alpha, void* out, int64_t n, int 
 /* the same over (hi, lo) pairs: out + out_lo = (a + a_lo) + alpha * (b + b_lo); any *_lo may be NULL */
 int ur_add_hilo(const void* a, const void* a_lo, const void* b, const void* b_lo, float alpha, void* out, void* out_lo,
                 int64_t n, int dtype, void* stream);
+
+/* ur_add_hilo (alpha = 1) over up to UR_ADD_MULTI_MAX independent tensor triples in ONE launch (ABI 10).  What a sampling
+ * loop with a loop-invariant exchange operand runs per step instead of 13 exchange GEMMs: in the inverse-rendering loop
+ * (models/pipeline.py:2629-2690) the UNet's skips are constant, so `control_down_blocks[i](skip_unet[i])`
+ * (models/controlnet.py:2446-2461, 2476-2477) is computed once per call and only the add remains per step; in the
+ * rendering loop (pipeline.py:1587-1629) the same holds for the encoder's `controlnet_down_blocks[i](skip_enc[i])`
+ * (controlnet.py:1752-1769, added at 1078-1087, 1114-1115). */
+#define UR_ADD_MULTI_MAX 16
+typedef struct ur_add_item {
+    const void* a;
+    const void* a_lo;   /* NULL: a has no low part */
+    const void* b;
+    const void* b_lo;
+    void* out;
+    void* out_lo;       /* NULL: the rounding remainder is dropped */
+    int64_t n;          /* elements, multiple of 8 */
+} ur_add_item;
+int ur_add_hilo_multi(const ur_add_item* items, int n, int dtype, void* stream);
+int ur_sizeof_add_item(void);
 
 /* Sinusoidal timestep embedding of nt (1 or B) fp32 timesteps: out[b][:] = [cos | sin] (flip) or
  * [sin | cos]; fp32 math. */

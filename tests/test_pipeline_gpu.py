@@ -381,3 +381,95 @@ def test_repeat_averaging_folds_into_one_batch(dev):
             assert rel_l2(a[i:i + 1], b) < 4e-3, (i, rel_l2(a[i:i + 1], b))
     mean_folded = folded[0].float().mean(0)  # the averaging of test_real.py:557-564 on the material group
     assert mean_folded.shape == (4, 16, 16) and bool(torch.isfinite(mean_folded).all())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# loop-invariant hoisting (uni_renderer_amd/hoist.py)
+# ---------------------------------------------------------------------------------------------------------------------
+def _run_loops(pipe, dev, img, mask, ehs, sched, guidance, fused, nipp=1, steps=5):
+    """Inverse + rendering loop on fixed noise; returns the list of final latents."""
+    if sched == "unipc":
+        _attach_unipc(pipe)
+    pipe.use_fused_sampler = fused
+    g = torch.Generator().manual_seed(31)
+    n = img.shape[0] * nipp
+    noise = torch.randn(n, 4, 16, 16, generator=g)
+    attr = torch.randn(n, 28, 16, 16, generator=g).to(dev)
+    inv = pipe.real_image2mask_3mod_albedo(
+        prompt_embeds=ehs.to(dev).half(), image_latents=img.to(dev), mask_latents=mask.to(dev), latents=noise,
+        num_inference_steps=steps, guidance_scale=guidance, num_images_per_prompt=nipp, output_type="latent")
+    ren = pipe.mask2image_3mod_albedo(prompt_embeds=ehs.to(dev).half(), attr_latents=attr, latents=noise,
+                                      num_inference_steps=steps, guidance_scale=guidance, output_type="latent")
+    return [t.clone() for t in inv] + [ren.clone()]
+
+
+@pytest.mark.parametrize("sched", ["ddim", "unipc"])
+@pytest.mark.parametrize("guidance", [0.0, 2.0])
+@pytest.mark.parametrize("fused", [True, False])
+def test_hoisted_loops_equal_unhoisted_loops_bitwise(dev, sched, guidance, fused):
+    """Hoisting the loop-invariant half (inverse: UNet down + mid and the decoder's exchange convs once per call, UNet up and the
+    encoder's exchange convs never; rendering: the encoder once per call -- ref pipeline.py:2629-2690, 1587-1629,
+    controlnet.py:1075-1115, 1716-1720) must not change a bit: the same executor with its prologue re-run in front of
+    EVERY step (= the un-hoisted loop on the same kernels) gives ``torch.equal`` final latents.  DDIM and UniPC, guidance
+    0 and != 0, on-device and step-by-step sampler, and the eval protocol's ``num_images_per_prompt = 5``."""
+    pipe, _, img, mask, ehs, _ = _setup(dev, seed=28)
+    assert pipe.hoist_invariants
+    for nipp, im, mk in ((1, img, mask), (5, img[:1], mask[:1])):
+        pipe.rerun_invariants = False
+        a = _run_loops(pipe, dev, im, mk, ehs, sched, guidance, fused, nipp)
+        a2 = _run_loops(pipe, dev, im, mk, ehs, sched, guidance, fused, nipp)  # replays: the prologue runs again per call
+        pipe.rerun_invariants = True
+        b = _run_loops(pipe, dev, im, mk, ehs, sched, guidance, fused, nipp)
+        for x, y, z in zip(a, a2, b):
+            assert torch.isfinite(x).all()
+            assert torch.equal(x, y) and torch.equal(x, z)
+    from uni_renderer_amd.graph import GraphedHoistedStep
+
+    assert pipe._graphs and all(isinstance(g, GraphedHoistedStep) for g in pipe._graphs.values())
+
+
+@pytest.mark.parametrize("sched", ["ddim", "unipc"])
+def test_hoisted_loops_match_every_network_every_step(dev, sched):
+    """The hoisted executor against the executor that runs all three networks on every step (the grouped enc || unet,
+    unet || dec launches of fused.py): same arithmetic, different launch shapes (z = 1 vs z = 2 tiles, the exchange as
+    conv-then-add like the reference instead of a GEMM epilogue) -> close, not bit-equal; and a second call with OTHER fixed
+    inputs must not see the first call's invariants."""
+    pipe, _, img, mask, ehs, _ = _setup(dev, seed=29)
+    a = _run_loops(pipe, dev, img, mask, ehs, sched, 0.0, True)
+    a_other = _run_loops(pipe, dev, img * 0.5, mask, ehs * 0.7, sched, 0.0, True)
+    pipe.hoist_invariants = False
+    b = _run_loops(pipe, dev, img, mask, ehs, sched, 0.0, True)
+    b_other = _run_loops(pipe, dev, img * 0.5, mask, ehs * 0.7, sched, 0.0, True)
+    for x, y, xo, yo in zip(a, b, a_other, b_other):
+        assert rel_l2(x, y) < 3e-3, rel_l2(x, y)
+        assert rel_l2(xo, yo) < 3e-3, rel_l2(xo, yo)
+        assert rel_l2(x, xo) > 1e-2  # the fixed inputs matter
+
+
+def test_add_multi(dev):
+    """ur_add_hilo_multi: 13 (hi, lo) + (hi, lo) sums of different sizes in one launch == ur_add_hilo one by one."""
+    from uni_renderer_amd import ops
+
+    for dt in (torch.float16, torch.bfloat16):
+        g = torch.Generator().manual_seed(2)
+        pairs = []
+        for k in range(13):
+            shp = (2, 3 + k, 5, 8 * (k % 4 + 1))
+            ab = []
+            for _ in range(2):
+                v = torch.randn(*shp, generator=g).to(dev)
+                hi = v.to(dt)
+                if k % 3 != 2:
+                    hi.lo = ops.lo_encode(v - hi.float(), dt)
+                ab.append(hi)
+            pairs.append(tuple(ab))
+        for hilo in (True, False):
+            outs = ops.add_multi(pairs, hilo=hilo)
+            for (a, b), o in zip(pairs, outs):
+                r = ops.add(a, b, hilo=hilo)
+                assert torch.equal(o, r)
+                if hilo:
+                    assert torch.equal(o.lo, r.lo)
+                full = (a.float() + (ops.lo_float(a.lo) if ops.lo_of(a) is not None else 0)
+                        + b.float() + (ops.lo_float(b.lo) if ops.lo_of(b) is not None else 0))
+                assert rel_l2(o, full.cpu()) < (1e-3 if dt == torch.float16 else 6e-3)

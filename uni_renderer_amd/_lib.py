@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must be imported first, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("UR_LIB_PATH", os.path.join(_HERE, "liburhip.so"))  # override = kernel experiments only
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
@@ -98,6 +98,8 @@ SYMBOLS = {
     "ur_attention": (C.c_int, [C.POINTER(AttnDesc), vp]),
     "ur_add": (C.c_int, [vp, vp, C.c_float, vp, C.c_int64, C.c_int, vp]),
     "ur_add_hilo": (C.c_int, [vp, vp, vp, vp, C.c_float, vp, vp, C.c_int64, C.c_int, vp]),
+    "ur_add_hilo_multi": (C.c_int, [vp, C.c_int, C.c_int, vp]),
+    "ur_sizeof_add_item": (C.c_int, []),
     "ur_timestep_embedding": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp, C.c_int, vp]),
     "ur_resize_nearest": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "ur_nchw_to_nhwc": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp]),
@@ -163,6 +165,7 @@ SYMBOLS = {
     "ur_build_info": (C.c_char_p, []),
     "ur_sizeof_igemm_desc": (C.c_int, []),
     "ur_has_wsconv": (C.c_int, []),
+    "ur_has_pp": (C.c_int, []),
     "ur_igemm_uses_dxs": (C.c_int, [vp]),
     "ur_igemm_splitk_gn": (C.c_int, [vp, vp, vp, i64, C.c_float, C.c_int, C.c_int, vp]),
     "ur_sizeof_attn_desc": (C.c_int, []),

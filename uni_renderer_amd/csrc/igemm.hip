@@ -682,7 +682,11 @@ int wsconv_launch(const ur_igemm_desc& d, hipStream_t s);  // wsconv.hip (make W
 #else
 static int wsconv_launch(const ur_igemm_desc&, hipStream_t) { return UR_E_UNSUPPORTED; }  // not in the product build
 #endif
-int igemm_pp_launch(const ur_igemm_desc& d, hipStream_t s);  // igemm_pp.hip
+#ifdef UR_WITH_PP
+int igemm_pp_launch(const ur_igemm_desc& d, hipStream_t s);  // igemm_pp.hip (make PP=1)
+#else
+static int igemm_pp_launch(const ur_igemm_desc&, hipStream_t) { return UR_E_UNSUPPORTED; }  // not in the product build
+#endif
 // igemm_dxs.hip: the 3x3 conv with the three dx taps sharing one staged pixel block.  Parity-green and 4-8 % SLOWER in the step
 // than the lock-step kernels, so an opt-in build like wsconv.hip: `make DXS=1`, then UR_DXS=1.
 #ifdef UR_WITH_DXS
@@ -812,6 +816,14 @@ static int64_t padded_ldp(const ur_igemm_desc& d, int tile) {
 }
 
 }  // namespace ur
+
+extern "C" int ur_has_pp(void) {
+#ifdef UR_WITH_PP
+    return 1;
+#else
+    return 0;
+#endif
+}
 
 extern "C" int ur_has_wsconv(void) {
 #ifdef UR_WITH_WSCONV

@@ -157,6 +157,75 @@ extern "C" int ur_add_hilo(const void* a, const void* a_lo, const void* b, const
     return e == hipSuccess ? 0 : -(int)e;
 }
 
+// ur_add_hilo over up to UR_ADD_MULTI_MAX tensor triples in ONE launch: the 13 exchange adds of a sampling step whose
+// 1x1-conv operand is loop-invariant (hoist.py).  Workgroup -> (item, chunk of 1024 8-element vectors) through a prefix table
+// in the kernel arguments; same per-element arithmetic as add_hilo_kernel with alpha = 1.
+struct AddMultiArgs {
+    ur_add_item t[UR_ADD_MULTI_MAX];
+    int blk0[UR_ADD_MULTI_MAX + 1];
+    int n;
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256) add_hilo_multi_kernel(const AddMultiArgs a) {
+    int it = 0;
+    while (it + 1 < a.n && (int)blockIdx.x >= a.blk0[it + 1]) ++it;
+    const ur_add_item e = a.t[it];
+    const T* pa = (const T*)e.a;
+    const T* pb = (const T*)e.b;
+    const lo_t<T>* la = (const lo_t<T>*)e.a_lo;
+    const lo_t<T>* lb = (const lo_t<T>*)e.b_lo;
+    T* po = (T*)e.out;
+    lo_t<T>* lo = (lo_t<T>*)e.out_lo;
+    const int64_t nvec = e.n / 8;
+    const int64_t v0 = (int64_t)((int)blockIdx.x - a.blk0[it]) * 1024;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int64_t i = v0 + u * 256 + threadIdx.x;
+        if (i >= nvec) break;
+        float x[8], y[8], t[8];
+        load8(pa + i * 8, x);
+        load8(pb + i * 8, y);
+        if (la) {
+            load_lo<8>(la + i * 8, t);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) x[k] += t[k];
+        }
+        if (lb) {
+            load_lo<8>(lb + i * 8, t);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) y[k] += t[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) x[k] = x[k] + 1.0f * y[k];
+        store8(po + i * 8, x);
+        if (lo) store_lo8<T>(lo + i * 8, x);
+    }
+}
+
+extern "C" int ur_add_hilo_multi(const ur_add_item* items, int n, int dtype, void* stream) {
+    if (!items || n <= 0 || n > UR_ADD_MULTI_MAX) return UR_E_BADARG;
+    AddMultiArgs a;
+    int blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!items[i].a || !items[i].b || !items[i].out || items[i].n <= 0 || (items[i].n & 7)) return UR_E_BADARG;
+        a.t[i] = items[i];
+        a.blk0[i] = blocks;
+        const int64_t nb = (items[i].n / 8 + 1023) / 1024;
+        if (nb + blocks > (1 << 30)) return UR_E_UNSUPPORTED;
+        blocks += (int)nb;
+    }
+    a.blk0[n] = blocks;
+    a.n = n;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == UR_DT_F16) hipLaunchKernelGGL((add_hilo_multi_kernel<f16>), dim3(blocks), dim3(256), 0, s, a);
+    else if (dtype == UR_DT_BF16) hipLaunchKernelGGL((add_hilo_multi_kernel<bf16>), dim3(blocks), dim3(256), 0, s, a);
+    else return UR_E_BADARG;
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : -(int)e;
+}
+extern "C" int ur_sizeof_add_item(void) { return (int)sizeof(ur_add_item); }
+
 extern "C" int ur_timestep_embedding(const float* t, int nt, int B, int dim, int flip_sin_to_cos, float freq_shift,
                                      void* out, int dtype, void* stream) {
     if (!t || !out || B <= 0 || dim < 2 || (nt != 1 && nt != B)) return UR_E_BADARG;

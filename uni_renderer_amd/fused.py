@@ -349,23 +349,29 @@ class GroupedDualStreamStep:
         return ops.conv3x3(x, w, b, stride=stride, ups=ups, streams=S, hilo=self.hilo, cblock=ops.conv_cblock(x.shape[-1]))
 
     # ------------------------------------------------------------------ per-phase context (temb, prompt K / V^T)
-    def _phase_ctx(self, nets, resnet_lists, cross_lists, semb, ehs):
+    def _phase_ctx(self, nets, resnet_lists, cross_lists, semb, ehs, temb=True, kv=True):
         """Batched per-resnet time projections and per-cross-attention prompt K / V^T of ONE phase, grouped over the
-        streams.  Column layouts are identical across streams because the module lists are."""
-        S, pk, dt = len(nets), self.pk, semb.dtype
-        key = tuple(id(r) for rl in resnet_lists for r in rl)
-        wt = pk.get(("p.wt", key), nets, [r.time_emb_proj.weight for rl in resnet_lists for r in rl], dt,
-                    lambda: _stk(torch.cat([pack_matrix(r.time_emb_proj.weight, dt) for r in rl], 0) for rl in resnet_lists))
-        bt = pk.get(("p.bt", key), nets, [r.time_emb_proj.bias for rl in resnet_lists for r in rl], dt,
-                    lambda: _stk(torch.cat([f32(r.time_emb_proj.bias) for r in rl], 0) for rl in resnet_lists))
-        temb = ops.linear(semb, wt, bt, streams=S)  # [S*B, sum Cout]
+        streams.  Column layouts are identical across streams because the module lists are.  ``temb`` / ``kv`` = False
+        leave that half out (None): the prompt half depends on ``ehs`` only and the sampling loops compute it once per
+        call (hoist.py), the time half once per step."""
+        S, pk = len(nets), self.pk
+        dt = semb.dtype if semb is not None else ehs.dtype
         tslices, off = {}, 0
         for r in resnet_lists[0]:
             tslices[id(r)] = (off, off + r.out_channels)
             off += r.out_channels
+        if temb:
+            key = tuple(id(r) for rl in resnet_lists for r in rl)
+            wt = pk.get(("p.wt", key), nets, [r.time_emb_proj.weight for rl in resnet_lists for r in rl], dt,
+                        lambda: _stk(torch.cat([pack_matrix(r.time_emb_proj.weight, dt) for r in rl], 0) for rl in resnet_lists))
+            bt = pk.get(("p.bt", key), nets, [r.time_emb_proj.bias for rl in resnet_lists for r in rl], dt,
+                        lambda: _stk(torch.cat([f32(r.time_emb_proj.bias) for r in rl], 0) for rl in resnet_lists))
+            temb = ops.linear(semb, wt, bt, streams=S)  # [S*B, sum Cout]
+        else:
+            temb = None
         kc = vtc = None
         kslices = {}
-        if cross_lists[0]:
+        if cross_lists[0] and kv:
             ckey = tuple(id(a) for al in cross_lists for a in al)
             wk = pk.get(("p.wk", ckey), nets, [a.to_k.weight for al in cross_lists for a in al], dt,
                         lambda: _stk(torch.cat([pack_matrix(a.to_k.weight, dt) for a in al], 0) for al in cross_lists))
@@ -406,130 +412,79 @@ class GroupedDualStreamStep:
     def _kvs(self, t0: Transformer2DModel, kslices):
         return [kslices[id(b.attn2)] for b in t0.transformer_blocks]
 
-    # ------------------------------------------------------------------ the step
-    @torch.no_grad()
-    def __call__(self, x_t, cond, ehs, t_img, t_attr, run_decoder: bool = True, conditioning_scale: float = 1.0
-                 ) -> Dict[str, torch.Tensor]:
-        unet, enc, dec, pk = self.unet, self.enc, self.dec, self.pk
-        dt = _compute_dtype(unet.dtype, unet.compute_dtype)
-        dev = x_t.device
-        B, _, H, W = x_t.shape
-        ehs = ehs.to(dt).contiguous() if (ehs.dtype != dt or not ehs.is_contiguous()) else ehs
-        if ehs.shape[0] == 1 and B > 1:
-            ehs = ehs.expand(B, -1, -1).contiguous()
-
-        def tvec(t):
-            t = torch.as_tensor(t, device=dev, dtype=torch.float32).reshape(-1)
-            return t.expand(B) if t.numel() == 1 else t
-
-        # --- time embeddings of the three networks in one grouped chain: rows [enc | unet | dec]
-        nets3 = [enc, unet, dec] if run_decoder else [enc, unet]
-        ts = torch.cat([tvec(t_attr), tvec(t_img)] + ([tvec(t_attr)] if run_decoder else [])).contiguous()
-        S3 = len(nets3)
-        c = unet.config
-        t_emb = ops.timestep_embedding(ts, S3 * B, c["block_out_channels"][0], c["flip_sin_to_cos"], c["freq_shift"], dt)
-        tes = [n.time_embedding for n in nets3]
+    # ------------------------------------------------------------------ building blocks of a step (S streams in lockstep)
+    def _time_embed(self, nets, tvals, B, dt):
+        """SiLU(time_embedding(Timesteps(t))) of ``nets`` as one grouped chain: rows [net 0 | net 1 | ...], ``tvals`` one [B]
+        fp32 vector per network (controlnet.py:909-916 of the reference; the SiLU is the resnets' ``nonlinearity(temb)``)."""
+        pk, S = self.pk, len(nets)
+        c = self.unet.config
+        ts = torch.cat(list(tvals)).contiguous() if S > 1 else tvals[0].contiguous()
+        t_emb = ops.timestep_embedding(ts, S * B, c["block_out_channels"][0], c["flip_sin_to_cos"], c["freq_shift"], dt)
+        tes = [n.time_embedding for n in nets]
         w1 = pk.get("te.w1", tes, [t.linear_1.weight for t in tes], dt, lambda: _stk(pack_matrix(t.linear_1.weight, dt) for t in tes))
         b1 = pk.get("te.b1", tes, [t.linear_1.bias for t in tes], dt, lambda: _stk(f32(t.linear_1.bias) for t in tes))
         w2 = pk.get("te.w2", tes, [t.linear_2.weight for t in tes], dt, lambda: _stk(pack_matrix(t.linear_2.weight, dt) for t in tes))
         b2 = pk.get("te.b2", tes, [t.linear_2.bias for t in tes], dt, lambda: _stk(f32(t.linear_2.bias) for t in tes))
-        semb = ops.linear(ops.linear(t_emb, w1, b1, act=ops.ACT_SILU, streams=S3), w2, b2, act=ops.ACT_SILU, streams=S3)
+        return ops.linear(ops.linear(t_emb, w1, b1, act=ops.ACT_SILU, streams=S), w2, b2, act=ops.ACT_SILU, streams=S)
 
-        # ---- the exchange (phase 2), defined first: exchange i only needs skip pair i, so it is issued on the sibling
-        # branch as soon as phase 1 has produced that pair
-        scale = float(conditioning_scale)
-
-        def exchange(name, z_enc, z_dec, t):
-            """t = [enc ; unet] stacked.  Returns [unet + zc(enc)*scale ; enc + cd(unet)] (or only the first half)."""
-            half = t.numel() // 2
-            Cc = t.shape[-1]
-            if run_decoder:
-                mods = [z_enc, z_dec]
-                w = pk.get((name, "w", scale), mods, [m.weight for m in mods], dt,
-                           lambda: _stk([pack_matrix(z_enc.weight, dt) * scale if scale != 1.0 else pack_matrix(z_enc.weight, dt),
-                                         pack_matrix(z_dec.weight, dt)]))
-                b = pk.get((name, "b", scale), mods, [m.bias for m in mods], dt,
-                           lambda: _stk([f32(z_enc.bias) * scale, f32(z_dec.bias)]))
-                tt = t.view(2, -1, Cc)
-                tl = ops.lo_of(t)
-                y = ops.linear(tt, w, b, res=tt[1], res_zstride=-half, streams=2, hilo=self.hilo,
-                               res_lo=(tl.view(2, -1, Cc)[1] if tl is not None else None))
-                return ops.view_hilo(y, *t.shape)
-            w = pk.get((name, "w1", scale), [z_enc], [z_enc.weight], dt, lambda: (pack_matrix(z_enc.weight, dt) * scale).contiguous())
-            b = pk.get((name, "b1", scale), [z_enc], [z_enc.bias], dt, lambda: f32(z_enc.bias) * scale)
+    def _exchange(self, name, z_enc, z_dec, t, B, scale, dt):
+        """t = [enc ; unet] stacked.  Returns [unet + zc(enc)*scale ; enc + cd(unet)] (z_dec given) or only the first half."""
+        pk = self.pk
+        half = t.numel() // 2
+        Cc = t.shape[-1]
+        if z_dec is not None:
+            mods = [z_enc, z_dec]
+            w = pk.get((name, "w", scale), mods, [m.weight for m in mods], dt,
+                       lambda: _stk([pack_matrix(z_enc.weight, dt) * scale if scale != 1.0 else pack_matrix(z_enc.weight, dt),
+                                     pack_matrix(z_dec.weight, dt)]))
+            b = pk.get((name, "b", scale), mods, [m.bias for m in mods], dt,
+                       lambda: _stk([f32(z_enc.bias) * scale, f32(z_dec.bias)]))
+            tt = t.view(2, -1, Cc)
             tl = ops.lo_of(t)
-            return ops.linear(t[:B], w, b, res=t[B:], hilo=self.hilo, res_lo=(tl[B:] if tl is not None else None))
+            y = ops.linear(tt, w, b, res=tt[1], res_zstride=-half, streams=2, hilo=self.hilo,
+                           res_lo=(tl.view(2, -1, Cc)[1] if tl is not None else None))
+            return ops.view_hilo(y, *t.shape)
+        w = pk.get((name, "w1", scale), [z_enc], [z_enc.weight], dt, lambda: (pack_matrix(z_enc.weight, dt) * scale).contiguous())
+        b = pk.get((name, "b1", scale), [z_enc], [z_enc.bias], dt, lambda: f32(z_enc.bias) * scale)
+        tl = ops.lo_of(t)
+        return ops.linear(t[:B], w, b, res=t[B:], hilo=self.hilo, res_lo=(tl[B:] if tl is not None else None))
 
-        up_skips, forks = [], []
-
-        late = []  # UR_EXCHANGE_EARLY=0: all exchange GEMMs after the mid block (round-1 order) instead of right behind
-        early = os.environ.get("UR_EXCHANGE_EARLY", "1") != "0"  # the kernel that produced their skip (input still in L2)
-
-        def exchange_skip(t):
-            if not early:
-                late.append(t)
-                return
-            i = len(up_skips)
-            with self._fork(t) as f:
-                y = exchange(f"ex{i}", enc.controlnet_down_blocks[i], dec.control_down_blocks[i] if run_decoder else None, t)
-            up_skips.append(y)
-            forks.append((f, y))
-
-        # ---- up-phase context (time projections, prompt K / V^T of the up blocks): depends on the inputs only
-        pair3 = [unet, dec] if run_decoder else [unet]
-        S = len(pair3)
-        rl3 = [self._resnets_of([n.up_blocks]) for n in pair3]
-        cl3 = [self._cross_of([n.up_blocks]) for n in pair3]
-        ctx3_early = os.environ.get("UR_CTX3_EARLY", "1") != "0"
-        with self._fork(semb, ehs) as f3:
-            ctx3 = self._phase_ctx(pair3, rl3, cl3, semb[B: B + S * B], ehs) if ctx3_early else None
-
-        # ================= phase 1: enc || unet : conv_in, down, mid =================
-        pair = [enc, unet]
-        parts = [[n.down_blocks, n.mid_block] for n in pair]
-        rl = [self._resnets_of(p) for p in parts]
-        cl = [self._cross_of(p) for p in parts]
-        temb, tsl, kc, vtc, ksl = self._phase_ctx(pair, rl, cl, semb[: 2 * B], ehs)
-        x_in = torch.cat([ops.to_nhwc(cond, dt, CIN_PAD), ops.to_nhwc(x_t, dt, CIN_PAD)], 0)
-        cins = [n.conv_in for n in pair]
+    def _conv_in(self, nets, x_in):
+        pk, dt = self.pk, x_in.dtype
+        cins = [n.conv_in for n in nets]
         wci = pk.get("cin.w", cins, [m.weight for m in cins], dt, lambda: _stk(pack_conv3x3(m.weight, dt, CIN_PAD) for m in cins))
         bci = pk.get("cin.b", cins, [m.bias for m in cins], dt, lambda: _stk(f32(m.bias) for m in cins))
-        x = ops.conv3x3(x_in, wci, bci, streams=2, hilo=self.hilo)
-        exchange_skip(x)
-        for bi_ in range(len(enc.down_blocks)):
-            blks = [n.down_blocks[bi_] for n in pair]
+        return ops.conv3x3(x_in, wci, bci, streams=len(nets), hilo=self.hilo)
+
+    def _down_mid(self, nets, x, ctx, on_skip):
+        """conv_in's output ``x`` through the down blocks and the mid block of ``nets`` (controlnet.py:1051-1115 / 1723-1748);
+        ``on_skip(t)`` sees every skip tensor in the reference's order (conv_in output first)."""
+        temb, tsl, kc, vtc, ksl = ctx
+        on_skip(x)
+        for bi_ in range(len(nets[0].down_blocks)):
+            blks = [n.down_blocks[bi_] for n in nets]
             for li, r0 in enumerate(blks[0].resnets):
                 x = self._resnet([b.resnets[li] for b in blks], x, temb, tsl[id(r0)])
                 if getattr(blks[0], "has_cross_attention", False):
                     tsf = [b.attentions[li] for b in blks]
                     x = self._transformer(tsf, x, kc, vtc, self._kvs(tsf[0], ksl))
-                exchange_skip(x)
+                on_skip(x)
             if blks[0].downsamplers is not None:
                 x = self._conv("ds", [b.downsamplers[0].conv for b in blks], x, stride=2)
-                exchange_skip(x)
-        mids = [n.mid_block for n in pair]
+                on_skip(x)
+        mids = [n.mid_block for n in nets]
         x = self._resnet([m.resnets[0] for m in mids], x, temb, tsl[id(mids[0].resnets[0])])
         for ai, a0 in enumerate(mids[0].attentions):
             tsf = [m.attentions[ai] for m in mids]
             x = self._transformer(tsf, x, kc, vtc, self._kvs(tsf[0], ksl))
             x = self._resnet([m.resnets[ai + 1] for m in mids], x, temb, tsl[id(mids[0].resnets[ai + 1])])
-        mid = x  # [enc_mid ; unet_mid]
+        return x
 
-        # ================= phase 2: the mid exchange; join the sibling branch =================
-        for i, t in enumerate(late):
-            up_skips.append(exchange(f"ex{i}", enc.controlnet_down_blocks[i], dec.control_down_blocks[i] if run_decoder else None, t))
-        x = exchange("exm", enc.controlnet_mid_block, dec.control_mid_block if run_decoder else None, mid)
-        for f, y in forks:
-            f.join(y)
-        if ctx3 is None:
-            ctx3 = self._phase_ctx(pair3, rl3, cl3, semb[B: B + S * B], ehs)
-        temb, tsl, kc, vtc, ksl = ctx3
-        f3.join(temb, kc, vtc)
-
-        # ================= phase 3: unet || dec : up path, conv_out =================
-        pair = pair3
-        for bi_ in range(len(unet.up_blocks)):
-            blks = [n.up_blocks[bi_] for n in pair]
+    def _up(self, nets, x, up_skips, ctx):
+        """The up blocks of ``nets`` (controlnet.py:1119-1151 / 2480-2512); ``up_skips`` is consumed from its end."""
+        temb, tsl, kc, vtc, ksl = ctx
+        for bi_ in range(len(nets[0].up_blocks)):
+            blks = [n.up_blocks[bi_] for n in nets]
             for li, r0 in enumerate(blks[0].resnets):
                 s = up_skips.pop()
                 x = self._resnet([b.resnets[li] for b in blks], x, temb, tsl[id(r0)], x1=s)
@@ -543,11 +498,16 @@ class GroupedDualStreamStep:
                     x = self._conv("us", ucs, x, ups=True)
                 else:  # latent side not a multiple of 8: general nearest resize, then the conv
                     x = self._conv("us", ucs, ops.resize_nearest(x, tgt))
-        norms = [n.conv_norm_out for n in pair]
+        return x
+
+    def _head(self, nets, x):
+        """conv_norm_out -> SiLU -> conv_out of ``nets`` (output channels padded to the widest): [S*B, H, W, n_out]."""
+        pk, dt, S = self.pk, x.dtype, len(nets)
+        norms = [n.conv_norm_out for n in nets]
         g = pk.get("out.g", norms, [m.weight for m in norms], dt, lambda: _stk(f32(m.weight) for m in norms))
         b_ = pk.get("out.b", norms, [m.bias for m in norms], dt, lambda: _stk(f32(m.bias) for m in norms))
         h = ops.groupnorm(x, g, b_, norms[0].eps, groups=norms[0].num_groups, silu=True, streams=S)
-        couts = [n.conv_out for n in pair]
+        couts = [n.conv_out for n in nets]
         n_out = max(m.weight.shape[0] for m in couts)  # 4 (image) / 28 (attributes): pad to the widest
 
         def pad_rows(t, n):
@@ -555,8 +515,86 @@ class GroupedDualStreamStep:
 
         wco = pk.get("out.w", couts, [m.weight for m in couts], dt, lambda: _stk(pad_rows(pack_conv3x3(m.weight, dt), n_out) for m in couts))
         bco = pk.get("out.cb", couts, [m.bias for m in couts], dt, lambda: _stk(pad_rows(f32(m.bias), n_out) for m in couts))
-        y = ops.conv3x3(h, wco, bco, n_out=n_out, streams=S)  # [S*B, H, W, n_out]
-        out = {"img_pred": ops.as_nchw_view(y[:B, :, :, : couts[0].weight.shape[0]])}
+        return ops.conv3x3(h, wco, bco, n_out=n_out, streams=S)
+
+    def _ctx_of(self, nets, parts, semb, ehs, temb=True, kv=True):
+        """``_phase_ctx`` of the sub-modules ``parts[i]`` of ``nets[i]``."""
+        rl = [self._resnets_of(p) for p in parts]
+        cl = [self._cross_of(p) for p in parts]
+        return self._phase_ctx(nets, rl, cl, semb, ehs, temb=temb, kv=kv)
+
+    # ------------------------------------------------------------------ the step
+    @torch.no_grad()
+    def __call__(self, x_t, cond, ehs, t_img, t_attr, run_decoder: bool = True, conditioning_scale: float = 1.0
+                 ) -> Dict[str, torch.Tensor]:
+        unet, enc, dec = self.unet, self.enc, self.dec
+        dt = _compute_dtype(unet.dtype, unet.compute_dtype)
+        dev = x_t.device
+        B, _, H, W = x_t.shape
+        ehs = self._prep_ehs(ehs, B, dt)
+        tvec = lambda t: self._tvec(t, B, dev)
+
+        # --- time embeddings of the three networks in one grouped chain: rows [enc | unet | dec]
+        nets3 = [enc, unet, dec] if run_decoder else [enc, unet]
+        semb = self._time_embed(nets3, [tvec(t_attr), tvec(t_img)] + ([tvec(t_attr)] if run_decoder else []), B, dt)
+
+        # ---- the exchange (phase 2): exchange i only needs skip pair i, so it is issued on the sibling branch as soon as
+        # phase 1 has produced that pair
+        scale = float(conditioning_scale)
+        up_skips, forks = [], []
+        late = []  # UR_EXCHANGE_EARLY=0: all exchange GEMMs after the mid block (round-1 order) instead of right behind
+        early = os.environ.get("UR_EXCHANGE_EARLY", "1") != "0"  # the kernel that produced their skip (input still in L2)
+
+        def exchange_skip(t):
+            if not early:
+                late.append(t)
+                return
+            i = len(up_skips)
+            with self._fork(t) as f:
+                y = self._exchange(f"ex{i}", enc.controlnet_down_blocks[i], dec.control_down_blocks[i] if run_decoder else None,
+                                   t, B, scale, dt)
+            up_skips.append(y)
+            forks.append((f, y))
+
+        # ---- up-phase context (time projections, prompt K / V^T of the up blocks): depends on the inputs only
+        pair3 = [unet, dec] if run_decoder else [unet]
+        S = len(pair3)
+        ctx3_early = os.environ.get("UR_CTX3_EARLY", "1") != "0"
+        with self._fork(semb, ehs) as f3:
+            ctx3 = self._ctx_of(pair3, [[n.up_blocks] for n in pair3], semb[B: B + S * B], ehs) if ctx3_early else None
+
+        # ================= phase 1: enc || unet : conv_in, down, mid =================
+        pair = [enc, unet]
+        ctx1 = self._ctx_of(pair, [[n.down_blocks, n.mid_block] for n in pair], semb[: 2 * B], ehs)
+        x_in = torch.cat([ops.to_nhwc(cond, dt, CIN_PAD), ops.to_nhwc(x_t, dt, CIN_PAD)], 0)
+        mid = self._down_mid(pair, self._conv_in(pair, x_in), ctx1, exchange_skip)  # [enc_mid ; unet_mid]
+
+        # ================= phase 2: the mid exchange; join the sibling branch =================
+        for i, t in enumerate(late):
+            up_skips.append(self._exchange(f"ex{i}", enc.controlnet_down_blocks[i],
+                                           dec.control_down_blocks[i] if run_decoder else None, t, B, scale, dt))
+        x = self._exchange("exm", enc.controlnet_mid_block, dec.control_mid_block if run_decoder else None, mid, B, scale, dt)
+        for f, y in forks:
+            f.join(y)
+        if ctx3 is None:
+            ctx3 = self._ctx_of(pair3, [[n.up_blocks] for n in pair3], semb[B: B + S * B], ehs)
+        f3.join(ctx3[0], ctx3[2], ctx3[3])
+
+        # ================= phase 3: unet || dec : up path, conv_out =================
+        y = self._head(pair3, self._up(pair3, x, up_skips, ctx3))  # [S*B, H, W, n_out]
+        out = {"img_pred": ops.as_nchw_view(y[:B, :, :, : unet.conv_out.weight.shape[0]])}
         if run_decoder:
             out["attr_pred"] = ops.as_nchw_view(y[B:])
         return out
+
+    @staticmethod
+    def _prep_ehs(ehs, B, dt):
+        ehs = ehs.to(dt).contiguous() if (ehs.dtype != dt or not ehs.is_contiguous()) else ehs
+        if ehs.shape[0] == 1 and B > 1:
+            ehs = ehs.expand(B, -1, -1).contiguous()
+        return ehs
+
+    @staticmethod
+    def _tvec(t, B, dev):
+        t = torch.as_tensor(t, device=dev, dtype=torch.float32).reshape(-1)
+        return t.expand(B) if t.numel() == 1 else t

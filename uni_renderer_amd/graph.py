@@ -156,3 +156,104 @@ class GraphedDualStreamStep:
 
     def replay(self):
         self.graph.replay()
+
+
+class GraphedHoistedStep:
+    """A sampling loop's step with the loop-invariant half hoisted (hoist.HoistedSamplingStep) as TWO replayable graphs over
+    one set of static buffers: ``begin()`` replays the prologue (once per sampling call, after ``load_inputs``), ``replay()``
+    the per-step part.  Same buffer names as ``GraphedDualStreamStep`` (``x_t``, ``cond``, ``ehs``, ``t_img``, ``t_attr``);
+    inverse direction (``run_decoder``): ``x_t`` / ``t_img`` / ``ehs`` are the fixed inputs and ``cond`` / ``t_attr`` evolve,
+    rendering direction: the reverse.  ``hoist=False`` replays the prologue in front of EVERY step -- the un-hoisted loop
+    with the same kernels, what the hoisting is tested against bit for bit."""
+
+    def __init__(self, unet, enc, dec, batch: int, latent_hw, cross_dim: int, dtype=torch.float16, device="cuda",
+                 run_decoder: bool = True, cond_channels: int = 28, img_channels: int = 4, ctx_len: int = 77,
+                 conditioning_scale: float = 1.0, hoist: bool = True):
+        from .hoist import HoistedSamplingStep
+
+        self.run_decoder, self.hoist = run_decoder, hoist
+        self.h = HoistedSamplingStep(unet, enc, dec, "inverse" if run_decoder else "render", conditioning_scale)
+        H, W = (latent_hw, latent_hw) if isinstance(latent_hw, int) else latent_hw
+        dev = torch.device(device)
+        self.x_t = torch.zeros(batch, img_channels, H, W, dtype=dtype, device=dev)
+        self.cond = torch.zeros(batch, cond_channels, H, W, dtype=dtype, device=dev)
+        self.ehs = torch.zeros(batch, ctx_len, cross_dim, dtype=dtype, device=dev)
+        self.t_img = torch.zeros(batch, dtype=torch.float32, device=dev)
+        self.t_attr = torch.zeros(batch, dtype=torch.float32, device=dev)
+        self.pro: Optional[torch.cuda.CUDAGraph] = None
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self.out: Optional[Dict[str, torch.Tensor]] = None
+
+    load_inputs = GraphedDualStreamStep.load_inputs
+
+    def _prologue(self):
+        if self.run_decoder:
+            self.h.prologue(self.x_t, self.ehs, self.t_img)
+        else:
+            self.h.prologue(self.cond, self.ehs, self.t_attr)
+
+    def _run(self):
+        return self.h.step(self.cond, self.t_attr) if self.run_decoder else self.h.step(self.x_t, self.t_img)
+
+    def load_evolving(self, x_t, cond, t_img, t_attr):
+        """Only what changes between two steps of a loop: the evolving latent and its timestep."""
+        src, dst, t, tb = (cond, self.cond, t_attr, self.t_attr) if self.run_decoder else (x_t, self.x_t, t_img, self.t_img)
+        dst.copy_(src)
+        tb.copy_(torch.as_tensor(t, device=tb.device).float().expand_as(tb))
+
+    @torch.no_grad()
+    def capture(self, warmup: int = 2):
+        warm = torch.cuda.Stream()
+        warm.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(warm):  # packs weights, sizes LDS attributes, fills the allocator
+            for _ in range(warmup):
+                self._prologue()
+                self._run()
+        torch.cuda.current_stream().wait_stream(warm)
+        torch.cuda.synchronize()
+        self.pro = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.pro):
+            self._prologue()  # its results (self.h.inv) live in this graph's pool for as long as this object does
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = self._run()
+        torch.cuda.synchronize()
+        return self
+
+    @torch.no_grad()
+    def capture_with(self, post_fn):
+        """The per-step graph followed by ``post_fn(out)`` (the on-device sampler update): ``(graph, out)``."""
+        if self.graph is None:
+            self.capture()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = self._run()
+            post_fn(out)
+        torch.cuda.synchronize()
+        return g, out
+
+    def begin(self):
+        """Once per sampling call, after the fixed inputs are in the static buffers."""
+        if self.graph is None:
+            self.capture()
+        self.pro.replay()
+
+    @torch.no_grad()
+    def step(self, x_t=None, cond=None, ehs=None, t_img=None, t_attr=None, first: bool = True):
+        """``first``: the fixed inputs are (re)loaded and the prologue runs; later steps of the same loop only load the
+        evolving latent and its timestep."""
+        if self.graph is None:
+            self.capture()
+        if first or not self.hoist:
+            if x_t is not None:
+                self.load_inputs(x_t, cond, ehs, t_img, t_attr)
+            self.pro.replay()
+        elif x_t is not None:
+            self.load_evolving(x_t, cond, t_img, t_attr)
+        self.graph.replay()
+        return self.out
+
+    def replay(self):
+        if not self.hoist:
+            self.pro.replay()
+        self.graph.replay()

@@ -1,0 +1,135 @@
+"""Sampling-loop steps with the loop-invariant half of the work hoisted out of the loop.
+
+The reference's sampling loops call all their networks on every step, but most of what they compute does not change
+between steps -- and part of it is never read:
+
+  inverse rendering  (models/pipeline.py:2629-2730, 2239-2269; ``real_image2mask_3mod_albedo`` / ``image2mask_3mod_albedo``)
+      The UNet is called on the CLEAN image latent with ``t_img = 0`` and the constant prompt (2670-2680), and its
+      ``sample`` and ``up_res`` outputs are dropped (``_, raw_unet, raw_mid_unet, _ =``).  The tensors the decoder takes
+      from it (``raw_down_block_res_samples`` / ``raw_mid``) are captured BEFORE the encoder's residuals are added
+      (models/controlnet.py:1075 vs 1078-1087, 1112 vs 1114-1115).  So
+        * UNet conv_in + down + mid does not depend on the step              -> once per call,
+        * UNet up + conv_out and the encoder's 13 ``controlnet_*`` 1x1 convs (1752-1769), whose only consumer is the
+          UNet's up path, are dead                                           -> never,
+        * the decoder's exchange product ``control_down_blocks[i](raw_unet[i])`` (2446-2461, 2476-2477) is invariant
+                                                                             -> once per call; per step only the add,
+        * the prompt's K / V^T of every cross-attention (77 keys)            -> once per call.
+      Per step: encoder conv_in + down + mid, 13 adds (one launch), decoder up + conv_out: 0.82 of 1.62 TFLOP per sample.
+
+  rendering  (pipeline.py:1587-1653; ``mask2image_3mod_albedo``)
+      The encoder sees the clean attribute latents at ``t_attr = 0`` (1455) and ignores ``sample`` (controlnet.py:1716-1720)
+      -> the whole encoder, including its 13 exchange convs, runs once per call.  Per step: the UNet, with the 13 residual
+      adds (controlnet.py:1078-1087, 1114-1115) in one launch.  0.80 of 1.07 TFLOP per sample.
+
+``prologue`` computes the invariant part, ``step`` the rest; running the prologue in front of every step reproduces the
+un-hoisted loop with the same kernels in the same order, which is how tests/test_pipeline_gpu.py shows the hoisting exact
+(``torch.equal`` on the final latents).  The leaves are ``fused.GroupedDualStreamStep``'s (same kernels, same packed weights),
+issued for one network at a time.
+
+Rounding points: the hoisted exchange is ``round(a) + round(conv(b))`` carried as (hi, lo) pairs -- the reference rounds at the
+same two points (conv output, then the add, controlnet.py:2455-2457) -- where the un-hoisted grouped step adds the residual
+inside the GEMM epilogue (one rounding).  With the (hi, lo) residual stream both are ~2^-14 relative.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+
+from . import ops
+from .controlnet import CIN_PAD, _compute_dtype
+from .fused import GroupedDualStreamStep, _stk
+from .layers import f32, pack_matrix
+
+
+class HoistedSamplingStep:
+    """direction = "inverse": prologue(x_t = image latent, t_img) / step(cond28, t_attr) -> {"attr_pred"};
+    direction = "render":  prologue(cond28, t_attr)            / step(x_t, t_img)      -> {"img_pred"}."""
+
+    def __init__(self, unet, enc, dec, direction: str, conditioning_scale: float = 1.0,
+                 precise_residual: Optional[bool] = None, leaves: Optional[GroupedDualStreamStep] = None):
+        if direction not in ("inverse", "render"):
+            raise ValueError(direction)
+        self.unet, self.enc, self.dec, self.direction = unet, enc, dec, direction
+        self.scale = float(conditioning_scale)
+        self.g = leaves if leaves is not None else GroupedDualStreamStep(unet, enc, dec, precise_residual)
+        self.inv: Dict[str, object] = {}
+
+    # ------------------------------------------------------------------ helpers
+    def _zero_conv(self, name, z, t, scale):
+        """scale * (z(t)) as a (hi, lo) pair: one exchange 1x1 conv (controlnet.py:1752-1769 / 2446-2461) without its add."""
+        g, dt = self.g, t.dtype
+        w = g.pk.get((name, "hw", scale), [z], [z.weight], dt,
+                     lambda: (pack_matrix(z.weight, dt) * scale).contiguous() if scale != 1.0 else pack_matrix(z.weight, dt))
+        b = g.pk.get((name, "hb", scale), [z], [z.bias], dt, lambda: f32(z.bias) * scale)
+        Bt, H, W, Cc = t.shape
+        y = ops.linear(ops.view_hilo(t, Bt, H * W, Cc), w, b, hilo=g.hilo)
+        return ops.view_hilo(y, Bt, H, W, w.shape[0])
+
+    def _run_down_mid(self, net, x_nchw, cin_pad, tvals, ehs, B, dt, kv=None):
+        """conv_in + down + mid of ONE network; returns (skips[12] + [mid], its prompt K / V^T context)."""
+        g = self.g
+        semb = g._time_embed([net], [tvals], B, dt)
+        parts = [[net.down_blocks, net.mid_block]]
+        temb, tsl, kc, vtc, ksl = g._ctx_of([net], parts, semb, ehs, kv=(kv is None))
+        if kv is not None:
+            kc, vtc, ksl = kv
+        skips: List[torch.Tensor] = []
+        x = g._conv_in([net], ops.to_nhwc(x_nchw, dt, cin_pad))
+        mid = g._down_mid([net], x, (temb, tsl, kc, vtc, ksl), skips.append)
+        return skips + [mid], (kc, vtc, ksl)
+
+    def _kv_only(self, net, parts, ehs):
+        _, _, kc, vtc, ksl = self.g._ctx_of([net], [parts], None, ehs, temb=False)
+        return kc, vtc, ksl
+
+    # ------------------------------------------------------------------ once per sampling call
+    @torch.no_grad()
+    def prologue(self, x_fixed, ehs, t_fixed):
+        unet, enc, dec, g = self.unet, self.enc, self.dec, self.g
+        dt = _compute_dtype(unet.dtype, unet.compute_dtype)
+        B = x_fixed.shape[0]
+        ehs = g._prep_ehs(ehs, B, dt)
+        tv = g._tvec(t_fixed, B, x_fixed.device)
+        inv = self.inv
+        inv["ehs"], inv["B"], inv["dt"] = ehs, B, dt
+        if self.direction == "inverse":
+            # the UNet's raw skips (captured before any residual is added: controlnet.py:1075, 1112)
+            raw, _ = self._run_down_mid(unet, x_fixed, CIN_PAD, tv, ehs, B, dt)
+            zs = list(dec.control_down_blocks) + [dec.control_mid_block]
+            inv["fixed"] = [self._zero_conv(f"hx{i}", z, t, 1.0) for i, (z, t) in enumerate(zip(zs, raw))]
+            inv["kv1"] = self._kv_only(enc, [enc.down_blocks, enc.mid_block], ehs)
+            inv["kv3"] = self._kv_only(dec, [dec.up_blocks], ehs)
+        else:
+            raw, _ = self._run_down_mid(enc, x_fixed, CIN_PAD, tv, ehs, B, dt)
+            zs = list(enc.controlnet_down_blocks) + [enc.controlnet_mid_block]
+            inv["fixed"] = [self._zero_conv(f"hr{i}", z, t, self.scale) for i, (z, t) in enumerate(zip(zs, raw))]
+            inv["kv1"] = self._kv_only(unet, [unet.down_blocks, unet.mid_block], ehs)
+            inv["kv3"] = self._kv_only(unet, [unet.up_blocks], ehs)
+        return self
+
+    # ------------------------------------------------------------------ once per step
+    @torch.no_grad()
+    def step(self, x_var, t_var) -> Dict[str, torch.Tensor]:
+        g, inv = self.g, self.inv
+        ehs, B, dt = inv["ehs"], inv["B"], inv["dt"]
+        tv = g._tvec(t_var, B, x_var.device)
+        if self.direction == "inverse":
+            first, last = self.enc, self.dec
+            semb = g._time_embed([first, last], [tv, tv], B, dt)
+            s1, s3 = semb[:B], semb[B:]
+        else:
+            first = last = self.unet
+            s1 = s3 = g._time_embed([first], [tv], B, dt)
+        temb3, tsl3, _, _, _ = g._ctx_of([last], [[last.up_blocks]], s3, ehs, kv=False)
+        temb1, tsl1, _, _, _ = g._ctx_of([first], [[first.down_blocks, first.mid_block]], s1, ehs, kv=False)
+        skips: List[torch.Tensor] = []
+        x = g._conv_in([first], ops.to_nhwc(x_var, dt, CIN_PAD))
+        mid = g._down_mid([first], x, (temb1, tsl1) + inv["kv1"], skips.append)
+        # the 13 exchange adds in one launch: skip_i + (invariant 1x1 conv of the other stream's skip_i)
+        summed = ops.add_multi(zip(skips + [mid], inv["fixed"]), hilo=g.hilo)
+        x = summed.pop()
+        y = g._head([last], g._up([last], x, summed, (temb3, tsl3) + inv["kv3"]))
+        if self.direction == "inverse":
+            return {"attr_pred": ops.as_nchw_view(y)}
+        return {"img_pred": ops.as_nchw_view(y[:, :, :, : self.unet.conv_out.weight.shape[0]])}

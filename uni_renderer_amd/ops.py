@@ -402,6 +402,11 @@ def wsconv_images(w: torch.Tensor, n_out: Optional[int] = None) -> torch.Tensor:
     return torch.gather(v, 3, idx).reshape(-1).contiguous()
 
 
+def pp_built() -> bool:
+    """The 8-wave ping-pong tiles (TILE_PP_*) are an opt-in build of the library (``make PP=1``, csrc/Makefile)."""
+    return bool(_lib.load().ur_has_pp())
+
+
 def wsconv_built() -> bool:
     """The weight-streaming conv tiles are an opt-in build of the library (``make WSCONV=1``, csrc/Makefile)."""
     return bool(_lib.load().ur_has_wsconv())
@@ -746,6 +751,40 @@ def add(a, b, alpha: float = 1.0, hilo=False):
                               _ptr(lo_of(out)), a.numel(), DT[a.dtype], _stream()), "ur_add_hilo")
     _prof_end(e0, "add", 0.0, 3.0 * out.numel() * out.element_size())
     return out
+
+
+class _AddItem(C.Structure):
+    _fields_ = [("a", C.c_void_p), ("a_lo", C.c_void_p), ("b", C.c_void_p), ("b_lo", C.c_void_p), ("out", C.c_void_p),
+                ("out_lo", C.c_void_p), ("n", C.c_int64)]
+
+
+_lib.register_layout("ur_sizeof_add_item", _AddItem)
+ADD_MULTI_MAX = 16
+
+
+def add_multi(pairs, hilo=False):
+    """[a_i + b_i for (a_i, b_i) in pairs] in ONE launch per 16 pairs (``ur_add_hilo_multi``): the low parts of either
+    operand are included when present, ``hilo`` also returns ``out.lo``.  All tensors of one dtype, contiguous."""
+    pairs = list(pairs)
+    if not pairs:
+        return []
+    _require_gpu(pairs[0][0])
+    lib = _lib.load()
+    outs = [_with_lo(torch.empty_like(a), hilo) for a, _ in pairs]
+    dt = pairs[0][0].dtype
+    e0 = _prof_begin()
+    for i in range(0, len(pairs), ADD_MULTI_MAX):
+        chunk = pairs[i:i + ADD_MULTI_MAX]
+        arr = (_AddItem * len(chunk))()
+        for k, (a, b) in enumerate(chunk):
+            if a.dtype != dt or b.dtype != dt or a.shape != b.shape or not (a.is_contiguous() and b.is_contiguous()):
+                raise RuntimeError("add_multi: operands of one pair must be contiguous tensors of one shape and dtype")
+            o = outs[i + k]
+            arr[k].a, arr[k].a_lo, arr[k].b, arr[k].b_lo = a.data_ptr(), _ptr(lo_of(a)), b.data_ptr(), _ptr(lo_of(b))
+            arr[k].out, arr[k].out_lo, arr[k].n = o.data_ptr(), _ptr(lo_of(o)), a.numel()
+        check(lib.ur_add_hilo_multi(arr, len(chunk), DT[dt], _stream()), "ur_add_hilo_multi")
+    _prof_end(e0, "add_multi", 0.0, sum(3.0 * o.numel() * o.element_size() for o in outs))
+    return outs
 
 
 def timestep_embedding(t: torch.Tensor, B: int, dim: int, flip: bool, shift: float, dtype) -> torch.Tensor:

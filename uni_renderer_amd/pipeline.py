@@ -25,7 +25,7 @@ import torch
 
 from .controlnet import AttributeDecoderModel, AttributeEncoderModel, UNet2DConditionModel
 from . import ops
-from .graph import GraphedDualStreamStep, dual_stream_step
+from .graph import GraphedDualStreamStep, GraphedHoistedStep, dual_stream_step
 from .schedulers import DDIMScheduler, retrieve_timesteps
 
 SCHEDULER_NAMES = ("img", "attr", "material", "albedo", "normal", "spec_light", "diff_light", "env")
@@ -44,6 +44,12 @@ class UniRendererPipeline:
         self.vae_scale_factor = 8
         self.use_hip_graph = True
         self.use_fused_sampler = True  # whole sampling loop on the device when the configuration allows (_fusable)
+        # The loops' invariant half once per call instead of once per step (hoist.py): inverse direction = UNet conv_in + down +
+        # mid and the decoder's exchange convs once, UNet up / conv_out and the encoder's exchange convs never (their results
+        # are dropped, ref 2670: ``_, ..., _ =``); rendering direction = the whole encoder once.  UR_HOIST=0 / False: every
+        # network on every step (the grouped enc || unet, unet || dec executor of fused.py).
+        self.hoist_invariants = os.environ.get("UR_HOIST", "1") != "0"
+        self.rerun_invariants = False  # tests: the hoisted executor with its prologue replayed before EVERY step
         self._sample_graphs: Dict[Any, Any] = {}
         self._graphs: Dict[Tuple, GraphedDualStreamStep] = {}
         self._progress_kwargs: Dict[str, Any] = {}
@@ -248,7 +254,8 @@ class UniRendererPipeline:
         changed since (``sig`` = a ``_weights_signature()`` the caller took once for its whole sampling call)."""
         B, _, h, w = x_img.shape
         dt = self.unet.dtype
-        key = (str(x_img.device), B, h, w, ehs.shape[1], ehs.shape[2], run_decoder, dt, float(cond_scale))
+        key = (str(x_img.device), B, h, w, ehs.shape[1], ehs.shape[2], run_decoder, dt, float(cond_scale),
+               self.hoist_invariants, self.rerun_invariants)
         sig = sig if sig is not None else self._weights_signature()
         g = self._graphs.get(key)
         if g is not None and g.weights_sig != sig:  # stale packed weights: drop it and every sampling graph built on it
@@ -257,9 +264,13 @@ class UniRendererPipeline:
                 del self._sample_graphs[k]
             g = None
         if g is None:
-            g = GraphedDualStreamStep(self.unet, self.controlnet, self.controldec, B, (h, w), ehs.shape[2], dtype=dt,
-                                      device=x_img.device, run_decoder=run_decoder, cond_channels=cond28.shape[1],
-                                      img_channels=x_img.shape[1], ctx_len=ehs.shape[1], conditioning_scale=cond_scale)
+            kw = dict(dtype=dt, device=x_img.device, run_decoder=run_decoder, cond_channels=cond28.shape[1],
+                      img_channels=x_img.shape[1], ctx_len=ehs.shape[1], conditioning_scale=cond_scale)
+            if self.hoist_invariants:
+                g = GraphedHoistedStep(self.unet, self.controlnet, self.controldec, B, (h, w), ehs.shape[2],
+                                       hoist=not self.rerun_invariants, **kw)
+            else:
+                g = GraphedDualStreamStep(self.unet, self.controlnet, self.controldec, B, (h, w), ehs.shape[2], **kw)
             g.load_inputs(x_img, cond28, ehs, 0, 0)
             g.capture()
             g.weights_sig = sig
@@ -327,15 +338,25 @@ class UniRendererPipeline:
         if unipc:
             st["last"].copy_(st["master"])  # L_0 = the initial sample
             st["hist"].zero_()
+        hoisted = isinstance(g, GraphedHoistedStep)
+        if hoisted:
+            g.begin()  # the loop-invariant half, once per call
         for _ in range(n):
+            if hoisted and not g.hoist:
+                g.pro.replay()
             st["graph"].replay()
         # a COPY: ``master`` is this sampling graph's static buffer and the next call with the same shapes overwrites it
         return st["master"].to(lat_dtype, copy=True)
 
-    def _step(self, x_img, cond28, ehs, t_img, t_attr, run_decoder: bool, cond_scale: float = 1.0, sig=None):
+    def _step(self, x_img, cond28, ehs, t_img, t_attr, run_decoder: bool, cond_scale: float = 1.0, sig=None, first: bool = True):
+        """One step of a sampling loop.  ``first``: the first step of a loop (the hoisted executor runs its prologue on the
+        loop-invariant inputs then and only reloads the evolving latent afterwards).  The inverse loops' ``img_pred`` is not
+        computed by the hoisted executor (the reference drops it, 2670)."""
         dt = self.unet.dtype
         if self.use_hip_graph and x_img.is_cuda:
             _, g = self._graph_for(x_img, cond28, ehs, run_decoder, cond_scale, sig=sig)
+            if isinstance(g, GraphedHoistedStep):
+                return g.step(x_img, cond28, ehs, t_img, t_attr, first=first)
             return g.step(x_img, cond28, ehs, t_img, t_attr)
         tb = lambda t: torch.as_tensor(t, device=x_img.device).float().reshape(-1)
         return dual_stream_step(self.unet, self.controlnet, self.controldec, x_img.to(dt), cond28.to(dt), ehs.to(dt),
@@ -417,7 +438,8 @@ class UniRendererPipeline:
                 cat = torch.cat([dup(lat[n]) for n in ATTR_GROUPS], dim=1)
                 cat = self.scheduler_attr.scale_model_input(cat, t_attr)
                 cond28 = torch.cat((x_mask.to(cat.dtype), cat), dim=1)  # mask latent first: 4 + 6*4 = 28 channels
-                out = self._step(x_img, cond28, prompt_embeds, t_img, t_attr, run_decoder=True, cond_scale=cond_scale, sig=sig)
+                out = self._step(x_img, cond28, prompt_embeds, t_img, t_attr, run_decoder=True, cond_scale=cond_scale, sig=sig,
+                                 first=(i == 0))
                 label_pred = out["attr_pred"][:, 4:]  # drop the mask group (ref 2691)
                 for k, n in enumerate(ATTR_GROUPS):
                     pred = label_pred[:, 4 * k:4 * k + 4]
@@ -498,7 +520,7 @@ class UniRendererPipeline:
                 t_img, t_attr = timesteps[i], timesteps_attr[i]
                 x = self.scheduler_img.scale_model_input(dup(latents_img), t_img)
                 out = self._step(x, cond28, prompt_embeds, t_img, t_attr, run_decoder=False,
-                                 cond_scale=float(controlnet_conditioning_scale), sig=sig)
+                                 cond_scale=float(controlnet_conditioning_scale), sig=sig, first=(i == 0))
                 img_pred = out["img_pred"]
                 if cfg:
                     p_cond, p_uncond = img_pred.chunk(2)  # ref 1642-1644
