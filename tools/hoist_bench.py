@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--latent", type=int, default=64)
     ap.add_argument("--replays", type=int, default=50)
     ap.add_argument("--dtype", default="f16")
+    ap.add_argument("--shape-table", default="", help="write per-(kernel, problem shape) event tables of the hoisted steps here")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     dt = torch.float16 if args.dtype == "f16" else torch.bfloat16
@@ -65,6 +66,13 @@ def main():
         ops.plan_igemm = orig
         res[name] = dict(prologue_ms=round(timed(g.pro.replay, args.replays), 4), step_ms=round(timed(g.graph.replay, args.replays), 4),
                          untuned=dict(sorted(missing.items())))
+        if args.shape_table:
+            _, table, total = bench.measure_roofline(g._run, by_shape=True)
+            res[name]["sum_kernel_ms_eager_step"] = round(total, 3)
+            res[name]["launches"] = sum(r["calls"] for r in table)
+            shapes = json.load(open(args.shape_table)) if os.path.exists(args.shape_table) else {}
+            shapes[name] = table
+            json.dump(shapes, open(args.shape_table, "w"))
         f = GraphedDualStreamStep(*models, batch=args.batch, latent_hw=args.latent, cross_dim=768, dtype=dt, device=dev,
                                   run_decoder=run_decoder)
         f.load_inputs(*inputs)

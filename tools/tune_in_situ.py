@@ -41,11 +41,16 @@ def main():
                     "level-0 feed-forward GEMM whose isolated optimum is 256x256)")
     ap.add_argument("--tiles", default="9,10,1,5,7,2,3,11,8,32,24,13", help="--broad: the tile ids tried per problem")
     ap.add_argument("--min-rows", type=int, default=0, help="--broad: only problems with M >= this")
+    ap.add_argument("--loop", default="", choices=["", "inverse", "render"], help="tune the per-step graph of a HOISTED sampling loop "
+                    "(uni_renderer_amd/hoist.py: one network at a time, z = 1 launches) instead of the full enc + unet + dec step; "
+                    "problems ranked by a flop / launch-latency estimate, candidates = --tiles x (current split-K, x2, /2)")
     ap.add_argument("--train", action="store_true", help="tune the captured TRAINING step (tools/train_bench.py --graph: cfg 4's "
                     "per-GPU shape, bf16) instead of the inference step; candidates = a fixed tile list at the current split-K")
     args = ap.parse_args()
     if args.train:
         return main_train(args)
+    if args.loop:
+        return main_loop(args)
     import bench
     import tune_igemm
     from uni_renderer_amd import ops
@@ -138,6 +143,93 @@ def main():
         json.dump(log, open(args.out.replace(".json", "_log.json"), "w"))
     final = measure()
     print(f"[in-situ] {min(base, base2):.4f} -> {final:.4f} ms per step (best seen {best:.4f})", flush=True)
+
+
+def main_loop(args):
+    import bench
+    from uni_renderer_amd import ops
+    from uni_renderer_amd.graph import GraphedHoistedStep
+
+    dev, dt = torch.device("cuda:0"), torch.float16
+    models = bench.build_models(dev, dt)
+    inputs = bench.make_inputs(args.batch, args.latent, dev, dt, seed=100)
+    ops.load_tuning_table()
+    run_decoder = args.loop == "inverse"
+    from uni_renderer_amd.fused import GroupedDualStreamStep
+
+    leaves = GroupedDualStreamStep(*models)  # one packed-weight cache for every capture
+
+    def build():
+        ops._plan_cache.clear()
+        r = GraphedHoistedStep(*models, batch=args.batch, latent_hw=args.latent, cross_dim=768, dtype=dt, device=dev,
+                               run_decoder=run_decoder, leaves=leaves)
+        r.load_inputs(*inputs)
+        return r
+
+    def measure():
+        r = build()
+        r.capture(warmup=1)
+        r.pro.replay()
+        for _ in range(5):
+            r.graph.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.replays):
+            r.graph.replay()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) * 1e3 / args.replays
+        del r
+        return ms
+
+    calls = {}
+    orig = ops.igemm
+    r = build()
+    with torch.no_grad():
+        r._prologue()
+
+        def spy(**kw):
+            key = (kw["M"], kw["N"], kw["K"], kw.get("taps", 1), kw.get("zbatch", 1), ops._site if args.sites else None)
+            calls[key] = calls.get(key, 0) + 1
+            return orig(**kw)
+
+        ops.igemm = spy
+        try:
+            r._run()
+            torch.cuda.synchronize()
+        finally:
+            ops.igemm = orig
+    del r
+    est = sorted(((n * max(2.0 * k[0] * k[1] * k[2] * k[4] / 5e14, 10e-6), k) for k, n in calls.items()
+                  if (k[5] or not args.sites) and k[0] >= args.min_rows), reverse=True)[args.skip: args.top]
+    base, base2 = measure(), measure()
+    print(f"[in-situ {args.loop} loop] baseline {base:.4f} / {base2:.4f} ms per step; {len(est)} problems to visit", flush=True)
+    best, log = min(base, base2), []
+    tiles = [int(v) for v in args.tiles.split(",")]
+    for _, key6 in est:
+        key, site = key6[:5], key6[5]
+        bkey = "%d,%d,%d,%d,%d" % key
+        skey = bkey + (f"@{site}" if site else "")
+        ops._plan_cache.clear()
+        cur = tuple(ops._tune_table.get(skey) or ops._tune_table.get(bkey) or ops.plan_igemm(*key))
+        sks = [cur[1]] + ([cur[1] * 2] if key[2] // 64 >= 8 * cur[1] * 2 and key[4] <= 4 else []) + ([cur[1] // 2] if cur[1] > 1 else [])
+        cands = [(t, sk) for sk in sks for t in tiles if (t, sk) != cur]
+        for cand in cands:
+            ops._tune_table[skey] = cand
+            try:
+                ms = measure()
+            except RuntimeError:
+                ms = float("inf")
+            ok = ms < best - args.eps
+            log.append(dict(problem=skey, launches=calls[key6], cur=list(cur), cand=list(cand), ms=round(ms, 4), best=round(best, 4), accepted=ok))
+            print(f"  {skey:32s} x{calls[key6]:2d} {cur} -> {cand}: {ms:.4f} ms (best {best:.4f}) {'ACCEPT' if ok else ''}", flush=True)
+            if ok:
+                best, cur = ms, cand
+        ops._tune_table[skey] = cur
+        os.makedirs(os.path.dirname(args.out), exist_ok=True)
+        json.dump({k: list(v) for k, v in ops._tune_table.items()}, open(args.out, "w"), indent=0, sort_keys=True)
+        json.dump(log, open(args.out.replace(".json", "_log.json"), "w"))
+    final = measure()
+    print(f"[in-situ {args.loop} loop] {min(base, base2):.4f} -> {final:.4f} ms per step (best seen {best:.4f})", flush=True)
 
 
 def main_train(args):

@@ -168,11 +168,12 @@ class GraphedHoistedStep:
 
     def __init__(self, unet, enc, dec, batch: int, latent_hw, cross_dim: int, dtype=torch.float16, device="cuda",
                  run_decoder: bool = True, cond_channels: int = 28, img_channels: int = 4, ctx_len: int = 77,
-                 conditioning_scale: float = 1.0, hoist: bool = True):
+                 conditioning_scale: float = 1.0, hoist: bool = True, leaves=None):
+        """``leaves``: a ``fused.GroupedDualStreamStep`` whose packed-weight cache is shared (tools: many captures of one model)."""
         from .hoist import HoistedSamplingStep
 
         self.run_decoder, self.hoist = run_decoder, hoist
-        self.h = HoistedSamplingStep(unet, enc, dec, "inverse" if run_decoder else "render", conditioning_scale)
+        self.h = HoistedSamplingStep(unet, enc, dec, "inverse" if run_decoder else "render", conditioning_scale, leaves=leaves)
         H, W = (latent_hw, latent_hw) if isinstance(latent_hw, int) else latent_hw
         dev = torch.device(device)
         self.x_t = torch.zeros(batch, img_channels, H, W, dtype=dtype, device=dev)
