@@ -80,3 +80,42 @@ def test_state_dict_does_not_cut_the_shared_step_counter():
     assert float(sd1["state"][0]["step"]) == 1.0 and float(sd1["state"][1]["step"]) == 1.0  # snapshots stay snapshots
     assert float(sd2["state"][0]["step"]) == 2.0 and float(sd2["state"][1]["step"]) == 2.0
     assert sd2["state"][0]["exp_avg"] is ours.state[ps[0]]["exp_avg"]  # like torch: moments are handed out uncopied
+
+
+def test_load_state_dict_keeps_the_addresses_a_captured_update_holds():
+    """``load_state_dict`` used to drop the device (lr, weight_decay) pair and replace the moment tensors, while a
+    captured ``ur_adamw_multi`` keeps the OLD addresses (stale lr / garbage moments after resume_from_checkpoint).  Now the
+    existing tensors receive the loaded values in place; only genuinely new state bumps ``generation`` (-> re-capture)."""
+    ps = _params()
+    ours = FusedAdamW(ps, lr=1e-3)
+    states = [ours._init_state(p) for p in ps]
+    states[1]["step"] = states[0]["step"]
+    states[0]["step"] += 3
+    for st in states:
+        st["exp_avg"].fill_(0.25)
+        st["exp_avg_sq"].fill_(0.5)
+    fake_hyper = [torch.zeros(2), (1e-3, 1e-2)]
+    ours.param_groups[0]["_ur_hyper"] = fake_hyper
+    sd = {"state": {k: {n: (v.clone() if torch.is_tensor(v) else v) for n, v in st.items()} for k, st in ours.state_dict()["state"].items()},
+          "param_groups": ours.state_dict()["param_groups"]}
+    ptrs = [(st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), st["step"].data_ptr()) for st in states]
+    for st in states:  # training went on ...
+        st["exp_avg"].fill_(9.0)
+        st["exp_avg_sq"].fill_(9.0)
+    states[0]["step"] += 5
+    gen = ours.generation
+    ours.load_state_dict(sd)  # ... and is rolled back to the checkpoint
+    assert ours.generation == gen  # nothing a captured graph points at moved
+    assert ours.param_groups[0]["_ur_hyper"] is fake_hyper and fake_hyper[1] is None  # same device pair, value to be re-sent
+    for p, ptr in zip(ps, ptrs):
+        st = ours.state[p]
+        assert (st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), st["step"].data_ptr()) == ptr
+        assert float(st["exp_avg"].flatten()[0]) == 0.25 and float(st["exp_avg_sq"].flatten()[0]) == 0.5 and float(st["step"]) == 3.0
+    assert ours.state[ps[0]]["step"] is ours.state[ps[1]]["step"]
+    # a fresh optimizer has no state yet: the loaded tensors are adopted and the generation moves
+    fresh = FusedAdamW([p.detach().clone().requires_grad_() for p in ps], lr=1e-3)
+    g0 = fresh.generation
+    fresh.load_state_dict(sd)
+    assert fresh.generation == g0 + 1 and float(fresh.state[fresh.param_groups[0]["params"][0]]["step"]) == 3.0
+    fresh.add_param_group({"params": [torch.zeros(2, requires_grad=True)]})
+    assert fresh.generation == g0 + 2

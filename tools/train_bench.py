@@ -20,6 +20,16 @@ from uni_renderer_amd.parallel import GradientBuckets  # noqa: E402
 from uni_renderer_amd.train_step import train_step  # noqa: E402
 
 
+def _queue_stats():
+    """Deferred weight gradients keep (dy, x) of every layer of a network alive until its barrier (backward.WgradQueue):
+    the peak of those bytes, the cap (UR_WGRAD_PENDING_MB) and how often it forced an early flush."""
+    from uni_renderer_amd import backward as B
+
+    q = B.wgrad_queue
+    return dict(deferred=B.WGRAD_DEFER, peak_pending_gb=round(q.peak_pending / 2**30, 2), cap_gb=round(q.cap / 2**30, 1),
+                early_flushes=q.early_flushes)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=4)
@@ -93,7 +103,8 @@ def main():
                               grad_norm=stats.get("grad_norm"), graph=bool(args.graph),
                               grad_sync=(dict(algorithm=args.algorithm, comm_dtype=args.comm_dtype, overlap=not args.no_overlap,
                                               buckets=len(buckets.buckets), launched_during_backward=buckets.launched_from_hooks)
-                                         if buckets is not None else None), peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2**30, 1))))
+                                         if buckets is not None else None), peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2**30, 1),
+                              wgrad_queue=_queue_stats())))
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

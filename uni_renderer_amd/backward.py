@@ -276,10 +276,20 @@ def wgrad_ok(dy2: torch.Tensor, x: torch.Tensor, conv: Optional[Tuple[int, int]]
         return False
     if dy2.shape[1] % 8 or dy2.data_ptr() % 16 or x.data_ptr() % 16 or x.stride(-1) != 1:
         return False
+    # the kernel's loaders form 32-bit byte offsets and pack column offsets into 24 bits (ur::wgrad_check): larger problems
+    # must take the transposed-operand fallback here instead of failing with UR_E_UNSUPPORTED at launch (for deferred items
+    # that would be at flush time, in the middle of a backward)
+    P, N = dy2.shape
+    if P * dy2.stride(0) * 2 >= 2 ** 32 or N * 2 >= 2 ** 24:
+        return False
     if conv is None:
-        return x.dim() == 2 and x.shape[1] % 8 == 0 and x.stride(0) % 8 == 0 and x.shape[0] == dy2.shape[0]
-    Ho, Wo = conv
-    return x.dim() == 4 and x.is_contiguous() and x.shape[3] % 64 == 0 and _pow2(Ho) and _pow2(Wo)
+        if not (x.dim() == 2 and x.shape[1] % 8 == 0 and x.stride(0) % 8 == 0 and x.shape[0] == dy2.shape[0]):
+            return False
+        return P * x.stride(0) * 2 < 2 ** 32 and x.shape[1] * 2 < 2 ** 24
+    Ho, Wo = conv[0], conv[1]
+    if not (x.dim() == 4 and x.is_contiguous() and x.shape[3] % 64 == 0 and _pow2(Ho) and _pow2(Wo)):
+        return False
+    return x.numel() * 2 < 2 ** 32 and x.shape[3] * 2 < 2 ** 24
 
 
 def wgrad(dy2: torch.Tensor, x: torch.Tensor, need_bias: bool = True, conv: Optional[Tuple[int, int, int]] = None,
@@ -345,6 +355,15 @@ class WgradQueue:
     def __init__(self):
         self.items, self.seen = [], set()
         self.trace: Optional[dict] = None   # set to a dict to count (problem, group size) per flush (tools/tune_wgrad.py)
+        # Every pending item keeps its (dy, x) alive until the flush, i.e. until the END of its network's backward: saved
+        # inputs are not released layer by layer any more and every layer's output gradient is alive at once.  ``pending``
+        # counts those bytes; past ``cap`` the queue flushes early (always safe: a flush only computes what is pending).
+        # Default 24 GiB = never reached at cfg 4's per-GPU shape (B = 4: <= 11 GiB pending at the end of the UNet's
+        # backward, tools/train_bench.py --mem prints the peaks); UR_WGRAD_PENDING_MB lowers it for larger batches.
+        self.pending = 0
+        self.peak_pending = 0
+        self.early_flushes = 0
+        self.cap = int(os.environ.get("UR_WGRAD_PENDING_MB", str(24 << 10))) << 20
 
     def add(self, dy2: torch.Tensor, x2: torch.Tensor, w_key: int, need_bias: bool, conv: Optional[Tuple[int, int, int]] = None):
         """``conv`` = (Ho, Wo, stride) with x2 the NHWC input of a 3x3 conv (dw then in the packed layout), else x2 [P, K]."""
@@ -356,16 +375,23 @@ class WgradQueue:
         dw = torch.empty(dy2.shape[1], K, dtype=dy2.dtype, device=dy2.device)
         db = torch.empty(dy2.shape[1], dtype=torch.float32, device=dy2.device) if need_bias else None
         self.items.append((dy2, x2, dw, db, conv))
+        self.pending += dy2.numel() * dy2.element_size() + x2.numel() * x2.element_size()
+        self.peak_pending = max(self.peak_pending, self.pending)
+        if self.pending > self.cap:
+            self.early_flushes += 1
+            self.flush(keep_seen=True)  # dw / db handed out above are filled now; a repeated weight is still recognised
         return dw, db
 
     def reset(self):
         """Drop whatever is pending (a backward that raised half-way leaves entries whose gradients nobody will read)."""
-        self.items, self.seen = [], set()
+        self.items, self.seen, self.pending = [], set(), 0
         norm_sums.reset()
 
-    def flush(self):
+    def flush(self, keep_seen: bool = False):
         norm_sums.flush()  # the deferred gamma / beta gradients ride on the same barriers
-        items, self.items, self.seen = self.items, [], set()
+        items, self.items, self.pending = self.items, [], 0
+        if not keep_seen:
+            self.seen = set()
         groups: dict = {}
         for it in items:
             dy2, x2, conv = it[0], it[1], it[4]

@@ -42,6 +42,9 @@ class FusedAdamW(torch.optim.Optimizer):
         defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, fused=True, capturable=True,
                         amsgrad=False, maximize=False, foreach=None, differentiable=False)
         super().__init__(params, defaults)
+        # bumped whenever the addresses a captured update may hold could have changed (load_state_dict that had to replace
+        # state tensors, add_param_group): train_step.GraphedTrainStep compares it and captures again
+        self.generation = 0
 
     def sync_hyper(self):
         """Copy every group's lr / weight_decay into its device scalar pair (created on first use).  The kernel reads them
@@ -60,7 +63,16 @@ class FusedAdamW(torch.optim.Optimizer):
                     continue
                 hy = group["_ur_hyper"] = [torch.empty(2, dtype=torch.float32, device=dev), None]
             if hy[1] != want:
-                hy[0].copy_(torch.tensor(want, dtype=torch.float32), non_blocking=False)
+                # staged through a pinned pair: an lr_scheduler changes lr on every step, and a blocking copy from pageable
+                # memory would host-synchronise the stream each time.  The staging buffer is rewritten only after the
+                # previous copy out of it has completed (event), so back-to-back changes never race.
+                if len(hy) < 4:
+                    hy += [torch.empty(2, dtype=torch.float32).pin_memory(), torch.cuda.Event()]
+                    hy[3].record()
+                hy[3].synchronize()
+                hy[2][0], hy[2][1] = want
+                hy[0].copy_(hy[2], non_blocking=True)
+                hy[3].record()
                 hy[1] = want
 
     def _init_state(self, p):
@@ -161,13 +173,50 @@ class FusedAdamW(torch.optim.Optimizer):
         sd["state"] = {k: ({**st, "step": st["step"].clone()} if "step" in st else dict(st)) for k, st in sd["state"].items()}
         return sd
 
+    def add_param_group(self, param_group):
+        super().add_param_group(param_group)
+        self.generation = getattr(self, "generation", 0) + 1
+
     def load_state_dict(self, state_dict):
+        """Loads IN PLACE where it can: existing ``exp_avg`` / ``exp_avg_sq`` / step-counter tensors and the device (lr,
+        weight_decay) pair keep their addresses and receive the loaded values, so a captured ``ur_adamw_multi`` (HIP-graph
+        replays of the training step) keeps reading live memory after ``resume_from_checkpoint`` (train.py:1191-1218).
+        Only state that did not exist yet, or changed shape, is adopted as new tensors -- ``generation`` is bumped then, and
+        GraphedTrainStep captures again."""
+        old_hyper = [g.get("_ur_hyper") for g in self.param_groups]
+        old_launch = [g.get("_ur_launches") for g in self.param_groups]
+        old_state = {p: dict(self.state[p]) for g in self.param_groups for p in g["params"] if self.state.get(p)}
         super().load_state_dict(state_dict)
-        for group in self.param_groups:
-            group.pop("_ur_launches", None)  # the state tensors were replaced
+        replaced = False
+        for gi, group in enumerate(self.param_groups):
+            group.pop("_ur_launches", None)
             group.pop("_ur_hyper", None)
-        for group in self.param_groups:  # private fp32 device scalars (torch may hand back the caller's tensors uncopied)
+            hy = old_hyper[gi] if gi < len(old_hyper) else None
+            if hy is not None:
+                hy[1] = None  # same device pair, value re-sent by the next sync_hyper()
+                group["_ur_hyper"] = hy
+            step_t = None
             for p in group["params"]:
                 st = self.state.get(p)
-                if st and "step" in st:
-                    st["step"] = torch.as_tensor(st["step"], dtype=torch.float32).to(p.device).reshape(()).clone()
+                if not st:
+                    continue
+                prev = old_state.get(p)
+                for k in ("exp_avg", "exp_avg_sq"):
+                    if k in st and prev is not None and k in prev and prev[k].shape == st[k].shape and prev[k].dtype == torch.float32:
+                        prev[k].copy_(st[k])
+                        st[k] = prev[k]
+                    elif k in st:
+                        replaced = True
+                if "step" in st:
+                    new = torch.as_tensor(st["step"], dtype=torch.float32).to(p.device).reshape(())
+                    if prev is not None and "step" in prev:
+                        if step_t is None or prev["step"] is not step_t:
+                            prev["step"].copy_(new)
+                        st["step"] = step_t = prev["step"]  # the group's one device counter keeps its address
+                    else:
+                        st["step"] = new.clone()  # private fp32 device scalar (torch may hand back the caller's tensor uncopied)
+                        replaced = True
+            if not replaced and gi < len(old_launch) and old_launch[gi] is not None:
+                group["_ur_launches"] = old_launch[gi]  # same addresses: the descriptor arrays are still right
+        if replaced:
+            self.generation = getattr(self, "generation", 0) + 1

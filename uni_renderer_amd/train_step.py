@@ -586,8 +586,12 @@ class GraphedTrainStep:
         lr and weight_decay are NOT among them when the optimizer keeps them in device memory (optim.FusedAdamW.sync_hyper):
         a scheduler step then only needs that copy refreshed before the replay."""
         dev_lr = hasattr(self.optimizer, "sync_hyper")
-        return tuple(((None if dev_lr else float(g["lr"])), tuple(float(b) for b in g["betas"]), float(g["eps"]),
-                      (None if dev_lr else float(g["weight_decay"]))) for g in self.optimizer.param_groups)
+        # ... and the ADDRESSES it holds: the device (lr, weight_decay) pair and the optimizer's ``generation`` (bumped when
+        # load_state_dict / add_param_group replaced state tensors a captured update points at)
+        return (getattr(self.optimizer, "generation", 0),) + tuple(
+            ((None if dev_lr else float(g["lr"])), tuple(float(b) for b in g["betas"]), float(g["eps"]),
+             (None if dev_lr else float(g["weight_decay"])),
+             (g["_ur_hyper"][0].data_ptr() if g.get("_ur_hyper") is not None else None)) for g in self.optimizer.param_groups)
 
     def _capture(self):
         nets, optimizer, buckets, kw, max_grad_norm = self.nets, self.optimizer, self.buckets, self._kw, self.max_grad_norm
