@@ -104,7 +104,9 @@ def _spawn_ranks(n, script=None):
     raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
 
-def build_models(dev, dtype, seed=1234):
+def build_models(dev, dtype, seed=1234, fp32_state=None):
+    """``fp32_state``: a list that receives the three networks' fp32 state dicts (CPU) before the cast to ``dtype`` -- the
+    parameters the CPU oracle of the ``cpu_baseline`` / parity leg loads."""
     import uni_renderer_amd as U
 
     torch.manual_seed(seed)
@@ -122,6 +124,8 @@ def build_models(dev, dtype, seed=1234):
     for z in list(enc.controlnet_down_blocks) + [enc.controlnet_mid_block] + list(dec.control_down_blocks) + [dec.control_mid_block]:
         z.weight.data.normal_(0, 0.02, generator=g)  # exchange convs live
         z.bias.data.normal_(0, 0.02, generator=g)
+    if fp32_state is not None:
+        fp32_state.extend({k: v.detach().float().cpu() for k, v in m.state_dict().items()} for m in (unet, enc, dec))
     return [m.to(dev).to(dtype).eval() for m in (unet, enc, dec)]
 
 
@@ -245,7 +249,7 @@ def measure_traffic_live(klass, extra_args, steps=2, timeout=150):
             out = os.path.join(tmp, counter)
             cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "-d", out, "-o", "p", "--output-format", "csv", "--",
                    sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(steps), "--warmup", "1", "--no-cpu-baseline",
-                   "--no-roofline"] + list(extra_args)
+                   "--no-roofline", "--no-loop"] + list(extra_args)
             proc = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
             try:
                 rc = proc.wait(timeout=timeout)
@@ -271,8 +275,12 @@ def measure_traffic_live(klass, extra_args, steps=2, timeout=150):
                             f"FETCH_SIZE x 2 x 1024 = {round(rd)} B read + WRITE_SIZE x 1024 = {round(wr)} B written per launch")
 
 
-def cpu_baseline(B, L):
-    """The oracle ("port") timed on this host: the same enc+unet+dec step, fp32, all cores."""
+def cpu_baseline(B, L, check=None):
+    """The oracle ("port") timed on this host: the same enc+unet+dec step, fp32, all cores.
+    ``check`` = (fp32 state dicts of [unet, enc, dec], the GPU step's inputs on the CPU, its outputs on the CPU, low dtype):
+    the timed CPU steps then run on THE BENCHMARKED networks and inputs, and their outputs double as the parity check of
+    the number above them -- rel-L2 of img_pred / attr_pred against the oracle holding the fp32 parameters and against the
+    oracle holding the parameters rounded to the product's dtype (``parity_rel_l2``; north_star: <= 1e-3 in fp16)."""
     from oracle import unirenderer_oracle as O
 
     cores = os.cpu_count() or 1
@@ -294,10 +302,13 @@ def cpu_baseline(B, L):
         dec = O.AttributeDecoderModel(**dict(O.SD15_CONFIG, out_channels=28))
     mods = []
     g = torch.Generator().manual_seed(1)
-    for m in (unet, enc, dec):
+    for i, m in enumerate((unet, enc, dec)):
         m = m.to_empty(device="cpu")
-        for p in m.parameters():
-            p.data.normal_(0, 0.02, generator=g)
+        if check is not None:
+            m.load_state_dict(check[0][i])  # the benchmarked networks' fp32 parameters
+        else:
+            for p in m.parameters():
+                p.data.normal_(0, 0.02, generator=g)
         mods.append(m.eval())
     # Bounded sample: one untimed batch-1 step (allocator / oneDNN primitive warm-up; also sizes the
     # budget), then THREE timed full steps at the benchmarked batch -- min and median reported, ``value`` = 1 / median
@@ -312,21 +323,43 @@ def cpu_baseline(B, L):
                     sample=f"ONE untimed-warm batch-1 step took {warm:.1f} s (over budget): value = 1/({warm:.1f} s x {B}); "
                            f"{L}x{L} latent, fp32, torch {torch.__version__} CPU ops")
     full = warm * B <= 25.0
-    x = O.make_inputs(B if full else 1, L, 768, seed=4)
-    times = []
-    for _ in range(3):
+    nb = B if full else 1
+    if check is not None:
+        x = tuple(t[:nb].float() if t.is_floating_point() else t[:nb] for t in check[1])
+    else:
+        x = O.make_inputs(nb, L, 768, seed=4)
+    times, parity = [], None
+    rel = lambda a, b: float((a.float() - b.float()).norm() / b.float().norm())
+    for k in range(3):
+        if check is not None and k == 2:  # the third timed step runs on the parameters ROUNDED like the product's
+            for m in mods:
+                for p in m.parameters():
+                    p.data = p.data.to(check[3]).to(torch.float32)
         t0 = time.perf_counter()
-        O.dual_stream_step(*mods, *x)
+        out = O.dual_stream_step(*mods, *x)
         times.append((time.perf_counter() - t0) * (1 if full else B))
+        if check is not None and k in (0, 2):
+            parity = parity or {}
+            parity["fp32_weights" if k == 0 else "same_weights"] = dict(
+                img_pred=round(rel(check[2]["img_pred"][:nb], out["img_pred"]), 7),
+                attr_pred=round(rel(check[2]["attr_pred"][:nb], out["attr_pred"]), 7))
     times.sort()
     med = times[1]
     what = (f"1 untimed batch-1 warm-up + 3 timed full steps at batch {B}" if full else
             f"1 untimed batch-1 warm-up + 3 timed batch-1 steps x {B} (samples are independent)")
     out = dict(value=round(1.0 / med, 5), unit="denoise-steps/sec", cores=cores, kind="port",
                step_seconds=dict(min=round(times[0], 3), median=round(med, 3), max=round(times[2], 3)),
-               sample=f"{what}: min {times[0]:.2f} s / median {med:.2f} s; same enc+unet+dec step, {L}x{L} latent, fp32, "
+               sample=f"{what}: min {times[0]:.2f} s / median {med:.2f} s; same enc+unet+dec step"
+                      f"{' on the benchmarked networks and inputs' if check is not None else ''}, {L}x{L} latent, fp32, "
                       f"torch {torch.__version__} CPU ops (oneDNN {'on' if torch.backends.mkldnn.is_available() else 'off'}), "
                       f"{cores} threads")
+    if parity is not None:
+        parity["samples_compared"] = nb
+        parity["note"] = ("rel-L2 of the timed GPU step's outputs against the CPU fp32 oracle (parity unpinned: restatement of the "
+                          "reference, SURVEY 8c) on the SAME networks and inputs: fp32_weights = oracle holds the fp32 parameters "
+                          "(includes the checkpoint's quantisation to the product's dtype), same_weights = oracle holds the "
+                          "parameters rounded like the product's (kernel arithmetic only; north_star's <= 1e-3 is claimed for this one)")
+        out["parity_rel_l2"] = parity
     # cfg 1 (BASELINE.json configs[0]): single-stream UNet forward, 64x64 latent, bs 1, 2 denoise steps, CPU fp32
     x1 = O.make_inputs(1, 64, 768, seed=5)
     with torch.no_grad():
@@ -336,6 +369,41 @@ def cpu_baseline(B, L):
         c1 = time.perf_counter() - t0
     out["cfg1_unet_only_bs1_2steps"] = dict(seconds=round(c1, 3), steps_per_sec=round(2.0 / c1, 4))
     return out
+
+
+def sampling_loops(models, B, L, dev, dtype, steps=50):
+    """cfg 3's actual workload: the 50-step DDIM sampling loops of the pipeline (latents in, latents out; VAE / CLIP outside),
+    inverse (real_image2mask_3mod_albedo) and rendering (mask2image_3mod_albedo) direction, with the loop-invariant half
+    hoisted out of the loop (uni_renderer_amd/hoist.py) -- wall time of a whole call, best of 3."""
+    from uni_renderer_amd.pipeline import UniRendererPipeline
+
+    pipe = UniRendererPipeline(unet=models[0], controlnet=models[1], controldec=models[2])
+    pipe.set_progress_bar_config(disable=True)
+    g = torch.Generator(device=dev).manual_seed(3)
+    img = torch.randn(B, 4, L, L, device=dev, generator=g).to(dtype)
+    msk = torch.randn(B, 4, L, L, device=dev, generator=g).to(dtype)
+    ehs = (torch.randn(B, 77, 768, device=dev, generator=g) * 0.5).to(dtype)
+    attr = torch.randn(B, 28, L, L, device=dev, generator=g).to(dtype)
+    res = dict(steps=steps, scheduler="DDIM (x0 prediction), on-device update", guidance_scale=0.0,
+               executor="hoisted: inverse = UNet down+mid + decoder exchange convs once per call, per step enc + 13 adds + dec; "
+                        "render = encoder once per call, per step UNet + 13 adds")
+    for name, fn in (
+        ("inverse", lambda: pipe.real_image2mask_3mod_albedo(prompt_embeds=ehs, image_latents=img, mask_latents=msk,
+                                                             num_inference_steps=steps, guidance_scale=0.0, output_type="latent")),
+        ("render", lambda: pipe.mask2image_3mod_albedo(prompt_embeds=ehs, attr_latents=attr, num_inference_steps=steps,
+                                                       guidance_scale=0.0, output_type="latent")),
+    ):
+        fn()  # capture + warm
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        res[name + "_ms_total"] = round(min(ts) * 1e3, 2)
+        res[name + "_ms_per_step"] = round(min(ts) * 1e3 / steps, 3)
+    return res
 
 
 def main():
@@ -349,6 +417,7 @@ def main():
     ap.add_argument("--direction", default="inverse", choices=["inverse", "render"],
                     help="inverse: enc+unet+dec (headline, cfg 3/5); render: enc+unet only (cfg 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-loop", action="store_true", help="skip the 50-step sampling-loop timings (the `loop` object)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="roofline.traffic from profiles/pmc_traffic.json instead of two rocprofv3 --pmc child runs (~1 min)")
@@ -383,7 +452,9 @@ def main():
     from uni_renderer_amd.graph import GraphedDualStreamStep, dual_stream_step
 
     _lib.load()  # no HIP library -> fail loudly
-    models = build_models(dev, dtype)
+    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
+    fp32_state = [] if want_cpu else None
+    models = build_models(dev, dtype, fp32_state=fp32_state)
     inputs = make_inputs(args.batch, args.latent, dev, dtype, seed=100 + rank)
     runner = GraphedDualStreamStep(*models, batch=args.batch, latent_hw=args.latent, cross_dim=768, dtype=dtype,
                                    device=dev, run_decoder=(args.direction == "inverse"),
@@ -469,9 +540,18 @@ def main():
                 _, stable, _ = measure_roofline(runner._run, by_shape=True)
                 with open(args.shape_table, "w") as f:
                     json.dump(stable, f)
-        if not args.no_cpu_baseline and world == 1:
+        if world == 1 and not args.no_loop and not args.eager:
+            out["loop"] = sampling_loops(models, args.batch, args.latent, dev, dtype)
+        if want_cpu:
+            check = None
+            if not args.eager and args.direction == "inverse":
+                one()  # the timed step's outputs on the benchmarked inputs
+                torch.cuda.synchronize()
+                check = (fp32_state, [t.cpu() for t in inputs], {k: v.float().cpu() for k, v in runner.out.items()}, dtype)
             del runner
-            out["cpu_baseline"] = cpu_baseline(args.batch, args.latent)
+            out["cpu_baseline"] = cpu_baseline(args.batch, args.latent, check)
+            if "parity_rel_l2" in out["cpu_baseline"]:
+                out["config"]["parity_rel_l2"] = out["cpu_baseline"].pop("parity_rel_l2")
         print(json.dumps(out), flush=True)
     if dist_on:
         torch.distributed.barrier()  # rank 0 may still have been in its roofline leg

@@ -7,12 +7,12 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd $R
 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
-python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-live-traffic --shape-table $OUT/per_shape_eager_events.json > /dev/null 2>&1
+python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-loop --no-live-traffic --shape-table $OUT/per_shape_eager_events.json > /dev/null 2>&1
 export TMPDIR=/tmp
-(cd /tmp && cd $R && rocprofv3 --kernel-trace --stats -d $OUT/stats -o $TAG --output-format csv -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-live-traffic > $OUT/bench_under_rocprofv3.json 2> $OUT/rocprof_stats.err)
-(cd $R && rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o p --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-live-traffic > /dev/null 2>&1)
-(cd $R && rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o p --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-live-traffic > /dev/null 2>&1)
-(cd $R && rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES --kernel-trace -d $OUT/pmc_mfma -o p --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-live-traffic > /dev/null 2>&1)
+(cd /tmp && cd $R && rocprofv3 --kernel-trace --stats -d $OUT/stats -o $TAG --output-format csv -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-loop --no-live-traffic > $OUT/bench_under_rocprofv3.json 2> $OUT/rocprof_stats.err)
+(cd $R && rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o p --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-loop --no-live-traffic > /dev/null 2>&1)
+(cd $R && rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o p --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-loop --no-live-traffic > /dev/null 2>&1)
+(cd $R && rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES --kernel-trace -d $OUT/pmc_mfma -o p --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-loop --no-live-traffic > /dev/null 2>&1)
 python tools/pmc_traffic.py $(find $OUT/pmc_fetch -name "*counter_collection.csv" | head -1) $(find $OUT/pmc_write -name "*counter_collection.csv" | head -1) $OUT/pmc_traffic.json > $OUT/pmc_traffic.log 2>&1
 python - <<PY
 import csv, collections, glob, json
