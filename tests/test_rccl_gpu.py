@@ -130,3 +130,84 @@ def test_bench_line_carries_the_contract_fields_with_a_live_roofline():
     assert roof["bound"] in ("hbm", "mfma") and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
     if roof["traffic"] is not None:
         assert roof["traffic"] > 0 and roof["traffic_source"].startswith(("LIVE", "STATIC"))
+
+
+GRAPH_WORKER = r'''
+import os, sys, json
+import torch, torch.distributed as dist
+sys.path.insert(0, os.environ["UR_ROOT"]); sys.path.insert(0, os.path.join(os.environ["UR_ROOT"], "tests"))
+from util_models import O, build_product_from_oracle
+from uni_renderer_amd.optim import FusedAdamW
+from uni_renderer_amd.parallel import GradientBuckets
+from uni_renderer_amd.train_step import GraphedTrainStep, train_step
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+
+def setup(algo, comm, overlap):
+    nets = build_product_from_oracle(*O.build_triplet(O.TINY_CONFIG, seed=44), torch.float32, dev)
+    for m in nets:
+        m.train(); m.requires_grad_(True)
+    b = GradientBuckets(nets, bucket_mb=0.5, comm_dtype=comm, algorithm=algo, overlap=overlap, force_collectives=True)
+    return nets, FusedAdamW([p for m in nets for p in m.parameters()], lr=2e-4), b
+
+def batch(it):
+    x, c, ehs, ti, ta = [t.to(dev) for t in O.make_inputs(2, 16, 64, seed=120 + it)]
+    g = torch.Generator().manual_seed(121 + it)
+    return dict(x_t=x, cond=c, ehs=ehs, t_img=ti, t_attr=ta, target_img=torch.randn(2, 4, 16, 16, generator=g).to(dev),
+                target_attr=torch.randn(2, 28, 16, 16, generator=g).to(dev))
+
+out = {}
+for algo in ("all_reduce", "rs_ag"):
+    for comm in (None, torch.bfloat16):
+        nets_e, opt_e, b_e = setup(algo, comm, True)
+        eager = [train_step(nets_e, batch(it), optimizer=opt_e, buckets=b_e, dtype=torch.bfloat16)["loss"] for it in range(3)]
+        nets_s, opt_s, b_s = setup(algo, comm, False)           # forward + backward graph | eager collectives | update graph
+        serial = GraphedTrainStep(nets_s, batch(0), opt_s, buckets=b_s, dtype=torch.bfloat16, warmup=0)
+        assert not serial.capture_collectives
+        ls = [float(serial.step(batch(it))["loss"]) for it in range(3)]
+        nets_g, opt_g, b_g = setup(algo, comm, True)             # ONE graph, collectives captured as parallel branches
+        assert len(b_g.buckets) >= 3
+        fused = GraphedTrainStep(nets_g, batch(0), opt_g, buckets=b_g, dtype=torch.bfloat16, warmup=0)
+        assert fused.capture_collectives and fused.g_up is None
+        lg = [float(fused.step(batch(it))["loss"]) for it in range(3)]
+        torch.cuda.synchronize()
+        same = all(torch.equal(a, b) and torch.equal(a, c) for a, b, c in zip((p for m in nets_e for p in m.parameters()),
+                   (p for m in nets_g for p in m.parameters()), (p for m in nets_s for p in m.parameters())))
+        ph = fused.phase_times(); ps = serial.phase_times()
+        out[f"{algo}/{comm}"] = dict(eager=eager, fused=lg, serial=ls, params_equal=bool(same), forked=fused.collectives_from_hooks,
+                                     buckets=len(b_g.buckets), phases_fused=sorted(ph), phases_serial=sorted(ps))
+try:
+    GraphedTrainStep(nets_g, batch(0), opt_g, buckets=b_g, dtype=torch.bfloat16, warmup=0, capture_collectives=False)
+    out["refuses_hooks_without_capture"] = False
+except ValueError:
+    out["refuses_hooks_without_capture"] = True
+dist.barrier()
+dist.destroy_process_group()
+print("RESULT " + json.dumps(out))
+'''
+
+
+def test_graphed_train_step_with_the_rccl_collectives_captured_in_the_graph(tmp_path):
+    """VERDICT r4 item 5b: the graphed training step used to run replay -> collectives -> update serially.  With RCCL the bucket
+    collectives are now captured INTO the step graph: the buckets' hooks enqueue them on RCCL's stream as the backward completes
+    each bucket (a fork inside the capture), ``finish()`` joins.  World size 1 on the leased GPU runs the real RCCL kernels as
+    graph nodes: three steps must equal the eager hook-overlapped step and the serial three-phase graphed step bit for bit
+    (losses and parameters), for all-reduce and reduce-scatter + all-gather, fp32 and bf16 transport, and some collectives
+    must have been forked from inside the backward."""
+    script = tmp_path / "graph_worker.py"
+    script.write_text(GRAPH_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), UR_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    print(json.dumps(res))
+    assert res.pop("refuses_hooks_without_capture") is True
+    assert len(res) == 4
+    for k, v in res.items():
+        assert v["eager"] == v["fused"] == v["serial"], (k, v)
+        assert v["params_equal"], k
+        assert v["forked"] > 0 and v["buckets"] >= 3, (k, v)
+        assert v["phases_fused"] == ["overlapped_total"] and v["phases_serial"] == ["collectives", "replay", "update"]

@@ -43,15 +43,20 @@ def main():
     ap.add_argument("--torch-adamw", action="store_true", help="torch.optim.AdamW(fused=True) instead of optim.FusedAdamW")
     ap.add_argument("--gpus", type=int, default=0, help="without a launcher: start this many ranks (one per GPU) ourselves")
     ap.add_argument("--graph", action="store_true", help="time HIP-graph replays (train_step.GraphedTrainStep): one GPU = the whole step "
-                    "as one graph; several = forward + backward graph, eager bucket collectives and update")
+                    "as one graph; several = ONE graph with the bucket collectives captured as parallel branches (overlapped "
+                    "with the backward), or with --no-overlap: forward + backward graph, eager collectives, update graph")
+    ap.add_argument("--force-collectives", action="store_true", help="one rank: still build the buckets and issue the RCCL "
+                    "collectives (world size 1), to time / profile the multi-GPU code path on one GPU")
     args = ap.parse_args()
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
     if args.gpus > 1 and world == 1 and "RANK" not in os.environ:
         bench._spawn_ranks(args.gpus, script=__file__)  # does not return
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    if world > 1 or args.force_collectives:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533"), ("RANK", "0"), ("WORLD_SIZE", "1")):
+            os.environ.setdefault(k, v)
         torch.distributed.init_process_group("nccl", device_id=dev)
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float16
     nets = bench.build_models(dev, torch.float32)  # fp32 master parameters
@@ -72,7 +77,8 @@ def main():
         from uni_renderer_amd.optim import FusedAdamW
         opt = FusedAdamW(params, lr=1e-5)
     buckets = GradientBuckets(nets, comm_dtype=(torch.bfloat16 if args.comm_dtype == "bf16" else None), algorithm=args.algorithm,
-                              overlap=not (args.no_overlap or args.graph)) if world > 1 else None
+                              overlap=not args.no_overlap, force_collectives=args.force_collectives) \
+        if (world > 1 or args.force_collectives) else None
     if args.graph:
         # one GPU: the whole step is one graph; several: forward + backward graph, eager bucket collectives and update
         from uni_renderer_amd.train_step import GraphedTrainStep
@@ -85,6 +91,10 @@ def main():
         torch.cuda.synchronize()
         dtm = (time.perf_counter() - t0) / args.steps
         stats = {k: float(v) for k, v in gstats.items()}
+        phases = {k: round(v, 2) for k, v in gstep.phase_times().items()}
+        phases["collectives_captured_in_graph"] = gstep.capture_collectives
+        if gstep.capture_collectives:
+            phases["collectives_forked_during_backward"] = gstep.collectives_from_hooks
     else:
         stats = train_step(nets, batch, optimizer=opt, buckets=buckets, dtype=dt)  # warm-up (packs nothing: weights change)
         torch.cuda.synchronize()
@@ -104,8 +114,8 @@ def main():
                               grad_sync=(dict(algorithm=args.algorithm, comm_dtype=args.comm_dtype, overlap=not args.no_overlap,
                                               buckets=len(buckets.buckets), launched_during_backward=buckets.launched_from_hooks)
                                          if buckets is not None else None), peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2**30, 1),
-                              wgrad_queue=_queue_stats())))
-    if world > 1:
+                              wgrad_queue=_queue_stats(), phase_ms=(phases if args.graph else None))))
+    if world > 1 or args.force_collectives:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

@@ -548,14 +548,36 @@ class GraphedTrainStep:
     checkpoint changed them and captures again."""
 
     def __init__(self, nets, batch: Dict[str, torch.Tensor], optimizer, buckets=None, dtype=torch.bfloat16,
-                 max_grad_norm: Optional[float] = 1.0, inverse: Optional[bool] = None, warmup: int = 2):
-        if buckets is not None and getattr(buckets, "_hooks", None):
-            raise ValueError("GraphedTrainStep needs GradientBuckets(..., overlap=False): hooks cannot run inside a capture")
+                 max_grad_norm: Optional[float] = 1.0, inverse: Optional[bool] = None, warmup: int = 2,
+                 capture_collectives: Optional[bool] = None):
+        """``capture_collectives`` (RCCL only; default: on when ``buckets`` were built with ``overlap=True`` on the nccl
+        backend): the bucket collectives are captured INTO the step graph.  The post-accumulate hooks of ``buckets`` enqueue
+        each bucket's all-reduce / reduce-scatter + all-gather on RCCL's stream the moment the bucket is complete -- inside a
+        capture that is a fork: the collective becomes a parallel branch of the graph that runs beside the rest of the
+        backward, joined by ``buckets.finish()`` in front of clipping + update.  With the weight gradients deferred to the end
+        of each network's backward (backward.WgradQueue) the buckets complete network by network: the decoder's collectives
+        overlap the UNet's backward, the UNet's the encoder's -- DDP's overlap at train/train.py:1421, with the whole step
+        ONE replay and no host in the loop.  Without it (gloo, or ``overlap=False`` buckets): forward + backward graph,
+        eager collectives, update graph, serially."""
+        import torch.distributed as dist
+        hooks = bool(buckets is not None and getattr(buckets, "_hooks", None))
+        nccl = bool(buckets is not None and dist.is_initialized() and dist.get_backend(getattr(buckets, "group", None)) == "nccl")
+        if capture_collectives is None:
+            capture_collectives = hooks and nccl
+        if capture_collectives and not (hooks and nccl):
+            raise ValueError("capture_collectives needs GradientBuckets(..., overlap=True) on the nccl (RCCL) backend")
+        if hooks and not capture_collectives:
+            raise ValueError("GraphedTrainStep without captured collectives needs GradientBuckets(..., overlap=False): "
+                             "hooks launching eager collectives cannot run inside a capture")
+        self.capture_collectives = bool(capture_collectives)
+        if self.capture_collectives:  # RCCL creates its communicator on first use: that must not happen inside a capture
+            t = torch.zeros(8, device=buckets.flat[0].device)
+            dist.all_reduce(t, group=buckets.group)
+            torch.cuda.synchronize()
         self.nets, self.optimizer, self.buckets = nets, optimizer, buckets
         # gloo (the CPU-side test transport) stages device tensors through the host; handing it a tensor whose producer
         # graph is still replaying was measured at 50-140 s per step with two ranks on one GPU (0.03 s after a stream
         # synchronise).  RCCL collectives are stream-ordered and need no host wait.
-        import torch.distributed as dist
         self._host_sync_before_collectives = bool(buckets is not None and dist.is_initialized()
                                                   and dist.get_backend(getattr(buckets, "group", None)) == "gloo")
         self.batch = {k: v.clone() for k, v in batch.items()}
@@ -599,11 +621,21 @@ class GraphedTrainStep:
             optimizer.sync_hyper()
         self._captured_hyper = self._hyper()
         self.g_fb = torch.cuda.CUDAGraph()
+        self.g_up = None
+        if self.capture_collectives:
+            buckets._reset()
+            before = buckets.launched_from_hooks
+            with torch.cuda.graph(self.g_fb):
+                # the hooks fire inside backward(): every complete bucket's collective forks onto RCCL's stream here
+                self.stats["loss"] = _forward_backward(nets, self.batch, None, buckets, **kw)
+                self.collectives_from_hooks = buckets.launched_from_hooks - before  # forked before finish() had to
+                buckets.finish()  # launches what the hooks could not, then joins RCCL's stream (work.wait = stream wait)
+                _clip_and_update(nets, optimizer, buckets, max_grad_norm, self.stats)
+            return
         with torch.cuda.graph(self.g_fb):
             self.stats["loss"] = _forward_backward(nets, self.batch, optimizer if buckets is None else None, buckets, **kw)
             if buckets is None:
                 _clip_and_update(nets, optimizer, None, max_grad_norm, self.stats)
-        self.g_up = None
         if buckets is not None:
             buckets._reset()
             self.g_up = torch.cuda.CUDAGraph()
@@ -630,9 +662,33 @@ class GraphedTrainStep:
             torch.cuda.synchronize()
             self._capture()
         self.g_fb.replay()
-        if self.buckets is not None:
+        if self.buckets is not None and not self.capture_collectives:
             if self._host_sync_before_collectives:
                 torch.cuda.current_stream().synchronize()
             self.buckets.finish()
             self.g_up.replay()  # clipping (torch._foreach_norm over the buckets) + optimizer step
         return self.stats
+
+    def phase_times(self) -> Dict[str, float]:
+        """One step with HIP events between the phases (synchronises): milliseconds of the forward + backward replay, of the
+        bucket collectives (launch to completion, as the compute stream sees them) and of clipping + update.  With captured
+        collectives the step is one graph and only its total is observable from outside (``overlapped_total``)."""
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        if hasattr(self.optimizer, "sync_hyper"):
+            self.optimizer.sync_hyper()
+        ev[0].record()
+        self.g_fb.replay()
+        ev[1].record()
+        if self.buckets is not None and not self.capture_collectives:
+            if self._host_sync_before_collectives:
+                torch.cuda.current_stream().synchronize()
+            self.buckets.finish()
+            ev[2].record()
+            self.g_up.replay()
+        else:
+            ev[2].record()
+        ev[3].record()
+        torch.cuda.synchronize()
+        if self.capture_collectives or self.buckets is None:
+            return dict(overlapped_total=ev[0].elapsed_time(ev[3]))
+        return dict(replay=ev[0].elapsed_time(ev[1]), collectives=ev[1].elapsed_time(ev[2]), update=ev[2].elapsed_time(ev[3]))
