@@ -20,6 +20,7 @@ from typing import Optional, Tuple
 
 import torch
 
+from . import _experiments as X
 from . import _lib, ops
 from ._lib import check
 from .ops import DT, _ptr, _require_gpu, _stream
@@ -54,11 +55,11 @@ _lib.register_layout("ur_sizeof_transpose_desc", _TransposeDesc)  # checked in _
 # Bias gradients inside the transpose launch (ur_transpose_desc.colsum): correct and deterministic, removes ~650 launches per
 # step, but every transposing workgroup then pays a memory-side store + counter round trip: 84.7 vs 84.6 ms per graphed
 # step (tools/experiments/r03_run14.sh) -- no gain, so off by default.
-FUSED_COLSUM = os.environ.get("UR_FUSED_COLSUM", "0") != "0"
+FUSED_COLSUM = X.flag("fused_colsum", False)
 # Column sums folded in the same launch by the last-arriving workgroup (ur_colsum_fused; identical bits, 476 launches fewer
 # per step): measured 81.4 vs 81.1 ms per step (tools/experiments/r03_run35.sh) -- the agent-scope hand-off costs what the fold launch
 # did -- so off by default.
-COLSUM_ONE_LAUNCH = os.environ.get("UR_COLSUM_ONE_LAUNCH", "0") != "0"
+COLSUM_ONE_LAUNCH = X.flag("colsum_one_launch", False)
 _colsum_counters: dict = {}
 
 
@@ -71,12 +72,12 @@ def _colsum_counter(device) -> torch.Tensor:
     return t
 
 
-MULTI_TRANSPOSE = os.environ.get("UR_MULTI_TRANSPOSE", "1") != "0"
-TRANSPOSE_MAX = 32  # UR_TRANSPOSE_MAX
+MULTI_TRANSPOSE = X.flag("multi_transpose", True)
+TRANSPOSE_MAX = 32
 # W^T of the Linear weights for dx = dy . W, made in a few multi-tensor launches right after the batched cast of the weights
 # (autograd_ops.CastParams) instead of one transpose launch per layer in the backward (426 launches, 3.1 ms per step):
-# (data_ptr, shape) of the compute-dtype weight -> its transpose.  UR_BATCH_WT=0: every linear_backward transposes its own.
-BATCH_WT = os.environ.get("UR_BATCH_WT", "1") != "0"
+# (data_ptr, shape) of the compute-dtype weight -> its transpose.  UR_EXPERIMENT=no_batch_wt: every linear_backward transposes its own.
+BATCH_WT = X.flag("batch_wt", True)
 weight_t: dict = {}
 
 
@@ -167,7 +168,7 @@ class GradSquares:
 
 
 grad_squares = GradSquares()
-FUSED_GRADNORM = os.environ.get("UR_FUSED_GRADNORM", "1") != "0"
+FUSED_GRADNORM = X.flag("fused_gradnorm", True)
 
 
 def cast_many(srcs, dtype, sumsq: bool = False, packed: bool = False):
@@ -244,10 +245,10 @@ class _WgradDesc(C.Structure):
 _lib.register_layout("ur_sizeof_wgrad_desc", _WgradDesc)
 
 # dW (+ db) straight from dy and x as they lie in memory (ur_wgrad: LDS transpose reads) instead of transposed copies +
-# the forward GEMM kernel.  UR_WGRAD=0 restores the round-3 path (the A/B of tools/experiments/r04_run24.sh).
-WGRAD = os.environ.get("UR_WGRAD", "1") != "0"
-WGRAD_TILE = int(os.environ.get("UR_WGRAD_TILE", "0"))
-WGRAD_SPLITS = int(os.environ.get("UR_WGRAD_SPLITS", "0"))
+# the forward GEMM kernel.  UR_EXPERIMENT=no_wgrad restores the round-3 path (A/B: profiles/r04_wgrad_step_ab.txt).
+WGRAD = X.flag("wgrad", True)
+WGRAD_TILE = X.number("wgrad_tile", 0)
+WGRAD_SPLITS = X.number("wgrad_splits", 0)
 # measured (tile, slices) per problem "P,N,K,taps,stride" (tools/tune_wgrad.py); anything else takes the library's choice
 WGRAD_TABLE_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "wgrad_tuning.json")
 _wgrad_table: Optional[dict] = None
@@ -258,7 +259,7 @@ def wgrad_table() -> dict:
     global _wgrad_table
     if _wgrad_table is None:
         _wgrad_table = {}
-        if os.environ.get("UR_WGRAD_TABLE", "1") != "0" and os.path.exists(WGRAD_TABLE_PATH):
+        if X.flag("wgrad_table", True) and os.path.exists(WGRAD_TABLE_PATH):
             import json
             with open(WGRAD_TABLE_PATH) as f:
                 _wgrad_table = {k: tuple(v) for k, v in json.load(f).items() if not k.startswith("_")}
@@ -441,10 +442,10 @@ class NormSums:
 
 
 norm_sums = NormSums()
-NORM_DEFER = os.environ.get("UR_NORM_DEFER", "1") != "0"
+NORM_DEFER = X.flag("norm_defer", True)
 wgrad_queue = WgradQueue()
-# Deferred + grouped Linear weight gradients (WgradQueue).  UR_WGRAD_DEFER=0: every Linear computes its own at once.
-WGRAD_DEFER = os.environ.get("UR_WGRAD_DEFER", "1") != "0"
+# Deferred + grouped Linear weight gradients (WgradQueue).  UR_EXPERIMENT=no_wgrad_defer: every Linear computes its own at once.
+WGRAD_DEFER = X.flag("wgrad_defer", True)
 
 
 def wgrad_group(items, tile: int = 0, splits: int = 0, trace: Optional[dict] = None, conv: Optional[Tuple[int, int, int]] = None):
@@ -660,7 +661,7 @@ def geglu_backward(h: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
 
 # GroupNorm backward of maps up to this many pixels per sample in ONE launch (ur_groupnorm_backward_fused) instead of
 # statistics + channel partials + fold + dx; 0 disables (the A/B of tools/experiments/r04_run35.sh)
-GN_BWD_FUSED_MAX_ROWS = int(os.environ.get("UR_GN_BWD_FUSED_MAX_ROWS", "1024"))
+GN_BWD_FUSED_MAX_ROWS = X.number("gn_bwd_fused_max_rows", 1024)
 
 
 def groupnorm_backward(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float,
@@ -760,7 +761,7 @@ class _HeadsDesc(C.Structure):
 
 _lib.register_layout("ur_sizeof_heads_desc", _HeadsDesc)
 # the per-head copies of the d = 40 flash backward (q, k, v, o, dO in; dq, dk, dv out) in one launch each way instead of 5 + 3
-HEADS_MULTI = os.environ.get("UR_HEADS_MULTI", "1") != "0"
+HEADS_MULTI = X.flag("heads_multi", True)
 
 
 def split_heads_many(items, H: int, d: int, dp: int):
@@ -786,8 +787,8 @@ def merge_heads_many(items, B: int, H: int, d: int):
     check(lib.ur_merge_heads_multi(arr, len(items), B, H, d, items[0][0].shape[2], DT[items[0][0].dtype], _stream()), "ur_merge_heads_multi")
 
 
-FLASH_BACKWARD = os.environ.get("UR_FLASH_BACKWARD", "1") != "0"  # 0: always the materialised-P path below
-FORWARD_LSE = os.environ.get("UR_FORWARD_LSE", "1") != "0"        # 0: the dq kernel recomputes the row log-sum-exp
+FLASH_BACKWARD = X.flag("flash_backward", True)  # 0: always the materialised-P path below
+FORWARD_LSE = X.flag("forward_lse", True)        # 0: the dq kernel recomputes the row log-sum-exp
 
 
 def flash_stats(B: int, H: int, Tq: int, Tk: int, d: int, device) -> Optional[torch.Tensor]:
@@ -798,7 +799,7 @@ def flash_stats(B: int, H: int, Tq: int, Tk: int, d: int, device) -> Optional[to
     return torch.empty(2, B * H, Tq, dtype=torch.float32, device=device)
 
 
-FLASH_DIRECT_MIN_D = int(os.environ.get("UR_FLASH_DIRECT_MIN_D", "64"))
+FLASH_DIRECT_MIN_D = X.number("flash_direct_min_d", 64)
 
 
 def _flash_attention_backward(q, k, v, o, do, H, scale, fused_qkv, oq, ok, ov, Cc, d, stats=None):

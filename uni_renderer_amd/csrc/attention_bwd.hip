@@ -796,10 +796,7 @@ static void launch_dkdv(const AttnBwdArgs& a, hipStream_t st) {
     }
 }
 
-static bool flash_m32() {
-    static const int v = [] { const char* e = std::getenv("UR_FLASH_M32"); return (e && e[0] == '0') ? 0 : 1; }();
-    return v != 0;
-}
+static constexpr bool flash_m32() { return true; }  // the 32x32x16 kernels for d <= 64 (an environment toggle during their A/B runs)
 // GEN = false: every tile is fully in bounds (d == DP, key rows allocated up to the padded count): the loaders, operand
 // loads and stores carry no predicates -- the per-head-copy mode of the host side
 static bool full_tiles(const AttnBwdArgs& a, int dp) { return a.d == dp && a.Tk_rows >= a.Tk; }

@@ -6,18 +6,11 @@
 
 #include <cstdlib>
 
-// UR_NORM_XCD=0 switches the XCD row-ownership remap of the norm kernels off (A/B runs); read once.
-// UR_GNF_XCD=0: the one-launch GroupNorm keeps the dispatcher's placement (group g of a sample on XCD g % 8) instead of
-// putting the groups of one sample on ONE XCD (A/B runs); read once.
-static int gnf_xcd() {
-    static const int v = [] { const char* e = std::getenv("UR_GNF_XCD"); return (e && e[0] == '0') ? 0 : 1; }();
-    return v;
-}
-
-static int norm_xcd() {
-    static const int v = [] { const char* e = std::getenv("UR_NORM_XCD"); return (e && e[0] == '0') ? 0 : 1; }();
-    return v;
-}
+// The one-launch GroupNorm puts the groups of one sample on ONE XCD (neighbouring groups share cache lines: 2.5x on large maps,
+// profiles/r04_gnf_xcd_ab.txt) and the row-chunked kernels use the XCD-contiguous mapping; both were environment toggles
+// during their A/B runs and are fixed now.
+static constexpr int gnf_xcd() { return 1; }
+static constexpr int norm_xcd() { return 1; }
 
 namespace ur {
 

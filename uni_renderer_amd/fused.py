@@ -26,6 +26,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
 
+from . import _experiments as X
 from . import ops, tchain
 from .controlnet import CIN_PAD, _compute_dtype
 from .layers import (LOG2E, Attention, BasicTransformerBlock, ResnetBlock2D, Transformer2DModel, f32, geglu_perm,
@@ -33,10 +34,10 @@ from .layers import (LOG2E, Attention, BasicTransformerBlock, ResnetBlock2D, Tra
 
 
 # q | k | v of a self-attention as ONE grouped GEMM with a transposed side output for V (ur_igemm_desc.out_vt, ABI 8);
-# UR_QKV_ONE_LAUNCH=0 restores the q | k GEMM + transposed V projection pair (same-box A/B runs)
-QKV_ONE_LAUNCH = os.environ.get("UR_QKV_ONE_LAUNCH", "1") != "0"
+# UR_EXPERIMENT=no_qkv_one_launch restores the q | k GEMM + transposed V projection pair (same-box A/B runs)
+QKV_ONE_LAUNCH = X.flag("qkv_one_launch", True)
 # the same for the prompt's K / V^T projections of a phase (one GEMM over [Wk; Wv] instead of a K GEMM + a V^T GEMM per stream)
-CTXKV_ONE_LAUNCH = os.environ.get("UR_CTXKV_ONE_LAUNCH", "1") != "0"
+CTXKV_ONE_LAUNCH = X.flag("ctxkv_one_launch", True)
 
 
 class _Packs:
@@ -74,17 +75,17 @@ class GroupedDualStreamStep:
         if precise_residual is None:
             precise_residual = os.environ.get("UR_PRECISE_RESIDUAL", "1") != "0"
         self.hilo = bool(precise_residual)
-        # row-local chain kernels at the 320-channel level (tchain.py); UR_TCHAIN=0: the unfused GEMM / LayerNorm launches
-        self.use_tchain = os.environ.get("UR_TCHAIN", "1") != "0"
+        # row-local chain kernels at the 320-channel level (tchain.py); UR_EXPERIMENT=no_tchain: the unfused GEMM / LayerNorm launches
+        self.use_tchain = X.flag("tchain", True)
         # Independent work on a second HIP stream (= a parallel branch of the captured graph): the 13 exchange GEMMs
         # (each only needs its own skip pair, which phase 1 produces early), the up phase's time / prompt projections
         # (inputs only) and every self-attention's V^T projection (beside its q|k projection).  These launches are
         # small (a few hundred workgroups, 15-25 us each); serialised behind the dependent chain they cost their full
-        # latency, on a sibling branch they fill the chip beside the chain's own launches.  UR_SIDE_STREAM=0: off.
+        # latency, on a sibling branch they fill the chip beside the chain's own launches.  Default: off.
         # MEASURED (r02, MI355X, cfg 3): 13.06 ms/step without, 13.53 ms with all three kinds of forks -- every
         # cross-stream edge of a hipGraph costs more in dependency signalling than the overlap returns -- so the default
-        # is OFF; UR_SIDE_STREAM=1 all forks, 2 only the off-critical-path ones (exchange + up-phase context), 3 only V^T.
-        self.side_level = int(os.environ.get("UR_SIDE_STREAM", "0"))
+        # is OFF; UR_EXPERIMENT=side_stream=1 all forks, 2 only the off-critical-path ones (exchange + up-phase context), 3 only V^T.
+        self.side_level = X.number("side_stream", 0)
         self.use_side = self.side_level != 0
         self._side = None
 
@@ -205,7 +206,7 @@ class GroupedDualStreamStep:
                 wqk = pk.get("a.wqk", as_, [p for a in as_ for p in (a.to_q.weight, a.to_k.weight)], dt,
                              lambda: _stk(torch.cat([pack_matrix(a.to_q.weight, dt), pack_matrix(a.to_k.weight, dt)], 0) for a in as_))
                 wv = pk.get("a.wv", as_, [a.to_v.weight for a in as_], dt, lambda: _stk(pack_matrix(a.to_v.weight, dt) for a in as_))
-                vt_first = os.environ.get("UR_VT_FIRST", "1") != "0"
+                vt_first = X.flag("vt_first", True)
                 ops.set_site("qk")
                 if not vt_first:
                     qk = ops.linear(xn, wqk, streams=S, out_scale=math.sqrt(cs))
@@ -542,8 +543,8 @@ class GroupedDualStreamStep:
         # phase 1 has produced that pair
         scale = float(conditioning_scale)
         up_skips, forks = [], []
-        late = []  # UR_EXCHANGE_EARLY=0: all exchange GEMMs after the mid block (round-1 order) instead of right behind
-        early = os.environ.get("UR_EXCHANGE_EARLY", "1") != "0"  # the kernel that produced their skip (input still in L2)
+        late = []  # UR_EXPERIMENT=no_exchange_early: all exchange GEMMs after the mid block (round-1 order) instead of right behind
+        early = X.flag("exchange_early", True)  # the kernel that produced their skip (input still in L2)
 
         def exchange_skip(t):
             if not early:
@@ -559,7 +560,7 @@ class GroupedDualStreamStep:
         # ---- up-phase context (time projections, prompt K / V^T of the up blocks): depends on the inputs only
         pair3 = [unet, dec] if run_decoder else [unet]
         S = len(pair3)
-        ctx3_early = os.environ.get("UR_CTX3_EARLY", "1") != "0"
+        ctx3_early = X.flag("ctx3_early", True)
         with self._fork(semb, ehs) as f3:
             ctx3 = self._ctx_of(pair3, [[n.up_blocks] for n in pair3], semb[B: B + S * B], ehs) if ctx3_early else None
 

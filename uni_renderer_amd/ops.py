@@ -12,6 +12,7 @@ from typing import Optional, Tuple
 
 import torch
 
+from . import _experiments as X
 from . import _lib
 from ._lib import AttnDesc, IGemmDesc, check
 
@@ -48,7 +49,7 @@ _TILES = {TILE_128x128: (128, 128, 1.0, 2), TILE_128x64: (128, 64, 0.85, 3), TIL
 TILE_PP_128x320, TILE_PP_128x320_S4, TILE_PP_256x128, TILE_PP_128x256, TILE_PP_256x256, TILE_PP_128x128, TILE_PP_256x320 = range(49, 56)
 TILE_WS320, TILE_WS320_W8 = 47, 48
 # which build ``conv3x3(ws=...)`` launches: 8 waves per workgroup (two instruction streams per SIMD) or 4 (one)
-WSCONV_TILE = TILE_WS320_W8 if os.environ.get("UR_WSCONV_WAVES", "8") == "8" else TILE_WS320
+WSCONV_TILE = TILE_WS320_W8 if X.number("wsconv_waves", 8) == 8 else TILE_WS320
 _PLANNER_TILES = (TILE_128x128, TILE_128x64, TILE_64x64)
 
 _zero_pages = {}
@@ -98,8 +99,8 @@ def _stream() -> int:
 
 
 # zero region the implicit-GEMM loaders read padding rows from: 1 MiB so that every (workgroup, wave) has its own line
-# (ur_igemm_desc.zero_page_bytes); UR_ZERO_PAGE_BYTES=4096 restores the single hot page (A/B)
-ZERO_PAGE_BYTES = int(os.environ.get("UR_ZERO_PAGE_BYTES", str(1 << 20)))
+# (ur_igemm_desc.zero_page_bytes); UR_EXPERIMENT=zero_page_bytes=4096 restores the single hot page (A/B)
+ZERO_PAGE_BYTES = X.number("zero_page_bytes", 1 << 20)
 
 
 def zero_page(device) -> torch.Tensor:
@@ -367,8 +368,8 @@ def linear(x, w, bias=None, *, x1=None, res=None, act=ACT_NONE, out_scale=1.0, r
     return out if vt is None else (out, vt)
 
 
-CONV_CBLOCK = int(os.environ.get("UR_CONV_CBLOCK", "320"))
-FOLD_SHORTCUT = os.environ.get("UR_FOLD_SHORTCUT", "1") != "0"  # resnet conv_shortcut as the 1x1 tail of conv2 (conv3x3 ``tail``)
+CONV_CBLOCK = X.number("conv_cblock", 320)
+FOLD_SHORTCUT = X.flag("fold_shortcut", True)  # resnet conv_shortcut as the 1x1 tail of conv2 (conv3x3 ``tail``)
 
 
 def conv_cblock(cin: int) -> int:
@@ -383,7 +384,7 @@ def conv_cblock(cin: int) -> int:
 # of prefetch with one wave per SIMD -- the same launches are ~10 % slower: 11.88 -> 12.20 ms per step with it on for
 # K >= 5000 (tools/experiments/r03_run13.sh, two alternating repetitions on one box).  ``conv3x3(..., ws=...)`` still takes it
 # explicitly (tests/test_wsconv_gpu.py).
-WSCONV = os.environ.get("UR_WSCONV", "0") != "0"
+WSCONV = X.flag("wsconv", False)
 WS_C = 320
 
 
@@ -425,7 +426,7 @@ def wsconv_ok(x, N, *, x1=None, stride=1, ups=False, pad=1, tail=None, streams=1
     return (Bt // streams * H * W + W + 2) * cmax * 2 < 2 ** 31
 
 
-WSCONV_MIN_K = int(os.environ.get("UR_WSCONV_MIN_K", "5000"))
+WSCONV_MIN_K = X.number("wsconv_min_k", 5000)
 
 
 def wsconv_prefer(x, N, K, **kw) -> bool:
@@ -520,8 +521,8 @@ def conv3x3(x, w, bias=None, *, x1=None, stride=1, ups=False, rowadd=None, res=N
 # green (tests/test_ops_gpu.py), but the step is 0.07 ms SLOWER with it (85.42 / 85.65 -> 85.01 / 84.92 steps/s alternating
 # on one box, profiles/r04_splitk_gn_ab.txt): one workgroup per (sample, group) reads its strip of the fp32 slabs in
 # 160-byte runs from 256 workgroups, where the plain reduce pass streams them fully coalesced from 4096 -- the slab traffic
-# (42 MB at the 16x16 level), not the launch, is what the second pass costs.  UR_SPLITK_GN=1 enables it.
-SPLITK_GN = os.environ.get("UR_SPLITK_GN", "0") != "0"
+# (42 MB at the 16x16 level), not the launch, is what the second pass costs.  UR_EXPERIMENT=splitk_gn enables it.
+SPLITK_GN = X.flag("splitk_gn", False)
 
 
 def splitk_gn_ok(rows: int, N: int, groups: int) -> bool:
@@ -551,16 +552,16 @@ def vt_proj(x, wv, streams=1, shared_x=False):
 # ---------------------------------------------------------------------------------------------
 # norms, attention, glue
 # ---------------------------------------------------------------------------------------------
-_GN_STAT_KB = int(os.environ.get("UR_GN_STAT_KB", "64"))
-_GN_APPLY_KB = int(os.environ.get("UR_GN_APPLY_KB", "20"))
-_GN_APPLY_MAX = int(os.environ.get("UR_GN_APPLY_MAX", "128"))
+_GN_STAT_KB = X.number("gn_stat_kb", 64)
+_GN_APPLY_KB = X.number("gn_apply_kb", 20)
+_GN_APPLY_MAX = X.number("gn_apply_max", 128)
 
 
 def _gn_chunks_bytes(B: int, rows: int, C: int, esize: int = 2):
     """Chunking by BYTES per workgroup (measured on MI355X with tools/bench_ops.py --what gn): a stats workgroup
     streams ~64 KB, an apply workgroup ~20 KB in + 20 KB out; never fewer than 2 rows per chunk, stats partials capped
-    at 32 per sample (every apply workgroup re-reduces them in its prologue).  UR_GN_STAT_KB / UR_GN_APPLY_KB /
-    UR_GN_APPLY_MAX override the three constants (in-situ A/B runs)."""
+    at 32 per sample (every apply workgroup re-reduces them in its prologue).  UR_EXPERIMENT entries gn_stat_kb / gn_apply_kb /
+    gn_apply_max override the three constants (in-situ A/B runs)."""
     sample_bytes = rows * C * esize
     nstat = max(1, min(sample_bytes // (_GN_STAT_KB << 10), rows // 2, 32))
     napply = max(1, min(sample_bytes // (_GN_APPLY_KB << 10), rows // 2, _GN_APPLY_MAX, max(1, 4096 // max(B, 1))))  # > 128: slower (gn_bench)
@@ -579,10 +580,10 @@ def resize_nearest(x, size):
 
 
 # maps of at most this many pixels per sample take the one-launch GroupNorm.  Round 4: with the groups of one sample placed on
-# ONE XCD (UR_GNF_XCD, csrc/norm.hip: neighbouring groups share cache lines) the one-launch kernel also wins at the 32x32
+# ONE XCD (csrc/norm.hip: neighbouring groups share cache lines) the one-launch kernel also wins at the 32x32
 # level (12-15 us against 14-16 for stats + apply; at 64x64 31 against 26: tools/gn_bench.py, profiles/r04_gnf_xcd_ab.txt);
 # in the step 256 -> 1024 rows is +0.45 % steps/s (tools/experiments/r04_run11.sh)
-GN_FUSED_MAX_ROWS = int(os.environ.get("UR_GN_FUSED_MAX_ROWS", "1024"))
+GN_FUSED_MAX_ROWS = X.number("gn_fused_max_rows", 1024)
 
 
 def groupnorm(x, gamma, beta, eps, *, x1=None, groups=32, silu=False, nstat=None, napply=None, streams=1, fused=None,

@@ -19,6 +19,7 @@ from typing import Dict, List, Optional, Sequence
 
 import torch
 
+from . import _experiments as X
 from . import autograd_ops as A
 from . import backward as B
 from . import ops
@@ -26,7 +27,7 @@ from .controlnet import CIN_PAD
 from .layers import BasicTransformerBlock, ResnetBlock2D
 
 
-BATCH_CASTS = os.environ.get("UR_BATCH_CASTS", "1") != "0"
+BATCH_CASTS = X.flag("batch_casts", True)
 _cast: Dict[int, torch.Tensor] = {}          # id(fp32 weight) -> its compute-dtype copy, valid inside one network forward
 _castable: Dict[int, tuple] = {}             # id(network) -> (network, its Linear / 1x1-conv weights)
 
