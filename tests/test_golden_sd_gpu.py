@@ -7,7 +7,7 @@ CPU forwards the same comparison costs live (tools/loop_parity.py).  The network
 Tolerances (north_star: <= 1e-3 rel-L2 in fp16): against the oracle holding the SAME fp16-rounded parameters ("fp16w")
 1e-3 on the single step; the fp32-parameter oracle ("fp32w") additionally contains the checkpoint's fp16 quantisation
 (the oracle alone moves 0.66e-3 / 0.78e-3 under it): 1.3e-3.  The 50-step loop feeds every step's error
-back through the scheduler; its bounds are the measured figures + margin, stated where asserted."""
+back through the scheduler; the same two bounds hold for its final latents (measured 0.50e-3 / 0.90e-3)."""
 import json
 import os
 
@@ -86,4 +86,5 @@ def test_cfg3_full_50_step_ddim_loop_at_batch_4_against_the_committed_golden(dev
     print(json.dumps(dict(cfg=3, loop="50 DDIM steps, batch 4, SD size, fp16", hoisted=hoist, final_latents_vs_fp16w=e16,
                           final_latents_vs_fp32w=e32, oracle_fp16w_vs_fp32w=base, latents_moved_by_the_loop=moved)))
     assert moved > 0.5  # the comparison is not dominated by the untouched initial noise
-    assert e16 < 1.5e-3 and e32 < 2e-3, (e16, e32)
+    # measured (round 5): 0.50e-3 / 0.90e-3 for both executors -- the loop as a whole meets north_star's 1e-3 against either oracle
+    assert e16 < 1e-3 and e32 < 1.3e-3, (e16, e32)
