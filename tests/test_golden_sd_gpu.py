@@ -37,7 +37,7 @@ def nets(dev, gold):
     from make_golden_sd import weights_probe
 
     oracle = O.build_triplet(O.SD15_CONFIG, seed=1234)
-    assert torch.equal(weights_probe(oracle), gold["weights_probe"]), "seeded weights differ from the golden's (RNG drift)"
+    assert torch.allclose(weights_probe(oracle), gold["weights_probe"], rtol=1e-10, atol=0), "seeded weights differ from the golden's (RNG drift)"  # float64 sums: the reduction order follows the thread count
     prod = build_product_from_oracle(*oracle, torch.float16, dev)
     del oracle
     return prod
