@@ -100,6 +100,15 @@ grouped launches of the deferred queue), `r04_wgrad_step_ab.txt` (graphed traini
 step and of the captured training step on the final tree), `r04_k32_ab.txt` (`tools/pp_ab.py --tiles 56..61`: the 32-deep-chunk
 tiles of `ur_igemm`, four workgroups per CU, against the table: slower on 39 of 40 problems; the tiles are not in the tree,
 `tools/experiments/r04_k32_tiles.patch`).
+Round-5 additions: `r05_hoist_shapes.json` / `r05_hoist_bench.json` / `r05_hoist_kernel_stats.csv` (`tools/hoist_bench.py`: prologue and
+per-step graph of the hoisted sampling loops, per-shape event tables, the step graph's kernels under `rocprofv3 --kernel-trace
+--stats`), `r05_hoist_ab.txt` (chain kernels on / off for the z = 1 launches; the cfg 2 shape), `r05_insitu_loop.txt`
+(`tools/tune_in_situ.py --loop inverse`: two in-situ tuning passes over the hoisted step), `r05_loop_bench.json` (50-step loops
+hoisted and with every network on every step), `r05_train_graph_rccl_w1_captured.json` / `..._serial.json`
+(`tools/train_bench.py --graph --force-collectives`: the bucketed training step on RCCL world size 1 with the collectives
+captured into the graph vs forward + backward graph | eager collectives | update graph, with per-phase times),
+`NOTEBOOK_r1_r4.md` (the measurement narratives of rounds 1-4, moved out of DESIGN.md verbatim).  The bench line of round 5
+carries `loop` and `config.parity_rel_l2`.
 Other summaries: `{tag}_parity_numbers.json` (every rel-L2 the `-m gpu` suite printed: the chain kernels, cfg 3 at batch 2 and 4
 and as a 5-step DDIM loop, cfg 5 vs the oracle, the 16384-token attention, UpRes, the module-surface and cfg-4 training steps
 incl. the inverse branch at SD size, the VAE, the RCCL world-size-1 collectives),
