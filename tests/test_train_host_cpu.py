@@ -36,3 +36,48 @@ def test_batched_casts_cover_linear_and_1x1_weights_and_fail_loudly_on_cpu():
     assert TS._cast == {}
     w = TS._wc(net.lin.weight, torch.bfloat16)             # outside a batched cast: the plain differentiable cast
     assert w.dtype == torch.bfloat16 and w.requires_grad
+
+
+def test_derived_weight_cache_never_serves_a_dead_buffer():
+    """the W^T / rotated-weight caches are keyed by raw address; an entry must die with the buffer it was derived
+    from (a later tensor at the same address with the same shape would otherwise pick up a stale transpose)."""
+    import gc
+
+    import torch
+
+    from uni_renderer_amd.backward import _DerivedWeights
+
+    cache = _DerivedWeights()
+    owner = torch.zeros(4, 4)
+    key = (owner.data_ptr(), (4, 4))
+    cache.put(key, owner, torch.ones(4, 4))
+    assert torch.equal(cache.lookup(key), torch.ones(4, 4))
+    del owner
+    gc.collect()
+    assert cache.lookup(key) is None and key not in cache  # the dead entry is a miss and is dropped
+    o2 = torch.zeros(2, 2)
+    cache.put((1, (2, 2)), o2, torch.ones(2, 2))
+    o3 = torch.zeros(3)
+    cache.put((2, (3,)), o3, torch.ones(3))
+    del o3
+    gc.collect()
+    cache.sweep()
+    assert list(cache) == [(1, (2, 2))]
+
+
+def test_norm_sums_defer_each_parameter_once_and_never_under_anomaly_detection():
+    """a norm layer (or tied gamma / beta) used twice before a flush must not hand out two uninitialised results
+    that autograd adds at once; anomaly detection inspects node outputs immediately."""
+    import torch
+
+    from uni_renderer_amd.backward import NormSums
+
+    ns = NormSums()
+    g1, g2 = torch.ones(8), torch.ones(8)
+    assert ns.fresh(g1) and ns.fresh(g2)
+    assert not ns.fresh(g1)  # the repeat takes the immediate path
+    ns.reset()
+    assert ns.fresh(g1)
+    ns.reset()
+    with torch.autograd.detect_anomaly(check_nan=False):
+        assert not ns.fresh(g1)

@@ -392,11 +392,12 @@ class PackConvWeights(Function):
             outs.append(out)
         # the dgrad form of every weight (taps rotated, channels transposed), 32 per launch (bw.weight_rot; dropped in the backward)
         ctx.rot_keys = []
+        bw.weight_rot.sweep()  # entries of a forward that was never backpropagated, whose packed weights are gone
         if bw.BATCH_WT:
             elig = [(o, g[2]) for o, g in zip(outs, ctx.geoms) if g[0] % 64 == 0 and g[2] % 8 == 0]
             for (o, _), r in zip(elig, bw.rot_weights_many(elig) if elig else []):
                 key = (o.data_ptr(), tuple(o.shape))
-                bw.weight_rot[key] = r
+                bw.weight_rot.put(key, o, r)  # valid while the packed weight `o` is alive
                 ctx.rot_keys.append(key)
         return tuple(outs)
 
@@ -459,13 +460,14 @@ class CastParams(Function):
         if outs and outs[0].is_cuda:
             flat = outs[0]._base if outs[0]._base is not None else outs[0]
             _deferred_w[flat.untyped_storage().data_ptr()] = weakref.ref(flat)
+            bw.weight_t.sweep()  # entries of a forward that was never backpropagated, whose cast buffer is gone
             if bw.BATCH_WT and bw.WGRAD:
                 # W^T for the dx GEMMs of the backward, 32 matrices per launch (bw.weight_t; dropped in the backward below)
                 w2 = [o.reshape(o.shape[0], -1) for o in outs if o.dim() >= 2]
                 w2 = [o for o in w2 if o.shape[0] % 8 == 0 and o.shape[1] % 8 == 0 and o.numel()]
                 for o, t in zip(w2, bw.transpose2d_many(w2) if w2 else []):
                     key = (o.data_ptr(), tuple(o.shape))
-                    bw.weight_t[key] = t
+                    bw.weight_t.put(key, flat, t)  # valid while the flat cast buffer is alive
                     ctx.wt_keys.append(key)
         return outs
 

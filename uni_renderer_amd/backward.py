@@ -78,7 +78,32 @@ TRANSPOSE_MAX = 32
 # (autograd_ops.CastParams) instead of one transpose launch per layer in the backward (426 launches, 3.1 ms per step):
 # (data_ptr, shape) of the compute-dtype weight -> its transpose.  UR_EXPERIMENT=no_batch_wt: every linear_backward transposes its own.
 BATCH_WT = X.flag("batch_wt", True)
-weight_t: dict = {}
+class _DerivedWeights(dict):
+    """(data_ptr, shape) of a compute-dtype weight -> a tensor derived from it (its transpose / its rotated form), valid only
+    while the buffer the weight lives in is alive: entries carry a weak reference to that buffer, a lookup whose buffer is gone
+    is a miss (a later tensor at the same address must not pick up a stale transpose -- ADVICE r4), and ``sweep`` drops the dead
+    entries (called when the next network's weights are cast, so a forward that is never backpropagated leaks at most until
+    the next differentiable forward)."""
+
+    def put(self, key, owner: torch.Tensor, value: torch.Tensor):
+        import weakref
+        self[key] = (weakref.ref(owner), value)
+
+    def lookup(self, key):
+        ent = dict.get(self, key)
+        if ent is None:
+            return None
+        if ent[0]() is None:
+            dict.pop(self, key, None)
+            return None
+        return ent[1]
+
+    def sweep(self):
+        for k in [k for k, (r, _) in self.items() if r() is None]:
+            dict.pop(self, k, None)
+
+
+weight_t = _DerivedWeights()
 
 
 def transpose2d_many(xs, colsum_of: Optional[int] = None, pad64=()):
@@ -368,7 +393,7 @@ class WgradQueue:
 
     def add(self, dy2: torch.Tensor, x2: torch.Tensor, w_key: int, need_bias: bool, conv: Optional[Tuple[int, int, int]] = None):
         """``conv`` = (Ho, Wo, stride) with x2 the NHWC input of a 3x3 conv (dw then in the packed layout), else x2 [P, K]."""
-        if w_key in self.seen:
+        if w_key in self.seen or torch.is_anomaly_enabled():  # anomaly detection reads every node's outputs at once
             self.flush()
             return None
         self.seen.add(w_key)
@@ -418,7 +443,20 @@ class NormSums:
     two launches per layer otherwise: ~310 per training step).  Only for parameters behind ``autograd_ops.ParamBarrier``."""
 
     def __init__(self):
-        self.items = []
+        self.items, self.seen = [], set()
+
+    def fresh(self, gamma: torch.Tensor) -> bool:
+        """May this layer's sums be deferred?  Not when the same affine parameters were already deferred since the last flush (a
+        norm layer used twice, tied gamma / beta: autograd would ADD the two uninitialised results the moment the second
+        arrives -- the repeat takes the immediate path instead), and not under anomaly detection (it inspects every node's
+        outputs, which are uninitialised until the flush)."""
+        if torch.is_anomaly_enabled():
+            return False
+        key = gamma.data_ptr()
+        if key in self.seen:
+            return False
+        self.seen.add(key)
+        return True
 
     def add(self, part: torch.Tensor, pair: bool) -> torch.Tensor:
         out = torch.empty(part.shape[1], dtype=torch.float32, device=part.device)
@@ -426,10 +464,10 @@ class NormSums:
         return out
 
     def reset(self):
-        self.items = []
+        self.items, self.seen = [], set()
 
     def flush(self):
-        items, self.items = self.items, []
+        items, self.items, self.seen = self.items, [], set()
         if not items:
             return
         lib = _lib.load()
@@ -508,7 +546,7 @@ def linear_backward(x: torch.Tensor, w: torch.Tensor, dy: torch.Tensor, need_bia
     K, N = x.shape[-1], w.shape[0]
     x2, dy2 = x.reshape(-1, K), dy.reshape(-1, N)
     if WGRAD and wgrad_ok(dy2, x2):
-        wt = weight_t.get((w.data_ptr(), tuple(w.shape)))
+        wt = weight_t.lookup((w.data_ptr(), tuple(w.shape)))
         dx = ops.linear(dy2, wt if wt is not None else transpose2d(w)).view(x.shape)   # [M, N] @ [K, N]^T
         later = wgrad_queue.add(dy2, x2, w.data_ptr(), need_bias) if (defer and WGRAD_DEFER) else None
         dw, db = later if later is not None else wgrad(dy2, x2, need_bias)
@@ -540,7 +578,7 @@ def _rot_weights(w_packed: torch.Tensor, cin: int) -> torch.Tensor:
     return out
 
 
-weight_rot: dict = {}  # (data_ptr, shape) of a packed conv weight -> its rotated / channel-transposed form (rot_weights_many)
+weight_rot = _DerivedWeights()  # (data_ptr, shape) of a packed conv weight -> its rotated / channel-transposed form (rot_weights_many)
 
 
 def rot_weights_many(ws) -> list:
@@ -603,7 +641,7 @@ def conv3x3_backward(x: torch.Tensor, w_packed: torch.Tensor, dy: torch.Tensor, 
     if need_dx:
         wpad = w_packed if Np == N else torch.cat([w_packed, w_packed.new_zeros(Np - N, w_packed.shape[1])], 0)
         src = dyp if stride == 1 else resample2x(dyp, 2)      # stride 2: zero insertion, then a stride-1 conv
-        rot = weight_rot.get((w_packed.data_ptr(), tuple(w_packed.shape))) if Np == N else None
+        rot = weight_rot.lookup((w_packed.data_ptr(), tuple(w_packed.shape))) if Np == N else None
         dx = ops.conv3x3(src, rot if rot is not None else _rot_weights(wpad, Cc))
         if dx.shape[1] != H or dx.shape[2] != W:
             raise RuntimeError("conv3x3_backward: odd input sizes are not supported with stride 2")
@@ -684,7 +722,7 @@ def groupnorm_backward(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, b
         check(lib.ur_groupnorm_backward_fused(x.data_ptr(), dy.data_ptr(), Cc, B, rows, groups, gamma.data_ptr(), beta.data_ptr(),
                                               float(eps), int(silu), chan_sum.data_ptr(), dx.data_ptr(), DT[x.dtype], s),
               "ur_groupnorm_backward_fused")
-        if defer and NORM_DEFER:
+        if defer and NORM_DEFER and norm_sums.fresh(gamma):
             sums = norm_sums.add(chan_sum.view(B, 2 * Cc), True).view(2, Cc)
             return dx, sums[1], sums[0]
         sums = torch.empty(2, Cc, dtype=torch.float32, device=x.device)
@@ -704,7 +742,7 @@ def groupnorm_backward(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, b
     check(lib.ur_groupnorm_backward(x.data_ptr(), dy.data_ptr(), Cc, B, rows, groups, nstat, part.data_ptr(),
                                     gamma.data_ptr(), beta.data_ptr(), float(eps), int(silu), nred, chan_part.data_ptr(),
                                     chan_sum.data_ptr(), nchunks, dx.data_ptr(), DT[x.dtype], s), "ur_groupnorm_backward")
-    if defer and NORM_DEFER:
+    if defer and NORM_DEFER and norm_sums.fresh(gamma):
         sums = norm_sums.add(chan_sum.view(B, 2 * Cc), True).view(2, Cc)
         return dx, sums[1], sums[0]
     sums = torch.empty(2, Cc, dtype=torch.float32, device=x.device)  # rows: sum dz (= dbeta), sum dz * xhat (= dgamma)
@@ -727,7 +765,7 @@ def layernorm_backward(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, e
     check(lib.ur_layernorm_backward_skip(x.data_ptr(), dy.data_ptr(), gamma.data_ptr(), float(eps), rows, Cc, rpw, dx.data_ptr(),
                                          part.data_ptr(), skip.data_ptr() if skip is not None else None, DT[x.dtype], _stream()),
           "ur_layernorm_backward_skip")
-    if defer and NORM_DEFER:
+    if defer and NORM_DEFER and norm_sums.fresh(gamma):
         sums = norm_sums.add(part.view(waves, 2 * Cc), False).view(2, Cc)
         return dx, sums[0], sums[1]
     sums = colsum(part.view(waves, 2 * Cc)).view(2, Cc)
