@@ -540,7 +540,9 @@ def main():
                 _, stable, _ = measure_roofline(runner._run, by_shape=True)
                 with open(args.shape_table, "w") as f:
                     json.dump(stable, f)
-        if world == 1 and not args.no_loop and not args.eager:
+        profiled = (any(k.startswith(("ROCPROF", "ROCPROFILER", "ROCP_")) for k in os.environ)
+                    or "rocprofiler" in os.environ.get("LD_PRELOAD", ""))  # a counter pass over 400 more graph replays takes minutes
+        if world == 1 and not args.no_loop and not args.eager and not profiled:
             out["loop"] = sampling_loops(models, args.batch, args.latent, dev, dtype)
         if want_cpu:
             check = None

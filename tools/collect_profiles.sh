@@ -4,19 +4,20 @@
 TAG=${1:-r01}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
-mkdir -p $OUT
+RAW=/tmp/ur_raw_$TAG   # raw traces / counter dumps are tens of MB: never under gpurun_out/ (64 MiB copy-back limit)
+mkdir -p $OUT $RAW
 cd $R
-python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
+timeout 600 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-loop --no-live-traffic --shape-table $OUT/per_shape_eager_events.json > /dev/null 2>&1
 export TMPDIR=/tmp
-(cd /tmp && cd $R && rocprofv3 --kernel-trace --stats -d $OUT/stats -o $TAG --output-format csv -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-loop --no-live-traffic > $OUT/bench_under_rocprofv3.json 2> $OUT/rocprof_stats.err)
-(cd $R && rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o p --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-loop --no-live-traffic > /dev/null 2>&1)
-(cd $R && rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o p --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-loop --no-live-traffic > /dev/null 2>&1)
-(cd $R && rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES --kernel-trace -d $OUT/pmc_mfma -o p --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-loop --no-live-traffic > /dev/null 2>&1)
-python tools/pmc_traffic.py $(find $OUT/pmc_fetch -name "*counter_collection.csv" | head -1) $(find $OUT/pmc_write -name "*counter_collection.csv" | head -1) $OUT/pmc_traffic.json > $OUT/pmc_traffic.log 2>&1
+(cd $R && timeout 420 rocprofv3 --kernel-trace --stats -d $RAW/stats -o $TAG --output-format csv -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-loop --no-live-traffic > $OUT/bench_under_rocprofv3.json 2> $OUT/rocprof_stats.err)
+(cd $R && timeout 420 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $RAW/pmc_fetch -o p --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-loop --no-live-traffic > /dev/null 2>&1)
+(cd $R && timeout 420 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $RAW/pmc_write -o p --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-loop --no-live-traffic > /dev/null 2>&1)
+(cd $R && timeout 420 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES --kernel-trace -d $RAW/pmc_mfma -o p --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-loop --no-live-traffic > /dev/null 2>&1)
+python tools/pmc_traffic.py $(find $RAW/pmc_fetch -name "*counter_collection.csv" | head -1) $(find $RAW/pmc_write -name "*counter_collection.csv" | head -1) $OUT/pmc_traffic.json > $OUT/pmc_traffic.log 2>&1
 python - <<PY
 import csv, collections, glob, json
-f = glob.glob("$OUT/pmc_mfma/**/*counter_collection.csv", recursive=True)[0]
+f = glob.glob("$RAW/pmc_mfma/**/*counter_collection.csv", recursive=True)[0]
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
 for r in csv.DictReader(open(f)):
     k = r["Kernel_Name"]
@@ -31,10 +32,10 @@ for k, v in agg.items():
 json.dump(out, open("$OUT/pmc_mfma_util.json", "w"), indent=1, sort_keys=True)
 for k, v in sorted(out.items(), key=lambda kv: -kv[1]["mfma_util"])[:12]: print(round(v["mfma_util"], 3), v["launches"], k[:90])
 PY
-bash $R/tools/pmc_l2_step.sh > $OUT/pmc_l2_step.log 2>&1; cp $R/gpurun_out/pmc_l2_step.json $OUT/pmc_l2_step.json
+timeout 420 bash $R/tools/pmc_l2_step.sh > $OUT/pmc_l2_step.log 2>&1; cp $R/gpurun_out/pmc_l2_step.json $OUT/pmc_l2_step.json
 cd $R
 # keep only the summaries (the raw kernel traces / counter dumps are tens of MB)
-cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
-rm -rf $OUT/stats $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_mfma
+cp $(find $RAW/stats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
+rm -rf $RAW
 ls -la $OUT
 tail -2 $OUT/bench_default.json | cut -c1-400

@@ -3,12 +3,12 @@
 # split-K launches of a symbol filed separately (tools/pmc_traffic.py rules).  Output: gpurun_out/pmc_l2_step.json
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-(cd $R && rocprofv3 --pmc TCC_HIT TCC_MISS TCC_REQ --kernel-trace -d $R/gpurun_out/pmc_l2s -o p --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-live-traffic > /dev/null 2>&1)
+(cd $R && rocprofv3 --pmc TCC_HIT TCC_MISS TCC_REQ --kernel-trace -d /tmp/ur_pmc_l2s -o p --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-loop --no-live-traffic > /dev/null 2>&1)
 cd $R && python - <<'PY'
 import glob, json, sys
 sys.path.insert(0, "tools")
 import pmc_traffic as P
-f = glob.glob("gpurun_out/pmc_l2s/**/*counter_collection.csv", recursive=True)[0]
+f = glob.glob("/tmp/ur_pmc_l2s/**/*counter_collection.csv", recursive=True)[0]
 hit, miss, req = (P.per_class(f, c) for c in ("TCC_HIT", "TCC_MISS", "TCC_REQ"))
 out = {}
 for k in sorted(hit):
@@ -20,4 +20,4 @@ json.dump(out, open("gpurun_out/pmc_l2_step.json", "w"), indent=1, sort_keys=Tru
 for k, v in sorted(out.items(), key=lambda kv: -kv[1]["miss_bytes_128B"])[:14]:
     print(f"{k:36s} n={v['launches']:4d} hit {v['hit_rate']:.3f} miss {v['miss_bytes_128B'] / 1e6:7.1f} MB/launch req {v['tcc_req'] * 128 / 1e6:8.1f} MB")
 PY
-rm -rf $R/gpurun_out/pmc_l2s
+rm -rf /tmp/ur_pmc_l2s
