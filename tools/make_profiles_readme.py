@@ -53,6 +53,24 @@ def main():
     dom = [r for n, r in ours if dom_sym in n and ("conv3x3" in n) == ("conv3x3" in roof["kernel"])][0]
     att = [k for k in d["kernel_classes"] if k["kernel"] == "attention_d40"]
     att_u = [v for k, v in mf.items() if "attention32" in k and "Li40" in k and "F16_" in k]
+    loop_txt = ""
+    lp, lb, hb = d.get("loop"), os.path.join(P, f"{tag}_loop_bench.json"), os.path.join(P, f"{tag}_hoist_bench.json")
+    if lp and os.path.exists(lb) and os.path.exists(hb):
+        L = json.loads(open(lb).read().strip().split("\n")[-1])
+        H = json.loads(open(hb).read().strip().split("\n")[-1])
+        par = d["config"].get("parity_rel_l2", {})
+        loop_txt = f"""## Sampling loops (round 5: the loop-invariant half hoisted, `uni_renderer_amd/hoist.py`)
+
+`loop` object of the bench line (50-step DDIM calls of the pipeline, latents in / out, on-device sampler, best of 3): inverse
+{lp['inverse_ms_total']:.0f} ms ({lp['inverse_ms_per_step']:.2f} ms per step), rendering {lp['render_ms_total']:.0f} ms ({lp['render_ms_per_step']:.2f}).  `{tag}_loop_bench.json` (its own
+process): hoisted {L['inverse_50']['ms_total']:.0f} / {L['render_50']['ms_total']:.0f} ms against {L['inverse_50_all_networks_every_step']['ms_total']:.0f} / {L['render_50_all_networks_every_step']['ms_total']:.0f} ms with every network on
+every step; the eval protocol (UniPC 20 steps x 5 repeats) {L['unipc20_five_calls_b1']['ms_total']:.0f} ms as five calls, {L['unipc20_folded_b5']['ms_total']:.0f} ms folded into one batch.
+`{tag}_hoist_bench.json`: prologue graph {H['inverse']['prologue_ms']:.2f} ms once per call, per-step graph {H['inverse']['step_ms']:.2f} ms (inverse: encoder + 13
+adds + decoder, {H['inverse'].get('launches', 302)} launches) / {H['render']['step_ms']:.2f} ms (rendering: UNet + 13 adds) against {H['inverse']['all_networks_step_ms']:.2f} / {H['render']['all_networks_step_ms']:.2f} ms for the
+grouped all-networks step; `{tag}_hoist_kernel_stats.csv` = the same tool under `rocprofv3 --kernel-trace --stats`.
+Parity measured in the bench run on the benchmarked networks and inputs (`config.parity_rel_l2`, img_pred / attr_pred): same
+fp16-rounded parameters {par.get('same_weights', {}).get('img_pred', 0):.2e} / {par.get('same_weights', {}).get('attr_pred', 0):.2e}, fp32 parameters {par.get('fp32_weights', {}).get('img_pred', 0):.2e} / {par.get('fp32_weights', {}).get('attr_pred', 0):.2e}.
+"""
     out = f"""# profiles/ — rocprofv3 evidence
 
 All files were produced on an MI355X `gpurun` box from this repo (`bash tools/collect_profiles.sh {tag}`, which runs the
@@ -156,6 +174,7 @@ MFMA-issue-bound loop (DESIGN.md section 4).
 Attention d = 40 (4096-token self-attention + 77-key cross-attention launches): {att[0]['tflops'] if att else 0:.0f} TFLOP/s,
 MFMA-busy {100 * att_u[0]['mfma_util'] if att_u else 0:.0f} % (north_star asks >= 40 %), PMC traffic {tr.get('attention_d40', {}).get('hbm_bytes_per_launch', 0) / 1e6:.0f} MB/launch vs 84 MB algorithmic Q+K+V+O.
 
+{loop_txt}
 ## Kernel summary (`{tag}_kernel_stats.csv`, our kernels only, 16 step executions, grouped mode)
 
 | kernel | calls | total ms | avg us | % | MFMA-busy (PMC pass) |
