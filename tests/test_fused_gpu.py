@@ -84,3 +84,39 @@ def test_odd_and_non_square_latents(dev, hw):
         assert out["img_pred"].shape == (2, 4, H, W) and out["attr_pred"].shape == (2, 28, H, W)
         for k in ("img_pred", "attr_pred"):
             assert rel_l2(out[k], ref[k]) < 3e-3, (hw, k, rel_l2(out[k], ref[k]))
+
+
+@pytest.mark.parametrize("hw", [(16, 16), (12, 20), (9, 14)])
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 3e-3), (torch.bfloat16, 2.5e-2)])
+def test_hoisted_steps_match_the_oracle_step(dev, hw, dtype, tol):
+    """hoist.HoistedSamplingStep op-level (no sampler around it): prologue on the fixed inputs + one step on the evolving ones
+    must be the oracle's enc -> unet -> dec step -- inverse direction (UNet down + mid and the decoder's exchange products from
+    the prologue, UNet up never run) and rendering direction (encoder from the prologue, conditioning scale 0.5) -- also on
+    latent sides that are not multiples of 8 / non-square maps, with per-sample timesteps, fp16 and bf16; a second step with
+    OTHER evolving inputs reuses the prologue."""
+    from uni_renderer_amd.hoist import HoistedSamplingStep
+
+    oracle = O.build_triplet(O.TINY_CONFIG, seed=71)
+    unet_o, enc_o, dec_o = oracle
+    unet, enc, dec = build_product_from_oracle(*oracle, dtype, dev)
+    g = torch.Generator().manual_seed(72)
+    H, W = hw
+    x, c = torch.randn(2, 4, H, W, generator=g), torch.randn(2, 28, H, W, generator=g)
+    c2, x2 = torch.randn(2, 28, H, W, generator=g), torch.randn(2, 4, H, W, generator=g)
+    ehs = torch.randn(2, 77, 64, generator=g) * 0.5
+    ti, ta, tb = torch.tensor([0, 0]), torch.tensor([999, 340]), torch.tensor([120, 7])
+    d = lambda t: t.to(dev)
+    inv = HoistedSamplingStep(unet, enc, dec, "inverse")
+    inv.prologue(d(x), d(ehs), d(ti))
+    for cond, t in ((c, ta), (c2, tb)):
+        out = inv.step(d(cond), d(t))["attr_pred"]
+        ref = O.dual_stream_step(*oracle, x, cond, ehs, ti, t)["attr_pred"]
+        assert out.shape == (2, 28, H, W) and rel_l2(out, ref) < tol, (hw, rel_l2(out, ref))
+    ren = HoistedSamplingStep(unet, enc, dec, "render", conditioning_scale=0.5)
+    ren.prologue(d(c), d(ehs), d(ti))  # clean attributes, t_attr = 0
+    for xt, t in ((x, ta), (x2, tb)):
+        out = ren.step(d(xt), d(t))["img_pred"]
+        with torch.no_grad():
+            res, mid, _, _ = enc_o(xt, ti, ehs, controlnet_cond=c, conditioning_scale=0.5)
+            ref = unet_o(xt, t, ehs, res, mid)[0]
+        assert out.shape == (2, 4, H, W) and rel_l2(out, ref) < tol, (hw, rel_l2(out, ref))
