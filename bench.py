@@ -543,7 +543,10 @@ def main():
         profiled = (any(k.startswith(("ROCPROF", "ROCPROFILER", "ROCP_")) for k in os.environ)
                     or "rocprofiler" in os.environ.get("LD_PRELOAD", ""))  # a counter pass over 400 more graph replays takes minutes
         if world == 1 and not args.no_loop and not args.eager and not profiled:
-            out["loop"] = sampling_loops(models, args.batch, args.latent, dev, dtype)
+            try:
+                out["loop"] = sampling_loops(models, args.batch, args.latent, dev, dtype)
+            except Exception as e:  # the headline line must not depend on this leg
+                out["loop"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         if want_cpu:
             check = None
             if not args.eager and args.direction == "inverse":
