@@ -38,7 +38,7 @@ import torch
 
 from . import ops
 from .controlnet import CIN_PAD, _compute_dtype
-from .fused import GroupedDualStreamStep, _stk
+from .fused import GroupedDualStreamStep
 from .layers import f32, pack_matrix
 
 

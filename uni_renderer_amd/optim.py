@@ -15,7 +15,7 @@ scalar): the whole training step still captures into one HIP graph.
 from __future__ import annotations
 
 import ctypes as C
-from typing import Iterable, Optional, Tuple
+from typing import Iterable, Tuple
 
 import torch
 

@@ -13,7 +13,6 @@ loss and gradients against the CPU restatement of the reference under autograd i
 """
 from __future__ import annotations
 
-import os
 
 from typing import Dict, List, Optional, Sequence
 
