@@ -403,6 +403,25 @@ def sampling_loops(models, B, L, dev, dtype, steps=50):
             ts.append(time.perf_counter() - t0)
         res[name + "_ms_total"] = round(min(ts) * 1e3, 2)
         res[name + "_ms_per_step"] = round(min(ts) * 1e3 / steps, 3)
+    # the reference's live eval protocol (eval/test_real.py:485-492, 547-564): UniPC, 20 steps, guidance 0, the same image five
+    # times (compute_times) -- folded into ONE batch of 5 (num_images_per_prompt = 5)
+    from uni_renderer_amd.pipeline import SCHEDULER_NAMES
+    from uni_renderer_amd.schedulers import UniPCMultistepScheduler
+
+    for n in SCHEDULER_NAMES:
+        setattr(pipe, f"scheduler_{n}", UniPCMultistepScheduler())
+    fn = lambda: pipe.real_image2mask_3mod_albedo(prompt_embeds=ehs[:1], image_latents=img[:1], mask_latents=msk[:1],
+                                                  num_inference_steps=20, guidance_scale=0.0, num_images_per_prompt=5,
+                                                  output_type="latent")
+    fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    res["eval_protocol_unipc20_x5_folded_ms_total"] = round(min(ts) * 1e3, 2)
     return res
 
 
