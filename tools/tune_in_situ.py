@@ -27,7 +27,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--top", type=int, default=40)
     ap.add_argument("--cands", type=int, default=5)
-    ap.add_argument("--skip", type=int, default=0, help="--train: leave out the heaviest N problems (a previous pass visited them)")
+    ap.add_argument("--skip", type=int, default=0, help="leave out the heaviest N problems (a previous pass visited them)")
     ap.add_argument("--replays", type=int, default=100)
     ap.add_argument("--eps", type=float, default=0.008)
     ap.add_argument("--batch", type=int, default=4)
@@ -96,8 +96,11 @@ def main():
     finally:
         ops.igemm = orig
     rep = {(r["M"], r["N"], r["K"], r["taps"], r["z"]): r for r in json.load(open(args.report))}
-    share = sorted(((rep[k[:5]]["best_us"] * n, k) for k, n in calls.items() if k[:5] in rep and (k[5] or not args.sites) and k[0] >= args.min_rows),
-                   reverse=True)[: args.top]
+    def est_us(k):  # isolated best time if the report has the problem, else a flop / launch-latency estimate (--broad only)
+        return rep[k[:5]]["best_us"] if k[:5] in rep else max(2.0 * k[0] * k[1] * k[2] * k[4] / 5e14, 10e-6) * 1e6
+
+    share = sorted(((est_us(k) * n, k) for k, n in calls.items()
+                    if (k[:5] in rep or args.broad) and (k[5] or not args.sites) and k[0] >= args.min_rows), reverse=True)[args.skip: args.top]
     base = measure()
     base2 = measure()
     print(f"[in-situ] baseline {base:.4f} / {base2:.4f} ms per step; {len(share)} problems to visit", flush=True)
@@ -108,7 +111,7 @@ def main():
         bkey = "%d,%d,%d,%d,%d" % key
         skey = bkey + (f"@{site}" if site else "")
         cur = tuple(ops._tune_table.get(skey) or ops._tune_table.get(bkey) or ops.plan_igemm(*key))
-        allc = sorted(rep[key]["all"].items(), key=lambda kv: kv[1])
+        allc = sorted(rep[key]["all"].items(), key=lambda kv: kv[1]) if key in rep else []
         cands = []
         if args.broad:
             sks = [cur[1]] + ([cur[1] * 2] if key[2] // 64 >= 8 * cur[1] and key[4] <= 4 else []) + ([cur[1] // 2] if cur[1] > 1 else [])
