@@ -151,8 +151,9 @@ rocprofv3 --kernel-trace --stats -d <out> -o {tag} --output-format csv -- python
 ## Headline (un-profiled, `{tag}_bench_default.json`)
 
 {d['value']:.2f} denoise-steps/s = {d['ms_per_step']:.2f} ms per dual-stream step (enc + unet + dec, SD-1.x size, B=4, 512x512, fp16,
-default (hi, lo) residual stream) on one MI355X (boxes of the pool differ by +-4 %: 11.7 .. 12.2 ms were seen for this
-build, 12.1 .. 12.9 ms for round 2's; same-box A/B of the chain kernels `UR_TCHAIN=0/1`: 12.16 -> 11.75 ms); CPU oracle on the same
+default (hi, lo) residual stream) on one MI355X (boxes of the pool differ by +-2 %: round 5's tree measured 11.44 .. 11.88 ms over
+the day's boxes -- 87.0 / 86.4 / 85.0 / 84.2 steps/s in four bench runs, the tuner's baselines 11.44 and 11.79 ms; only same-box
+A/Bs compare code); CPU oracle on the same
 host ({cpu['cores']}-core cgroup quota) {cpu['value']:.4f} steps/s (median of 3 timed steps).  6.49 TFLOP/step => {6.49 / d['ms_per_step']:.3f} PFLOP/s
 algorithmic = {100 * 6.49 / d['ms_per_step'] / 2.5:.0f} % of the dense fp16 MFMA roofline for the whole step (round 1 ended at 12.3 .. 13.1 ms, round 2 at 12.0 .. 12.9 ms;
 DESIGN.md section 4, "Round 3").
