@@ -494,7 +494,11 @@ extern "C" int ur_prefetch(const void* ptr, int64_t bytes, int wgs, void* stream
 }
 
 extern "C" int ur_abi_version(void) { return UR_ABI_VERSION; }
-extern "C" const char* ur_build_info(void) { return "liburhip gfx950 (hipcc, MFMA 16x16x32 + 32x32x16, LDS-DMA) abi 9"; }
+#define UR_STR2(x) #x
+#define UR_STR(x) UR_STR2(x)
+extern "C" const char* ur_build_info(void) {
+    return "liburhip gfx950 (hipcc, MFMA 16x16x32 + 32x32x16, LDS-DMA) abi " UR_STR(UR_ABI_VERSION);
+}
 extern "C" int ur_sizeof_igemm_desc(void) { return (int)sizeof(ur_igemm_desc); }
 extern "C" int ur_sizeof_attn_desc(void) { return (int)sizeof(ur_attn_desc); }
 extern "C" int ur_sizeof_attn_bwd_desc(void) { return (int)sizeof(ur_attn_bwd_desc); }
