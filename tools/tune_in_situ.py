@@ -300,7 +300,8 @@ def main_train(args):
     for _, key in est:
         skey = "%d,%d,%d,%d,%d" % key
         cur = tuple(ops._tune_table.get(skey, ops.plan_igemm(*key)))
-        cands = [(t, cur[1]) for t in (9, 10, 1, 5, 7, 2, 3, 11) if t != cur[0]][: args.cands]
+        tlist = [int(v) for v in args.tiles.split(",")] if args.broad else [9, 10, 1, 5, 7, 2, 3, 11]  # --broad --tiles: another family
+        cands = [(t, cur[1]) for t in tlist if t != cur[0]][: args.cands]
         if cur[1] > 1:
             cands.append((cur[0], cur[1] // 2))
             if cur[1] * 2 <= 16 and key[2] // 64 >= 8 * cur[1] and key[4] <= 4:
