@@ -390,3 +390,32 @@ def test_pmc_traffic_reduction_rule(tmp_path):
     assert agg["igemm_128x320s2_conv3x3"] == [210.0, 2]          # dispatches 1 and 5: plain launches
     assert agg["igemm_128x320s2_conv3x3_splitk"] == [300.0, 1]   # dispatch 2: followed by the reduce kernel
     assert agg["igemm_splitk_reduce"] == [7.0, 1] and agg["attention_d40"] == [50.0, 1]
+
+
+def test_hoisted_loop_executor_has_no_cpu_fallback_and_experiments_switch_is_strict(monkeypatch):
+    """Round 5: the hoisted sampling-loop step (hoist.py) is HIP-only like every other executor -- CPU tensors raise instead
+    of silently computing elsewhere; and ``UR_EXPERIMENT`` rejects unknown entries (a typo must not run the default)."""
+    import importlib
+
+    from util_models import O, build_product_from_oracle
+
+    from uni_renderer_amd.hoist import HoistedSamplingStep
+
+    nets = build_product_from_oracle(*O.build_triplet(O.TINY_CONFIG, seed=3), torch.float16)
+    x, c, ehs, ti, ta = O.make_inputs(1, 16, 64, seed=4)
+    for direction, fixed in (("inverse", x), ("render", c)):
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            HoistedSamplingStep(*nets, direction).prologue(fixed.half(), ehs.half(), ti)
+    with pytest.raises(ValueError):
+        HoistedSamplingStep(*nets, "sideways")
+    from uni_renderer_amd import _experiments as X
+
+    monkeypatch.setenv("UR_EXPERIMENT", "no_tchain,side_stream=2")
+    X = importlib.reload(X)
+    assert X.flag("tchain", True) is False and X.number("side_stream", 0) == 2 and X.flag("splitk_gn", False) is False
+    monkeypatch.setenv("UR_EXPERIMENT", "no_tchian")
+    X = importlib.reload(X)
+    with pytest.raises(ValueError, match="unknown entry"):
+        X.flag("tchain", True)
+    monkeypatch.delenv("UR_EXPERIMENT")
+    importlib.reload(X)
