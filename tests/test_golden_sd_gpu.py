@@ -80,6 +80,8 @@ def test_cfg3_full_50_step_ddim_loop_at_batch_4_against_the_committed_golden(dev
     sched.set_timesteps(50)
     fin = pipe._fused_loop(x.half(), c, ehs.half(), sched.timesteps, sched, run_decoder=True, lat_dtype=torch.float32)
     assert fin.shape == (4, 24, 64, 64) and bool(torch.isfinite(fin).all())
+    again = pipe._fused_loop(x.half(), c, ehs.half(), sched.timesteps, sched, run_decoder=True, lat_dtype=torch.float32)
+    assert torch.equal(fin, again), "the 50-step loop is not bitwise reproducible"  # 50 x ~300 launches, no run-dependent order
     e16, e32 = rel_l2(fin, gold["loop.final_latents.fp16w"]), rel_l2(fin, gold["loop.final_latents.fp32w"])
     base = rel_l2(gold["loop.final_latents.fp16w"], gold["loop.final_latents.fp32w"])
     moved = rel_l2(gold["loop.final_latents.fp32w"], c[:, 4:].cpu())  # how far the 50 steps take the latents from the initial noise
