@@ -419,3 +419,40 @@ def test_hoisted_loop_executor_has_no_cpu_fallback_and_experiments_switch_is_str
         X.flag("tchain", True)
     monkeypatch.delenv("UR_EXPERIMENT")
     importlib.reload(X)
+
+
+def test_round5_advice_host_fixes(monkeypatch):
+    """ADVICE r5, the host-only parts: (a) retired UR_* variables are an error, not silently ignored; (b) an early flush of the
+    deferred weight-gradient queue keeps the norm-sum `seen` set; (c) the hoisted inverse step names the missing output."""
+    import importlib
+
+    from uni_renderer_amd import _experiments as X
+
+    monkeypatch.setenv("UR_WGRAD", "0")
+    X = importlib.reload(X)
+    with pytest.raises(ValueError, match="retired environment variable.*UR_WGRAD"):
+        X.flag("wgrad", True)
+    monkeypatch.delenv("UR_WGRAD")
+    X = importlib.reload(X)
+    assert X.flag("wgrad", True) is True
+
+    from uni_renderer_amd import backward as B
+
+    ns = B.norm_sums
+    ns.reset()
+    gamma = torch.zeros(4)
+    assert ns.fresh(gamma) is True and ns.fresh(gamma) is False
+    ns.flush(keep_seen=True)            # the early (memory-cap) flush of WgradQueue
+    assert ns.fresh(gamma) is False     # a tied gamma is still recognised: never deferred twice before its barrier
+    ns.flush()                          # the real barrier flush
+    assert ns.fresh(gamma) is True
+    ns.reset()
+    src = open(os.path.join(ROOT, "uni_renderer_amd", "backward.py")).read()
+    assert "norm_sums.flush(keep_seen=keep_seen)" in src
+
+    from uni_renderer_amd.hoist import _HoistedInverseOut
+
+    out = _HoistedInverseOut(attr_pred=torch.zeros(1))
+    assert "attr_pred" in out and "img_pred" not in out
+    with pytest.raises(KeyError, match="does not run the UNet's up path"):
+        out["img_pred"]

@@ -119,3 +119,29 @@ def test_load_state_dict_keeps_the_addresses_a_captured_update_holds():
     assert fresh.generation == g0 + 1 and float(fresh.state[fresh.param_groups[0]["params"][0]]["step"]) == 3.0
     fresh.add_param_group({"params": [torch.zeros(2, requires_grad=True)]})
     assert fresh.generation == g0 + 2
+
+
+def test_load_state_dict_without_entries_for_live_state_forces_a_recapture():
+    """a parameter with LIVE state loading a dict that has no (or a partial) entry for it -- a checkpoint written
+    before the first step -- loses its moments inside torch's load_state_dict; the cached descriptor arrays and a captured
+    ur_adamw_multi would keep the addresses of freed tensors.  The launch cache must go and ``generation`` must move."""
+    ps = _params()
+    ours = FusedAdamW(ps, lr=1e-3)
+    for p in ps:
+        ours._init_state(p)
+    ours.param_groups[0]["_ur_launches"] = object()  # stands for the ctypes descriptor arrays of the last step
+    empty = FusedAdamW([p.detach().clone().requires_grad_() for p in ps], lr=1e-3).state_dict()  # no state yet
+    assert empty["state"] == {}
+    gen = ours.generation
+    ours.load_state_dict(empty)
+    assert ours.generation == gen + 1 and "_ur_launches" not in ours.param_groups[0]
+    # partial: only the first parameter has state in the loaded dict
+    ours2 = FusedAdamW(ps, lr=1e-3)
+    for p in ps:
+        ours2._init_state(p)
+    ours2.param_groups[0]["_ur_launches"] = object()
+    sd = ours2.state_dict()
+    sd = {"state": {0: sd["state"][0]}, "param_groups": sd["param_groups"]}
+    gen = ours2.generation
+    ours2.load_state_dict(sd)
+    assert ours2.generation == gen + 1 and "_ur_launches" not in ours2.param_groups[0]

@@ -1,7 +1,9 @@
 """ONE switch for everything that is not the product path.
 
 The product has six environment variables (README.md): ``UR_LIB_PATH``, ``UR_IGEMM_TUNING``, ``UR_PRECISE_RESIDUAL``,
-``UR_HOIST``, ``UR_WGRAD_PENDING_MB`` and the smoke test's ``UR_SMOKE_CONFIG``.  Every other toggle -- the A/B off-switches
+``UR_HOIST``, ``UR_WGRAD_PENDING_MB`` and the smoke test's ``UR_SMOKE_CONFIG``; two more are read by opt-in EXPERIMENT BUILDS of
+the native library only (``UR_DXS=1`` with ``make DXS=1``, csrc/igemm.hip; ``UR_WGRAD_ABLATE`` with ``make WGRAD_ABL=1``,
+csrc/wgrad.hip) and do nothing in the product build.  Every other toggle -- the A/B off-switches
 of accepted optimisations and the on-switches of paths that were built, measured slower and left in for the record
 ("tried and rejected") -- is an entry of
 
@@ -45,12 +47,29 @@ KNOWN = {
     "flash_direct_min_d": "",
 }
 
+# Environment variables of rounds 1-4 that UR_EXPERIMENT replaced.  They are NOT read any more; a script that still sets one
+# would silently measure the default path, so their presence is an error.  UR_NORM_XCD / UR_FLASH_M32 / UR_NO_*
+# style C++ toggles were hardwired in the same prune.
+RETIRED = {
+    "UR_ATTN_BWD_TRN", "UR_BATCH_CASTS", "UR_BATCH_WT", "UR_COLSUM_ONE_LAUNCH", "UR_CONV_CBLOCK", "UR_CTX3_EARLY",
+    "UR_CTXKV_ONE_LAUNCH", "UR_EXCHANGE_EARLY", "UR_FLASH_BACKWARD", "UR_FLASH_DIRECT_MIN_D", "UR_FLASH_M32", "UR_FOLD_SHORTCUT",
+    "UR_FORWARD_LSE", "UR_FUSED_COLSUM", "UR_FUSED_GRADNORM", "UR_GNF_XCD", "UR_GN_APPLY_KB", "UR_GN_APPLY_MAX",
+    "UR_GN_BWD_FUSED_MAX_ROWS", "UR_GN_FUSED_MAX_ROWS", "UR_GN_STAT_KB", "UR_HEADS_MULTI", "UR_MULTI_TRANSPOSE", "UR_NORM_DEFER",
+    "UR_NORM_XCD", "UR_QKV_ONE_LAUNCH", "UR_SIDE_STREAM", "UR_SPLITK_GN", "UR_TCHAIN", "UR_TCHAIN_FF", "UR_TCHAIN_PRE",
+    "UR_TCHAIN_Q", "UR_TRANSPOSE_MAX", "UR_VT_FIRST", "UR_WGRAD", "UR_WGRAD_DEFER", "UR_WGRAD_SPLITS", "UR_WGRAD_TABLE",
+    "UR_WGRAD_TILE", "UR_WSCONV", "UR_WSCONV_MIN_K", "UR_WSCONV_WAVES", "UR_ZERO_PAGE_BYTES",
+}
+
 _parsed = None
 
 
 def _load():
     global _parsed
     if _parsed is None:
+        stale = sorted(k for k in os.environ if k in RETIRED)
+        if stale:
+            raise ValueError(f"retired environment variable(s) {', '.join(stale)}: no longer read -- use UR_EXPERIMENT=... "
+                             f"(uni_renderer_amd/_experiments.py lists the entries)")
         d = {}
         for item in os.environ.get("UR_EXPERIMENT", "").replace(";", ",").split(","):
             item = item.strip()

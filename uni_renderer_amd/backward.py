@@ -414,7 +414,9 @@ class WgradQueue:
         norm_sums.reset()
 
     def flush(self, keep_seen: bool = False):
-        norm_sums.flush()  # the deferred gamma / beta gradients ride on the same barriers
+        # the deferred gamma / beta gradients ride on the same barriers; an EARLY flush (memory cap) must keep their `seen` set
+        # too, or a tied / re-used gamma would be deferred a second time before its ParamBarrier
+        norm_sums.flush(keep_seen=keep_seen)
         items, self.items, self.pending = self.items, [], 0
         if not keep_seen:
             self.seen = set()
@@ -466,8 +468,10 @@ class NormSums:
     def reset(self):
         self.items, self.seen = [], set()
 
-    def flush(self):
-        items, self.items, self.seen = self.items, [], set()
+    def flush(self, keep_seen: bool = False):
+        items, self.items = self.items, []
+        if not keep_seen:
+            self.seen = set()
         if not items:
             return
         lib = _lib.load()

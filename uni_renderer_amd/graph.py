@@ -184,6 +184,7 @@ class GraphedHoistedStep:
         self.pro: Optional[torch.cuda.CUDAGraph] = None
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.out: Optional[Dict[str, torch.Tensor]] = None
+        self._fixed_sig = None
 
     load_inputs = GraphedDualStreamStep.load_inputs
 
@@ -245,14 +246,34 @@ class GraphedHoistedStep:
         evolving latent and its timestep."""
         if self.graph is None:
             self.capture()
+        fixed = (x_t, ehs, t_img) if self.run_decoder else (cond, ehs, t_attr)
+        if not first and self.hoist and self._fixed_sig is not None and any(f is not None for f in fixed) \
+                and self._sig(fixed) != self._fixed_sig:
+            # a caller (e.g. a callback_on_step_end) handed over DIFFERENT fixed inputs in mid-loop: the prologue's results
+            # are stale -- run it again instead of silently ignoring the change (ADVICE r5).  The check is by object
+            # (storage address, version counter, shape), no device synchronisation.
+            first = True
         if first or not self.hoist:
             if x_t is not None:
                 self.load_inputs(x_t, cond, ehs, t_img, t_attr)
+            self._fixed_sig = self._sig(fixed)
             self.pro.replay()
-        elif x_t is not None:
+        elif x_t is not None or cond is not None:
             self.load_evolving(x_t, cond, t_img, t_attr)
         self.graph.replay()
         return self.out
+
+    @staticmethod
+    def _sig(tensors):
+        """Identity of the caller's fixed inputs without touching the device: (address, version, shape) per tensor; Python
+        numbers by value."""
+        sig = []
+        for t in tensors:
+            if isinstance(t, torch.Tensor):
+                sig.append((t.data_ptr(), t._version, tuple(t.shape)))
+            else:
+                sig.append(t)
+        return tuple(sig)
 
     def replay(self):
         if not self.hoist:

@@ -42,6 +42,18 @@ from .fused import GroupedDualStreamStep
 from .layers import f32, pack_matrix
 
 
+class _HoistedInverseOut(dict):
+    """The hoisted inverse step's outputs.  ``img_pred`` is NOT among them -- the reference's inverse loops drop the UNet's
+    prediction (``_, raw, raw_mid, _ =``, models/pipeline.py:2670) and the hoisted executor never computes it; asking for it says
+    so instead of a bare KeyError."""
+
+    def __missing__(self, key):
+        if key == "img_pred":
+            raise KeyError("img_pred: the hoisted inverse-rendering step does not run the UNet's up path (its prediction is dropped "
+                           "by the reference's loop, models/pipeline.py:2670); use GraphedDualStreamStep / hoist=None for it")
+        raise KeyError(key)
+
+
 class HoistedSamplingStep:
     """direction = "inverse": prologue(x_t = image latent, t_img) / step(cond28, t_attr) -> {"attr_pred"};
     direction = "render":  prologue(cond28, t_attr)            / step(x_t, t_img)      -> {"img_pred"}."""
@@ -131,5 +143,5 @@ class HoistedSamplingStep:
         x = summed.pop()
         y = g._head([last], g._up([last], x, summed, (temb3, tsl3) + inv["kv3"]))
         if self.direction == "inverse":
-            return {"attr_pred": ops.as_nchw_view(y)}
+            return _HoistedInverseOut(attr_pred=ops.as_nchw_view(y))
         return {"img_pred": ops.as_nchw_view(y[:, :, :, : self.unet.conv_out.weight.shape[0]])}

@@ -198,9 +198,14 @@ class FusedAdamW(torch.optim.Optimizer):
             step_t = None
             for p in group["params"]:
                 st = self.state.get(p)
+                prev = old_state.get(p)
+                if prev is not None and not (st and all(k in st for k in ("exp_avg", "exp_avg_sq", "step"))):
+                    # live state that the loaded dict lacks (a checkpoint from before the first step, a partial state):
+                    # torch dropped the old moments, so the cached descriptor arrays / a captured ur_adamw_multi would
+                    # keep the addresses of freed tensors -- rebuild them
+                    replaced = True
                 if not st:
                     continue
-                prev = old_state.get(p)
                 for k in ("exp_avg", "exp_avg_sq"):
                     if k in st and prev is not None and k in prev and prev[k].shape == st[k].shape and prev[k].dtype == torch.float32:
                         prev[k].copy_(st[k])

@@ -158,8 +158,9 @@ class GradientBuckets:
       * Transport: ``comm_dtype`` (e.g. bf16: 3.5 GB instead of 7 GB per step) and ``algorithm``: "all_reduce", or
         "rs_ag" = reduce-scatter + all-gather of the flat bucket, the form that uses all seven xGMI links of a GPU at
         once (~11 ms vs ~80 ms for a ring over 6.98 GB of fp32).
-    The collectives are issued from Python hooks during ``backward()``; they are not part of a captured HIP graph (the
-    single-GPU graphed step of tools/train_bench.py stays a separate path).
+    The collectives are issued from Python hooks during ``backward()``.  Eagerly that is DDP's overlap; inside
+    ``train_step.GraphedTrainStep(capture_collectives=True)`` (RCCL) the same hooks fire during the capture and every
+    collective becomes a parallel branch of the ONE step graph.
     """
 
     def __init__(self, modules: Iterable[torch.nn.Module], bucket_mb: float = 256.0, comm_dtype=None,

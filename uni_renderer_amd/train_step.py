@@ -631,6 +631,7 @@ class GraphedTrainStep:
                 self.collectives_from_hooks = buckets.launched_from_hooks - before  # forked before finish() had to
                 buckets.finish()  # launches what the hooks could not, then joins RCCL's stream (work.wait = stream wait)
                 _clip_and_update(nets, optimizer, buckets, max_grad_norm, self.stats)
+            self._validate_captured_collectives()
             return
         with torch.cuda.graph(self.g_fb):
             self.stats["loss"] = _forward_backward(nets, self.batch, optimizer if buckets is None else None, buckets, **kw)
@@ -641,6 +642,37 @@ class GraphedTrainStep:
             self.g_up = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g_up):
                 _clip_and_update(nets, optimizer, buckets, max_grad_norm, self.stats)
+
+    def _validate_captured_collectives(self):
+        """The split "forked by a hook during the backward" / "launched by finish()" is baked into the graph at capture time.
+        Buckets always launch in index order (GradientBuckets._launch), so the SEQUENCE of collectives is the same on every
+        rank by construction; what could differ is where they sit in each rank's graph -- harmless for correctness (RCCL
+        matches them by order on its own stream), but a rank whose buckets all fell to finish() serialises every other rank's
+        overlap behind its backward.  Cross-check the count once per capture and refuse a mixed capture: a
+        parameter that got no gradient on one rank during the capture step would otherwise go unnoticed for the whole run."""
+        import torch.distributed as dist
+        b = self.buckets
+        if not dist.is_initialized() or dist.get_world_size(b.group) < 2:
+            return
+        n = float(self.collectives_from_hooks)
+        t = torch.tensor([n, -n], dtype=torch.float32, device=b.flat[0].device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=b.group)
+        hi, lo = float(t[0]), -float(t[1])
+        if hi != lo:
+            raise RuntimeError(f"captured bucket collectives differ across ranks: between {int(lo)} and {int(hi)} of {len(b.buckets)} "
+                               "buckets were launched from the backward's hooks (a parameter without a gradient on some rank "
+                               "during the capture step?); capture with a batch that reaches every parameter on every rank")
+
+    def _ensure_current(self):
+        """Refresh the device (lr, weight_decay) pair and capture again if a hyper-parameter held by value, or an address the
+        captured update points at, changed since the capture."""
+        if hasattr(self.optimizer, "sync_hyper"):
+            self.optimizer.sync_hyper()  # lr / weight_decay of an lr_scheduler step -> the device pair the kernel reads
+        if self._hyper() != self._captured_hyper:
+            # betas / eps changed (resume_from_checkpoint with other settings), or an optimizer that holds lr by value:
+            # the captured update has the old values as kernel arguments.  Capture again (tens of ms, once per change)
+            torch.cuda.synchronize()
+            self._capture()
 
     def _eager(self, kw, max_grad_norm):
         st = {"loss": _forward_backward(self.nets, self.batch, self.optimizer, self.buckets, **kw)}
@@ -654,13 +686,7 @@ class GraphedTrainStep:
         if batch is not None:
             for k, v in batch.items():
                 self.batch[k].copy_(v)
-        if hasattr(self.optimizer, "sync_hyper"):
-            self.optimizer.sync_hyper()  # lr / weight_decay of an lr_scheduler step -> the device pair the kernel reads
-        if self._hyper() != self._captured_hyper:
-            # betas / eps changed (resume_from_checkpoint with other settings), or an optimizer that holds lr by value:
-            # the captured update has the old values as kernel arguments.  Capture again (tens of ms, once per change)
-            torch.cuda.synchronize()
-            self._capture()
+        self._ensure_current()
         self.g_fb.replay()
         if self.buckets is not None and not self.capture_collectives:
             if self._host_sync_before_collectives:
@@ -674,8 +700,7 @@ class GraphedTrainStep:
         bucket collectives (launch to completion, as the compute stream sees them) and of clipping + update.  With captured
         collectives the step is one graph and only its total is observable from outside (``overlapped_total``)."""
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-        if hasattr(self.optimizer, "sync_hyper"):
-            self.optimizer.sync_hyper()
+        self._ensure_current()  # the same staleness check as step(): never replay an update holding freed addresses
         ev[0].record()
         self.g_fb.replay()
         ev[1].record()
