@@ -119,7 +119,16 @@ extern "C" {
 #define UR_TILE_PP_256x256 53     /* 4 x 2 waves of 64 x 128, 4 slots (128 KB) */
 #define UR_TILE_PP_128x128 54     /* 4 x 2 waves of 32 x 64, 5 slots (80 KB) */
 #define UR_TILE_PP_256x320 55     /* 4 x 2 waves of 64 x 160, 4 slots (144 KB) */
-#define UR_TILE_COUNT 56
+/* round 6: FEW waves with BIG per-wave tiles on the lock-step loop (one wave per SIMD): a 64 x 160 wave tile reads 0.044 B of LDS
+ * fragments per MAC against 0.0625 for the 64 x 64 wave tile of UR_TILE_128x320 -- the conv loop's LDS port (DMA writes +
+ * fragment reads: ~1700 of ~1300 MFMA cycles per chunk) is what these go after */
+#define UR_TILE_256x160_W4_M32 56 /* 4 waves (4 x 1, 64 x 160 each), 2-deep, 104 KB */
+#define UR_TILE_256x320_W8_M32 57 /* 8 waves (4 x 2, 64 x 160 each), 2-deep, 144 KB */
+#define UR_TILE_128x320_W4_M32 58 /* 4 waves (2 x 2, 64 x 160 each), 2-deep, 112 KB */
+#define UR_TILE_256x128_W4_M32 59 /* 4 waves (4 x 1, 64 x 128 each), 2-deep, 96 KB */
+#define UR_TILE_256x256_W8_M32 60 /* 8 waves (4 x 2, 64 x 128 each), 2-deep, 128 KB */
+#define UR_TILE_256x320_W10 61    /* 10 waves (2 x 5, 128 x 64 each) on the 16x16x32 MFMA, 2-deep, 144 KB */
+#define UR_TILE_COUNT 62
 
 /*
  * Implicit GEMM:  out[m][n] = epilogue( sum_k X[m][k] * W[n][k] )

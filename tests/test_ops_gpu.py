@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 TOL = {torch.float16: 2e-3, torch.bfloat16: 1.2e-2}
 DTYPES = [torch.float16, torch.bfloat16]
 PP_TILES = list(range(49, 56))  # 8-wave ping-pong builds (csrc/igemm_pp.hip)
-ALL_TILES = [t for t in range(1, 47) if t != 39] + PP_TILES
+ALL_TILES = [t for t in range(1, 47) if t != 39] + PP_TILES + list(range(56, 62))  # 56-61: round-6 big-wave-tile builds
 
 
 def _need(tile):

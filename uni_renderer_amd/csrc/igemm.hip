@@ -627,7 +627,9 @@ static const TileCfg kTiles[UR_TILE_COUNT] = {{0, 0, 0},      {128, 128, 2}, {12
                                               {128, 320, 2}, {128, 320, 2},
                                               // 8-wave ping-pong builds (igemm_pp.hip)
                                               {128, 320, 5}, {128, 320, 4}, {256, 128, 5}, {128, 256, 5}, {256, 256, 4},
-                                              {128, 128, 5}, {256, 320, 4}};
+                                              {128, 128, 5}, {256, 320, 4},
+                                              // round 6: few waves, big per-wave tiles (UR_TILE_*_W4_M32 / _W8_M32)
+                                              {256, 160, 2}, {256, 320, 2}, {128, 320, 2}, {256, 128, 2}, {256, 256, 2}, {256, 320, 2}};
 
 static int pick_tile(const ur_igemm_desc& d) {
     // Cost model: the busiest CU runs ceil(workgroups / 256) tiles; bigger tiles have a better
@@ -802,6 +804,12 @@ static int launch_dtype(ur_igemm_desc& d, hipStream_t s, bool reduce) {
         case UR_TILE_128x160_M32: return launch_cfg<T, 128, 160, 4, 1, 2, 32>(d, s, reduce);
         case UR_TILE_128x160_S3_M32: return launch_cfg<T, 128, 160, 4, 1, 3, 32>(d, s, reduce);
         case UR_TILE_64x320_M32: return launch_cfg<T, 64, 320, 2, 2, 2, 32>(d, s, reduce);
+        case UR_TILE_256x160_W4_M32: return launch_cfg<T, 256, 160, 4, 1, 2, 32>(d, s, reduce);
+        case UR_TILE_256x320_W8_M32: return launch_cfg<T, 256, 320, 4, 2, 2, 32>(d, s, reduce);
+        case UR_TILE_128x320_W4_M32: return launch_cfg<T, 128, 320, 2, 2, 2, 32>(d, s, reduce);
+        case UR_TILE_256x128_W4_M32: return launch_cfg<T, 256, 128, 4, 1, 2, 32>(d, s, reduce);
+        case UR_TILE_256x256_W8_M32: return launch_cfg<T, 256, 256, 4, 2, 2, 32>(d, s, reduce);
+        case UR_TILE_256x320_W10: return launch_cfg<T, 256, 320, 2, 5, 2>(d, s, reduce);
         case UR_TILE_WS320: return launch_ws<T>(d, s, reduce);
         case UR_TILE_WS320_W8: return launch_ws<T>(d, s, reduce);
         case UR_TILE_PP_128x320: case UR_TILE_PP_128x320_S4: case UR_TILE_PP_256x128: case UR_TILE_PP_128x256:

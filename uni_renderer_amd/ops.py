@@ -45,7 +45,10 @@ _TILES = {TILE_128x128: (128, 128, 1.0, 2), TILE_128x64: (128, 64, 0.85, 3), TIL
           47: (128, 320, 1.4, "ws"), 48: (128, 320, 1.4, "ws8"),
           # 8-wave ping-pong builds (csrc/igemm_pp.hip): "pp<ring slots>"
           49: (128, 320, 1.5, "pp5"), 50: (128, 320, 1.5, "pp4"), 51: (256, 128, 1.4, "pp5"), 52: (128, 256, 1.4, "pp5"),
-          53: (256, 256, 1.5, "pp4"), 54: (128, 128, 1.2, "pp5"), 55: (256, 320, 1.5, "pp4")}
+          53: (256, 256, 1.5, "pp4"), 54: (128, 128, 1.2, "pp5"), 55: (256, 320, 1.5, "pp4"),
+          # round 6: few waves with big per-wave tiles (64 x 160 / 64 x 128 per wave, one or two waves per SIMD)
+          56: (256, 160, 1.3, "2w4m32"), 57: (256, 320, 1.4, "2w8m32"), 58: (128, 320, 1.3, "2w4m32"), 59: (256, 128, 1.2, "2w4m32"),
+          60: (256, 256, 1.4, "2w8m32"), 61: (256, 320, 1.4, "2w10")}
 TILE_PP_128x320, TILE_PP_128x320_S4, TILE_PP_256x128, TILE_PP_128x256, TILE_PP_256x256, TILE_PP_128x128, TILE_PP_256x320 = range(49, 56)
 TILE_WS320, TILE_WS320_W8 = 47, 48
 # which build ``conv3x3(ws=...)`` launches: 8 waves per workgroup (two instruction streams per SIMD) or 4 (one)
