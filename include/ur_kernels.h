@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define UR_ABI_VERSION 10
+#define UR_ABI_VERSION 11
 
 #define UR_E_BADARG (-1001)   /* inconsistent descriptor (shape / alignment / null pointer)   */
 #define UR_E_UNSUPPORTED (-1002) /* shape outside what the kernels are instantiated for       */
@@ -365,6 +365,15 @@ int ur_ddim_update(const void* pred, int pred_ld, int pred_c0, void* lat, int64_
                    const float* coef, const int* step, int nsteps, float* master, int round_master, int cfg,
                    float guidance, int cfg_channels, int dtype, void* stream);
 int ur_sampler_advance(int* step, const float* tsteps, int nsteps, float* t_out, int B, void* stream);
+/*
+ * ur_select_step_rows (round 6): dst[k][0 .. bytes[k]) = src[k] + clamp(*step, 0, nsteps-1) * bytes[k] for ntab <= 4 tables, one
+ * launch.  The sampling loops (models/pipeline.py:2629-2730, 1587-1653) evaluate the time embedding and every resnet's
+ * `time_emb_proj(SiLU(emb))` (unet_2d_blocks.py:1100-1111) on every step although they depend on the timestep only: the
+ * hoisted loops compute them for ALL steps once per call and each step only picks its rows with the device-side step
+ * counter.  Pointers and byte counts 16-byte aligned.
+ */
+int ur_select_step_rows(const void* const* src, void* const* dst, const int64_t* bytes, int ntab, const int* step, int nsteps,
+                        void* stream);
 
 /*
  * ur_unipc_update: the UniPCMultistepScheduler.step() calls of the live sampling loops (eval/test_real.py:485-492

@@ -429,6 +429,43 @@ def test_hoisted_loops_equal_unhoisted_loops_bitwise(dev, sched, guidance, fused
 
 
 @pytest.mark.parametrize("sched", ["ddim", "unipc"])
+@pytest.mark.parametrize("guidance", [0.0, 2.0])
+def test_time_tables_of_a_loop_equal_per_step_time_embeddings_bitwise(dev, sched, guidance):
+    """Round 6: the on-device hoisted loops compute the time embedding and every resnet's time projection for ALL steps once
+    per call (hoist.time_tables, planned with the per-step launches' tiles) and each step picks its rows with the device-side
+    step counter (ur_select_step_rows).  Same bits as recomputing them on every step (controlnet.py:909-916 is a function of
+    the timestep only), also for the folded batch of the eval protocol and with the prologue re-run before every step."""
+    pipe, _, img, mask, ehs, _ = _setup(dev, seed=31)
+    for nipp, im, mk in ((1, img, mask), (5, img[:1], mask[:1])):
+        pipe.precompute_time_tables = True
+        a = _run_loops(pipe, dev, im, mk, ehs, sched, guidance, True, nipp)
+        a2 = _run_loops(pipe, dev, im, mk, ehs, sched, guidance, True, nipp)
+        pipe.rerun_invariants = True
+        a3 = _run_loops(pipe, dev, im, mk, ehs, sched, guidance, True, nipp)
+        pipe.rerun_invariants = False
+        pipe.precompute_time_tables = False
+        b = _run_loops(pipe, dev, im, mk, ehs, sched, guidance, True, nipp)
+        for x, x2, x3, y in zip(a, a2, a3, b):
+            assert torch.isfinite(x).all()
+            assert torch.equal(x, x2) and torch.equal(x, x3) and torch.equal(x, y)
+    assert any(st.get("tgraph") is not None for st in pipe._sample_graphs.values())
+
+
+def test_select_step_rows(dev):
+    from uni_renderer_amd import ops
+
+    g = torch.Generator().manual_seed(5)
+    t1 = torch.randn(7, 4, 40, generator=g).half().to(dev)
+    t2 = torch.randn(7, 3, 8, generator=g).to(dev)
+    o1, o2 = torch.empty_like(t1[0]), torch.empty_like(t2[0])
+    for st in (0, 3, 6, 9):  # 9: clamped to the last step
+        ops.select_step_rows([t1, t2], [o1, o2], torch.tensor([st], dtype=torch.int32, device=dev), 7)
+        assert torch.equal(o1, t1[min(st, 6)]) and torch.equal(o2, t2[min(st, 6)])
+    with pytest.raises(ValueError):
+        ops.select_step_rows([t1], [o2], torch.zeros(1, dtype=torch.int32, device=dev), 7)
+
+
+@pytest.mark.parametrize("sched", ["ddim", "unipc"])
 def test_hoisted_loops_match_every_network_every_step(dev, sched):
     """The hoisted executor against the executor that runs all three networks on every step (the grouped enc || unet,
     unet || dec launches of fused.py): same arithmetic, different launch shapes (z = 1 vs z = 2 tiles, the exchange as

@@ -46,6 +46,26 @@ def main():
                 ts.append(time.perf_counter() - t0)
             res[name + sfx] = dict(ms_total=round(min(ts) * 1e3, 2), ms_per_step=round(min(ts) * 1e3 / steps, 3))
     pipe.hoist_invariants = True
+    # round 6: the same hoisted loops WITHOUT the per-call time-projection tables (every step recomputes its time embedding)
+    pipe.precompute_time_tables = False
+    for name, fn in (
+        ("inverse_50_no_time_tables", lambda: pipe.real_image2mask_3mod_albedo(prompt_embeds=ehs, image_latents=img, mask_latents=msk,
+                                                                              num_inference_steps=steps, guidance_scale=0.0,
+                                                                              output_type="latent")),
+        ("render_50_no_time_tables", lambda: pipe.mask2image_3mod_albedo(prompt_embeds=ehs, attr_latents=attr,
+                                                                         num_inference_steps=steps, guidance_scale=0.0,
+                                                                         output_type="latent")),
+    ):
+        fn()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        res[name] = dict(ms_total=round(min(ts) * 1e3, 2), ms_per_step=round(min(ts) * 1e3 / steps, 3))
+    pipe.precompute_time_tables = True
     # the reference's live eval protocol (eval/test_real.py:485-492, 547-564): UniPC, 20 steps, guidance 0, the same image
     # 5 times (compute_times) -- as five calls at batch 1 and folded into ONE batch of 5 (num_images_per_prompt=5)
     from uni_renderer_amd.pipeline import SCHEDULER_NAMES

@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must be imported first, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("UR_LIB_PATH", os.path.join(_HERE, "liburhip.so"))  # override = kernel experiments only
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
@@ -107,6 +107,7 @@ SYMBOLS = {
     "ur_ddim_update": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int64, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp,
                                  C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, vp]),
     "ur_sampler_advance": (C.c_int, [vp, vp, C.c_int, vp, C.c_int, vp]),
+    "ur_select_step_rows": (C.c_int, [vp, vp, vp, C.c_int, vp, C.c_int, vp]),
     "ur_prefetch": (C.c_int, [vp, C.c_int64, C.c_int, vp]),
     "ur_pack_conv_weight": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "ur_unpack_conv_weight_grad": (C.c_int, [vp, C.c_int64, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),

@@ -475,6 +475,39 @@ extern "C" int ur_sampler_advance(int* step, const float* tsteps, int nsteps, fl
     return e == hipSuccess ? 0 : -(int)e;
 }
 
+// dst[k][0..bytes_k) = src[k][*step][0..bytes_k) for up to 4 tables: the rows of the CURRENT step of per-step tables a sampling
+// loop's prologue computed for all its steps (the time projections of every resnet: a function of the timestep only).
+struct StepRows { const char* src[4]; char* dst[4]; int64_t bytes[4]; };
+__global__ void __launch_bounds__(256) select_step_rows_kernel(StepRows a, int ntab, const int* __restrict__ step, int nsteps) {
+    const int k = blockIdx.y;
+    if (k >= ntab) return;
+    const int st = min(max(*step, 0), nsteps - 1);
+    const uint4* s = reinterpret_cast<const uint4*>(a.src[k] + (int64_t)st * a.bytes[k]);
+    uint4* d = reinterpret_cast<uint4*>(a.dst[k]);
+    const int64_t n = a.bytes[k] >> 4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) d[i] = s[i];
+}
+
+extern "C" int ur_select_step_rows(const void* const* src, void* const* dst, const int64_t* bytes, int ntab, const int* step,
+                                   int nsteps, void* stream) {
+    if (!src || !dst || !bytes || !step || ntab <= 0 || ntab > 4 || nsteps <= 0) return UR_E_BADARG;
+    StepRows a{};
+    int64_t most = 0;
+    for (int k = 0; k < ntab; ++k) {
+        if (!src[k] || !dst[k] || bytes[k] <= 0 || (bytes[k] & 15) || ((uintptr_t)src[k] & 15) || ((uintptr_t)dst[k] & 15)) return UR_E_BADARG;
+        a.src[k] = reinterpret_cast<const char*>(src[k]);
+        a.dst[k] = reinterpret_cast<char*>(dst[k]);
+        a.bytes[k] = bytes[k];
+        most = bytes[k] > most ? bytes[k] : most;
+    }
+    int blocks = (int)((most / 16 + 255) / 256);
+    blocks = blocks < 1 ? 1 : (blocks > 64 ? 64 : blocks);
+    hipLaunchKernelGGL(select_step_rows_kernel, dim3(blocks, ntab), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a, ntab, step,
+                       nsteps);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : -(int)e;
+}
+
 // One 4-byte load per 128-byte line, grid-strided; the value is consumed by an empty asm so the load is not dropped.
 __global__ void __launch_bounds__(256) prefetch_kernel(const char* __restrict__ p, int64_t lines) {
     unsigned acc = 0;

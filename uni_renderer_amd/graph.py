@@ -194,8 +194,28 @@ class GraphedHoistedStep:
         else:
             self.h.prologue(self.cond, self.ehs, self.t_attr)
 
-    def _run(self):
-        return self.h.step(self.cond, self.t_attr) if self.run_decoder else self.h.step(self.x_t, self.t_img)
+    def _run(self, tables=None):
+        if self.run_decoder:
+            return self.h.step(self.cond, self.t_attr, tables=tables)
+        return self.h.step(self.x_t, self.t_img, tables=tables)
+
+    @torch.no_grad()
+    def capture_time_tables(self, tvals: torch.Tensor):
+        """A graph that fills the loop's per-step time-projection tables from the device vector ``tvals`` [n] (the loop's
+        timesteps): ``(graph, (temb1_all, temb3_all))``.  Replay it once per sampling call after writing ``tvals``."""
+        if self.graph is None:
+            self.capture()
+        warm = torch.cuda.Stream()
+        warm.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(warm):
+            self.h.time_tables(tvals)  # tile lookups, allocator
+        torch.cuda.current_stream().wait_stream(warm)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            tabs = self.h.time_tables(tvals)
+        torch.cuda.synchronize()
+        return g, tabs
 
     def load_evolving(self, x_t, cond, t_img, t_attr):
         """Only what changes between two steps of a loop: the evolving latent and its timestep."""
@@ -223,13 +243,15 @@ class GraphedHoistedStep:
         return self
 
     @torch.no_grad()
-    def capture_with(self, post_fn):
-        """The per-step graph followed by ``post_fn(out)`` (the on-device sampler update): ``(graph, out)``."""
+    def capture_with(self, post_fn, tables=None):
+        """The per-step graph followed by ``post_fn(out)`` (the on-device sampler update): ``(graph, out)``.  ``tables`` =
+        (temb1_all, temb3_all, step counter): the step reads its time projections from per-call tables
+        (``capture_time_tables``) at the row of the device-side step counter ``post_fn`` advances."""
         if self.graph is None:
             self.capture()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            out = self._run()
+            out = self._run(tables)
             post_fn(out)
         torch.cuda.synchronize()
         return g, out

@@ -120,21 +120,54 @@ class HoistedSamplingStep:
             inv["kv3"] = self._kv_only(unet, [unet.up_blocks], ehs)
         return self
 
-    # ------------------------------------------------------------------ once per step
-    @torch.no_grad()
-    def step(self, x_var, t_var) -> Dict[str, torch.Tensor]:
+    # ------------------------------------------------------------------ once per sampling call, for ALL its steps
+    def _time_projections(self, tv, rows):
+        """(temb1, tsl1, temb3, tsl3): every resnet's ``time_emb_proj(SiLU(time_embedding(t)))`` of the per-step networks for
+        the ``rows`` timesteps ``tv`` (controlnet.py:909-916; unet_2d_blocks.py:1100-1111)."""
         g, inv = self.g, self.inv
-        ehs, B, dt = inv["ehs"], inv["B"], inv["dt"]
-        tv = g._tvec(t_var, B, x_var.device)
+        ehs, dt = inv["ehs"], inv["dt"]
         if self.direction == "inverse":
             first, last = self.enc, self.dec
-            semb = g._time_embed([first, last], [tv, tv], B, dt)
-            s1, s3 = semb[:B], semb[B:]
+            semb = g._time_embed([first, last], [tv, tv], rows, dt)
+            s1, s3 = semb[:rows], semb[rows:]
         else:
             first = last = self.unet
-            s1 = s3 = g._time_embed([first], [tv], B, dt)
+            s1 = s3 = g._time_embed([first], [tv], rows, dt)
         temb3, tsl3, _, _, _ = g._ctx_of([last], [[last.up_blocks]], s3, ehs, kv=False)
         temb1, tsl1, _, _, _ = g._ctx_of([first], [[first.down_blocks, first.mid_block]], s1, ehs, kv=False)
+        return temb1, tsl1, temb3, tsl3
+
+    @torch.no_grad()
+    def time_tables(self, tvals: torch.Tensor):
+        """The time projections of EVERY step of a loop whose timesteps are ``tvals`` [n] (all samples of a step share the
+        timestep): two ``[n, B, sum Cout]`` tables.  They depend on nothing but the timestep, so a sampling call computes them
+        once (7 launches over n * B rows) instead of n times; ``step(tables=...)`` picks its rows."""
+        B = self.inv["B"]
+        n = tvals.numel()
+        tv = tvals.to(torch.float32).reshape(n, 1).expand(n, B).reshape(-1).contiguous()
+        with ops.plan_rows_as(B):  # the (tile, split-K) of the per-step launches: the tables are then bit-identical to them
+            temb1, _, temb3, _ = self._time_projections(tv, n * B)
+        return temb1.view(n, B, -1), temb3.view(n, B, -1)
+
+    # ------------------------------------------------------------------ once per step
+    @torch.no_grad()
+    def step(self, x_var, t_var, tables=None) -> Dict[str, torch.Tensor]:
+        """``tables`` = (temb1_all, temb3_all, step counter [1] int32): read this step's time projections from the per-call
+        tables of ``time_tables`` (one small launch) instead of recomputing them from ``t_var``."""
+        g, inv = self.g, self.inv
+        ehs, B, dt = inv["ehs"], inv["B"], inv["dt"]
+        if self.direction == "inverse":
+            first, last = self.enc, self.dec
+        else:
+            first = last = self.unet
+        if tables is not None:
+            tab1, tab3, counter = tables
+            _, tsl3, _, _, _ = g._ctx_of([last], [[last.up_blocks]], None, ehs, temb=False, kv=False)
+            _, tsl1, _, _, _ = g._ctx_of([first], [[first.down_blocks, first.mid_block]], None, ehs, temb=False, kv=False)
+            temb1, temb3 = torch.empty_like(tab1[0]), torch.empty_like(tab3[0])
+            ops.select_step_rows([tab1, tab3], [temb1, temb3], counter, tab1.shape[0])
+        else:
+            temb1, tsl1, temb3, tsl3 = self._time_projections(g._tvec(t_var, B, x_var.device), B)
         skips: List[torch.Tensor] = []
         x = g._conv_in([first], ops.to_nhwc(x_var, dt, CIN_PAD))
         mid = g._down_mid([first], x, (temb1, tsl1) + inv["kv1"], skips.append)

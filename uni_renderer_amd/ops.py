@@ -150,6 +150,28 @@ def set_site(name: Optional[str]):
     _site = name
 
 
+_plan_rows = None  # while set: 1x1 GEMMs are planned as if they had this many rows (see plan_rows_as)
+
+
+class plan_rows_as:
+    """Context: plan every Linear launched inside as if it had ``m`` rows.  A GEMM row's arithmetic depends on the (tile, split-K)
+    choice only, not on how many rows the launch has -- so a table computed for n x B rows under ``plan_rows_as(B)`` holds, row for
+    row, the bits the B-row launches of the individual steps produce (hoist.time_tables)."""
+
+    def __init__(self, m: int):
+        self.m = int(m)
+
+    def __enter__(self):
+        global _plan_rows
+        self.prev, _plan_rows = _plan_rows, self.m
+        return self
+
+    def __exit__(self, *exc):
+        global _plan_rows
+        _plan_rows = self.prev
+        return False
+
+
 def plan_igemm(M: int, N: int, K: int, taps: int = 1, zbatch: int = 1) -> Tuple[int, int]:
     """(tile, splitk) for an implicit GEMM.  Measured table first, analytic model otherwise."""
     global _tune_table
@@ -207,7 +229,7 @@ def igemm(*, x0, w, out, M, N, K, c0, c1=0, x1=None, ldx0, ldx1=0, ldw, ldc, tap
     _require_gpu(x0)
     lib = _lib.load()
     if tile is None or splitk is None:
-        pt, ps = plan_igemm(M, N, K, taps, zbatch)
+        pt, ps = plan_igemm(_plan_rows if (_plan_rows is not None and taps == 1) else M, N, K, taps, zbatch)
         tile = pt if tile is None else tile
         splitk = ps if splitk is None else splitk
     d = IGemmDesc()  # zero-initialised: only what differs from 0 / NULL is written (every field set is host time,
@@ -738,6 +760,24 @@ def sampler_advance(step, tsteps, nsteps: int, t_out=None):
     lib = _lib.load()
     check(lib.ur_sampler_advance(step.data_ptr(), tsteps.data_ptr(), nsteps, _ptr(t_out),
                                  (t_out.numel() if t_out is not None else 0), _stream()), "ur_sampler_advance")
+
+
+def select_step_rows(tables, outs, step, nsteps: int):
+    """outs[k] = tables[k][*step] for up to four per-step tables ``[nsteps, ...]`` in ONE launch (``ur_select_step_rows``): the
+    current step's rows of what a sampling loop computed for all of its steps up front, picked by the device-side step counter
+    so that the step stays a pure graph replay."""
+    _require_gpu(tables[0])
+    import ctypes as C
+    lib = _lib.load()
+    k = len(tables)
+    src = (C.c_void_p * k)(*[t.data_ptr() for t in tables])
+    dst = (C.c_void_p * k)(*[o.data_ptr() for o in outs])
+    nbytes = (C.c_int64 * k)(*[o.numel() * o.element_size() for o in outs])
+    for t, o in zip(tables, outs):
+        if t.shape[0] != nsteps or t.numel() != nsteps * o.numel() or t.dtype != o.dtype or not t.is_contiguous() or not o.is_contiguous():
+            raise ValueError("select_step_rows: tables are contiguous [nsteps, ...] stacks of the outputs")
+    check(lib.ur_select_step_rows(src, dst, nbytes, k, step.data_ptr(), int(nsteps), _stream()), "ur_select_step_rows")
+    return outs
 
 
 def add(a, b, alpha: float = 1.0, hilo=False):

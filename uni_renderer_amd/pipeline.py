@@ -50,6 +50,8 @@ class UniRendererPipeline:
         # network on every step (the grouped enc || unet, unet || dec executor of fused.py).
         self.hoist_invariants = os.environ.get("UR_HOIST", "1") != "0"
         self.rerun_invariants = False  # tests: the hoisted executor with its prologue replayed before EVERY step
+        # hoisted on-device loops: time embedding + every resnet's time projection for ALL steps once per call (hoist.time_tables)
+        self.precompute_time_tables = True
         self._sample_graphs: Dict[Any, Any] = {}
         self._graphs: Dict[Tuple, GraphedDualStreamStep] = {}
         self._progress_kwargs: Dict[str, Any] = {}
@@ -298,7 +300,7 @@ class UniRendererPipeline:
             coef, tvals = sched.coefficient_table(), timesteps.detach().cpu().to(torch.float32)
         else:
             coef, tvals = self._ddim_tables(sched, timesteps)
-        skey = key + (n, lat_dtype, guidance, "unipc" if unipc else "ddim")
+        skey = key + (n, lat_dtype, guidance, self.precompute_time_tables, "unipc" if unipc else "ddim")
         st = self._sample_graphs.get(skey)
         if st is None:
             dev = x_img.device
@@ -328,7 +330,13 @@ class UniRendererPipeline:
                     update(out["img_pred"].permute(0, 2, 3, 1), 0, g.x_t, g.x_t.shape[1])
                     ops.sampler_advance(st["step"], st["tvals"], n, g.t_img)
 
-            st["graph"], st["out"] = g.capture_with(post)
+            if isinstance(g, GraphedHoistedStep) and self.precompute_time_tables:
+                # the time projections of all n steps once per call (they depend on the timestep only); the step graph picks
+                # its rows with the device-side step counter
+                st["tgraph"], (tab1, tab3) = g.capture_time_tables(st["tvals"])
+                st["graph"], st["out"] = g.capture_with(post, tables=(tab1, tab3, st["step"]))
+            else:
+                st["graph"], st["out"] = g.capture_with(post)
             self._sample_graphs[skey] = st
             g.load_inputs(x_img, cond28, ehs, 0.0 if run_decoder else t0, t0 if run_decoder else 0.0)  # capture ran no kernel, but be explicit
         st["step"].zero_()
@@ -339,6 +347,8 @@ class UniRendererPipeline:
             st["last"].copy_(st["master"])  # L_0 = the initial sample
             st["hist"].zero_()
         hoisted = isinstance(g, GraphedHoistedStep)
+        if st.get("tgraph") is not None:
+            st["tgraph"].replay()  # time projections of every step of this call (st["tvals"] was written above)
         if hoisted:
             g.begin()  # the loop-invariant half, once per call
         for _ in range(n):
