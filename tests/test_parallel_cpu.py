@@ -80,18 +80,21 @@ def _train_worker(rank, world, port, q):
             h = h + enc(x * 0.5)          # second encoder pass: its parameters are used twice in one backward
         u = unet(h)
         loss = (u ** 2).mean()
-        if not (it == 0 and r == 1):
-            loss = loss + (dec(u) ** 2).mean()  # rank 1 takes the branch without the decoder in iteration 0
+        if not (it in (0, 2) and r == 1):
+            # rank 1 takes the branch without the decoder in iterations 0 and 2 -- in 2 its bucket slices still hold iteration 1's
+            # gradients (round 6: the buckets are not zeroed any more; finish() must zero what the backward did not reach)
+            loss = loss + (dec(u) ** 2).mean()
         return loss
 
-    data = [[torch.randn(5, 6, generator=torch.Generator().manual_seed(10 * it + r)) for r in range(world)] for it in range(2)]
+    data = [[torch.randn(5, 6, generator=torch.Generator().manual_seed(10 * it + r)) for r in range(world)] for it in range(3)]
     nets = build()
     opt = torch.optim.SGD([p for m in nets for p in m.parameters()], lr=0.1)
     gb = parallel.GradientBuckets(nets, bucket_mb=2e-4)  # ~50 floats per bucket: many buckets
     assert len(gb.buckets) >= 6
     hooked = 0
-    for it in range(2):
+    for it in range(3):
         gb.zero_grad()
+        assert all(p.grad is None for m in nets for p in m.parameters())  # direct-write protocol: nothing zeroed, grads dropped
         loss_fn(nets, data[it][rank], it, rank).backward()
         hooked += gb.launched_from_hooks
         gb.finish()
@@ -100,7 +103,7 @@ def _train_worker(rank, world, port, q):
     # reference: one process, gradient = mean over the two ranks' losses
     ref = build()
     ropt = torch.optim.SGD([p for m in ref for p in m.parameters()], lr=0.1)
-    for it in range(2):
+    for it in range(3):
         ropt.zero_grad(set_to_none=True)
         sum(loss_fn(ref, data[it][r], it, r) for r in range(world)).div(world).backward()
         for p in (p for m in ref for p in m.parameters()):

@@ -81,3 +81,28 @@ def test_norm_sums_defer_each_parameter_once_and_never_under_anomaly_detection()
     ns.reset()
     with torch.autograd.detect_anomaly(check_nan=False):
         assert not ns.fresh(g1)
+
+
+def test_grad_sink_first_writer_stores_later_writers_add():
+    """Round 6: gradients living in communication buckets are WRITTEN there by the kernels that produce them
+    (backward.GradSink) instead of being added into zeroed buckets by autograd.  Host logic: the first ``take`` of a parameter
+    since ``begin`` hands out the destination, later ones (second pass of the cycle branch, accumulation micro-steps) get None
+    = the ordinary add path; anomaly mode and ``end()`` switch the sink off."""
+    import torch
+    from uni_renderer_amd import backward as B
+
+    store = {1: torch.zeros(3), 2: torch.zeros(2)}
+    sink = B.GradSink()
+    assert sink.take(1) is None  # no provider installed
+    sink.begin(lambda pid: store.get(pid))
+    assert sink.take(1) is store[1] and sink.take(1) is None and sink.take(3) is None and sink.take(2) is store[2]
+    sink.begin(lambda pid: store.get(pid))  # next optimisation step
+    with torch.autograd.detect_anomaly(check_nan=False):
+        assert sink.take(1) is None
+    assert sink.take(1) is store[1]
+    sink.end()
+    assert sink.take(2) is None
+    # cast_many(outs=...) validates its destinations before touching the device
+    import pytest
+    with pytest.raises(ValueError):
+        B.cast_many([torch.zeros(4, dtype=torch.bfloat16)], torch.float32, outs=[torch.zeros(3)])

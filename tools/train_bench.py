@@ -47,6 +47,8 @@ def main():
                     "with the backward), or with --no-overlap: forward + backward graph, eager collectives, update graph")
     ap.add_argument("--force-collectives", action="store_true", help="one rank: still build the buckets and issue the RCCL "
                     "collectives (world size 1), to time / profile the multi-GPU code path on one GPU")
+    ap.add_argument("--accumulate-into-buckets", action="store_true", help="round-5 gradient protocol (zero the flat buckets, autograd "
+                    "adds every gradient into them) instead of round 6's direct writes (backward.GradSink): A/B runs")
     args = ap.parse_args()
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
     if args.gpus > 1 and world == 1 and "RANK" not in os.environ:
@@ -79,6 +81,8 @@ def main():
     buckets = GradientBuckets(nets, comm_dtype=(torch.bfloat16 if args.comm_dtype == "bf16" else None), algorithm=args.algorithm,
                               overlap=not args.no_overlap, force_collectives=args.force_collectives) \
         if (world > 1 or args.force_collectives) else None
+    if buckets is not None and args.accumulate_into_buckets:
+        buckets.direct_write = False
     if args.graph:
         # one GPU: the whole step is one graph; several: forward + backward graph, eager bucket collectives and update
         from uni_renderer_amd.train_step import GraphedTrainStep

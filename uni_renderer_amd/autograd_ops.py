@@ -71,6 +71,7 @@ class ParamBarrier(Function):
     def forward(ctx, *params):
         import weakref
         ctx.set_materialize_grads(False)
+        ctx.pids = [id(p) for p in params]
         outs = tuple(torch.empty(0, dtype=p.dtype, device=p.device).set_(p.untyped_storage(), p.storage_offset(), p.shape, p.stride())
                      for p in params)
         for o in outs:
@@ -80,7 +81,22 @@ class ParamBarrier(Function):
     @staticmethod
     def backward(ctx, *grads):
         bw.wgrad_queue.flush()
-        return grads
+        if bw.grad_sink.provider is None:
+            return grads
+        # gradients living in communication buckets: ONE multi-tensor copy puts the (~1000 small) bias / norm gradients of
+        # the network into their bucket slices; autograd receives those views and adopts them as p.grad (no add launches)
+        res, src, dst = list(grads), [], []
+        for i, (g, pid) in enumerate(zip(grads, ctx.pids)):
+            if g is None or g.dtype != torch.float32:
+                continue
+            v = bw.grad_sink.take(pid)
+            if v is not None and v.shape == g.shape:
+                src.append(g)
+                dst.append(v)
+                res[i] = v
+        if dst:
+            torch._foreach_copy_(dst, src)
+        return tuple(res)
 
 
 class Conv3x3(Function):
@@ -358,7 +374,9 @@ class PackConvWeight(Function):
         co, ci, cp = ctx.geom
         if dwp.stride(-1) != 1:
             dwp = dwp.contiguous()
-        g = torch.empty(co, ci, 3, 3, dtype=torch.float32, device=dwp.device)
+        g = bw.grad_sink.take(ctx.pid)  # the parameter's slice of its communication bucket, or None
+        if g is None or tuple(g.shape) != (co, ci, 3, 3):
+            g = torch.empty(co, ci, 3, 3, dtype=torch.float32, device=dwp.device)
         if bw.FUSED_GRADNORM:
             part = torch.empty(int(lib.ur_unpack_conv_weight_grad_blocks(co, ci)), dtype=torch.float32, device=dwp.device)
             check(lib.ur_unpack_conv_weight_grad_sumsq(dwp.data_ptr(), dwp.stride(0), g.data_ptr(), co, ci, cp, part.data_ptr(),
@@ -414,7 +432,9 @@ class PackConvWeights(Function):
                 continue
             if dwp.stride(-1) != 1:
                 dwp = dwp.contiguous()
-            g = torch.empty(co, ci, 3, 3, dtype=torch.float32, device=dwp.device)
+            g = bw.grad_sink.take(pid)  # the parameter's slice of its communication bucket, or None
+            if g is None or tuple(g.shape) != (co, ci, 3, 3):
+                g = torch.empty(co, ci, 3, 3, dtype=torch.float32, device=dwp.device)
             if bw.FUSED_GRADNORM:
                 part = torch.empty(int(lib.ur_unpack_conv_weight_grad_blocks(co, ci)), dtype=torch.float32, device=dwp.device)
                 check(lib.ur_unpack_conv_weight_grad_sumsq(dwp.data_ptr(), dwp.stride(0), g.data_ptr(), co, ci, cp, part.data_ptr(),
@@ -479,12 +499,17 @@ class CastParams(Function):
         idx = [i for i, g in enumerate(grads) if g is not None]
         res = [None] * len(grads)
         if idx:
+            # destinations: the parameters' slices of their communication buckets where a sink is installed (bw.GradSink)
+            sink = None
+            if bw.grad_sink.provider is not None:
+                sink = [bw.grad_sink.take(ctx.pids[i]) for i in idx]
+                sink = [v if (v is not None and v.numel() == grads[i].numel()) else None for v, i in zip(sink, idx)]
             if bw.FUSED_GRADNORM:  # the sums of squares of what is written here feed the clipping norm (bw.GradSquares)
-                outs, part = bw.cast_many([grads[i] for i in idx], torch.float32, sumsq=True)
+                outs, part = bw.cast_many([grads[i] for i in idx], torch.float32, sumsq=True, outs=sink)
                 if part is not None:
                     bw.grad_squares.add(part, [ctx.pids[i] for i in idx if grads[i].numel()])
             else:
-                outs = bw.cast_many([grads[i] for i in idx], torch.float32)
+                outs = bw.cast_many([grads[i] for i in idx], torch.float32, outs=sink)
             for i, o_ in zip(idx, outs):
                 res[i] = o_
         return (None, *res)

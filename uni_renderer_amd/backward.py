@@ -196,13 +196,53 @@ grad_squares = GradSquares()
 FUSED_GRADNORM = X.flag("fused_gradnorm", True)
 
 
-def cast_many(srcs, dtype, sumsq: bool = False, packed: bool = False):
+class GradSink:
+    """Where the fp32 parameter gradients of a backward are WRITTEN when they live in flat communication buckets
+    (parallel.GradientBuckets): the kernels that produce them -- the multi-tensor cast of the Linear weight gradients, the conv
+    weight unpack, the bias / norm-parameter sums -- store straight into the parameter's slice of its bucket and hand autograd
+    that very view, which ``AccumulateGrad`` adopts as ``p.grad`` without a copy.  Before round 6 every gradient was produced
+    in a fresh tensor and then ADDED into the (zeroed) bucket by autograd: 1430 extra launches and ~8 ms per step of cfg 4,
+    plus the 7 GB of zeroing.
+
+    ``take(pid)`` returns the destination view for the FIRST contribution to a parameter since ``begin()`` and None afterwards
+    (a second contribution -- the cycle-consistency branch runs enc + unet twice, gradient-accumulation micro-steps -- takes the
+    ordinary path: a fresh tensor, which autograd then adds in place to the view ``p.grad`` already is)."""
+
+    def __init__(self):
+        self.provider, self.written = None, set()
+
+    def begin(self, provider):
+        """``provider``: pid -> a NEW fp32 view object over the parameter's gradient storage (or None); None switches off."""
+        self.provider, self.written = provider, set()
+
+    def end(self):
+        self.provider, self.written = None, set()
+
+    def take(self, pid):
+        if self.provider is None or pid in self.written or torch.is_anomaly_enabled():
+            return None
+        v = self.provider(pid)
+        if v is not None:
+            self.written.add(pid)
+        return v
+
+
+grad_sink = GradSink()
+
+
+def cast_many(srcs, dtype, sumsq: bool = False, packed: bool = False, outs=None):
     """``[s.to(dtype) for s in srcs]`` for fp32 -> fp16 / bf16 or fp16 / bf16 -> fp32, 128 tensors per launch
     (``ur_cast_multi``).  ``sumsq`` (to fp32 only): also returns the per-workgroup sums of squares of everything written,
-    one 1-D fp32 tensor (``ur_cast_multi_sumsq``)."""
+    one 1-D fp32 tensor (``ur_cast_multi_sumsq``).  ``outs``: write into these contiguous tensors (entries may be None:
+    allocated here) instead of fresh ones -- the gradient views of a bucket (GradSink)."""
     lib = _lib.load()
     srcs = [s_.contiguous() for s_ in srcs]
-    if packed and srcs:
+    if outs is not None:
+        outs = [o if o is not None else torch.empty_like(s_, dtype=dtype) for s_, o in zip(srcs, outs)]
+        for s_, o in zip(srcs, outs):
+            if o.dtype != dtype or o.numel() != s_.numel() or not o.is_contiguous():
+                raise ValueError("cast_many(outs=...): contiguous tensors of the target dtype and the sources' sizes")
+    elif packed and srcs:
         # one flat buffer, the copies back to back in the order given: consecutive tensors with the same trailing shape can
         # then be used as ONE matrix without a torch.cat (autograd_ops.cat_adjacent)
         flat = torch.empty(sum(s_.numel() for s_ in srcs), dtype=dtype, device=srcs[0].device)

@@ -216,6 +216,11 @@ class GradientBuckets:
                 self._offset[p] = off
                 off += (p.numel() + 3) // 4 * 4
             self.flat.append(flat)
+        self._by_id = {id(p): p for p in self.params}
+        # gradients are written straight into the bucket slices by the kernels that produce them (backward.GradSink) instead of
+        # being added into zeroed buckets by autograd; False restores the round-5 protocol (zero + accumulate) for A/B runs
+        self.direct_write = True
+        self.sumsq_parts: Optional[List[torch.Tensor]] = None  # sums of squares collected by finish()'s copy-back pass
         self._comm: List[Optional[torch.Tensor]] = [None] * len(self.buckets)
         self._arrived = [0] * len(self.buckets)
         self._launched = 0
@@ -311,6 +316,9 @@ class GradientBuckets:
         """After ``backward()``: launch the buckets the hooks could not (missing gradients on this rank), wait for all
         collectives, and leave the mean gradients in the flat buffers (= in every ``p.grad``)."""
         if self._single():
+            from . import backward as bw
+            bw.grad_sink.end()
+            self.sumsq_parts = None
             self._reset()
             return
         if not self._sync:  # accumulation micro-step: keep the local sums, adopt gradients re-created outside the buckets
@@ -326,15 +334,48 @@ class GradientBuckets:
                 self._adopt(p)
         while self._launched < len(self.buckets):
             self._launch(self._launched)
+        from . import backward as bw
+        parts = []
         for bi, w, kind in self._work:
             w.wait()
             buf = self._comm[bi] if self._comm[bi] is not None else self.flat[bi]
             if buf is not self.flat[bi]:
-                self.flat[bi].copy_(buf)
+                if buf.is_cuda and bw.FUSED_GRADNORM:
+                    # reduced half-precision means -> the fp32 gradients, and the clipping norm's sums of squares from the same
+                    # pass (ur_cast_multi_sumsq) instead of another sweep over the 7 GB (train.py:1422)
+                    _, part = bw.cast_many([buf], torch.float32, sumsq=True, outs=[self.flat[bi]])
+                    parts.append(part)
+                else:
+                    self.flat[bi].copy_(buf)
+        self.sumsq_parts = parts if parts and len(parts) == len(self.flat) else None
+        bw.grad_sink.end()
         self._reset()
 
+    @torch.no_grad()
+    def adopt_all(self) -> int:
+        """After ``backward()``: every gradient that did NOT arrive through the sink or a hook's adoption (a parameter outside the
+        batched cast / pack / barrier nodes: autograd then keeps its own tensor as ``p.grad``) is copied into its bucket slice
+        with ONE multi-tensor launch.  train_step calls this right behind ``backward()`` -- INSIDE the captured forward + backward
+        graph -- because those tensors live in the graph's pool: on a replay nothing on the host would notice that they changed
+        (``finish()`` compares ``p.grad`` objects, which a replay does not touch).  Returns how many were copied."""
+        src, dst, ps = [], [], []
+        for p in self.params:
+            if p.grad is not None and p.grad.data_ptr() != self._view_ptr(p):
+                src.append(p.grad)
+                dst.append(self._view(p))
+                ps.append(p)
+        if dst:
+            torch._foreach_copy_(dst, src)
+            for p, v in zip(ps, dst):
+                p.grad = v
+        self.adopted_last = len(dst)
+        return len(dst)
+
     def _adopt_none(self, p):
-        p.grad = self._view(p)  # zeros unless written
+        v = self._view(p)
+        if self.direct_write:
+            v.zero_()  # nobody wrote this slice in this step (it still holds the previous step's gradient)
+        p.grad = v  # zeros
 
     def _reset(self):
         self._arrived = [0] * len(self.buckets)
@@ -344,11 +385,29 @@ class GradientBuckets:
     # kept name of the round-1 API (all-reduce after the backward): now the tail of the overlapped protocol
     all_reduce_mean = finish
 
+    def _sink_view(self, pid):
+        p = self._by_id.get(pid)
+        return None if p is None else self._view(p)  # a NEW tensor object: AccumulateGrad adopts it only if nobody else holds it
+
     @torch.no_grad()
     def zero_grad(self):
-        """Zero the flat buffers (the gradients stay views into them)."""
-        for f in self.flat:
-            f.zero_()
+        """Start an optimisation step.  ``direct_write`` (default): nothing is zeroed -- every ``p.grad`` is dropped and the
+        backward's kernels STORE the gradients into the bucket slices (backward.GradSink; autograd adopts the views as
+        ``p.grad``); a parameter the backward does not reach gets its slice zeroed in ``finish()``.  Otherwise (round-5
+        protocol): zero the flat buffers, the gradients stay views into them and autograd adds into them."""
+        from . import backward as bw
+        if self.direct_write:
+            for p in self.params:
+                p.grad = None
+            bw.grad_sink.begin(self._sink_view)
+        else:
+            bw.grad_sink.end()
+            for p in self.params:
+                if p.grad is None or p.grad.data_ptr() != self._view_ptr(p):
+                    p.grad = self._view(p)
+            for f in self.flat:
+                f.zero_()
+        self.sumsq_parts = None
         self._reset()
 
     @torch.no_grad()

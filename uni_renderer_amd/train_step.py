@@ -427,6 +427,9 @@ def _forward_backward(nets, batch, optimizer, buckets, dtype, inverse, grad_accu
     else:
         loss.backward()  # with ``buckets``: complete buckets are all-reduced (async) while the backward is still running
     B.wgrad_queue.flush()  # nothing pending after a complete backward (CastParams / ParamBarrier flush); a partial graph may leave some
+    if buckets is not None and getattr(buckets, "direct_write", False) and not buckets._hooks:
+        # no hooks adopted stray gradients during the backward (overlap=False / gloo): do it here, inside a capture if there is one
+        buckets.adopt_all()
     return report
 
 
@@ -473,7 +476,11 @@ def _clip_and_update(nets, optimizer, buckets, max_grad_norm, stats, scaler=None
         fold = (optimizer is not None and getattr(optimizer, "_step_supports_amp_scaling", False)
                 and all(g.get("fused") for g in optimizer.param_groups))
         if fold:
-            if buckets is not None:
+            if buckets is not None and getattr(buckets, "sumsq_parts", None):
+                # finish() converted the reduced half-precision buckets back to fp32 and summed the squares in the same pass
+                norm = torch.cat(buckets.sumsq_parts).sum().sqrt()
+                buckets.sumsq_parts = None
+            elif buckets is not None:
                 # _foreach_norm, not vector_norm per bucket: a CAPTURED vector_norm over a 32 MB tensor returns wrong
                 # values on replay in this torch / ROCm build (tools/graph_norm_repro.py)
                 norm = torch.linalg.vector_norm(torch.stack(torch._foreach_norm(list(buckets.flat))))
