@@ -530,9 +530,10 @@ def test_qkv_projection_with_transposed_value_output(dev, dtype, tile, splitk, S
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("tile", [2, 44, 9])  # 16x16x32 tile, a 32x32x16 tile (its own accumulator layout), the 128x320 tile (ragged N)
 @pytest.mark.parametrize("cfg", [(16, 640, 1280, 4, 2, True), (8, 1280, 1280, 8, 2, True), (16, 320, 640, 2, 1, False),
                                  (8, 640, 1280, 16, 1, True), (32, 320, 640, 2, 2, True)])
-def test_conv_groupnorm_as_the_splitk_second_pass(dev, dtype, cfg, monkeypatch):
+def test_conv_groupnorm_as_the_splitk_second_pass(dev, dtype, cfg, tile, monkeypatch):
     """ur_igemm_splitk_gn: split-K conv3x3 (+bias, + per-sample time-embedding row) whose second pass IS the GroupNorm
     (+ SiLU) of its output -- against fp32 conv2d -> storage rounding -> group_norm -> silu, and against the unfused
     product path (split-K reduce, then the one-launch GroupNorm), which rounds at the same point: both streams of a grouped
@@ -540,7 +541,7 @@ def test_conv_groupnorm_as_the_splitk_second_pass(dev, dtype, cfg, monkeypatch):
     to conv + groupnorm with the same result."""
     from uni_renderer_amd import ops
     from uni_renderer_amd.layers import pack_conv3x3
-    monkeypatch.setattr(ops, "SPLITK_GN", True)  # off by default (measured slower in the step): exercised here
+    monkeypatch.setattr(ops, "SPLITK_GN", True)  # (round 6: the slabs are group-blocked, the second pass reads contiguous strips)
     L, Ci, Co, sk, S, silu = cfg
     B = 2
     x = _rand((S * B, L, L, Ci), dtype, dev, seed=1)
@@ -552,7 +553,7 @@ def test_conv_groupnorm_as_the_splitk_second_pass(dev, dtype, cfg, monkeypatch):
     temb = _rand((S * B, 2 * Co), dtype, dev, seed=11)
     if S == 1:
         w, bias, gam, bet = w[0], bias[0], gam[0], bet[0]
-    kw = dict(rowadd=temb[:, Co // 2: Co // 2 + Co], streams=S, splitk=sk, tile=2)
+    kw = dict(rowadd=temb[:, Co // 2: Co // 2 + Co], streams=S, splitk=sk, tile=tile)
     fused = ops.conv3x3(x, w, bias, gn=(gam, bet, 1e-5, 32, silu), **kw)
     h = ops.conv3x3(x, w, bias, **kw)
     unfused = ops.groupnorm(h, gam, bet, 1e-5, groups=32, silu=silu, streams=S)

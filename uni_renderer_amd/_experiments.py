@@ -44,7 +44,7 @@ KNOWN = {
     # ---- numeric knobs of the A/B runs ----
     "wsconv_min_k": "", "wsconv_waves": "", "zero_page_bytes": "", "conv_cblock": "", "gn_stat_kb": "", "gn_apply_kb": "",
     "gn_apply_max": "", "gn_fused_max_rows": "", "gn_bwd_fused_max_rows": "", "wgrad_tile": "", "wgrad_splits": "",
-    "flash_direct_min_d": "",
+    "flash_direct_min_d": "", "tchain_min_rows": "",
 }
 
 # Environment variables of rounds 1-4 that UR_EXPERIMENT replaced.  They are NOT read any more; a script that still sets one

@@ -38,6 +38,10 @@ from .layers import (LOG2E, Attention, BasicTransformerBlock, ResnetBlock2D, Tra
 QKV_ONE_LAUNCH = X.flag("qkv_one_launch", True)
 # the same for the prompt's K / V^T projections of a phase (one GEMM over [Wk; Wv] instead of a K GEMM + a V^T GEMM per stream)
 CTXKV_ONE_LAUNCH = X.flag("ctxkv_one_launch", True)
+# token rows per launch from which the 320-channel chain kernels (128 rows per workgroup) replace the GEMM-by-GEMM path:
+# 32768 rows (grouped step at batch 4) and 16384 (hoisted step; grouped step at batch 2: 8.65 vs 8.72 ms) are wins, 8192 (hoisted step
+# at batch 2: 6.47 vs 6.24 ms) and 4096 (cfg 2: 4.55 vs 4.14 ms) losses -- profiles/r06_tchain_rows_ab.txt, r05_hoist_ab.txt
+TCHAIN_MIN_ROWS = X.number("tchain_min_rows", 16384)
 
 
 class _Packs:
@@ -327,7 +331,10 @@ class GroupedDualStreamStep:
         b0 = ts[0].transformer_blocks[0]
         # the chain kernels hard-code C = 320 (tchain.supported), 8 heads of 40, bias-free q / k / v and a feed-forward of
         # 2 x 1280 -> 320; anything else takes the GEMM-by-GEMM path
+        # ... and one chain workgroup owns 128 token rows: below TCHAIN_MIN_ROWS rows per launch the chain leaves most of the 256 CUs
+        # idle (cfg 2: 4096 rows = 32 workgroups, 109 us for the feed-forward chain at 75 TFLOP/s) and the tiled GEMMs win
         if (self.use_tchain and len(ts[0].transformer_blocks) == 1 and tchain.supported(h) and self.hilo
+                and Bt * H * W >= TCHAIN_MIN_ROWS
                 and (H * W) % 32 == 0 and b0.attn1.dim_head == 40 and b0.attn1.heads * 40 == Cc
                 and b0.ff.net[2].weight.shape[1] == tchain.FF_HIDDEN and b0.ff.net[0].proj.weight.shape[0] == 2 * tchain.FF_HIDDEN
                 and all(getattr(a, nm).bias is None for a in (b0.attn1, b0.attn2) for nm in ("to_q", "to_k", "to_v"))):
