@@ -52,7 +52,7 @@ def algorithmic_flops(L, B=1, direction="inverse", cross_tokens=77, cross_dim=76
         f += 2 * lin(T, C, C) + 2 * lin(cross_tokens, cross_dim, C) + 4 * T * cross_tokens * C  # cross
         return f + lin(T, C, 8 * C) + lin(T, 4 * C, C)         # GEGLU feed-forward
 
-    def net(part, cin=4, cout=4):
+    def net(part, cin=4, cout=4, exchange=True):
         f, H, prev = 0, L, 320
         if part in ("unet", "enc"):
             f += conv(cin, 320, L) + 2 * 320 * 1280 + 2 * 1280 * 1280
@@ -75,13 +75,23 @@ def algorithmic_flops(L, B=1, direction="inverse", cross_tokens=77, cross_dim=76
                     H *= 2
                     f += conv(c, c, H)
             f += conv(320, cout, L) + (2 * 320 * 1280 + 2 * 1280 * 1280 if part == "dec" else 0)
-        if part in ("enc", "dec"):  # the 12 + 1 exchange 1x1 convs
+        if part in ("enc", "dec") and exchange:  # the 12 + 1 exchange 1x1 convs
             for h, c in zip([L] * 3 + [L // 2] * 3 + [L // 4] * 3 + [L // 8] * 4, [320] * 4 + [640] * 3 + [1280] * 6):
                 f += lin(h * h, c, c)
         return f
 
-    total = net("unet") + net("enc", cin=28) + (net("dec", cout=28) if direction == "inverse" else 0)
+    if direction == "hoisted_inverse":
+        # per step of the hoisted inverse loop (uni_renderer_amd/hoist.py): encoder conv_in + down + mid (its 13 exchange convs are
+        # dead there) and decoder up + conv_out (its 13 exchange products are computed once per call)
+        total = net("enc", cin=28, exchange=False) + net("dec", cout=28, exchange=False)
+    elif direction == "hoisted_render":  # per step: the UNet (the encoder runs once per call)
+        total = net("unet")
+    else:
+        total = net("unet") + net("enc", cin=28) + (net("dec", cout=28) if direction == "inverse" else 0)
     return float(B) * total
+
+
+_FLOP_DIRECTIONS = ("inverse", "render", "hoisted_inverse", "hoisted_render")
 
 
 def _spawn_ranks(n, script=None):
@@ -422,7 +432,60 @@ def sampling_loops(models, B, L, dev, dtype, steps=50):
         torch.cuda.synchronize()
         ts.append(time.perf_counter() - t0)
     res["eval_protocol_unipc20_x5_folded_ms_total"] = round(min(ts) * 1e3, 2)
+    # roofline of the per-step half of the hoisted inverse loop (what a sampling call replays 50 times): one eager run with every
+    # launch bracketed by HIP events, dominant kernel by symbol as for the full step
+    try:
+        from uni_renderer_amd.graph import GraphedHoistedStep
+
+        gh = next(g for g in pipe._graphs.values() if isinstance(g, GraphedHoistedStep) and g.run_decoder and g.x_t.shape[0] == B)
+        gh.begin()
+        roof, table, total_ms = measure_roofline(gh._run)
+        # per-step FLOP of the hoisted inverse loop: encoder conv_in + down + mid and decoder up + conv_out
+        fl = (algorithmic_flops(L, B, "hoisted_inverse") if "hoisted_inverse" in _FLOP_DIRECTIONS else None)
+        res["roofline"] = dict(roof, launches_per_step=sum(r["calls"] for r in table), sum_kernel_ms_eager_step=round(total_ms, 3),
+                               traffic_source="not measured for the loop step (the full step's line carries the PMC traffic of the same kernel)")
+        if fl:
+            res["algorithmic_tflop_per_step"] = round(fl / 1e12, 3)
+            res["inverse_step_frac_of_mfma_peak"] = round(fl / 1e12 / res["inverse_ms_per_step"] / PEAK_MFMA_TFLOPS * 1e3, 4)
+    except Exception as e:
+        res["roofline"] = {"error": f"{type(e).__name__}: {e}"[:200]}
     return res
+
+
+def loop_parity(dev, dtype):
+    """CHECKER leg (with ``cpu_baseline``): the pipeline's hoisted 50-step DDIM inverse loop -- the loop ``loop.inverse_ms_total``
+    times -- on the SD-size networks the oracle builds from seed 1234, against the final latents of the same loop on the CPU
+    fp32 oracle, COMMITTED as tests/golden/sd_cfg3_b4.safetensors (tests/golden/make_golden_sd.py: ~50 min of CPU in the build
+    container).  rel-L2 of the [4, 24, 64, 64] attribute latents after 50 steps against the oracle holding the same fp16-rounded
+    parameters and the fp32 parameters.  fp16, batch 4, 64x64 only (what the golden holds)."""
+    gold_path = os.path.join(ROOT, "tests", "golden", "sd_cfg3_b4.safetensors")
+    if dtype != torch.float16 or not os.path.exists(gold_path):
+        return None
+    from safetensors.torch import load_file
+
+    from oracle import unirenderer_oracle as O
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from util_models import build_product_from_oracle
+    from uni_renderer_amd.pipeline import UniRendererPipeline
+
+    gold = load_file(gold_path)
+    t0 = time.perf_counter()
+    oracle = O.build_triplet(O.SD15_CONFIG, seed=1234)
+    nets = build_product_from_oracle(*oracle, dtype, dev)
+    del oracle
+    pipe = UniRendererPipeline(unet=nets[0], controlnet=nets[1], controldec=nets[2])
+    pipe.set_progress_bar_config(disable=True)
+    x, c, ehs, _, _ = [t.to(dev) for t in O.make_inputs(4, 64, 768, seed=28, t_img=0)]
+    sched = pipe.scheduler_attr
+    sched.set_timesteps(50)
+    fin = pipe._fused_loop(x.to(dtype), c, ehs.to(dtype), sched.timesteps, sched, run_decoder=True, lat_dtype=torch.float32).float().cpu()
+    rel = lambda a, b: float((a.float() - b.float()).norm() / b.float().norm())
+    return dict(final_latents_same_weights=round(rel(fin, gold["loop.final_latents.fp16w"]), 7),
+                final_latents_fp32_weights=round(rel(fin, gold["loop.final_latents.fp32w"]), 7),
+                oracle_fp16w_vs_fp32w=round(rel(gold["loop.final_latents.fp16w"], gold["loop.final_latents.fp32w"]), 7),
+                seconds=round(time.perf_counter() - t0, 1),
+                note="hoisted on-device 50-step DDIM inverse loop (B = 4, 64x64, fp16) vs the committed CPU-oracle loop "
+                     "(tests/golden/sd_cfg3_b4.safetensors); networks rebuilt from the golden's seed")
 
 
 def main():
@@ -576,6 +639,15 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.batch, args.latent, check)
             if "parity_rel_l2" in out["cpu_baseline"]:
                 out["config"]["parity_rel_l2"] = out["cpu_baseline"].pop("parity_rel_l2")
+            if isinstance(out.get("loop"), dict) and "error" not in out["loop"] and args.batch == 4 and args.latent == 64:
+                try:  # the checker of the loop timings above: its final latents against the committed oracle loop
+                    del models
+                    torch.cuda.empty_cache()
+                    lp = loop_parity(dev, dtype)
+                    if lp is not None:
+                        out["loop"]["parity_rel_l2"] = lp
+                except Exception as e:
+                    out["loop"]["parity_rel_l2"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         print(json.dumps(out), flush=True)
     if dist_on:
         torch.distributed.barrier()  # rank 0 may still have been in its roofline leg

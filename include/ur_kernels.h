@@ -267,9 +267,13 @@ int ur_groupnorm_apply(const void* x0, const void* x1, const void* x0_lo, const 
                        const float* beta, float eps, int silu, int bper, int pstride, void* out, int dtype,
                        void* stream);
 
-/* The same GroupNorm in ONE launch (one workgroup per (sample, group), two sweeps over its strip; statistics over the
- * hi parts, normalisation of hi + lo): for the maps of the deep levels, where stats + apply are launch-bound.  Group
- * width (c0 + c1) / groups must be even and <= 128 (UR_E_UNSUPPORTED otherwise). */
+/* The same GroupNorm in ONE launch (one workgroup per (sample, group); statistics over the hi parts, normalisation of
+ * hi + lo): for the maps of the deep levels, where stats + apply are launch-bound.  Group width (c0 + c1) / groups must be
+ * even and <= 128 (UR_E_UNSUPPORTED otherwise).  Strips of at most 4 (16-byte pieces) / 8 (8- / 4-byte pieces) pieces per
+ * thread are loaded once and stay in registers across the block reduction (round 6: one memory round trip); larger ones take
+ * two sweeps, the second out of L2.  `silu`: bit 0 = SiLU after the affine map; bit 1 (UR_GN_TWO_SWEEP) = always the two-sweep
+ * kernel (A/B runs, tests: the two kernels produce the same bits). */
+#define UR_GN_TWO_SWEEP 2
 int ur_groupnorm_fused(const void* x0, const void* x1, const void* x0_lo, const void* x1_lo, int c0, int c1, int B,
                        int rows, int groups, const float* gamma, const float* beta, float eps, int silu, int bper,
                        int pstride, void* out, int dtype, void* stream);

@@ -195,6 +195,39 @@ def test_groupnorm(dev, dtype, cfg, silu, fused):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", [(1280, 0, 256, 2), (1280, 1280, 64, 2), (640, 0, 1024, 1), (320, 0, 1024, 2), (1920, 0, 256, 1),
+                                 (1280, 640, 256, 2), (1280, 0, 1024, 1), (64, 0, 16, 1)])
+@pytest.mark.parametrize("hilo", [False, True])
+def test_groupnorm_register_resident_equals_two_sweeps_bitwise(dev, dtype, cfg, hilo):
+    """Round 6: the one-launch GroupNorm loads small strips ONCE and keeps them in registers across the block reduction
+    (gn_resident_kernel) instead of sweeping them twice.  Same statistics order, same arithmetic: the output must equal the
+    two-sweep kernel's bit for bit -- grouped streams with per-stream affine parameters, two sources, (hi, lo) inputs, strips of
+    1 .. 8 pieces per thread (the last two cases exceed the resident limit / are tiny: both take their usual path) -- and
+    match fp32 group_norm."""
+    from uni_renderer_amd import ops
+    c0, c1, rows, S = cfg
+    B = 2 * S
+    x0 = _rand((B, rows, 1, c0), dtype, dev, seed=1) * 2 + 0.5
+    x1 = (_rand((B, rows, 1, c1), dtype, dev, seed=2) - 1.0) if c1 else None
+    if hilo:
+        x0.lo = ops.lo_encode(torch.randn(B, rows, 1, c0, generator=torch.Generator().manual_seed(5)).to(dev) * 2e-4, dtype)
+    C = c0 + c1
+    g = torch.randn(S * C, generator=torch.Generator().manual_seed(3)).to(dev)
+    b = torch.randn(S * C, generator=torch.Generator().manual_seed(4)).to(dev)
+    kw = dict(x1=x1, groups=32, silu=True, fused=True, streams=S)
+    a = ops.groupnorm(x0, g, b, 1e-5, resident=True, **kw)
+    t = ops.groupnorm(x0, g, b, 1e-5, resident=False, **kw)
+    assert torch.equal(a, t)
+    xc = (torch.cat([x0, x1], -1) if c1 else x0).float().cpu()
+    if hilo:
+        xc[..., :c0] += ops.lo_float(x0.lo).cpu()
+    for s_ in range(S):
+        sl = slice(s_ * 2, s_ * 2 + 2)
+        ref = F.silu(F.group_norm(xc[sl].permute(0, 3, 1, 2), 32, g[s_ * C:(s_ + 1) * C].cpu(), b[s_ * C:(s_ + 1) * C].cpu(), 1e-5))
+        assert rel_l2(a[sl], ref.permute(0, 2, 3, 1)) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("C", [64, 320, 640, 1280])
 def test_layernorm(dev, dtype, C):
     from uni_renderer_amd import ops

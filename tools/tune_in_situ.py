@@ -46,6 +46,9 @@ def main():
                     "problems ranked by a flop / launch-latency estimate, candidates = --tiles x (current split-K, x2, /2)")
     ap.add_argument("--train", action="store_true", help="tune the captured TRAINING step (tools/train_bench.py --graph: cfg 4's "
                     "per-GPU shape, bf16) instead of the inference step; candidates = a fixed tile list at the current split-K")
+    ap.add_argument("--direction", default="inverse", choices=["inverse", "render"], help="full step: inverse = enc + unet + dec, render = "
+                    "enc + unet (cfg 2 of BASELINE.json: --direction render --batch 2 --latent 32 --dtype bf16)")
+    ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"])
     args = ap.parse_args()
     if args.train:
         return main_train(args)
@@ -57,14 +60,16 @@ def main():
     from uni_renderer_amd.graph import GraphedDualStreamStep
 
     dev = torch.device("cuda:0")
-    dt = torch.float16
+    dt = torch.float16 if args.dtype == "f16" else torch.bfloat16
+    run_decoder = args.direction == "inverse"
     models = bench.build_models(dev, dt)
     inputs = bench.make_inputs(args.batch, args.latent, dev, dt, seed=100)
     table = dict(ops.load_tuning_table())
 
     def measure():
         ops._plan_cache.clear()
-        r = GraphedDualStreamStep(*models, batch=args.batch, latent_hw=args.latent, cross_dim=768, dtype=dt, device=dev)
+        r = GraphedDualStreamStep(*models, batch=args.batch, latent_hw=args.latent, cross_dim=768, dtype=dt, device=dev,
+                                  run_decoder=run_decoder)
         r.load_inputs(*inputs)
         r.capture(warmup=1)
         for _ in range(10):
@@ -91,7 +96,7 @@ def main():
     try:
         from uni_renderer_amd.fused import GroupedDualStreamStep
         with torch.no_grad():
-            GroupedDualStreamStep(*models)(*inputs)
+            GroupedDualStreamStep(*models)(*inputs, run_decoder=run_decoder)
         torch.cuda.synchronize()
     finally:
         ops.igemm = orig

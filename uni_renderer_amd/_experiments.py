@@ -35,6 +35,7 @@ KNOWN = {
     "flash_backward": "flash attention backward instead of the materialised-P path (backward.py)",
     "forward_lse": "the forward attention hands its row log-sum-exp to the backward (backward.py)",
     "batch_casts": "fp32 -> bf16 parameter casts of a network in one launch group (train_step.py)",
+    "gn_resident": "one-launch GroupNorm keeps small strips in registers: one memory round trip (ops.py, csrc/norm.hip)",
     # ---- on-switches of measured-slower paths ----
     "splitk_gn": "GroupNorm as the split-K second pass (0.07 ms slower: profiles/r04_splitk_gn_ab.txt)",
     "colsum_one_launch": "column sums with an in-launch ticket instead of two launches (slower)",
@@ -44,7 +45,7 @@ KNOWN = {
     # ---- numeric knobs of the A/B runs ----
     "wsconv_min_k": "", "wsconv_waves": "", "zero_page_bytes": "", "conv_cblock": "", "gn_stat_kb": "", "gn_apply_kb": "",
     "gn_apply_max": "", "gn_fused_max_rows": "", "gn_bwd_fused_max_rows": "", "wgrad_tile": "", "wgrad_splits": "",
-    "flash_direct_min_d": "", "tchain_min_rows": "",
+    "flash_direct_min_d": "", "tchain_min_rows": "", "gn_resident_max_rows": "",
 }
 
 # Environment variables of rounds 1-4 that UR_EXPERIMENT replaced.  They are NOT read any more; a script that still sets one

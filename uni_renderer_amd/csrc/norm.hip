@@ -10,6 +10,8 @@
 // profiles/r04_gnf_xcd_ab.txt) and the row-chunked kernels use the XCD-contiguous mapping; both were environment toggles
 // during their A/B runs and are fixed now.
 static constexpr int gnf_xcd() { return 1; }
+// round 6: the one-launch GroupNorm keeps small strips in registers (gn_resident_kernel).  Bit 1 of ur_groupnorm_fused's `silu`
+// argument (UR_GN_TWO_SWEEP) asks for the two-sweep kernel instead: A/B runs and the bitwise test of the two against each other.
 static constexpr int norm_xcd() { return 1; }
 
 namespace ur {
@@ -551,6 +553,137 @@ __global__ void __launch_bounds__(GNF_THREADS) gn_fused_kernel(const T* __restri
     }
 }
 
+// Register-resident variant of the one-launch GroupNorm (round 6): when a (sample, group) strip is at most NP pieces per thread,
+// every piece (hi AND lo) is loaded ONCE, all loads issued back to back, kept as raw bits in registers across the block
+// reduction, then normalised and stored -- one memory round trip instead of two (the second sweep of gn_fused_kernel re-read
+// the strip from L2: on these 5-12 us launches a dependent round trip is 1-2 us).  Statistics over the hi parts only, in the
+// same per-thread order and the same block reduction as gn_fused_kernel: results are bit-identical to it.
+template <typename T, int P> struct RawPiece;
+template <typename T> struct RawPiece<T, 8> { uint4 v; };
+template <typename T> struct RawPiece<T, 4> { uint2 v; };
+template <typename T> struct RawPiece<T, 2> { unsigned v; };
+template <typename L, int P> struct RawLo;  // P low parts: e5m2 bytes (fp16 streams) or bf16
+template <> struct RawLo<unsigned char, 8> { uint2 v; };
+template <> struct RawLo<unsigned char, 4> { unsigned v; };
+template <> struct RawLo<unsigned char, 2> { unsigned short v; };
+template <> struct RawLo<bf16, 8> { uint4 v; };
+template <> struct RawLo<bf16, 4> { uint2 v; };
+template <> struct RawLo<bf16, 2> { unsigned v; };
+
+__device__ __forceinline__ void opaque(uint4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
+__device__ __forceinline__ void opaque(uint2& v) { asm volatile("" : "+v"(v.x), "+v"(v.y)); }
+__device__ __forceinline__ void opaque(unsigned& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void opaque(unsigned short& v) { unsigned t = v; asm volatile("" : "+v"(t)); v = (unsigned short)t; }
+
+template <typename T, int P>
+__device__ __forceinline__ void unpack_piece(const RawPiece<T, P>& r, float (&v)[P]) {
+    T h[P];
+    __builtin_memcpy(h, &r.v, sizeof(T) * P);
+#pragma unroll
+    for (int i = 0; i < P; ++i) v[i] = to_f(h[i]);
+}
+template <typename L, int P>
+__device__ __forceinline__ void unpack_lo(const RawLo<L, P>& r, float (&v)[P]) {
+    L h[P];
+    __builtin_memcpy(h, &r.v, sizeof(L) * P);
+#pragma unroll
+    for (int i = 0; i < P; ++i) v[i] = lo_to_f(h[i]);
+}
+
+template <typename T, int P, int NP>
+__global__ void __launch_bounds__(GNF_THREADS) gn_resident_kernel(const T* __restrict__ x0, const T* __restrict__ x1,
+                                                          const lo_t<T>* __restrict__ x0_lo, const lo_t<T>* __restrict__ x1_lo, int c0,
+                                                          int c1, int rows, int groups, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float eps, int silu, int bper,
+                                                          int pstride, T* __restrict__ out, int xcd) {
+    __shared__ float2 red[GNF_THREADS / 64];
+    __shared__ __attribute__((aligned(16))) float2 aff[128];
+    const int lid_ = xcd ? xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y) : blockIdx.x + gridDim.x * blockIdx.y;
+    const int t = threadIdx.x, g = lid_ % gridDim.x, b = lid_ / gridDim.x;
+    const int C = c0 + c1, cpg = C / groups, ppr = cpg / P;
+    const int total = rows * ppr;
+    const int64_t row0 = (int64_t)b * rows;
+    const bool first = g * cpg < c0;  // a group lies entirely in one source (c0 is a multiple of the group width when c1 > 0)
+    const T* src = first ? x0 : x1;
+    const lo_t<T>* lsrc = first ? x0_lo : x1_lo;
+    const int cs = first ? c0 : c1, cbase = first ? g * cpg : g * cpg - c0;
+
+    RawPiece<T, P> hi[NP];
+    RawLo<lo_t<T>, P> lo[NP];
+    // element offset of piece i of the strip inside its source (recomputed where needed: an offset array would cost 2 * NP registers)
+    auto piece_off = [&](int i) __attribute__((always_inline)) {
+        const int r = i / ppr, pc = i - r * ppr;
+        return (row0 + r) * cs + cbase + pc * P;
+    };
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+        const int i = min(t + u * GNF_THREADS, total - 1);  // clamped: out-of-range slots re-read the last piece, weighted 0 below
+        hi[u].v = *reinterpret_cast<const decltype(hi[u].v)*>(src + piece_off(i));
+    }
+    if (lsrc) {
+#pragma unroll
+        for (int u = 0; u < NP; ++u)
+            lo[u].v = *reinterpret_cast<const decltype(lo[u].v)*>(lsrc + piece_off(min(t + u * GNF_THREADS, total - 1)));
+    }
+    // statistics over the hi parts, pieces in gn_fused_kernel's per-thread order (i = t, t + 1024, ...)
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+        if (t + u * GNF_THREADS < total) {
+            float v[P];
+            unpack_piece<T, P>(hi[u], v);
+#pragma unroll
+            for (int k = 0; k < P; ++k) { s1 += v[k]; s2 += v[k] * v[k]; }
+        }
+    }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if ((t & 63) == 0) red[t >> 6] = make_float2(s1, s2);
+    __syncthreads();
+    const float n = (float)rows * (float)cpg;
+    float sum = 0.f, sq = 0.f;
+#pragma unroll
+    for (int w = 0; w < GNF_THREADS / 64; ++w) { sum += red[w].x; sq += red[w].y; }  // fixed order
+    const float mean = sum / n;
+    const float rstd = rsqrtf(fmaxf(sq / n - mean * mean, 0.f) + eps);
+    const int poff = bper > 0 ? (b / bper) * pstride : 0;
+    if (t < cpg) {
+        const float a = gamma[poff + g * cpg + t] * rstd;
+        aff[t] = make_float2(a, beta[poff + g * cpg + t] - mean * a);
+    }
+    __syncthreads();
+    // keep the strip as RAW bits across the reduction: without this the compiler holds the unpacked floats of the statistics
+    // pass alive (2-4x the registers) and the larger instantiations spill
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+        opaque(hi[u].v);
+        opaque(lo[u].v);
+    }
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+        const int i = t + u * GNF_THREADS;
+        if (i < total) {
+            const int r = i / ppr, pc = i - r * ppr;
+            float v[P], y[P];
+            unpack_piece<T, P>(hi[u], v);
+            if (lsrc) {
+                float w[P];
+                unpack_lo<lo_t<T>, P>(lo[u], w);
+#pragma unroll
+                for (int k = 0; k < P; ++k) v[k] += w[k];
+            }
+#pragma unroll
+            for (int k = 0; k < P; ++k) {
+                const float2 ab = aff[pc * P + k];
+                float z = fmaf(v[k], ab.x, ab.y);
+                if (silu) z = silu_f(z);
+                y[k] = z;
+            }
+            store_piece<T, P>(out + (row0 + r) * C + g * cpg + pc * P, y);
+        }
+    }
+}
+
 }  // namespace ur
 
 using namespace ur;
@@ -610,10 +743,36 @@ static int launch_gn_fused(const void* x0, const void* x1, const void* x0_lo, co
                            int pstride, void* out, hipStream_t s) {
     const int cpg = (c0 + c1) / groups;
     dim3 grid(groups, B);
+    if (cpg > 128) return UR_E_UNSUPPORTED;  // the group's affine pairs are staged in a 128-entry LDS table
+    {
+        // register-resident single sweep where the strip fits (<= 4 / 8 pieces per thread) and no group straddles the two sources
+        const int P = (cpg % 8 == 0) ? 8 : (cpg % 4 == 0) ? 4 : (cpg % 2 == 0) ? 2 : 0;
+        const int64_t per_thread = P ? ((int64_t)rows * (cpg / P) + GNF_THREADS - 1) / GNF_THREADS : 0;
+        const bool whole = c1 == 0 || (c0 % cpg) == 0;
+                // bounds = the instantiations that fit 128 VGPRs (1024 threads per workgroup) without spilling
+        const int64_t most = P == 8 ? (sizeof(lo_t<T>) == 1 ? 8 : 4) : P == 4 ? 16 : 20;
+        if (!(silu & 2) && P && whole && per_thread >= 1 && per_thread <= most) {
+            const int np = per_thread <= 2 ? 2 : per_thread <= 4 ? 4 : per_thread <= 8 ? 8 : per_thread <= 16 ? 16 : 20;
+#define UR_GNR(PP, NN)                                                                                                  \
+    hipLaunchKernelGGL((gn_resident_kernel<T, PP, NN>), grid, dim3(GNF_THREADS), 0, s, (const T*)x0, (const T*)x1, (const lo_t<T>*)x0_lo, \
+                       (const lo_t<T>*)x1_lo, c0, c1, rows, groups, gamma, beta, eps, silu & 1, bper, pstride, (T*)out, gnf_xcd())
+#define UR_GNR_P(PP)                                                                \
+    do {                                                                            \
+        if (np == 2) UR_GNR(PP, 2); else if (np == 4) UR_GNR(PP, 4); else if (np == 8) UR_GNR(PP, 8); else UR_GNR(PP, 16); \
+    } while (0)
+            if (P == 8) { if (np == 2) UR_GNR(8, 2); else if (np == 4) UR_GNR(8, 4); else UR_GNR(8, 8); }
+            else if (P == 4) UR_GNR_P(4);
+            else if (np == 20) UR_GNR(2, 20);
+            else UR_GNR_P(2);
+#undef UR_GNR_P
+#undef UR_GNR
+            hipError_t e = hipGetLastError();
+            return e == hipSuccess ? 0 : -(int)e;
+        }
+    }
 #define UR_GNF(PP)                                                                                                     \
     hipLaunchKernelGGL((gn_fused_kernel<T, PP>), grid, dim3(GNF_THREADS), 0, s, (const T*)x0, (const T*)x1, (const lo_t<T>*)x0_lo, \
-                       (const lo_t<T>*)x1_lo, c0, c1, rows, groups, gamma, beta, eps, silu, bper, pstride, (T*)out, gnf_xcd())
-    if (cpg > 128) return UR_E_UNSUPPORTED;  // the group's affine pairs are staged in a 128-entry LDS table
+                       (const lo_t<T>*)x1_lo, c0, c1, rows, groups, gamma, beta, eps, silu & 1, bper, pstride, (T*)out, gnf_xcd())
     if (cpg % 8 == 0) UR_GNF(8);
     else if (cpg % 4 == 0) UR_GNF(4);
     else if (cpg % 2 == 0) UR_GNF(2);

@@ -611,10 +611,26 @@ def resize_nearest(x, size):
 # level (12-15 us against 14-16 for stats + apply; at 64x64 31 against 26: tools/gn_bench.py, profiles/r04_gnf_xcd_ab.txt);
 # in the step 256 -> 1024 rows is +0.45 % steps/s (tools/experiments/r04_run11.sh)
 GN_FUSED_MAX_ROWS = X.number("gn_fused_max_rows", 1024)
+# round 6: small strips of the one-launch GroupNorm stay in registers (one memory round trip); no_gn_resident = always two sweeps
+GN_RESIDENT = X.flag("gn_resident", True)
+# ... and maps LARGER than GN_FUSED_MAX_ROWS pixels take the one-launch kernel too when their strips still fit in registers (the
+# 64x64 level at 320 channels: 20 four-byte pieces per thread) -- one read of the map instead of stats + apply's two
+GN_RESIDENT_MAX_ROWS = X.number("gn_resident_max_rows", 1024)
+
+
+def gn_resident_fits(rows: int, c0: int, c1: int, groups: int, dtype) -> bool:
+    """Mirror of csrc/norm.hip's launch_gn_fused: does the register-resident single-sweep kernel take this GroupNorm?"""
+    cpg = (c0 + c1) // groups
+    P = 8 if cpg % 8 == 0 else 4 if cpg % 4 == 0 else 2 if cpg % 2 == 0 else 0
+    if not P or cpg > 128 or not (c1 == 0 or c0 % cpg == 0):
+        return False
+    per_thread = (rows * (cpg // P) + 1023) // 1024
+    most = (8 if dtype == torch.float16 else 4) if P == 8 else 16 if P == 4 else 20
+    return 1 <= per_thread <= most
 
 
 def groupnorm(x, gamma, beta, eps, *, x1=None, groups=32, silu=False, nstat=None, napply=None, streams=1, fused=None,
-              return_stats=False):
+              return_stats=False, resident=None):
     """GroupNorm over NHWC x (or over cat(x, x1)); returns one contiguous [B,H,W,C0+C1] tensor.
     ``fused``: one launch (ur_groupnorm_fused) instead of stats + apply; default: maps of <= GN_FUSED_MAX_ROWS pixels.
     ``return_stats``: (out, partial statistics of the stats pass | None on the one-launch path) -- the training backward
@@ -627,12 +643,15 @@ def groupnorm(x, gamma, beta, eps, *, x1=None, groups=32, silu=False, nstat=None
     rows = x.numel() // (B * C0)
     if fused is None:
         cpg = (C0 + C1) // groups
-        fused = nstat is None and napply is None and cpg % 2 == 0 and cpg <= 128 and rows <= GN_FUSED_MAX_ROWS
+        fused = nstat is None and napply is None and cpg % 2 == 0 and cpg <= 128 and (
+            rows <= GN_FUSED_MAX_ROWS
+            or (GN_RESIDENT and resident is not False and rows <= GN_RESIDENT_MAX_ROWS and gn_resident_fits(rows, C0, C1, groups, x.dtype)))
     if fused:
         out = torch.empty(*x.shape[:-1], C0 + C1, dtype=x.dtype, device=x.device)
         e0 = _prof_begin()
         check(lib.ur_groupnorm_fused(_ptr(x), _ptr(x1), _ptr(lo_of(x)), _ptr(lo_of(x1)), C0, C1, B, rows, groups,
-                                     gamma.data_ptr(), beta.data_ptr(), float(eps), int(silu),
+                                     gamma.data_ptr(), beta.data_ptr(), float(eps),
+                                     int(bool(silu)) | (0 if (GN_RESIDENT if resident is None else resident) else 2),
                                      (B // streams if streams > 1 else 0), (C0 + C1 if streams > 1 else 0), out.data_ptr(),
                                      DT[x.dtype], _stream()), "ur_groupnorm_fused")
         _prof_end(e0, "gn_fused", 0.0, 2.0 * out.numel() * out.element_size())
