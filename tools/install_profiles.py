@@ -27,7 +27,20 @@ def main():
     shutil.copy(os.path.join(src, "pmc_traffic.json"), os.path.join(PROF, "pmc_traffic.json"))  # bench.py reads this one
     for f in sorted(os.listdir(OUT)):
         if f.startswith("final_") and f.endswith((".json", ".csv", ".txt")):
-            shutil.copy(os.path.join(OUT, f), os.path.join(PROF, f"{tag}_{f[len('final_'):]}"))
+            dst = os.path.join(PROF, f"{tag}_{f[len('final_'):]}")
+            shutil.copy(os.path.join(OUT, f), dst)
+            if f.endswith(".json"):
+                # a tool's stdout can carry foreign lines (RCCL prints its version banner there): keep the JSON lines only, so that
+                # every committed .json parses
+                keep = []
+                for line in open(dst, errors="replace"):
+                    try:
+                        json.loads(line)
+                        keep.append(line if line.endswith("\n") else line + "\n")
+                    except ValueError:
+                        pass
+                if keep:
+                    open(dst, "w").writelines(keep)
     rows, test = [], None
     log = os.path.join(OUT, "final_pytest.log")
     if os.path.exists(log):

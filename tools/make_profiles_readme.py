@@ -125,8 +125,23 @@ per-step graph of the hoisted sampling loops, per-shape event tables, the step g
 hoisted and with every network on every step), `r05_train_graph_rccl_w1_captured.json` / `..._serial.json`
 (`tools/train_bench.py --graph --force-collectives`: the bucketed training step on RCCL world size 1 with the collectives
 captured into the graph vs forward + backward graph | eager collectives | update graph, with per-phase times),
-`NOTEBOOK_r1_r4.md` (the measurement narratives of rounds 1-4, moved out of DESIGN.md verbatim).  The bench line of round 5
+`docs/NOTEBOOK_r1_r4.md` (the measurement narratives of rounds 1-4, moved out of DESIGN.md verbatim).  The bench line of round 5
 carries `loop` and `config.parity_rel_l2`.
+Round-6 additions: `r06_gridbar.txt` (`tools/ubench/gridbar.hip`: a device-wide barrier inside one persistent kernel -- fences +
+counter / counter only with `sc1` data / fences by one workgroup per XCD / hierarchical -- against one kernel launch per phase in
+a graph, 128 / 256 / 512 workgroups, with a cross-XCD data check), `r06_bigwave_sweep.txt` (`tools/ab_gemm.py --sweep --tiles
+9,22,42,43,44,11,28,56..59`: the few-wave / big-wave-tile igemm builds of round 6 on the seven heaviest problems, isolated),
+`r06_insitu_bigwave.txt` / `r06_insitu_cfg2.txt` (`tools/tune_in_situ.py --broad`: the new tiles on the headline step; cfg 2 after
+the chain gate became row-aware), `r06_parity_sweep.json` (`tests/test_parity_sweep_gpu.py -s`: max / mean / min rel-L2 over 8 seeds
+x 4 timestep settings, both executors, both oracles), `r06_loop_bench.json` (incl. the loops WITHOUT the per-call time tables),
+`r06_train_graph_rccl_w1_captured.json` / `..._r05_protocol.json` / `..._serial.json` / `r06_train_graph.json` and
+`r06_train_rccl_kernel_stats_r05_protocol.csv` (`tools/r06_train_ab.sh`, `tools/r06_train_prof.sh`: the bucketed training step with
+gradients written into the buckets vs added into zeroed buckets, one box; the kernel statistics of the old protocol show the 1430
+`add` launches per step), `r06_splitk_gn_ab.txt` (GroupNorm as the split-K second pass over group-blocked slabs, in-step
+alternation), `r06_tchain_rows_ab.txt` (chain kernels forced on / off at 4096 / 8192 / 16384 rows per launch),
+`r06_gn_resident_ab.txt` (`tools/gn_bench.py` + in-step alternation: register-resident one-launch GroupNorm),
+`r06_runtime_env_ab.txt` (HIP runtime knobs against the captured step).  The bench line of round 6 carries `loop.roofline` and
+`loop.parity_rel_l2`.
 Other summaries: `{tag}_parity_numbers.json` (every rel-L2 the `-m gpu` suite printed: the chain kernels, cfg 3 at batch 2 and 4
 and as a 5-step DDIM loop, cfg 5 vs the oracle, the 16384-token attention, UpRes, the module-surface and cfg-4 training steps
 incl. the inverse branch at SD size, the VAE, the RCCL world-size-1 collectives),
