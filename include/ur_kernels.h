@@ -218,11 +218,6 @@ typedef struct ur_igemm_desc {
      * a large region every (workgroup, wave) reads its own 128-byte line instead of all 256 CUs hammering one line of one L2
      * channel (round 4: the conv kernels read 2 - 8 padding rows per K step). */
     int32_t zero_page_bytes;
-    /* INTERNAL (ABI 11; callers leave it 0, ur_igemm_splitk_gn sets it): > 0 = channels per GroupNorm group; the split-K main
-     * pass then writes its fp32 slabs GROUP-BLOCKED, slab[z][sample][group][row][channel in group], so that the second pass of
-     * ur_igemm_splitk_gn -- one workgroup per (z, sample, group) -- reads its strip of every slab as ONE contiguous run instead
-     * of (N / groups) * 4-byte pieces of every row (what made the round-4 version slower than reduce + GroupNorm). */
-    int32_t slab_cpg;
 } ur_igemm_desc;
 
 int ur_igemm(const ur_igemm_desc* d, void* stream);

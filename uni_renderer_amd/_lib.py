@@ -40,7 +40,7 @@ class IGemmDesc(C.Structure):
         ("t0", vp), ("t1", vp), ("ldt0", i64), ("ldt1", i64), ("zt0", i64), ("zt1", i64), ("ct0", i32), ("ct1", i32),
         ("pad", i32),
         ("out_vt", vp), ("ldvt", i64), ("vt_bstride", i64), ("zvt", i64), ("vt_n0", i32), ("vt_rows", i32),
-        ("zero_page_bytes", i32), ("slab_cpg", i32),
+        ("zero_page_bytes", i32),
     ]
 
 

@@ -452,35 +452,18 @@ __global__ void __launch_bounds__((WM * WN + NL) * 64) igemm_kernel(const ur_ige
     auto finish = [&](int m, int nc, float (&v)[16]) __attribute__((always_inline)) {
         if (p.splitk > 1) {
             if (m < p.M) {
-                if (p.slab_cpg > 0) {
-                    // group-blocked slabs for ur_igemm_splitk_gn: slab[zidx][sample][group][row][channel in group]; a quad of
-                    // channels never straddles a group (cpg % 4 == 0)
-                    const int cpg = p.slab_cpg, rows = p.Hout * p.Wout;
-                    const int b = m / rows, r = m - b * rows;
-                    float* base = p.partial + (int64_t)zidx * p.M * p.N + (int64_t)b * rows * p.N;
+                float4* pp = reinterpret_cast<float4*>(p.partial + ((int64_t)zidx * p.M + m) * p.ldp + nc);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int c = nc + 4 * i;
-                        if (c < p.N) {
-                            const int g = c / cpg;
-                            *reinterpret_cast<float4*>(base + ((int64_t)g * rows + r) * cpg + (c - g * cpg)) =
-                                make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
-                        }
-                    }
-                } else {
-                    float4* pp = reinterpret_cast<float4*>(p.partial + ((int64_t)zidx * p.M + m) * p.ldp + nc);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) pp[i] = make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
-                }
+                for (int i = 0; i < 4; ++i) pp[i] = make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
             }
         } else {
-            epilogue16<T>(p, reinterpret_cast<T*>(p.out) + (int64_t)zb * p.zout,
-                          p.bias ? p.bias + (int64_t)zb * p.zbias : nullptr,
-                          p.rowadd ? reinterpret_cast<const T*>(p.rowadd) + (int64_t)zb * p.zrow : nullptr,
-                          p.res ? reinterpret_cast<const T*>(p.res) + (int64_t)zb * p.zres : nullptr, m, nc, v,
-                          HiLo<T>{p.res_lo ? reinterpret_cast<const lo_t<T>*>(p.res_lo) + (int64_t)zb * p.zres : nullptr,
-                                  p.out_lo ? reinterpret_cast<lo_t<T>*>(p.out_lo) + (int64_t)zb * p.zout : nullptr},
-                          p.out_vt ? reinterpret_cast<T*>(p.out_vt) + (int64_t)zb * p.zvt : nullptr);
+            epilogue16<T, CONV>(p, reinterpret_cast<T*>(p.out) + (int64_t)zb * p.zout,
+                                p.bias ? p.bias + (int64_t)zb * p.zbias : nullptr,
+                                p.rowadd ? reinterpret_cast<const T*>(p.rowadd) + (int64_t)zb * p.zrow : nullptr,
+                                p.res ? reinterpret_cast<const T*>(p.res) + (int64_t)zb * p.zres : nullptr, m, nc, v,
+                                HiLo<T>{p.res_lo ? reinterpret_cast<const lo_t<T>*>(p.res_lo) + (int64_t)zb * p.zres : nullptr,
+                                        p.out_lo ? reinterpret_cast<lo_t<T>*>(p.out_lo) + (int64_t)zb * p.zout : nullptr},
+                                (!CONV && p.out_vt) ? reinterpret_cast<T*>(p.out_vt) + (int64_t)zb * p.zvt : nullptr);
         }
     };
     if constexpr (MF == 32) {
@@ -574,26 +557,9 @@ __global__ void __launch_bounds__(RGN_THREADS) igemm_splitk_reduce_gn(const ur_i
             const int r = e / qpr, c = c0 + (e - r * qpr) * 4;
             const int m = b * rows + r;
             float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p.slab_cpg > 0) {
-                // group-blocked slabs (igemm_kernel's finish): this workgroup's strip of a slab is ONE contiguous run, quad e of it.
-                // Four slabs' loads are issued before the first add (a runtime-length loop of load -> add is a chain of
-                // memory latencies: that, not the access pattern, is what made this pass slow); the sum keeps slab order.
-                const float* sp = p.partial + (int64_t)zb * p.splitk * p.M * p.N + ((int64_t)b * groups + g) * rows * cpg + (int64_t)e * 4;
-                const int64_t sstride = (int64_t)p.M * p.N;
-                for (int ks = 0; ks < p.splitk; ks += 4) {
-                    float4 t[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        t[j] = *reinterpret_cast<const float4*>(sp + (int64_t)min(ks + j, p.splitk - 1) * sstride);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (ks + j < p.splitk) { a.x += t[j].x; a.y += t[j].y; a.z += t[j].z; a.w += t[j].w; }
-                }
-            } else {
-                for (int ks = 0; ks < p.splitk; ++ks) {
-                    const float4 t = *reinterpret_cast<const float4*>(p.partial + (((int64_t)zb * p.splitk + ks) * p.M + m) * p.ldp + c);
-                    a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
-                }
+            for (int ks = 0; ks < p.splitk; ++ks) {
+                const float4 t = *reinterpret_cast<const float4*>(p.partial + (((int64_t)zb * p.splitk + ks) * p.M + m) * p.ldp + c);
+                a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
             }
             float x[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
@@ -901,6 +867,7 @@ static int igemm_run(ur_igemm_desc& d, void* stream, bool reduce = true) {
     if (d.K != d.taps * (d.c0 + d.c1) + d.ct0 + d.ct1) return UR_E_BADARG;
     if ((d.ldx0 % 8) || (d.c1 > 0 && (d.ldx1 % 8)) || (d.ldw % 8)) return UR_E_BADARG;
     if (d.taps == 9) {
+        if (d.act == UR_ACT_GEGLU || d.out_vt) return UR_E_BADARG;  // the conv instantiations carry the lean epilogue (igemm_epi.h)
         if (d.B <= 0 || d.Hin <= 0 || d.Win <= 0 || d.Hout <= 0 || d.Wout <= 0) return UR_E_BADARG;
         if (d.stride != 1 && d.stride != 2) return UR_E_BADARG;
         if (d.M != d.B * d.Hout * d.Wout) return UR_E_BADARG;
@@ -943,7 +910,6 @@ extern "C" int ur_igemm_uses_dxs(const ur_igemm_desc* d) {
 extern "C" int ur_igemm(const ur_igemm_desc* din, void* stream) {
     if (!din) return UR_E_BADARG;
     ur_igemm_desc d = *din;
-    d.slab_cpg = 0;  // internal to ur_igemm_splitk_gn
     return igemm_run(d, stream);
 }
 
@@ -958,10 +924,6 @@ extern "C" int ur_igemm_splitk_gn(const ur_igemm_desc* din, const float* gamma, 
         return UR_E_UNSUPPORTED;
     if (d.rowadd && d.rows_per_b != rows) return UR_E_BADARG;
     if (d.n_store > 0 && d.n_store != d.N) return UR_E_BADARG;
-    // group-blocked slabs where the main pass is igemm_kernel itself (the opt-in experiment kernels keep the row-major layout)
-    const bool plain_tile = d.tile != UR_TILE_AUTO && d.tile != UR_TILE_WS320 && d.tile != UR_TILE_WS320_W8 &&
-                            !(d.tile >= UR_TILE_PP_128x320 && d.tile <= UR_TILE_PP_256x320) && !dxs_enabled();
-    d.slab_cpg = (plain_tile && d.M == d.B * rows) ? d.N / groups : 0;
     const int rc = igemm_run(d, stream, /*reduce=*/false);
     if (rc) return rc;
     if (d.splitk <= 1) return UR_E_BADARG;  // (clamped away: K too short for a split)

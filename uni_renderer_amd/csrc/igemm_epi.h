@@ -63,12 +63,15 @@ __device__ __noinline__ void epilogue16_slow(EpiArgs p, T* __restrict__ outz, co
         }
 }
 
-template <typename T>
+// LEAN = true (the 3x3 conv instantiations): no transposed side output and no GEGLU -- neither exists for a conv (igemm_run rejects
+// the combination), and every byte of epilogue code is inlined once per accumulator fragment of the wave tile (4 - 10 copies) and
+// fetched cold by every workgroup of a launch: code size is launch latency (profiles/r06_slab_binary_ab.txt: +6 KB = +1.3 % step time).
+template <typename T, bool LEAN = false>
 __device__ __forceinline__ void epilogue16(const ur_igemm_desc& p, T* __restrict__ outz, const float* biasz,
                                            const T* rowaddz, const T* resz, int m, int nc, float (&v)[16], HiLo<T> hl,
                                            T* __restrict__ vtz = nullptr) {
     if (m >= p.M) return;
-    if (vtz != nullptr && nc >= p.vt_n0) {
+    if (!LEAN && vtz != nullptr && nc >= p.vt_n0) {
         // transposed side output (ur_igemm_desc.out_vt): this lane's 16 channels of token m go to 16 rows of V^T; the
         // lanes of a 16- / 32-lane group hold consecutive tokens, so every store instruction writes 32- / 64-byte runs
         if (nc + 16 > p.N) return;  // vt_n0 and N - vt_n0 are multiples of 16 (checked on the host)
@@ -83,7 +86,7 @@ __device__ __forceinline__ void epilogue16(const ur_igemm_desc& p, T* __restrict
         return;
     }
     const bool vec = (((p.ldc | p.ldres | (int64_t)p.ld_rowadd) & 7) == 0);
-    const int n_out_end = (p.act == ACT_GEGLU) ? (nc >> 1) + 8 : nc + 16;
+    const int n_out_end = (!LEAN && p.act == ACT_GEGLU) ? (nc >> 1) + 8 : nc + 16;
     if (__builtin_expect(!(vec && nc + 16 <= p.N && n_out_end <= p.n_store), 0)) {
         V16 a;
 #pragma unroll
@@ -110,7 +113,7 @@ __device__ __forceinline__ void epilogue16(const ur_igemm_desc& p, T* __restrict
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[8 + i] += t[i];
     }
-    if (p.act == ACT_GEGLU) {
+    if (!LEAN && p.act == ACT_GEGLU) {
         float o[8];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {

@@ -544,11 +544,12 @@ def conv3x3(x, w, bias=None, *, x1=None, stride=1, ups=False, rowadd=None, res=N
 
 # conv -> GroupNorm (+ SiLU) with the normalisation as the split-K second pass (ur_igemm_splitk_gn).  OFF by default: parity is
 # green (tests/test_ops_gpu.py), but the step is 0.07 ms SLOWER with it (85.42 / 85.65 -> 85.01 / 84.92 steps/s alternating
-# on one box, profiles/r04_splitk_gn_ab.txt).  Round 4 blamed the 160-byte runs in which one workgroup per (sample, group) read
-# its strip of the row-major slabs; round 6 made the slabs GROUP-BLOCKED (every strip one contiguous run, ur_igemm_desc.slab_cpg)
-# and issued four slabs' loads before the first add -- still 0.05-0.06 ms slower (11.47 vs 11.41 ms, profiles/r06_splitk_gn_ab.txt):
-# 256 workgroups with two block-wide reductions lose to 4096 independent reduce blocks + the one-launch GroupNorm reading fp16
-# from L2; the access pattern was not the cause.  UR_EXPERIMENT=splitk_gn enables it.
+# on one box, profiles/r04_splitk_gn_ab.txt).  Round 4 blamed the 160-byte runs in which one workgroup per (sample, group) reads
+# its strip of the row-major slabs; round 6 tried GROUP-BLOCKED slabs (every strip one contiguous run) with four slabs' loads in
+# flight -- still 0.05-0.06 ms slower (profiles/r06_splitk_gn_ab.txt: 256 workgroups with two block-wide reductions lose to 4096
+# independent reduce blocks + the one-launch GroupNorm), AND the extra code in igemm_kernel's split-K epilogue cost every other
+# launch 1.3 % (profiles/r06_slab_binary_ab.txt), so that variant is a patch (tools/patches/r06_group_blocked_slabs.patch), not
+# in the tree.  UR_EXPERIMENT=splitk_gn enables the round-4 form.
 SPLITK_GN = X.flag("splitk_gn", False)
 
 
