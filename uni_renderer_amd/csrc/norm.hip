@@ -176,10 +176,16 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const T* __restrict__ x0,
         float s = 0.f, ss = 0.f;
         if (g < groups) {
             const float2* src = reinterpret_cast<const float2*>(partial) + (int64_t)b * nstat * groups + g;
-            for (int k = j; k < nstat; k += 4) {
-                float2 a = src[(int64_t)k * groups];
-                s += a.x;
-                ss += a.y;
+            // eight partials in flight per thread (round 6): the runtime-length load -> add loop was a chain of up to eight memory
+            // round trips in the prologue of EVERY workgroup (nstat = 32), longer than the streaming part at the 64x64 level;
+            // same summation order
+            for (int k0 = j; k0 < nstat; k0 += 32) {
+                float2 a[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a[u] = src[(int64_t)min(k0 + 4 * u, nstat - 1) * groups];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (k0 + 4 * u < nstat) { s += a[u].x; ss += a[u].y; }
             }
         }
         red[j][g] = make_float2(s, ss);
