@@ -493,11 +493,27 @@ __global__ void __launch_bounds__((WM * WN + NL) * 64) igemm_kernel(const ur_ige
     }
 }
 
-// Second pass of split-K: sum the fp32 slabs and run the epilogue.  One thread per (row, 16 columns).
-template <typename T>
+// Second pass of split-K: sum the fp32 slabs and run the epilogue.  One thread per (row, 16 columns).  Round 6: the epilogue's
+// operand loads are issued BEFORE the slab loads and the slabs four at a time (igemm_epi.h, epi_preload / epi_apply): the kernel has
+// ~2.5 waves per SIMD on the small maps and its run time was the length of its chain of dependent loads.  Same sums in the same
+// order: bit-identical results.
+// PIPE = true only for SMALL second passes (< REDUCE_PIPE_MAX_THREADS threads: the 8x8 level, everything at cfg 2): there the launch is
+// under one wave per SIMD and pure latency; from the 16x16 level up the kernel is L2 / HBM-bound and the extra loads in flight made it
+// 5 % SLOWER in the step (profiles/r06_splitk_reduce_ab.txt, r06_reduce_prof.txt), so those keep the slab-after-slab loop.
+constexpr int64_t REDUCE_PIPE_MAX_THREADS = 65536;
+template <typename T, bool PIPE>
 __global__ void __launch_bounds__(256) igemm_splitk_reduce(const ur_igemm_desc p) {
     const int groups = (int)(p.ldp / 16);
     const int64_t total = (int64_t)p.M * groups;
+    const int zb = blockIdx.y;
+    T* outz = reinterpret_cast<T*>(p.out) + (int64_t)zb * p.zout;
+    const float* biasz = p.bias ? p.bias + (int64_t)zb * p.zbias : nullptr;
+    const T* rowz = p.rowadd ? reinterpret_cast<const T*>(p.rowadd) + (int64_t)zb * p.zrow : nullptr;
+    const T* resz = p.res ? reinterpret_cast<const T*>(p.res) + (int64_t)zb * p.zres : nullptr;
+    const lo_t<T>* rloz = p.res_lo ? reinterpret_cast<const lo_t<T>*>(p.res_lo) + (int64_t)zb * p.zres : nullptr;
+    lo_t<T>* oloz = p.out_lo ? reinterpret_cast<lo_t<T>*>(p.out_lo) + (int64_t)zb * p.zout : nullptr;
+    T* vtz = p.out_vt ? reinterpret_cast<T*>(p.out_vt) + (int64_t)zb * p.zvt : nullptr;
+    const int64_t sstride = (int64_t)p.M * p.ldp;  // floats between two slabs of one problem
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (int64_t)gridDim.x * blockDim.x) {
         const int m = (int)(idx / groups);
@@ -505,24 +521,43 @@ __global__ void __launch_bounds__(256) igemm_splitk_reduce(const ur_igemm_desc p
         float v[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) v[i] = 0.f;
-        const int zb = blockIdx.y;
-        for (int z = 0; z < p.splitk; ++z) {
-            const float4* pp =
-                reinterpret_cast<const float4*>(p.partial + (((int64_t)zb * p.splitk + z) * p.M + m) * p.ldp + nc);
+        const float* base = p.partial + ((int64_t)zb * p.splitk * p.M + m) * p.ldp + nc;
+        if constexpr (!PIPE) {
+            for (int z = 0; z < p.splitk; ++z) {
+                const float4* pp = reinterpret_cast<const float4*>(base + (int64_t)z * sstride);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float4 a = pp[i];
-                v[4 * i] += a.x; v[4 * i + 1] += a.y; v[4 * i + 2] += a.z; v[4 * i + 3] += a.w;
+                for (int i = 0; i < 4; ++i) {
+                    float4 a = pp[i];
+                    v[4 * i] += a.x; v[4 * i + 1] += a.y; v[4 * i + 2] += a.z; v[4 * i + 3] += a.w;
+                }
             }
+            if (nc < p.n_store || nc < p.N) epilogue16<T>(p, outz, biasz, rowz, resz, m, nc, v, HiLo<T>{rloz, oloz}, vtz);
+            continue;
         }
-        if (nc < p.n_store || nc < p.N)
-            epilogue16<T>(p, reinterpret_cast<T*>(p.out) + (int64_t)zb * p.zout,
-                          p.bias ? p.bias + (int64_t)zb * p.zbias : nullptr,
-                          p.rowadd ? reinterpret_cast<const T*>(p.rowadd) + (int64_t)zb * p.zrow : nullptr,
-                          p.res ? reinterpret_cast<const T*>(p.res) + (int64_t)zb * p.zres : nullptr, m, nc, v,
-                          HiLo<T>{p.res_lo ? reinterpret_cast<const lo_t<T>*>(p.res_lo) + (int64_t)zb * p.zres : nullptr,
-                                  p.out_lo ? reinterpret_cast<lo_t<T>*>(p.out_lo) + (int64_t)zb * p.zout : nullptr},
-                          p.out_vt ? reinterpret_cast<T*>(p.out_vt) + (int64_t)zb * p.zvt : nullptr);
+        const bool split = epi_split_ok<T>(p, nc, vtz);
+        EpiOperands<T> op;
+        if (split) epi_preload<T>(p, op, biasz, rowz, resz, rloz, m, nc, p.zero_page);
+        for (int z0 = 0; z0 < p.splitk; z0 += 4) {  // four slabs (16 loads) in flight, summed in slab order
+            float4 a[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float4* pp = reinterpret_cast<const float4*>(base + (int64_t)min(z0 + u, p.splitk - 1) * sstride);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a[u][i] = pp[i];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (z0 + u < p.splitk) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        v[4 * i] += a[u][i].x; v[4 * i + 1] += a[u][i].y; v[4 * i + 2] += a[u][i].z; v[4 * i + 3] += a[u][i].w;
+                    }
+                }
+        }
+        if (split)
+            epi_apply<T>(p, op, outz, biasz != nullptr, rowz != nullptr, resz != nullptr, rloz != nullptr, oloz, m, nc, v);
+        else if (nc < p.n_store || nc < p.N)
+            epilogue16<T>(p, outz, biasz, rowz, resz, m, nc, v, HiLo<T>{rloz, oloz}, vtz);
     }
 }
 
@@ -672,7 +707,8 @@ static int launch_cfg(const ur_igemm_desc& d, hipStream_t s, bool reduce) {
         const int64_t total = (int64_t)d.M * (d.ldp / 16);
         int blocks = (int)((total + 255) / 256);
         if (blocks > 4096) blocks = 4096;
-        hipLaunchKernelGGL((igemm_splitk_reduce<T>), dim3(blocks, d.zbatch), dim3(256), 0, s, d);
+        if (total * d.zbatch < REDUCE_PIPE_MAX_THREADS) hipLaunchKernelGGL((igemm_splitk_reduce<T, true>), dim3(blocks, d.zbatch), dim3(256), 0, s, d);
+        else hipLaunchKernelGGL((igemm_splitk_reduce<T, false>), dim3(blocks, d.zbatch), dim3(256), 0, s, d);
         e = hipGetLastError();
         if (e != hipSuccess) return -(int)e;
     }
@@ -715,7 +751,8 @@ static int launch_pp(const ur_igemm_desc& d, hipStream_t s, bool reduce) {
         const int64_t total = (int64_t)d.M * (d.ldp / 16);
         int blocks = (int)((total + 255) / 256);
         if (blocks > 4096) blocks = 4096;
-        hipLaunchKernelGGL((igemm_splitk_reduce<T>), dim3(blocks, d.zbatch), dim3(256), 0, s, d);
+        if (total * d.zbatch < REDUCE_PIPE_MAX_THREADS) hipLaunchKernelGGL((igemm_splitk_reduce<T, true>), dim3(blocks, d.zbatch), dim3(256), 0, s, d);
+        else hipLaunchKernelGGL((igemm_splitk_reduce<T, false>), dim3(blocks, d.zbatch), dim3(256), 0, s, d);
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) return -(int)e;
     }
@@ -731,7 +768,8 @@ static int launch_ws(const ur_igemm_desc& d, hipStream_t s, bool reduce) {
         const int64_t total = (int64_t)d.M * (d.ldp / 16);
         int blocks = (int)((total + 255) / 256);
         if (blocks > 4096) blocks = 4096;
-        hipLaunchKernelGGL((igemm_splitk_reduce<T>), dim3(blocks, d.zbatch), dim3(256), 0, s, d);
+        if (total * d.zbatch < REDUCE_PIPE_MAX_THREADS) hipLaunchKernelGGL((igemm_splitk_reduce<T, true>), dim3(blocks, d.zbatch), dim3(256), 0, s, d);
+        else hipLaunchKernelGGL((igemm_splitk_reduce<T, false>), dim3(blocks, d.zbatch), dim3(256), 0, s, d);
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) return -(int)e;
     }
@@ -750,7 +788,8 @@ static int launch_dtype(ur_igemm_desc& d, hipStream_t s, bool reduce) {
                 const int64_t total = (int64_t)d.M * (d.ldp / 16);
                 int blocks = (int)((total + 255) / 256);
                 if (blocks > 4096) blocks = 4096;
-                hipLaunchKernelGGL((igemm_splitk_reduce<T>), dim3(blocks, d.zbatch), dim3(256), 0, s, d);
+                if (total * d.zbatch < REDUCE_PIPE_MAX_THREADS) hipLaunchKernelGGL((igemm_splitk_reduce<T, true>), dim3(blocks, d.zbatch), dim3(256), 0, s, d);
+        else hipLaunchKernelGGL((igemm_splitk_reduce<T, false>), dim3(blocks, d.zbatch), dim3(256), 0, s, d);
                 const hipError_t e = hipGetLastError();
                 if (e != hipSuccess) return -(int)e;
             }

@@ -169,4 +169,93 @@ __device__ __forceinline__ void epilogue16(const ur_igemm_desc& p, T* __restrict
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Epilogue in two halves for the split-K second pass (round 6).  igemm_splitk_reduce is one thread per (row, 16 columns) with only
+// ~2.5 waves per SIMD on the 16x16 / 8x8 maps, so its run time was the LENGTH OF ITS LOAD CHAIN: split-K slab after slab (a
+// runtime-length load -> add loop), then bias -> wait -> time-embedding row -> wait -> residual -> wait -> low part -> wait ->
+// store: 8 - 20 dependent memory round trips for 10 us of a launch that moves 47 MB.  epi_preload issues every epilogue
+// operand load up front and UNCONDITIONALLY (an absent operand reads the zero page and is ignored), the caller then issues its
+// slab loads, and epi_apply does the arithmetic in epilogue16's order (bit-identical results) and stores.  Straight-line case
+// only (epi_split_ok); anything else goes through epilogue16.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T> struct EpiOperands {
+    float4 b4[4];                            // bias, 16 channels
+    typename Vec8<T>::type ra[2], rs[2];     // time-embedding row, residual: 16 channels each
+    uint2 lo[sizeof(lo_t<T>) == 1 ? 2 : 4];  // low part of the residual in 8-byte pieces (e5m2 rows are only 8-byte aligned)
+};
+
+template <typename T>
+__device__ __forceinline__ bool epi_split_ok(const ur_igemm_desc& p, int nc, const void* vtz) {
+    return (((p.ldc | p.ldres | (int64_t)p.ld_rowadd) & 7) == 0) && p.act != ACT_GEGLU && vtz == nullptr && nc + 16 <= p.N &&
+           nc + 16 <= p.n_store;
+}
+
+template <typename T>
+__device__ __forceinline__ void epi_preload(const ur_igemm_desc& p, EpiOperands<T>& op, const float* biasz, const T* rowaddz,
+                                            const T* resz, const lo_t<T>* res_lo, int m, int nc, const void* zero_page) {
+    typedef typename Vec8<T>::type vec8;
+    const char* zp = reinterpret_cast<const char*>(zero_page);
+    const float4* bs = biasz ? reinterpret_cast<const float4*>(biasz + nc) : reinterpret_cast<const float4*>(zp);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) op.b4[i] = bs[i];
+    const vec8* ra = rowaddz ? reinterpret_cast<const vec8*>(rowaddz + (int64_t)(m / p.rows_per_b) * p.ld_rowadd + nc)
+                             : reinterpret_cast<const vec8*>(zp);
+    const vec8* rs = resz ? reinterpret_cast<const vec8*>(resz + (int64_t)m * p.ldres + nc) : reinterpret_cast<const vec8*>(zp);
+    op.ra[0] = ra[0]; op.ra[1] = ra[1];
+    op.rs[0] = rs[0]; op.rs[1] = rs[1];
+    const char* rl = res_lo ? reinterpret_cast<const char*>(res_lo + (int64_t)m * p.ldres + nc) : zp;
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(op.lo) / sizeof(uint2)); ++i) op.lo[i] = reinterpret_cast<const uint2*>(rl)[i];
+}
+
+template <typename T>
+__device__ __forceinline__ void epi_apply(const ur_igemm_desc& p, const EpiOperands<T>& op, T* __restrict__ outz, bool has_b,
+                                          bool has_ra, bool has_rs, bool has_lo, lo_t<T>* out_lo, int m, int nc, float (&x)[16]) {
+    if (has_b) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            x[4 * i + 0] += op.b4[i].x; x[4 * i + 1] += op.b4[i].y; x[4 * i + 2] += op.b4[i].z; x[4 * i + 3] += op.b4[i].w;
+        }
+    }
+    if (has_ra) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { x[i] += (float)op.ra[0][i]; x[8 + i] += (float)op.ra[1][i]; }
+    }
+    if (p.act == ACT_SILU) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) x[i] = silu_f(x[i]);
+    }
+    if (has_rs) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { x[i] += (float)op.rs[0][i]; x[8 + i] += (float)op.rs[1][i]; }
+        if (has_lo) {
+            lo_t<T> l[16];
+            __builtin_memcpy(l, op.lo, sizeof(op.lo));
+#pragma unroll
+            for (int i = 0; i < 16; ++i) x[i] += lo_to_f(l[i]);
+        }
+    }
+    if (p.out_scale != 1.0f) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) x[i] *= p.out_scale;
+    }
+    T* dst = outz + (int64_t)m * p.ldc + nc;
+    float t[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t[i] = x[i];
+    store8(dst, t);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t[i] = x[8 + i];
+    store8(dst + 8, t);
+    if (out_lo) {
+        lo_t<T>* dlo = out_lo + (int64_t)m * p.ldc + nc;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t[i] = x[i];
+        store_lo8<T>(dlo, t);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t[i] = x[8 + i];
+        store_lo8<T>(dlo + 8, t);
+    }
+}
+
 }  // namespace ur
