@@ -451,6 +451,36 @@ def test_time_tables_of_a_loop_equal_per_step_time_embeddings_bitwise(dev, sched
     assert any(st.get("tgraph") is not None for st in pipe._sample_graphs.values())
 
 
+def test_step_by_step_loops_run_the_invariant_half_once_and_notice_changed_fixed_inputs(dev):
+    """the hoisted executor re-runs its prologue when a FIXED input of the loop changes identity in mid-loop (address /
+    version / shape check, no device sync) -- and only then: the step-by-step loops of the pipeline hand it the same objects on every
+    step, so a loop of n steps runs the prologue once per direction, not n times."""
+    from uni_renderer_amd.graph import GraphedHoistedStep
+
+    pipe, _, img, mask, ehs, _ = _setup(dev, seed=33)
+    _run_loops(pipe, dev, img, mask, ehs, "ddim", 0.0, False, steps=5)  # fused=False: the step-by-step sampler
+    gs = [g for g in pipe._graphs.values() if isinstance(g, GraphedHoistedStep)]
+    assert len(gs) == 2
+    base = [g.prologue_runs for g in gs]
+    _run_loops(pipe, dev, img, mask, ehs, "ddim", 0.0, False, steps=5)
+    assert [g.prologue_runs - b for g, b in zip(gs, base)] == [1, 1]
+    # a changed fixed input in mid-loop is noticed: the prologue runs again and the result follows the new input
+    g = next(x for x in gs if x.run_decoder)
+    x = torch.randn(2, 4, 16, 16, device=dev).half()
+    c = torch.randn(2, 28, 16, 16, device=dev).half()
+    e = (torch.randn(2, 77, 64, device=dev) * 0.5).half()
+    t0 = torch.zeros((), device=dev)
+    a = g.step(x, c, e, t0, 500.0, first=True)["attr_pred"].clone()
+    n0 = g.prologue_runs
+    b = g.step(x, c, e, t0, 500.0, first=False)["attr_pred"].clone()
+    assert g.prologue_runs == n0 and torch.equal(a, b)
+    x2 = x * 0.5
+    c2 = g.step(x2, c, e, t0, 500.0, first=False)["attr_pred"].clone()
+    assert g.prologue_runs == n0 + 1 and not torch.equal(a, c2)
+    ref = g.step(x2, c, e, t0, 500.0, first=True)["attr_pred"].clone()
+    assert torch.equal(c2, ref)
+
+
 def test_select_step_rows(dev):
     from uni_renderer_amd import ops
 

@@ -185,6 +185,7 @@ class GraphedHoistedStep:
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.out: Optional[Dict[str, torch.Tensor]] = None
         self._fixed_sig = None
+        self.prologue_runs = 0  # diagnostics / tests: how often the loop-invariant half ran
 
     load_inputs = GraphedDualStreamStep.load_inputs
 
@@ -261,6 +262,7 @@ class GraphedHoistedStep:
         if self.graph is None:
             self.capture()
         self.pro.replay()
+        self.prologue_runs += 1
 
     @torch.no_grad()
     def step(self, x_t=None, cond=None, ehs=None, t_img=None, t_attr=None, first: bool = True):
@@ -280,6 +282,7 @@ class GraphedHoistedStep:
                 self.load_inputs(x_t, cond, ehs, t_img, t_attr)
             self._fixed_sig = self._sig(fixed)
             self.pro.replay()
+            self.prologue_runs += 1
         elif x_t is not None or cond is not None:
             self.load_evolving(x_t, cond, t_img, t_attr)
         self.graph.replay()

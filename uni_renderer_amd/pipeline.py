@@ -444,7 +444,12 @@ class UniRendererPipeline:
             timesteps_img = timesteps_attr = []  # loop below is skipped
         sig = self._weights_signature() if len(timesteps_attr) else None  # once per call, not per step
         with self.progress_bar(total=num_inference_steps) as bar:
-            for i, (t_img, t_attr) in enumerate(zip(timesteps_img, timesteps_attr)):
+            # the clean image latent's timestep is the constant 0 (ref 2476): hand the hoisted executor the SAME tensor object on every
+            # step -- it re-runs its prologue when a fixed input changes identity (graph.GraphedHoistedStep.step), and the per-step
+            # elements of `timesteps_img` are distinct views
+            t_img_fixed = timesteps_img[0] if len(timesteps_img) else None
+            for i, (_, t_attr) in enumerate(zip(timesteps_img, timesteps_attr)):
+                t_img = t_img_fixed
                 cat = torch.cat([dup(lat[n]) for n in ATTR_GROUPS], dim=1)
                 cat = self.scheduler_attr.scale_model_input(cat, t_attr)
                 cond28 = torch.cat((x_mask.to(cat.dtype), cat), dim=1)  # mask latent first: 4 + 6*4 = 28 channels
@@ -526,8 +531,9 @@ class UniRendererPipeline:
             timesteps = timesteps[:0]  # loop below is skipped
         sig = self._weights_signature() if len(timesteps) else None
         with self.progress_bar(total=num_inference_steps) as bar:
+            t_attr_fixed = timesteps_attr[0] if len(timesteps) else None  # clean attributes: the constant 0, one object (see above)
             for i in range(len(timesteps)):
-                t_img, t_attr = timesteps[i], timesteps_attr[i]
+                t_img, t_attr = timesteps[i], t_attr_fixed
                 x = self.scheduler_img.scale_model_input(dup(latents_img), t_img)
                 out = self._step(x, cond28, prompt_embeds, t_img, t_attr, run_decoder=False,
                                  cond_scale=float(controlnet_conditioning_scale), sig=sig, first=(i == 0))
