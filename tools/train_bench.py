@@ -47,6 +47,8 @@ def main():
                     "with the backward), or with --no-overlap: forward + backward graph, eager collectives, update graph")
     ap.add_argument("--force-collectives", action="store_true", help="one rank: still build the buckets and issue the RCCL "
                     "collectives (world size 1), to time / profile the multi-GPU code path on one GPU")
+    ap.add_argument("--gradient-checkpointing", action="store_true", help="enable_gradient_checkpointing() on the three networks "
+                    "(train/train.py:1073-1074): the resnets of the flagged blocks are recomputed in the backward")
     ap.add_argument("--accumulate-into-buckets", action="store_true", help="round-5 gradient protocol (zero the flat buckets, autograd "
                     "adds every gradient into them) instead of round 6's direct writes (backward.GradSink): A/B runs")
     args = ap.parse_args()
@@ -65,6 +67,8 @@ def main():
     for m in nets:
         m.train()
         m.requires_grad_(True)
+        if args.gradient_checkpointing:
+            m.enable_gradient_checkpointing()
     B, L = args.batch, args.latent
     g = torch.Generator(device=dev).manual_seed(7 + rank)
     mk = lambda *s: torch.randn(*s, device=dev, generator=g)

@@ -419,7 +419,7 @@ class WgradQueue:
     appears a second time before a flush (autograd would ADD the two gradients right away) forces the flush."""
 
     def __init__(self):
-        self.items, self.seen = [], set()
+        self.items, self.seen, self.keep = [], set(), []
         self.trace: Optional[dict] = None   # set to a dict to count (problem, group size) per flush (tools/tune_wgrad.py)
         # Every pending item keeps its (dy, x) alive until the flush, i.e. until the END of its network's backward: saved
         # inputs are not released layer by layer any more and every layer's output gradient is alive at once.  ``pending``
@@ -431,8 +431,15 @@ class WgradQueue:
         self.early_flushes = 0
         self.cap = int(os.environ.get("UR_WGRAD_PENDING_MB", str(24 << 10))) << 20
 
-    def add(self, dy2: torch.Tensor, x2: torch.Tensor, w_key: int, need_bias: bool, conv: Optional[Tuple[int, int, int]] = None):
+    def add(self, dy2: torch.Tensor, x2: torch.Tensor, w_key, need_bias: bool, conv: Optional[Tuple[int, int, int]] = None):
         """``conv`` = (Ho, Wo, stride) with x2 the NHWC input of a 3x3 conv (dw then in the packed layout), else x2 [P, K]."""
+        if isinstance(w_key, torch.Tensor):
+            # the weight itself: kept alive until the flush so that its ADDRESS -- the identity `seen` goes by -- cannot be handed
+            # to another weight in the meantime.  (Under gradient checkpointing the recomputed packed weights are short-lived
+            # temporaries; their addresses were reused resnet after resnet, every reuse looked like a repeated weight and
+            # flushed the queue early: smaller groups, other (tile, slices) plans, gradients a bf16 ulp off the plain step's.)
+            self.keep.append(w_key)
+            w_key = w_key.data_ptr()
         if w_key in self.seen or torch.is_anomaly_enabled():  # anomaly detection reads every node's outputs at once
             self.flush()
             return None
@@ -450,7 +457,7 @@ class WgradQueue:
 
     def reset(self):
         """Drop whatever is pending (a backward that raised half-way leaves entries whose gradients nobody will read)."""
-        self.items, self.seen, self.pending = [], set(), 0
+        self.items, self.seen, self.pending, self.keep = [], set(), 0, []
         norm_sums.reset()
 
     def flush(self, keep_seen: bool = False):
@@ -459,7 +466,7 @@ class WgradQueue:
         norm_sums.flush(keep_seen=keep_seen)
         items, self.items, self.pending = self.items, [], 0
         if not keep_seen:
-            self.seen = set()
+            self.seen, self.keep = set(), []
         groups: dict = {}
         for it in items:
             dy2, x2, conv = it[0], it[1], it[4]
@@ -592,7 +599,7 @@ def linear_backward(x: torch.Tensor, w: torch.Tensor, dy: torch.Tensor, need_bia
     if WGRAD and wgrad_ok(dy2, x2):
         wt = weight_t.lookup((w.data_ptr(), tuple(w.shape)))
         dx = ops.linear(dy2, wt if wt is not None else transpose2d(w)).view(x.shape)   # [M, N] @ [K, N]^T
-        later = wgrad_queue.add(dy2, x2, w.data_ptr(), need_bias) if (defer and WGRAD_DEFER) else None
+        later = wgrad_queue.add(dy2, x2, w, need_bias) if (defer and WGRAD_DEFER) else None
         dw, db = later if later is not None else wgrad(dy2, x2, need_bias)
         return dx, dw, db
     dy2p = dy2  # transpose2d zero-pads the row count (M = batch rows in the time-embedding GEMMs) to a multiple of 8
@@ -694,7 +701,7 @@ def conv3x3_backward(x: torch.Tensor, w_packed: torch.Tensor, dy: torch.Tensor, 
     if WGRAD and wgrad_ok(dyp.reshape(P, Np), xc, (Ho, Wo)):
         later = None
         if defer and WGRAD_DEFER and Np == N:
-            later = wgrad_queue.add(dyp.reshape(P, Np), xc, w_packed.data_ptr(), need_bias, conv=(Ho, Wo, stride))
+            later = wgrad_queue.add(dyp.reshape(P, Np), xc, w_packed, need_bias, conv=(Ho, Wo, stride))
         if later is not None:
             return dx, later[0], later[1]
         dw, db = wgrad(dyp.reshape(P, Np), xc, need_bias, conv=(Ho, Wo, stride))

@@ -144,17 +144,27 @@ class ConfigModelMixin:
         return None
 
     def enable_gradient_checkpointing(self):
-        """The reference recomputes the down blocks' resnets in the backward (unet_2d_blocks.py:1172-1197, caller
-        train.py:1073-1074) to fit its GPUs.  Not needed here -- cfg 4's per-GPU step peaks at 35 GB of the 288 GB --
-        so nothing is recomputed; the caller is told once instead of being silently ignored."""
-        import warnings
+        """Activation recompute as the reference does it (caller train.py:1073-1074; ``_set_gradient_checkpointing``,
+        controlnet.py:745-747 / 1653-1655 / 2338-2340: every sub-block that HAS a ``gradient_checkpointing`` attribute gets it
+        set; unet_2d_blocks.py:1172-1197: in training mode a checkpointed block runs each of its ResnetBlock2D under
+        ``torch.utils.checkpoint.checkpoint(..., use_reentrant=False)``, its attention is not checkpointed).  The training
+        forward (train_step._down_mid / _up_out) honours the flag: the resnet's activations (two GroupNorm outputs, the conv1
+        output) are dropped after the forward and recomputed by the same HIP kernels in the backward -- bit-identical
+        gradients (tests/test_train_gpu.py).  Not needed for memory here (cfg 4's per-GPU step peaks at ~38 GB of 288 GB)."""
+        self._set_gc(True)
 
-        if not getattr(ConfigModelMixin, "_warned_gc", False):
-            ConfigModelMixin._warned_gc = True
-            warnings.warn("uni_renderer_amd: enable_gradient_checkpointing() keeps all activations (no recompute): the "
-                          "training step of cfg 4 peaks at ~35 GB of the MI355X's 288 GB", stacklevel=2)
-        self.gradient_checkpointing = False
-        return None
+    def disable_gradient_checkpointing(self):
+        self._set_gc(False)
+
+    def _set_gc(self, value: bool):
+        self.gradient_checkpointing = bool(value)
+        for m in self.modules():
+            if m is not self and hasattr(m, "gradient_checkpointing"):
+                m.gradient_checkpointing = bool(value)
+
+    @property
+    def is_gradient_checkpointing(self) -> bool:
+        return any(getattr(m, "gradient_checkpointing", False) for m in self.modules())
 
     def set_attention_slice(self, *_):
         return None

@@ -140,6 +140,21 @@ def _resnet(r, x, temb, dt, x1=None):
     return A.conv3x3(h, A.pack_conv_weight(r.conv2.weight, dt), r.conv2.bias, res=sc)
 
 
+def _resnet_ckpt(blk, r, x, temb, dt, x1=None):
+    """``_resnet``, recomputed in the backward when the block asks for it (unet_2d_blocks.py:1172-1197: training mode and
+    ``gradient_checkpointing``; ``use_reentrant=False`` like the reference).  The recompute runs the same kernels on the same
+    inputs, so the saved tensors -- and with them every gradient -- are bit-identical to the ones the plain forward keeps."""
+    if getattr(blk, "gradient_checkpointing", False) and torch.is_grad_enabled() and blk.training:
+        from torch.utils.checkpoint import checkpoint
+
+        t = temb[id(r)]
+        fn = (lambda x_, t_, x1_: _resnet(r, x_, {id(r): t_}, dt, x1=x1_)) if x1 is not None else \
+             (lambda x_, t_: _resnet(r, x_, {id(r): t_}, dt))
+        args = (x, t, x1) if x1 is not None else (x, t)
+        return checkpoint(fn, *args, use_reentrant=False)
+    return _resnet(r, x, temb, dt, x1=x1)
+
+
 def _self_attn(a, xn, res, dt):
     """q | k | v as ONE projection (one forward and two backward GEMMs instead of three of each)."""
     Cc = a.to_q.weight.shape[0]
@@ -211,7 +226,7 @@ def _down_mid(net, x, temb_act, ehs, dt):
     skips = [x]
     for blk in net.down_blocks:
         for i, r in enumerate(blk.resnets):
-            x = _resnet(r, x, temb, dt)
+            x = _resnet_ckpt(blk, r, x, temb, dt)
             if getattr(blk, "has_cross_attention", False):
                 x = _transformer(blk.attentions[i], x, ehs, dt)
             skips.append(x)
@@ -235,7 +250,7 @@ def _up_out(net, x, skips: List[torch.Tensor], temb_act, ehs, dt, extras=None, c
     k = 0
     for blk in net.up_blocks:
         for i, r in enumerate(blk.resnets):
-            x = _resnet(r, x, temb, dt, x1=skips.pop())
+            x = _resnet_ckpt(blk, r, x, temb, dt, x1=skips.pop())
             if getattr(blk, "has_cross_attention", False):
                 x = _transformer(blk.attentions[i], x, ehs, dt)
             if extras is not None and getattr(blk, "adds_up_states", False):
