@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define UR_ABI_VERSION 11
+#define UR_ABI_VERSION 12
 
 #define UR_E_BADARG (-1001)   /* inconsistent descriptor (shape / alignment / null pointer)   */
 #define UR_E_UNSUPPORTED (-1002) /* shape outside what the kernels are instantiated for       */
@@ -287,6 +287,11 @@ int ur_layernorm(const void* x, const void* x_lo, const float* gamma, const floa
  *                     vt + b * vt_bstride elements (lets several layers share one batched projection)
  *   o  [B][Tq][ldo]   head h at columns h*d .. +d
  * d in {32, 40, 64, 80, 128, 160}.
+ * q_hstride / k_hstride (ABI 12; d <= 64 only, UR_E_UNSUPPORTED otherwise): 0 = the column-block image above.  > 0 = HEAD-MAJOR
+ *   image [B][H][T][d]: head h of sample b starts at q + q_off + b * Tq * ldq + h * q_hstride (so ldq = H * d still sizes a
+ *   sample and q_hstride = Tq * d) and its rows are d elements apart.  What ur_tchain's qk_heads mode writes: a head's keys
+ *   are one contiguous run instead of 2d-byte slices of (2 H d)-byte token rows, which at H = 8, d = 40 cost 2.4 cache lines
+ *   fetched per line used (profiles/r06_pmc_attn_l2_cfg5.json).
  * scale > 0: the usual softmax scale (the reference passes d^-1/2, AttnProcessor2_0).
  * scale <= 0: Q.K^T is ALREADY in log2 units, i.e. the caller folded scale*log2(e) into the q / k projections
  *             (ur_igemm out_scale, applied in fp32 before the single rounding); p = exp2(q.k - max).
@@ -299,6 +304,7 @@ typedef struct ur_attn_desc {
     const void* zero_page;
     int64_t ldq, ldk, ldvt, ldo;
     int64_t vt_bstride;
+    int64_t q_hstride, k_hstride;  /* 0, or the head stride of a head-major q / k image (see above) */
     int32_t q_off, k_off;
     int32_t B, H, Tq, Tk, d;
     float scale;  /* see above: <= 0 selects "scores already in log2 units" */
@@ -702,6 +708,9 @@ typedef struct ur_tchain_desc {
     int M, zbatch, mode, dtype, channels;
     int rows_per_b;      /* PRE: tokens per sample (multiple of 32, divides M) */
     int ld_vt;           /* PRE: row stride of V^T in elements (>= rows_per_b, multiple of 8) */
+    int qk_heads;        /* ABI 12.  0: `out` (PRE, Q) and `out2` (PRE) are token matrices like every other operand.  8: they leave
+                          * HEAD-MAJOR, [zbatch * M / rows_per_b][8][rows_per_b][40] -- the q / k images ur_attention reads with
+                          * q_hstride = k_hstride = rows_per_b * 40 (needs rows_per_b in mode Q too); other values UR_E_UNSUPPORTED */
     float eps;           /* LayerNorm epsilon */
     void* profile;       /* diagnostics, normally NULL: int64 [workgroups][64] s_memtime stamps (0..15 phases, 16..63 stage starts) of each workgroup's wave 0 */
 } ur_tchain_desc;

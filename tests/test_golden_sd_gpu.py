@@ -90,3 +90,22 @@ def test_cfg3_full_50_step_ddim_loop_at_batch_4_against_the_committed_golden(dev
     assert moved > 0.5  # the comparison is not dominated by the untouched initial noise
     # measured (round 5): 0.50e-3 / 0.90e-3 for both executors -- the loop as a whole meets north_star's 1e-3 against either oracle
     assert e16 < 1e-3 and e32 < 1.3e-3, (e16, e32)
+
+
+def test_head_major_q_k_images_do_not_change_a_bit_of_the_step(dev, nets, monkeypatch):
+    """Round 6: the chain kernels of the 320-channel level hand q / k to the d = 40 attention as [sample][head][token][40] images
+    (fused.HEAD_MAJOR_QK).  Addresses only: the cfg-3 step with and without them is the same bits."""
+    from uni_renderer_amd import fused
+    from uni_renderer_amd.graph import GraphedDualStreamStep
+
+    unet, enc, dec = nets
+    x, c, ehs, ti, ta = [t.to(dev) for t in O.make_inputs(4, 64, 768, seed=19)]
+    kw = dict(batch=4, latent_hw=64, cross_dim=768, dtype=torch.float16, device=dev)
+    outs = []
+    for flag in (True, False):
+        monkeypatch.setattr(fused, "HEAD_MAJOR_QK", flag)
+        out = GraphedDualStreamStep(unet, enc, dec, **kw).step(x.half(), c.half(), ehs.half(), ti, ta)
+        outs.append({k: v.clone() for k, v in out.items()})
+    assert fused.HEAD_MAJOR_QK is False
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[1][k]), k

@@ -189,3 +189,67 @@ def test_chain_rejects_other_widths(dev):
     assert not tchain.supported(x)
     with pytest.raises(RuntimeError):
         tchain.chain_q(x, x, torch.zeros(10 * 20480, device=dev, dtype=torch.float16), torch.zeros(960, device=dev), 1e-5)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("B,T,S", [(2, 128, 1), (2, 1024, 2), (3, 96, 2)])
+def test_head_major_q_k_are_the_token_matrices_permuted_and_attention_reads_them_bit_for_bit(dev, dtype, B, T, S):
+    """Round 6 (ur_tchain_desc.qk_heads, ur_attn_desc.q_hstride / k_hstride): the chains hand q / k to the d = 40 attention as
+    [sample][head][token][40] images.  Same values, other addresses: the images equal the token matrices permuted, and the
+    attention over them returns the same bits as over the token matrices (self-attention with both operands head-major; the
+    cross-attention form with only q head-major and ragged 77 keys)."""
+    from uni_renderer_amd import ops, tchain
+
+    H, d = 8, 40
+    W = _weights(dev, 7, S)
+    g = torch.Generator(device=dev).manual_seed(30)
+    for w in W:
+        w["wk"] = torch.randn(C, C, device=dev, generator=g) * C ** -0.5
+        w["wv"] = torch.randn(C, C, device=dev, generator=g) * C ** -0.5
+    M = B * T
+    h0 = _stream(dev, dtype, M, S, 31, False)
+    sc = math.sqrt(40 ** -0.5 * 1.4426950408889634)
+    packs = [tchain.pack_chain_pre(w["wo"].view(C, C, 1, 1), w["bo"], w["g"], w["b"], w["wq"], w["wk"], w["wv"], sc, dtype) for w in W]
+    ws = torch.stack([p[0] for p in packs]).contiguous()
+    cs = torch.stack([p[1] for p in packs]).contiguous()
+    if S == 1:
+        ws, cs = ws[0], cs[0]
+    y0, q0, k0, vt0 = tchain.chain_pre(h0, ws, cs, 1e-5, tokens_per_sample=T, streams=S)
+    y1, q1, k1, vt1 = tchain.chain_pre(h0, ws, cs, 1e-5, tokens_per_sample=T, streams=S, head_major=True)
+    hm = lambda t: t.view(S * B, T, H, d).permute(0, 2, 1, 3).contiguous().view(S * M, C)
+    assert torch.equal(y0, y1) and torch.equal(ops.lo_of(y0), ops.lo_of(y1)) and torch.equal(vt0, vt1)
+    assert torch.equal(q1, hm(q0)) and torch.equal(k1, hm(k0))
+    kw = dict(B=S * B, H=H, Tq=T, Tk=T, d=d, ldq=C, ldk=C, scale=0.0)
+    o0 = ops.attention(q0, k0, vt0, **kw)
+    o1 = ops.attention(q1, k1, vt1, q_hstride=T * d, k_hstride=T * d, **kw)
+    assert torch.equal(o0, o1)
+    # chain_q: the cross-attention query
+    packs = [tchain.pack_chain_q(w["wo"], w["bo"], w["g"], w["b"], w["wq"], sc * sc, dtype) for w in W]
+    wsq = torch.stack([p[0] for p in packs]).contiguous()
+    csq = torch.stack([p[1] for p in packs]).contiguous()
+    if S == 1:
+        wsq, csq = wsq[0], csq[0]
+    res = _stream(dev, dtype, M, S, 11, True)
+    ya, qa = tchain.chain_q(o0.view(S * M, C), res, wsq, csq, 1e-5, streams=S)
+    yb, qb = tchain.chain_q(o0.view(S * M, C), res, wsq, csq, 1e-5, streams=S, head_major_tokens=T)
+    assert torch.equal(ya, yb) and torch.equal(ops.lo_of(ya), ops.lo_of(yb)) and torch.equal(qb, hm(qa))
+    Tk = 77
+    kc = (torch.randn(S * B, Tk, C, device=dev, generator=g) * 0.5).to(dtype)
+    vtc = torch.zeros(S * B, C, 128, device=dev, dtype=dtype)
+    vtc[:, :, :Tk] = torch.randn(S * B, C, Tk, device=dev, generator=g).to(dtype)
+    kx = dict(B=S * B, H=H, Tq=T, Tk=Tk, d=d, ldq=C, ldk=C, scale=0.0)
+    assert torch.equal(ops.attention(qa, kc, vtc, **kx), ops.attention(qb, kc, vtc, q_hstride=T * d, **kx))
+
+
+def test_head_major_images_are_refused_where_they_are_not_built(dev):
+    from uni_renderer_amd import ops, tchain
+
+    B, T, H, d = 1, 128, 8, 80  # the d = 80 kernel reads token matrices only
+    q = torch.zeros(B, T, H * d, device=dev, dtype=torch.float16)
+    vt = torch.zeros(B, H * d, T, device=dev, dtype=torch.float16)
+    with pytest.raises(RuntimeError):
+        ops.attention(q, q, vt, B=B, H=H, Tq=T, Tk=T, d=d, ldq=H * d, ldk=H * d, q_hstride=T * d, k_hstride=T * d)
+    x = torch.zeros(2 * 100, C, device=dev, dtype=torch.float16)  # 100 tokens per sample: a wave would straddle two samples
+    with pytest.raises(RuntimeError):
+        tchain.chain_q(x, x, torch.zeros(10 * 20480, device=dev, dtype=torch.float16), torch.zeros(960, device=dev), 1e-5,
+                       head_major_tokens=100)

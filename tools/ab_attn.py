@@ -47,19 +47,32 @@ def main():
                 f = (d ** -0.5 * 1.4426950408889634) ** 0.5
                 q, k = (q.float() * f).to(dt), (k.float() * f).to(dt)
                 kw = dict(scale=0.0)
+            if os.environ.get("AB_ATTN_HEAD_MAJOR") and d <= 64:  # q / k as [B][H][T][d] images (what the chain kernels write, round 6)
+                hm = lambda t, n: t.view(B, n, H, d).permute(0, 2, 1, 3).contiguous().view(B, n, C)
+                tm = lambda t, n: t.view(B, H, n, d).permute(0, 2, 1, 3).contiguous().view(B, n, C)
+                o_tm = ops.attention(q, k, vt, B=B, H=H, Tq=T, Tk=Tk, d=d, ldq=C, ldk=C, **kw)
+                q, k = hm(q, T), hm(k, Tk)
+                kw = dict(kw, q_hstride=T * d, k_hstride=Tk * d)
+                assert torch.equal(o_tm, ops.attention(q, k, vt, B=B, H=H, Tq=T, Tk=Tk, d=d, ldq=C, ldk=C, **kw))
             o = ops.attention(q, k, vt, B=B, H=H, Tq=T, Tk=Tk, d=d, ldq=C, ldk=C, **kw)
+            if "q_hstride" in kw:
+                q, k = tm(q, T), tm(k, Tk)  # the reference and the pre-scaled leg below read token matrices
             ref = torch.nn.functional.scaled_dot_product_attention(
                 q.view(B, T, H, d).transpose(1, 2).float(), k.view(B, Tk, H, d).transpose(1, 2).float(),
                 v.view(B, Tk, H, d).transpose(1, 2).float()).transpose(1, 2).reshape(B, T, C)
             err = float((o.float() - ref).norm() / ref.norm())
-            us = timeit(lambda: ops.attention(q, k, vt, B=B, H=H, Tq=T, Tk=Tk, d=d, ldq=C, ldk=C, **kw))
+            qa, ka = (hm(q, T), hm(k, Tk)) if "q_hstride" in kw else (q, k)
+            us = timeit(lambda: ops.attention(qa, ka, vt, B=B, H=H, Tq=T, Tk=Tk, d=d, ldq=C, ldk=C, **kw))
             # the modules' path: scale * log2(e) folded into q by the projection epilogue, kernel called with scale 0
             cs = d ** -0.5 * 1.4426950408889634
             qs = (q.float() * cs).to(dt)
-            o0 = ops.attention(qs, k, vt, B=B, H=H, Tq=T, Tk=Tk, d=d, ldq=C, ldk=C, scale=0.0)
+            k0, kw0 = k, {}
+            if "q_hstride" in kw:
+                qs, k0, kw0 = hm(qs, T), hm(k, Tk), dict(q_hstride=T * d, k_hstride=Tk * d)
+            o0 = ops.attention(qs, k0, vt, B=B, H=H, Tq=T, Tk=Tk, d=d, ldq=C, ldk=C, scale=0.0, **kw0)
             err0 = float((o0.float() - ref).norm() / ref.norm())
-            us0 = timeit(lambda: ops.attention(qs, k, vt, B=B, H=H, Tq=T, Tk=Tk, d=d, ldq=C, ldk=C, scale=0.0))
-            out.append(dict(dtype=str(dt), B=B, H=H, T=T, Tk=Tk, d=d, us=round(us, 1), rel_l2=err,
+            us0 = timeit(lambda: ops.attention(qs, k0, vt, B=B, H=H, Tq=T, Tk=Tk, d=d, ldq=C, ldk=C, scale=0.0, **kw0))
+            out.append(dict(dtype=str(dt), head_major=bool("q_hstride" in kw), B=B, H=H, T=T, Tk=Tk, d=d, us=round(us, 1), rel_l2=err,
                             tflops=round(4.0 * B * H * T * Tk * d / us / 1e6, 1), us_prescaled=round(us0, 1),
                             rel_l2_prescaled=err0, tflops_prescaled=round(4.0 * B * H * T * Tk * d / us0 / 1e6, 1)))
             print(json.dumps(out[-1]), flush=True)

@@ -9,17 +9,17 @@ export AB_ATTN_ONLY=${AB_ATTN_ONLY:-2,8,16384,16384,40}
 i=0
 for set in "TCC_HIT TCC_MISS TCC_REQ TCC_READ" "TCC_EA0_RDREQ TCC_EA0_RDREQ_32B TCC_EA0_RDREQ_DRAM" "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_WRREQ TCC_EA0_WRREQ_64B TCC_WRITE"; do
   i=$((i+1))
-  (cd $R && timeout 200 rocprofv3 --pmc $set --kernel-trace -d /tmp/pmc_attn_l2/s$i -o p --output-format csv -- python tools/ab_attn.py > /dev/null 2>&1)
+  (cd $R && timeout 200 rocprofv3 --pmc $set --kernel-trace -d /tmp/pmc_attn_l2/s$i -o p --output-format csv -- python tools/ab_attn.py > /tmp/pmc_attn_l2_s$i.log 2>&1; tail -2 /tmp/pmc_attn_l2_s$i.log >&2)
 done
 cd $R && python - <<'PY'
-import csv, collections, glob, json
+import csv, collections, glob, json, os
 agg=collections.defaultdict(list)
 for f in glob.glob("/tmp/pmc_attn_l2/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         if "attention" in r["Kernel_Name"] and "ur" in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
 m={k: sum(v)/len(v) for k,v in agg.items()}
-B,H,T,Tk,d=(int(v) for v in "${AB_ATTN_ONLY}".split(","))
+B,H,T,Tk,d=(int(v) for v in os.environ["AB_ATTN_ONLY"].split(","))
 alg=4*B*H*T*d*2   # q, k, v, o once, dense
 out=dict(problem=dict(B=B,H=H,T=T,Tk=Tk,d=d), counters_per_launch={k: round(v) for k,v in sorted(m.items())}, algorithmic_bytes=alg)
 if "TCC_HIT" in m and "TCC_MISS" in m: out["l2_hit_rate"]=round(m["TCC_HIT"]/(m["TCC_HIT"]+m["TCC_MISS"]),4)

@@ -36,6 +36,7 @@ KNOWN = {
     "forward_lse": "the forward attention hands its row log-sum-exp to the backward (backward.py)",
     "batch_casts": "fp32 -> bf16 parameter casts of a network in one launch group (train_step.py)",
     "gn_resident": "one-launch GroupNorm keeps small strips in registers: one memory round trip (ops.py, csrc/norm.hip)",
+    "head_major_qk": "the chain kernels write q / k of the d = 40 attention as [sample][head][token][40] images (fused.py)",
     # ---- on-switches of measured-slower paths ----
     "splitk_gn": "GroupNorm as the split-K second pass (0.07 ms slower: profiles/r04_splitk_gn_ab.txt)",
     "colsum_one_launch": "column sums with an in-launch ticket instead of two launches (slower)",

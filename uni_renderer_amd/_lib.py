@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must be imported first, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("UR_LIB_PATH", os.path.join(_HERE, "liburhip.so"))  # override = kernel experiments only
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
@@ -50,6 +50,7 @@ class AttnDesc(C.Structure):
     _fields_ = [
         ("q", vp), ("k", vp), ("vt", vp), ("o", vp), ("zero_page", vp),
         ("ldq", i64), ("ldk", i64), ("ldvt", i64), ("ldo", i64), ("vt_bstride", i64),
+        ("q_hstride", i64), ("k_hstride", i64),
         ("q_off", i32), ("k_off", i32),
         ("B", i32), ("H", i32), ("Tq", i32), ("Tk", i32), ("d", i32),
         ("scale", f32), ("dtype", i32),
@@ -79,7 +80,7 @@ class TChainDesc(C.Structure):
         ("out", vp), ("out_lo", vp), ("out2", vp), ("out3", vp), ("wstream", vp), ("consts", vp),
         ("z_wstream", i64), ("z_consts", i64),
         ("M", i32), ("zbatch", i32), ("mode", i32), ("dtype", i32), ("channels", i32),
-        ("rows_per_b", i32), ("ld_vt", i32),
+        ("rows_per_b", i32), ("ld_vt", i32), ("qk_heads", i32),
         ("eps", f32),
         ("profile", vp),
     ]

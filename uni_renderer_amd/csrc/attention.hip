@@ -355,8 +355,11 @@ __global__ void __launch_bounds__(256) attention32_kernel(const ur_attn_desc p) 
     const int b = bh / p.H, h = bh - b * p.H;
     const int q0 = qt * 128 + wave * 32;
 
-    const T* Q = reinterpret_cast<const T*>(p.q) + (int64_t)b * p.Tq * p.ldq + p.q_off + h * D;
-    const T* K = reinterpret_cast<const T*>(p.k) + (int64_t)b * p.Tk * p.ldk + p.k_off + h * D;
+    // head-major images (q_hstride / k_hstride > 0: [sample][head][token][D], round 6): a head's rows are D elements apart and
+    // contiguous, so a 64-key tile is ONE 64*D*2-byte run instead of 64 slices of 2*D bytes inside (H*D*2)-byte token rows
+    const int64_t qrs = p.q_hstride > 0 ? D : p.ldq, krs = p.k_hstride > 0 ? D : p.ldk;
+    const T* Q = reinterpret_cast<const T*>(p.q) + (int64_t)b * p.Tq * p.ldq + p.q_off + (p.q_hstride > 0 ? h * p.q_hstride : (int64_t)h * D);
+    const T* K = reinterpret_cast<const T*>(p.k) + (int64_t)b * p.Tk * p.ldk + p.k_off + (p.k_hstride > 0 ? h * p.k_hstride : (int64_t)h * D);
     const T* VT = reinterpret_cast<const T*>(p.vt) + (int64_t)b * p.vt_bstride + (int64_t)h * D * p.ldvt;
     const char* zpc = reinterpret_cast<const char*>(p.zero_page);
 
@@ -367,7 +370,7 @@ __global__ void __launch_bounds__(256) attention32_kernel(const ur_attn_desc p) 
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
             const int dc = ks * 16 + hh * 8;
-            const void* src = (qrow < p.Tq && dc < D) ? (const void*)(Q + (int64_t)qrow * p.ldq + dc) : (const void*)zpc;
+            const void* src = (qrow < p.Tq && dc < D) ? (const void*)(Q + (int64_t)qrow * qrs + dc) : (const void*)zpc;
             qf[ks] = *reinterpret_cast<const vec8*>(src);
         }
     }
@@ -375,14 +378,14 @@ __global__ void __launch_bounds__(256) attention32_kernel(const ur_attn_desc p) 
     // loader: lane owns (row = 8*piece + lane/8, LDS chunk lane%8) of every 1 KiB piece; pointers walk 64 keys per tile
     const char* kptr[2];
     int kinc[2], krow[2];
-    const int kstep = 64 * (int)p.ldk * (int)sizeof(T);
+    const int kstep = 64 * (int)krs * (int)sizeof(T);
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
         const int row = (wave * 2 + it) * 8 + (lane >> 3);
         const int cl = (lane & 7) ^ ((row >> 1) & 7);
         const bool real = cl * 8 < D;
         krow[it] = real ? row : (1 << 30);
-        kptr[it] = real ? reinterpret_cast<const char*>(K + (int64_t)row * p.ldk + cl * 8) : zpc;
+        kptr[it] = real ? reinterpret_cast<const char*>(K + (int64_t)row * krs + cl * 8) : zpc;
         kinc[it] = real ? kstep : 0;
     }
     const char* vptr[VI];
@@ -595,6 +598,7 @@ static int launch_attn32(const ur_attn_desc& d, hipStream_t s) {
 
 template <typename T, int D>
 static int launch_attn(const ur_attn_desc& d, hipStream_t s) {
+    if (d.q_hstride > 0 || d.k_hstride > 0) return UR_E_UNSUPPORTED;  // head-major images: the d <= 64 kernel only
     constexpr int DK = (D + 31) / 32 * 32, DV = (D + 15) / 16 * 16;
     constexpr size_t lds = 2 * (64 * DK * 2 + DV * 128);
     static std::atomic<uint64_t> done{0};  // per (instantiation, device)
@@ -628,6 +632,7 @@ extern "C" int ur_attention(const ur_attn_desc* d, void* stream) {
         return UR_E_BADARG;
     if (d->ldvt < (d->Tk + 63) / 64 * 64 || (d->vt_bstride & 7)) return UR_E_BADARG;
     if (d->lse && !(d->scale > 0.f)) return UR_E_BADARG;  // the pre-scaled (reference slot) mode keeps no row reference
+    if (d->q_hstride < 0 || d->k_hstride < 0 || (d->q_hstride & 7) || (d->k_hstride & 7)) return UR_E_BADARG;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (d->dtype == UR_DT_F16) return launch_attn_d<f16>(*d, s);
     if (d->dtype == UR_DT_BF16) return launch_attn_d<bf16>(*d, s);

@@ -213,6 +213,32 @@ __global__ void __launch_bounds__(256, 1) tchain_kernel(const ur_tchain_desc p) 
                     *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(base) + ((int64_t)z * p.M + m0w + r) * row_bytes + c * 16) = v;
             }
     };
+    // q / k rows: token matrices like every other operand, or (qk_heads = 8, round 6) a HEAD-MAJOR image
+    // [sample][8 heads][token][40], whose 64-key tiles the d = 40 attention then reads as contiguous runs (csrc/attention.hip).
+    // ONE code path for both: piece c of row r goes to base + qk_base + r * qk_row + c * 16 + (c / 5) * qk_head with
+    // wave-uniform scalars (token matrix: row stride 640, no head term).  A wave never straddles two samples.
+    int64_t qk_base;
+    int qk_row, qk_head;
+    if (p.qk_heads > 0) {
+        const int b = m0w / p.rows_per_b, tok0 = m0w - b * p.rows_per_b;
+        qk_base = ((int64_t)z * p.M + (int64_t)b * p.rows_per_b) * HI_ROW + (int64_t)tok0 * (HI_ROW / 8);
+        qk_row = HI_ROW / 8;
+        qk_head = (p.rows_per_b - 1) * (HI_ROW / 8);
+    } else {
+        qk_base = ((int64_t)z * p.M + m0w) * HI_ROW;
+        qk_row = HI_ROW;
+        qk_head = 0;
+    }
+    auto stage_out_qk = [&](void* base) __attribute__((always_inline)) {
+        const int ln = launder(lane);
+        char* dst = reinterpret_cast<char*>(base) + qk_base;
+#pragma unroll
+        for (int k = 0; k < 20; ++k) {
+            const int e = 64 * k + ln, r = e / 40, c = e - r * 40;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(io + r * (HI_ROW + 16) + c * 16);
+            if (m0w + r < p.M) *reinterpret_cast<u32x4*>(dst + (int64_t)r * qk_row + c * 16 + (int64_t)(c / 5) * qk_head) = v;
+        }
+    };
     // residual-stream tensor (hi [+ lo]) -> fp32 in the accumulator arrangement, ADDED to acc.  The staging region must
     // be free (ring slots 1 / 2 idle); wave-private, so only the wave's own LDS ordering is needed.
     auto add_stream = [&](Acc<T>& acc, const void* hi_, const void* lo_) __attribute__((always_inline)) {
@@ -244,7 +270,8 @@ __global__ void __launch_bounds__(256, 1) tchain_kernel(const ur_tchain_desc p) 
         }
     };
     // accumulator -> global: hi (+ lo when asked)
-    auto store_stream = [&](const Acc<T>& acc, void* hi_, void* lo_) __attribute__((always_inline)) {
+    auto store_stream = [&](const Acc<T>& acc, void* hi_, void* lo_, auto qk_tag) __attribute__((always_inline)) {
+        constexpr bool qk = decltype(qk_tag)::value;
         const int ln = launder(lane);
         const int lrow = ln & 31, lh = ln >> 5;
 #pragma unroll
@@ -257,7 +284,8 @@ __global__ void __launch_bounds__(256, 1) tchain_kernel(const ur_tchain_desc p) 
                 for (int r = 0; r < 4; ++r) v[r] = (T)acc.t[t][4 * q + r];
                 *reinterpret_cast<t4*>(reinterpret_cast<T*>(io + lrow * (HI_ROW + 16)) + 32 * t + 8 * q + 4 * lh) = v;
             }
-        stage_out(hi_, HI_ROW);
+        if (qk) stage_out_qk(hi_);
+        else stage_out(hi_, HI_ROW);
         if (lo_) {
 #pragma unroll
             for (int t = 0; t < TC_NT; ++t)
@@ -375,19 +403,19 @@ __global__ void __launch_bounds__(256, 1) tchain_kernel(const ur_tchain_desc p) 
     stamp(3);
     // a tile leaves through the staging area in the middle of the chain: the last two stages before it copied nothing
     // (slots 1 / 2 stay free), the ring is refilled afterwards
-    auto store_mid = [&](const Acc<T>& a, void* hi_, void* lo_) __attribute__((always_inline)) {
+    auto store_mid = [&](const Acc<T>& a, void* hi_, void* lo_, auto qk_tag) __attribute__((always_inline)) {
         __syncthreads();  // the other waves have left the last stage (slot 1 or 2)
-        store_stream(a, hi_, lo_);
+        store_stream(a, hi_, lo_, qk_tag);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores have left before LDS-DMA pieces are counted again
         __syncthreads();  // staging slices read back: refill the ring
         issue();
         issue();
     };
-    if constexpr (MODE == UR_TCHAIN_PRE) store_mid(acc, p.y_out, p.y_out_lo);
+    if constexpr (MODE == UR_TCHAIN_PRE) store_mid(acc, p.y_out, p.y_out_lo, std::false_type{});
     if constexpr (MODE == UR_TCHAIN_Q) {
         // the updated residual stream leaves here through the staging area (no weight stage is in flight: `limit`)
         __syncthreads();  // the other waves have left stage 4 (slot 1)
-        store_stream(acc, p.y_out, p.y_out_lo);
+        store_stream(acc, p.y_out, p.y_out_lo, std::false_type{});
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores have left before LDS-DMA pieces are counted again
         __syncthreads();  // staging slices read back: refill the ring
         issue();
@@ -431,10 +459,10 @@ __global__ void __launch_bounds__(256, 1) tchain_kernel(const ur_tchain_desc p) 
         // =============================== q, k, V^T of the self-attention from one normalised operand ===============================
         zero(acc);
         gemm320(acc, bop, 3);
-        store_mid(acc, p.out, nullptr);         // q  (softmax scale * log2(e) split evenly over q and k by the host)
+        store_mid(acc, p.out, nullptr, std::true_type{});   // q  (softmax scale * log2(e) split evenly over q and k by the host)
         zero(acc);
         gemm320(acc, bop, 3);
-        store_mid(acc, p.out2, nullptr);        // k
+        store_mid(acc, p.out2, nullptr, std::true_type{});  // k
         zero(acc);
         gemm320(acc, bop, 3);
         // V^T[b][channel][token]: a wave's 32 tokens are 64 contiguous bytes of every channel row.  Stage [channel][32
@@ -467,7 +495,7 @@ __global__ void __launch_bounds__(256, 1) tchain_kernel(const ur_tchain_desc p) 
         zero(acc);
         gemm320(acc, bop, 3);
         stamp(6);
-        store_stream(acc, p.out, nullptr);
+        store_stream(acc, p.out, nullptr, std::true_type{});
         stamp(7);
     } else {
         // =============================== GEGLU feed-forward: acc = y + b2 + sum_j h_j W2_j^T ===============================
@@ -556,7 +584,7 @@ __global__ void __launch_bounds__(256, 1) tchain_kernel(const ur_tchain_desc p) 
         add_cvec(acc, TCC_BPO);
         add_stream(acc, p.blk, p.blk_lo);
         stamp(8);
-        store_stream(acc, p.out, p.out_lo);
+        store_stream(acc, p.out, p.out_lo, std::false_type{});
         stamp(9);
     }
 }
@@ -598,6 +626,11 @@ extern "C" int ur_tchain(const ur_tchain_desc* din, void* stream) {
         return UR_E_BADARG;
     }
     if (d.channels != TC_C) return UR_E_UNSUPPORTED;
+    if (d.qk_heads) {  // head-major q / k: 8 heads of 40, whole samples of a multiple of 32 tokens (a wave never straddles two)
+        if (d.mode == UR_TCHAIN_FF) return UR_E_BADARG;
+        if (d.qk_heads != 8) return UR_E_UNSUPPORTED;
+        if (d.rows_per_b <= 0 || (d.rows_per_b % 32) || (d.M % d.rows_per_b)) return UR_E_BADARG;
+    }
     if ((reinterpret_cast<uintptr_t>(d.wstream) | (uintptr_t)d.z_wstream) & 15) return UR_E_BADARG;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (d.dtype == UR_DT_F16)

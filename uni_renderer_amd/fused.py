@@ -42,6 +42,8 @@ CTXKV_ONE_LAUNCH = X.flag("ctxkv_one_launch", True)
 # 32768 rows (grouped step at batch 4) and 16384 (hoisted step; grouped step at batch 2: 8.65 vs 8.72 ms) are wins, 8192 (hoisted step
 # at batch 2: 6.47 vs 6.24 ms) and 4096 (cfg 2: 4.55 vs 4.14 ms) losses -- profiles/r06_tchain_rows_ab.txt, r05_hoist_ab.txt
 TCHAIN_MIN_ROWS = X.number("tchain_min_rows", 16384)
+# the chain kernels hand q / k to the d = 40 attention as head-major images; UR_EXPERIMENT=no_head_major_qk: token matrices (A/B)
+HEAD_MAJOR_QK = X.flag("head_major_qk", True)
 
 
 class _Packs:
@@ -289,8 +291,13 @@ class GroupedDualStreamStep:
             t.proj_in.weight, t.proj_in.bias, b.norm1.weight, b.norm1.bias, b.attn1.to_q.weight, b.attn1.to_k.weight,
             b.attn1.to_v.weight)], dt, build_pre)
         # x = the GroupNorm output: proj_in + LayerNorm1 + q / k / V^T projections in one launch
-        xr, q1, k1, vt = tchain.chain_pre(x.reshape(Bt * T, C), wsp, csp, bs[0].norm1.eps, tokens_per_sample=T, streams=S)
-        o1 = ops.attention(q1, k1, vt, B=Bt, H=H, Tq=T, Tk=T, d=d, ldq=C, ldk=C, scale=0.0)
+        # q / k leave the chain HEAD-MAJOR ([sample][head][token][40], round 6): a head's 64-key tile is one 5 KB run instead of 64
+        # 80-byte slices of 640-byte token rows -- at the 128x128 level the slices made every XCD fetch 2.4 lines per line used and
+        # a head's keys no longer fit its L2 (profiles/r06_pmc_attn_l2_cfg5.json)
+        hm = HEAD_MAJOR_QK and H == tchain.HEADS and T % 32 == 0
+        xr, q1, k1, vt = tchain.chain_pre(x.reshape(Bt * T, C), wsp, csp, bs[0].norm1.eps, tokens_per_sample=T, streams=S, head_major=hm)
+        o1 = ops.attention(q1, k1, vt, B=Bt, H=H, Tq=T, Tk=T, d=d, ldq=C, ldk=C, scale=0.0, q_hstride=T * d if hm else 0,
+                           k_hstride=T * d if hm else 0)
         x = xr.view(Bt, T, C)
         x.lo = xr.lo.view(Bt, T, C)
 
@@ -301,10 +308,11 @@ class GroupedDualStreamStep:
 
         wsq, csq = pk.get("tc.q", bs, [p for b in bs for p in (b.attn1.to_out[0].weight, b.attn1.to_out[0].bias, b.norm2.weight,
                                                                b.norm2.bias, b.attn2.to_q.weight)], dt, build_q)
-        y1, q2 = tchain.chain_q(o1.view(Bt * T, C), ops.view_hilo(x, Bt * T, C), wsq, csq, bs[0].norm2.eps, streams=S)
+        y1, q2 = tchain.chain_q(o1.view(Bt * T, C), ops.view_hilo(x, Bt * T, C), wsq, csq, bs[0].norm2.eps, streams=S,
+                                head_major_tokens=T if hm else 0)
         lo, hi = kv_slice
         o2 = ops.attention(q2.view(Bt, T, C), kc[:, :, lo:hi], vtc[:, lo:hi], B=Bt, H=H, Tq=T, Tk=kc.shape[1], d=d, ldq=C,
-                           ldk=kc.stride(1), scale=0.0)
+                           ldk=kc.stride(1), scale=0.0, q_hstride=T * d if hm else 0)
 
         def build_ff():
             packs = [tchain.pack_chain_ff(b.attn2.to_out[0].weight, b.attn2.to_out[0].bias, b.norm3.weight, b.norm3.bias,

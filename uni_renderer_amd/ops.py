@@ -693,9 +693,11 @@ def layernorm(x, gamma, beta, eps=1e-5, streams=1):
     return out
 
 
-def attention(q, k, vt, *, B, H, Tq, Tk, d, ldq, ldk, q_off=0, k_off=0, scale=None, lse=None):
+def attention(q, k, vt, *, B, H, Tq, Tk, d, ldq, ldk, q_off=0, k_off=0, scale=None, lse=None, q_hstride=0, k_hstride=0):
     """q/k are token matrices holding head h at columns off + h*d (row strides ldq/ldk, batches contiguous);
     vt is a [B, H*d, Tk_pad] tensor or a row-slice view of a wider batched projection.
+    ``q_hstride`` / ``k_hstride`` > 0 (d <= 64): that operand is a HEAD-MAJOR image [B, H, T, d] instead (head stride in
+    elements, normally T * d; ldq / ldk still size one sample: H * d) -- what ``tchain.chain_pre(head_major=True)`` writes.
     ``scale=None``: d**-0.5.  ``scale=0``: q.k is already in log2 units (the projections folded scale*log2(e) in),
     which for head dims with a zero-padded k column (d = 40) also selects the kernel without per-score multiply-adds.
     ``lse``: optional contiguous fp32 [B*H, Tq] output, the row log-sum-exp in log2 units (training: the flash backward
@@ -709,6 +711,7 @@ def attention(q, k, vt, *, B, H, Tq, Tk, d, ldq, ldk, q_off=0, k_off=0, scale=No
     a.ldq, a.ldk, a.ldvt, a.ldo = ldq, ldk, vt.stride(1), H * d
     a.vt_bstride = vt.stride(0)
     a.q_off, a.k_off = q_off, k_off
+    a.q_hstride, a.k_hstride = int(q_hstride), int(k_hstride)
     a.B, a.H, a.Tq, a.Tk, a.d = B, H, Tq, Tk, d
     a.scale = float(scale if scale is not None else d ** -0.5)
     a.dtype = DT[q.dtype]

@@ -33,6 +33,7 @@ from ._lib import TChainDesc, check
 MODE_Q, MODE_FF, MODE_PRE = 0, 1, 2
 CH = 320           # the level the kernel is built for
 FF_HIDDEN = 4 * CH  # GEGLU hidden width the feed-forward chain is built for (TC_FF in csrc/tchain.hip)
+HEADS = 8          # heads of the head-major q / k images (ur_tchain_desc.qk_heads)
 STAGE = 40960      # bytes per stage image
 KPERM16 = (0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15)
 
@@ -129,7 +130,7 @@ def pack_chain_ff(wo: torch.Tensor, bo: torch.Tensor, gamma: torch.Tensor, beta:
 
 
 def _launch(mode, a0, res, wstream, consts, eps, *, blk=None, y_out=None, out=None, streams=1, profile=None, out2=None,
-            out3=None, rows_per_b=0):
+            out3=None, rows_per_b=0, qk_heads=0):
     ops._require_gpu(a0)
     lib = _lib.load()
     Cn = a0.shape[-1]
@@ -140,6 +141,8 @@ def _launch(mode, a0, res, wstream, consts, eps, *, blk=None, y_out=None, out=No
         d.res, d.res_lo = res.data_ptr(), ops._ptr(ops.lo_of(res))
     if out2 is not None:
         d.out2, d.out3, d.rows_per_b, d.ld_vt = out2.data_ptr(), out3.data_ptr(), rows_per_b, out3.shape[-1]
+    if qk_heads:
+        d.qk_heads, d.rows_per_b = int(qk_heads), int(rows_per_b)
     d.out_lo = ops._ptr(ops.lo_of(out))
     if blk is not None:
         d.blk, d.blk_lo = blk.data_ptr(), ops._ptr(ops.lo_of(blk))
@@ -174,9 +177,11 @@ def supported(x: torch.Tensor) -> bool:
     return x.is_cuda and x.shape[-1] == CH and x.dtype in (torch.float16, torch.bfloat16)
 
 
-def chain_pre(x_norm, wstream, consts, eps, *, tokens_per_sample, streams=1, hilo=True, profile=None):
+def chain_pre(x_norm, wstream, consts, eps, *, tokens_per_sample, streams=1, hilo=True, profile=None, head_major=False):
     """x_norm [S*B*T, 320] (the GroupNorm output).  Returns (y, q, k, vt): y = proj_in(x_norm) as a (hi, lo) tensor, q / k
-    [S*B*T, 320] already carrying sqrt(scale * log2 e) each, vt [S*B, 320, Tpad] (columns >= T zero)."""
+    [S*B*T, 320] already carrying sqrt(scale * log2 e) each, vt [S*B, 320, Tpad] (columns >= T zero).
+    ``head_major``: q / k leave as [S*B, 8, T, 40] images (same storage; ``ops.attention(..., q_hstride=T * 40,
+    k_hstride=T * 40)`` reads them): a head's keys are contiguous instead of 80-byte slices of 640-byte token rows."""
     T = tokens_per_sample
     rows = x_norm.shape[0]
     Tpad = (T + 63) // 64 * 64
@@ -184,15 +189,17 @@ def chain_pre(x_norm, wstream, consts, eps, *, tokens_per_sample, streams=1, hil
     q, k = torch.empty_like(x_norm), torch.empty_like(x_norm)
     vt = (torch.zeros if Tpad != T else torch.empty)(rows // T, CH, Tpad, dtype=x_norm.dtype, device=x_norm.device)
     _launch(MODE_PRE, x_norm, None, wstream, consts, eps, y_out=y, out=q, out2=k, out3=vt, rows_per_b=T, streams=streams,
-            profile=profile)
+            profile=profile, qk_heads=HEADS if head_major else 0)
     return y, q, k, vt
 
 
-def chain_q(attn_out, residual, wstream, consts, eps, *, streams=1, hilo=True, profile=None):
-    """Returns (y, q): y = attn_out Wo^T + bo + residual as a (hi, lo) tensor (``y.lo`` when ``hilo``), q = LN(y) Wq^T."""
+def chain_q(attn_out, residual, wstream, consts, eps, *, streams=1, hilo=True, profile=None, head_major_tokens=0):
+    """Returns (y, q): y = attn_out Wo^T + bo + residual as a (hi, lo) tensor (``y.lo`` when ``hilo``), q = LN(y) Wq^T.
+    ``head_major_tokens`` = T > 0: q leaves as a [S*B, 8, T, 40] image (see ``chain_pre``)."""
     y = ops._with_lo(torch.empty_like(attn_out), hilo)
     q = torch.empty_like(attn_out)
-    _launch(MODE_Q, attn_out, residual, wstream, consts, eps, y_out=y, out=q, streams=streams, profile=profile)
+    _launch(MODE_Q, attn_out, residual, wstream, consts, eps, y_out=y, out=q, streams=streams, profile=profile,
+            rows_per_b=head_major_tokens, qk_heads=HEADS if head_major_tokens else 0)
     return y, q
 
 
