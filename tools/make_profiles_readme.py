@@ -127,7 +127,13 @@ hoisted and with every network on every step), `r05_train_graph_rccl_w1_captured
 captured into the graph vs forward + backward graph | eager collectives | update graph, with per-phase times),
 `docs/NOTEBOOK_r1_r4.md` (the measurement narratives of rounds 1-4, moved out of DESIGN.md verbatim).  The bench line of round 5
 carries `loop` and `config.parity_rel_l2`.
-Round-6 additions: `r06_gridbar.txt` (`tools/ubench/gridbar.hip`: a device-wide barrier inside one persistent kernel -- fences +
+Round-6 additions: `r06_pmc_attn_l2_cfg5.json` / `r06_pmc_attn_l2_cfg5_head_major.json` / `r06_pmc_attn_l2_cfg3.json` (`tools/pmc_attn_l2.sh`: L2 hit rate,
+memory-side read requests by size, FETCH_SIZE / WRITE_SIZE of the d = 40 attention in separate `--pmc` passes -- token-matrix q / k vs
+the head-major images of round 6: 247.7 -> 90.7 MB per 16384-token launch for 83.9 MB algorithmic), `r06_head_major_ab.txt`
+(`tools/r06_head_major_ab.sh`: the step with / without the images alternating on one box, the isolated launches),
+`r06_xcd_raster_ab.txt` (per-launch tile order inside an XCD's run: feature and library A/B, rejected), `r06_tchain_io_ab.txt` (chain
+kernels: loads in flight, store drain, phase offset -- no effect), `r06_insitu_loop_render.txt` (in-situ pass on the rendering loop),
+`r06_gridbar.txt` (`tools/ubench/gridbar.hip`: a device-wide barrier inside one persistent kernel -- fences +
 counter / counter only with `sc1` data / fences by one workgroup per XCD / hierarchical -- against one kernel launch per phase in
 a graph, 128 / 256 / 512 workgroups, with a cross-XCD data check), `r06_bigwave_sweep.txt` (`tools/ab_gemm.py --sweep --tiles
 9,22,42,43,44,11,28,56..59`: the few-wave / big-wave-tile igemm builds of round 6 on the seven heaviest problems, isolated),
